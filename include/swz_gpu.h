@@ -1,0 +1,161 @@
+/*
+ * swz_gpu.h -- C ABI of the MI355X-native Schwarzwald tiler hot path (libswz_gpu.so).
+ *
+ * The reference (igd-geo/schwarzwald, paths below relative to schwarzwald/) has no plugin
+ * loader or C ABI for this path; its "plugin surface" is three compile-time C++ seams
+ * (SURVEY.md section 8(b)).  This header is the C-ABI boundary a maintainer binds behind
+ * those seams (INTEGRATION.md shows the adapter).  Conventions follow the only C ABI the
+ * reference itself consumes (LASzip, core/io/LASFile.cpp:14-75): every call returns an int
+ * status, 0 = OK, and the message of the last failure is read with swz_last_error().
+ *
+ * Ownership: the library owns all device workspace inside swz_ctx.  "host" entry points take
+ * caller-owned host buffers (what PointBuffer::positions().data() hands over,
+ * core/datastructures/PointBuffer.h:291-304); "_device" entry points take device pointers
+ * (hipMalloc'd or a torch tensor's data_ptr()) and run on the context's stream.
+ * Threading: one call in flight per context; independent contexts (one per GPU) may run
+ * concurrently.  Nothing here throws; the adapter turns a non-zero status into
+ * std::runtime_error like the rest of the tiler does (executable/main.cpp:599-602).
+ * There is NO CPU fallback: without a usable HIP device swz_create() fails.
+ */
+#ifndef SWZ_GPU_H
+#define SWZ_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWZ_ABI_VERSION 1
+
+/* status codes */
+enum {
+  SWZ_OK = 0,
+  SWZ_ERR_HIP = 1,                   /* a HIP runtime call failed (message has the HIP error) */
+  SWZ_ERR_BAD_ARG = 2,
+  SWZ_ERR_JITTER_GRID_TOO_SMALL = 3, /* JitteredSampling throws: Sampling.h:632-635 */
+  SWZ_ERR_JITTER_NODE_TOO_DEEP = 4,  /* JitteredSampling throws: Sampling.h:642-653 */
+  SWZ_ERR_REROOT_UNSUPPORTED = 5,    /* node needs Morton re-rooting, TilingAlgorithms.cpp:444-483 */
+  SWZ_ERR_TOO_MANY_POINTS = 6,       /* more than 2^32-2 points in one batch */
+  SWZ_ERR_INTERNAL = 7
+};
+
+/* --sampling values, TilerProcess::make_sampling_strategy (core/process/TilerProcess.cpp:491-516)
+ * -> Sampling.h:187-308 / :314-416 / :421-471 / :598-759 */
+enum { SWZ_RANDOM_GRID = 0, SWZ_GRID_CENTER = 1, SWZ_MIN_DISTANCE = 2, SWZ_JITTERED = 3 };
+/* SamplingBehaviour, Sampling.h:170-181 */
+enum { SWZ_TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS = 0, SWZ_ALWAYS_ADHERE_TO_MIN_SPACING = 1 };
+/* --tiling-strategy values, executable/main.cpp:484-497 -> TilingAlgorithmV1 / V3 */
+enum { SWZ_ACCURATE = 0, SWZ_FAST = 1 };
+
+typedef struct swz_ctx swz_ctx;
+
+/* Creates a context on HIP device `device` (ordinal).  Fails with SWZ_ERR_HIP when no device. */
+int swz_create(swz_ctx** ctx_out, int device);
+int swz_destroy(swz_ctx* ctx);
+const char* swz_last_error(const swz_ctx* ctx); /* ctx may be NULL: returns the create() error */
+int swz_abi_version(void);
+/* Run on an existing hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+int swz_set_stream(swz_ctx* ctx, void* hip_stream);
+/* Frees all device workspace held by the context (it regrows on demand). */
+int swz_release_workspace(swz_ctx* ctx);
+/* Bytes of device workspace currently held. */
+uint64_t swz_workspace_bytes(const swz_ctx* ctx);
+
+/* ---- index_points<21>(..., ClampToBounds): core/tiling/OctreeAlgorithms.h:145-197 with
+ * calculate_morton_index<21> :64-87.  xyz is N x 3 doubles (AoS).  Outliers are clamped to the
+ * bounds IN PLACE (index_point mutates the PointBuffer, :167-169), so xyz is read-write.
+ * keys_out[i] is the 63-bit MortonIndex64 of point i. */
+int swz_morton_encode(swz_ctx* ctx, double* xyz, uint64_t n, const double bounds_min[3],
+                      const double bounds_max[3], uint64_t* keys_out);
+int swz_morton_encode_device(swz_ctx* ctx, double* d_xyz, uint64_t n, const double bounds_min[3],
+                             const double bounds_max[3], uint64_t* d_keys_out);
+
+/* ---- Range::sort of IndexedPoint64 by key: util/containers/Range.h:62-66, operator<
+ * core/tiling/Sampling.h:159-164.  std::sort leaves the order of equal keys unspecified; this
+ * sort is stable: perm_out lists original indices ordered by (key, original index).
+ * keys_sorted_out may be NULL. */
+int swz_sort_by_key(swz_ctx* ctx, const uint64_t* keys, uint64_t n, uint32_t* perm_out,
+                    uint64_t* keys_sorted_out);
+int swz_sort_by_key_device(swz_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t* d_perm_out,
+                           uint64_t* d_keys_sorted_out);
+
+/* ---- sample_points(strategy, begin, end, node_key, node_level, root_bounds, spacing_at_root,
+ * behaviour): core/tiling/Sampling.h:799-821.  keys/idx describe a Morton-sorted range of n
+ * IndexedPoint64 (idx[i] = row of xyz).  taken_out[i] = 1 when element i belongs to the
+ * [begin, partition_point) half of the reference's stable partition, else 0 (both halves keep
+ * their order, so the partition itself is a stable compaction by this flag). */
+int swz_sample_points(swz_ctx* ctx, int sampler, uint64_t max_points_per_node, const uint64_t* keys,
+                      const uint32_t* idx, uint64_t n, const double* xyz, uint64_t num_points,
+                      uint64_t node_key, int32_t node_level, const double root_min[3],
+                      const double root_max[3], float spacing_at_root, int behaviour,
+                      uint8_t* taken_out, uint64_t* num_taken_out);
+
+/* ---- one batch through the tiling algorithm: TilingAlgorithmBase::build_execution_graph
+ * (core/tiling/TilingAlgorithms.h:81-85), V1 = ACCURATE (TilingAlgorithms.cpp:577-626),
+ * V3 = FAST first iteration + finalize (:1250-1360, :1661-1784). */
+typedef struct {
+  int32_t sampler;              /* SWZ_RANDOM_GRID ... */
+  uint64_t max_points_per_node; /* TilerMetaParameters::max_points_per_node (Tiler.h:64-75) */
+  float spacing_at_root;        /* TilerMetaParameters::spacing_at_root */
+  uint32_t max_depth;           /* TilerMetaParameters::max_depth (<=0 means 100 upstream) */
+  int32_t strategy;             /* SWZ_ACCURATE | SWZ_FAST */
+  uint32_t fast_concurrency;    /* FAST: num_indexing_threads, decides the start level
+                                   (TilingAlgorithms.cpp:1473-1535) */
+} swz_tile_params;
+
+typedef struct {
+  uint64_t num_nodes;         /* nodes that persisted points (incl. FAST reconstructed ones) */
+  uint64_t points_visited;    /* sum over levels of the points handed to sample_points/terminal */
+  int32_t max_level;          /* deepest node level that took points (-1 = root) */
+  int32_t fast_start_levels;  /* FAST: _level_of_start_nodes, else -1 */
+  uint32_t num_levels;        /* level iterations executed */
+  uint32_t min_distance_rounds; /* MIN_DISTANCE: dependency rounds executed, all levels */
+} swz_tile_stats;
+
+/* Outputs are in Morton-sorted order: keys_out[i] ascending (ties by original index),
+ * perm_out[i] = original point index, level_out[i] = level of the octree node that persists the
+ * point (-1 = root "r"); the node is the first level_out[i]+1 octants of keys_out[i]
+ * (node name "r" + digits, TilingAlgorithms.cpp:139).  dup_mask_out (may be NULL; FAST only)
+ * has bit (l+1) set when the point is additionally stored in the reconstructed node at level l.
+ * xyz is clamped in place like index_point does. */
+int swz_tile(swz_ctx* ctx, double* xyz, uint64_t n, const double bounds_min[3],
+             const double bounds_max[3], const swz_tile_params* params, uint64_t* keys_out,
+             uint32_t* perm_out, int8_t* level_out, uint32_t* dup_mask_out, swz_tile_stats* stats);
+int swz_tile_device(swz_ctx* ctx, double* d_xyz, uint64_t n, const double bounds_min[3],
+                    const double bounds_max[3], const swz_tile_params* params, uint64_t* d_keys_out,
+                    uint32_t* d_perm_out, int8_t* d_level_out, uint32_t* d_dup_mask_out,
+                    swz_tile_stats* stats);
+
+/* ---- what PointsPersistence::persist_points needs (core/io/PointsPersistence.h:23-31): the
+ * points of every node, contiguous and in Morton order.  From swz_tile's outputs builds
+ * order_out[n] (sorted positions grouped by node; nodes ordered by (level, key prefix)) and the
+ * node table.  node_* arrays must hold max_nodes entries; *num_nodes_out is the count found
+ * (SWZ_ERR_BAD_ARG when it exceeds max_nodes).  Host buffers. */
+int swz_build_node_lists(swz_ctx* ctx, const uint64_t* keys_sorted, const int8_t* level, uint64_t n,
+                         uint32_t* order_out, uint64_t max_nodes, int8_t* node_level_out,
+                         uint64_t* node_key_out, uint64_t* node_offset_out, uint64_t* node_count_out,
+                         uint64_t* num_nodes_out);
+
+/* ---- synthetic workload of BASELINE.json / SURVEY.md section 8(d): uniform points in the unit
+ * cube from a counter-based splitmix64 stream (point i draws x,y,z = draws 3i..3i+2). */
+int swz_generate_uniform_device(swz_ctx* ctx, uint64_t seed, uint64_t first_point, uint64_t n,
+                                double* d_xyz_out);
+
+/* ---- per-kernel timing (HIP events on the context's stream) for bench.py's roofline.
+ * When enabled every kernel class is bracketed by events; totals accumulate until reset. */
+typedef struct {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+  uint64_t algorithmic_bytes; /* bytes the launches had to move at minimum */
+} swz_kernel_stat;
+int swz_profile_enable(swz_ctx* ctx, int enabled);
+int swz_profile_reset(swz_ctx* ctx);
+/* Copies up to max_stats entries; returns the number of kernel classes via *num_out. */
+int swz_profile_get(swz_ctx* ctx, swz_kernel_stat* stats_out, uint32_t max_stats, uint32_t* num_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,446 @@
+// swz_api.hip -- the C-ABI entry points of include/swz_gpu.h: context, workspace, profiling,
+// host-buffer wrappers around the device-resident stages.
+#include <cstring>
+
+#include "swz_device.h"
+#include "swz_internal.h"
+
+// ------------------------------------------------------------------------------ context plumbing
+int swz_ctx::get(const char* name, size_t bytes, void** out) {
+  swz::DevBuf& b = bufs[name];
+  if (bytes == 0) bytes = 16;
+  if (b.cap < bytes) {
+    if (b.ptr) {
+      SWZ_HIP(this, hipStreamSynchronize(stream));
+      SWZ_HIP(this, hipFree(b.ptr));
+      b.ptr = nullptr;
+      b.cap = 0;
+    }
+    // a little head-room so slowly growing requests do not reallocate every call
+    size_t want = bytes + bytes / 16;
+    want = (want + 255) & ~size_t(255);
+    hipError_t e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {
+      b.ptr = nullptr;
+      return fail(SWZ_ERR_HIP, std::string("hipMalloc(") + name + ", " + std::to_string(want) +
+                                 " bytes): " + hipGetErrorString(e));
+    }
+    b.cap = want;
+  }
+  *out = b.ptr;
+  return SWZ_OK;
+}
+
+void swz_ctx::release_all() {
+  if (stream) (void)hipStreamSynchronize(stream);
+  for (auto& kv : bufs)
+    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  bufs.clear();
+}
+
+uint64_t swz_ctx::held_bytes() const {
+  uint64_t s = 0;
+  for (const auto& kv : bufs) s += kv.second.cap;
+  return s;
+}
+
+hipEvent_t swz_ctx::take_event() {
+  if (!event_pool.empty()) {
+    hipEvent_t e = event_pool.back();
+    event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+void swz_ctx::prof_begin(const char*) {
+  if (!profile) return;
+  cur_e0_ = take_event();
+  (void)hipEventRecord(cur_e0_, stream);
+}
+
+void swz_ctx::prof_end(const char* name, uint64_t launches, uint64_t bytes) {
+  if (!profile || !cur_e0_) return;
+  hipEvent_t e1 = take_event();
+  (void)hipEventRecord(e1, stream);
+  pending.push_back({name, cur_e0_, e1, launches, bytes});
+  cur_e0_ = nullptr;
+}
+
+void swz_ctx::prof_collect() {
+  for (auto& p : pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.e1) == hipSuccess && hipEventElapsedTime(&ms, p.e0, p.e1) == hipSuccess) {
+      swz::KernelStat& k = kstats[p.name];
+      k.launches += p.launches;
+      k.total_ms += ms;
+      k.bytes += p.bytes;
+    }
+    event_pool.push_back(p.e0);
+    event_pool.push_back(p.e1);
+  }
+  pending.clear();
+}
+
+static std::string g_create_error;
+
+namespace {
+
+// Host-buffer helpers ---------------------------------------------------------------------------
+int upload(swz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return SWZ_OK;
+  SWZ_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return SWZ_OK;
+}
+int download(swz_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (bytes == 0) return SWZ_OK;
+  SWZ_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return SWZ_OK;
+}
+int sync(swz_ctx* c) {
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  c->prof_collect();
+  return SWZ_OK;
+}
+int check_n(swz_ctx* c, uint64_t n) {
+  if (n > 0xFFFFFFFEull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-2 points in one batch");
+  return SWZ_OK;
+}
+int check_bounds(swz_ctx* c, const double mn[3], const double mx[3]) {
+  if (!mn || !mx) return c->fail(SWZ_ERR_BAD_ARG, "bounds must not be NULL");
+  for (int a = 0; a < 3; ++a)
+    if (!(mx[a] > mn[a])) return c->fail(SWZ_ERR_BAD_ARG, "bounds must have positive extent on every axis");
+  return SWZ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int swz_abi_version(void) { return SWZ_ABI_VERSION; }
+
+int swz_create(swz_ctx** ctx_out, int device) {
+  if (!ctx_out) return SWZ_ERR_BAD_ARG;
+  *ctx_out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    g_create_error = std::string("swz_create: no usable HIP device (") +
+                     (e != hipSuccess ? hipGetErrorString(e) : "device count is 0") +
+                     "); this library has no CPU fallback";
+    return SWZ_ERR_HIP;
+  }
+  if (device < 0 || device >= count) {
+    g_create_error = "swz_create: device ordinal out of range";
+    return SWZ_ERR_BAD_ARG;
+  }
+  e = hipSetDevice(device);
+  if (e != hipSuccess) {
+    g_create_error = std::string("swz_create: hipSetDevice: ") + hipGetErrorString(e);
+    return SWZ_ERR_HIP;
+  }
+  swz_ctx* c = new swz_ctx();
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    g_create_error = std::string("swz_create: hipStreamCreate: ") + hipGetErrorString(e);
+    delete c;
+    return SWZ_ERR_HIP;
+  }
+  c->stream = c->own_stream;
+  *ctx_out = c;
+  return SWZ_OK;
+}
+
+int swz_destroy(swz_ctx* c) {
+  if (!c) return SWZ_OK;
+  (void)hipSetDevice(c->device);
+  c->release_all();
+  c->prof_collect();
+  for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+  return SWZ_OK;
+}
+
+const char* swz_last_error(const swz_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int swz_set_stream(swz_ctx* c, void* hip_stream) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  return SWZ_OK;
+}
+
+int swz_release_workspace(swz_ctx* c) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  c->release_all();
+  return SWZ_OK;
+}
+
+uint64_t swz_workspace_bytes(const swz_ctx* c) { return c ? c->held_bytes() : 0; }
+
+int swz_profile_enable(swz_ctx* c, int enabled) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  c->profile = enabled != 0;
+  return SWZ_OK;
+}
+int swz_profile_reset(swz_ctx* c) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_TRY(sync(c));
+  c->kstats.clear();
+  return SWZ_OK;
+}
+int swz_profile_get(swz_ctx* c, swz_kernel_stat* out, uint32_t max_stats, uint32_t* num_out) {
+  if (!c || !num_out) return SWZ_ERR_BAD_ARG;
+  SWZ_TRY(sync(c));
+  uint32_t k = 0;
+  for (const auto& kv : c->kstats) {
+    if (k < max_stats && out) {
+      std::memset(&out[k], 0, sizeof(out[k]));
+      std::strncpy(out[k].name, kv.first.c_str(), sizeof(out[k].name) - 1);
+      out[k].launches = kv.second.launches;
+      out[k].total_ms = kv.second.total_ms;
+      out[k].algorithmic_bytes = kv.second.bytes;
+    }
+    ++k;
+  }
+  *num_out = k;
+  return SWZ_OK;
+}
+
+// ------------------------------------------------------------------------------ encode
+int swz_morton_encode_device(swz_ctx* c, double* d_xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                             uint64_t* d_keys_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  if (n && (!d_xyz || !d_keys_out)) return c->fail(SWZ_ERR_BAD_ARG, "swz_morton_encode_device: NULL buffer");
+  SWZ_TRY(swz::encode_device(c, d_xyz, (uint32_t)n, bmin, bmax, d_keys_out));
+  return sync(c);
+}
+
+int swz_morton_encode(swz_ctx* c, double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                      uint64_t* keys_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  if (n == 0) return SWZ_OK;
+  if (!xyz || !keys_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_morton_encode: NULL buffer");
+  double* d_xyz = nullptr;
+  uint64_t* d_keys = nullptr;
+  SWZ_TRY(c->get("h_xyz", (size_t)n * 3, &d_xyz));
+  SWZ_TRY(c->get("h_keys", (size_t)n, &d_keys));
+  SWZ_TRY(upload(c, d_xyz, xyz, (size_t)n * 24));
+  SWZ_TRY(swz::encode_device(c, d_xyz, (uint32_t)n, bmin, bmax, d_keys));
+  SWZ_TRY(download(c, keys_out, d_keys, (size_t)n * 8));
+  SWZ_TRY(download(c, xyz, d_xyz, (size_t)n * 24));  // clamped in place, like index_point
+  return sync(c);
+}
+
+// ------------------------------------------------------------------------------ sort
+int swz_sort_by_key_device(swz_ctx* c, const uint64_t* d_keys, uint64_t n, uint32_t* d_perm_out,
+                           uint64_t* d_keys_sorted_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  if (n == 0) return SWZ_OK;
+  if (!d_keys || !d_perm_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_sort_by_key_device: NULL buffer");
+  uint64_t *ka = nullptr, *kb = nullptr;
+  uint32_t* vb = nullptr;
+  if (d_keys_sorted_out) {
+    ka = d_keys_sorted_out;
+  } else {
+    SWZ_TRY(c->get("sort_keys_a", (size_t)n, &ka));
+  }
+  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &kb));
+  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vb));
+  SWZ_HIP(c, hipMemcpyAsync(ka, d_keys, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+  SWZ_TRY(swz::radix_sort_pairs(c, ka, d_perm_out, kb, vb, (uint32_t)n, true));
+  return sync(c);
+}
+
+int swz_sort_by_key(swz_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* perm_out, uint64_t* keys_sorted_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  if (n == 0) return SWZ_OK;
+  if (!keys || !perm_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_sort_by_key: NULL buffer");
+  uint64_t *ka = nullptr, *kb = nullptr;
+  uint32_t *va = nullptr, *vb = nullptr;
+  SWZ_TRY(c->get("sort_keys_a", (size_t)n, &ka));
+  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &kb));
+  SWZ_TRY(c->get("sort_vals_a", (size_t)n, &va));
+  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vb));
+  SWZ_TRY(upload(c, ka, keys, (size_t)n * 8));
+  SWZ_TRY(swz::radix_sort_pairs(c, ka, va, kb, vb, (uint32_t)n, true));
+  SWZ_TRY(download(c, perm_out, va, (size_t)n * 4));
+  if (keys_sorted_out) SWZ_TRY(download(c, keys_sorted_out, ka, (size_t)n * 8));
+  return sync(c);
+}
+
+// ------------------------------------------------------------------------------ synthetic input
+int swz_generate_uniform_device(swz_ctx* c, uint64_t seed, uint64_t first_point, uint64_t n, double* d_xyz_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (n && !d_xyz_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_generate_uniform_device: NULL buffer");
+  SWZ_TRY(swz::generate_uniform_device(c, seed, first_point, n, d_xyz_out));
+  return sync(c);
+}
+
+// ------------------------------------------------------------------------------ tile
+static int check_params(swz_ctx* c, const swz_tile_params* p) {
+  if (!p) return c->fail(SWZ_ERR_BAD_ARG, "params must not be NULL");
+  if (p->sampler < SWZ_RANDOM_GRID || p->sampler > SWZ_JITTERED) return c->fail(SWZ_ERR_BAD_ARG, "unknown sampler");
+  if (p->strategy != SWZ_ACCURATE && p->strategy != SWZ_FAST) return c->fail(SWZ_ERR_BAD_ARG, "unknown strategy");
+  if (!(p->spacing_at_root > 0.f)) return c->fail(SWZ_ERR_BAD_ARG, "spacing_at_root must be > 0");
+  if (p->strategy == SWZ_FAST && p->fast_concurrency == 0)
+    return c->fail(SWZ_ERR_BAD_ARG, "FAST needs fast_concurrency >= 1");
+  return SWZ_OK;
+}
+
+int swz_tile_device(swz_ctx* c, double* d_xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                    const swz_tile_params* params, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
+                    uint32_t* d_dup_mask_out, swz_tile_stats* stats) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  SWZ_TRY(check_params(c, params));
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (stats) {
+    stats->max_level = -1;
+    stats->fast_start_levels = -1;
+  }
+  if (n == 0) return SWZ_OK;
+  if (!d_xyz || !d_keys_out || !d_perm_out || !d_level_out)
+    return c->fail(SWZ_ERR_BAD_ARG, "swz_tile_device: NULL buffer");
+  swz::TileDeviceOut out{d_keys_out, d_perm_out, d_level_out, d_dup_mask_out};
+  int st = swz::tile_device(c, d_xyz, (uint32_t)n, bmin, bmax, *params, out, stats);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
+}
+
+int swz_tile(swz_ctx* c, double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
+             const swz_tile_params* params, uint64_t* keys_out, uint32_t* perm_out, int8_t* level_out,
+             uint32_t* dup_mask_out, swz_tile_stats* stats) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  SWZ_TRY(check_params(c, params));
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->max_level = -1;
+    stats->fast_start_levels = -1;
+  }
+  if (n == 0) return SWZ_OK;
+  if (!xyz || !keys_out || !perm_out || !level_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_tile: NULL buffer");
+  double* d_xyz = nullptr;
+  uint64_t* d_keys = nullptr;
+  uint32_t *d_perm = nullptr, *d_dup = nullptr;
+  int8_t* d_level = nullptr;
+  SWZ_TRY(c->get("h_xyz", (size_t)n * 3, &d_xyz));
+  SWZ_TRY(c->get("h_keys", (size_t)n, &d_keys));
+  SWZ_TRY(c->get("h_perm", (size_t)n, &d_perm));
+  SWZ_TRY(c->get("h_level", (size_t)n, &d_level));
+  if (dup_mask_out) SWZ_TRY(c->get("h_dup", (size_t)n, &d_dup));
+  SWZ_TRY(upload(c, d_xyz, xyz, (size_t)n * 24));
+  swz::TileDeviceOut out{d_keys, d_perm, d_level, d_dup};
+  int st = swz::tile_device(c, d_xyz, (uint32_t)n, bmin, bmax, *params, out, stats);
+  if (st != SWZ_OK) {
+    (void)sync(c);
+    return st;
+  }
+  SWZ_TRY(download(c, keys_out, d_keys, (size_t)n * 8));
+  SWZ_TRY(download(c, perm_out, d_perm, (size_t)n * 4));
+  SWZ_TRY(download(c, level_out, d_level, (size_t)n));
+  if (dup_mask_out) SWZ_TRY(download(c, dup_mask_out, d_dup, (size_t)n * 4));
+  SWZ_TRY(download(c, xyz, d_xyz, (size_t)n * 24));
+  return sync(c);
+}
+
+// ------------------------------------------------------------------------------ sample_points
+int swz_sample_points(swz_ctx* c, int sampler, uint64_t max_points_per_node, const uint64_t* keys,
+                      const uint32_t* idx, uint64_t n, const double* xyz, uint64_t num_points, uint64_t node_key,
+                      int32_t node_level, const double root_min[3], const double root_max[3], float spacing_at_root,
+                      int behaviour, uint8_t* taken_out, uint64_t* num_taken_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_n(c, num_points));
+  SWZ_TRY(check_bounds(c, root_min, root_max));
+  if (sampler < SWZ_RANDOM_GRID || sampler > SWZ_JITTERED) return c->fail(SWZ_ERR_BAD_ARG, "unknown sampler");
+  if (node_level < -1 || node_level > 20) return c->fail(SWZ_ERR_BAD_ARG, "node_level out of range");
+  if (num_taken_out) *num_taken_out = 0;
+  if (n == 0) return SWZ_OK;
+  if (!keys || !idx || !xyz || !taken_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_sample_points: NULL buffer");
+  double* d_xyz = nullptr;
+  uint64_t* d_keys = nullptr;
+  uint32_t* d_idx = nullptr;
+  uint8_t* d_taken = nullptr;
+  SWZ_TRY(c->get("h_xyz", (size_t)num_points * 3, &d_xyz));
+  SWZ_TRY(c->get("h_keys", (size_t)n, &d_keys));
+  SWZ_TRY(c->get("h_perm", (size_t)n, &d_idx));
+  SWZ_TRY(c->get("h_taken", (size_t)n, &d_taken));
+  SWZ_TRY(upload(c, d_xyz, xyz, (size_t)num_points * 24));
+  SWZ_TRY(upload(c, d_keys, keys, (size_t)n * 8));
+  SWZ_TRY(upload(c, d_idx, idx, (size_t)n * 4));
+  int st = swz::sample_points_device(c, sampler, max_points_per_node, d_keys, d_idx, (uint32_t)n, d_xyz, node_key,
+                                     node_level, root_min, root_max, spacing_at_root, behaviour, d_taken,
+                                     num_taken_out);
+  if (st != SWZ_OK) {
+    (void)sync(c);
+    return st;
+  }
+  SWZ_TRY(download(c, taken_out, d_taken, (size_t)n));
+  return sync(c);
+}
+
+// ------------------------------------------------------------------------------ node lists
+// Pure host bookkeeping on swz_tile's outputs (the adapter calls persist_points per node with it):
+// a stable counting sort of the sorted positions by level, then run detection on the key prefix.
+int swz_build_node_lists(swz_ctx* c, const uint64_t* keys_sorted, const int8_t* level, uint64_t n,
+                         uint32_t* order_out, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
+                         uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out) {
+  if (!c || !num_nodes_out) return SWZ_ERR_BAD_ARG;
+  *num_nodes_out = 0;
+  if (n == 0) return SWZ_OK;
+  if (!keys_sorted || !level || !order_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_build_node_lists: NULL buffer");
+  uint64_t hist[23] = {0};
+  for (uint64_t i = 0; i < n; ++i) {
+    const int l = level[i];
+    if (l < -1 || l > 20) return c->fail(SWZ_ERR_BAD_ARG, "level out of range");
+    hist[l + 2]++;
+  }
+  for (int l = 1; l < 23; ++l) hist[l] += hist[l - 1];
+  for (uint64_t i = 0; i < n; ++i) order_out[hist[level[i] + 1]++] = (uint32_t)i;
+  uint64_t nn = 0;
+  uint64_t i = 0;
+  while (i < n) {
+    const uint64_t p = order_out[i];
+    const int l = level[p];
+    const uint32_t sh = (l < 0) ? 63u : swz::level_shift(l);
+    const uint64_t prefix = keys_sorted[p] >> sh;
+    uint64_t j = i + 1;
+    while (j < n && level[order_out[j]] == l && (keys_sorted[order_out[j]] >> sh) == prefix) ++j;
+    if (nn < max_nodes && node_level_out && node_key_out && node_offset_out && node_count_out) {
+      node_level_out[nn] = (int8_t)l;
+      node_key_out[nn] = (l < 0) ? 0 : (prefix << sh);
+      node_offset_out[nn] = i;
+      node_count_out[nn] = j - i;
+    }
+    ++nn;
+    i = j;
+  }
+  *num_nodes_out = nn;
+  if (nn > max_nodes) return c->fail(SWZ_ERR_BAD_ARG, "max_nodes too small");
+  return SWZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// swz_internal.h -- context, workspace and launch bookkeeping shared by the HIP translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/swz_gpu.h"
+
+namespace swz {
+
+constexpr uint32_t MAX_LEVELS = 21;  // MortonIndex64Levels, core/datastructures/MortonIndex.h:222-226
+
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t cap = 0;
+};
+
+struct KernelStat {
+  uint64_t launches = 0;
+  double total_ms = 0.0;
+  uint64_t bytes = 0;
+};
+
+struct PendingEvent {
+  std::string name;
+  hipEvent_t e0, e1;
+  uint64_t launches;
+  uint64_t bytes;
+};
+
+}  // namespace swz
+
+struct swz_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::map<std::string, swz::DevBuf> bufs;
+  // profiling
+  bool profile = false;
+  std::map<std::string, swz::KernelStat> kstats;
+  std::vector<swz::PendingEvent> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  // ---- error helpers
+  int fail(int code, const std::string& msg) {
+    err = msg;
+    return code;
+  }
+  int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    err = std::string(what) + ": " + hipGetErrorString(e) + " (" + file + ":" + std::to_string(line) + ")";
+    return SWZ_ERR_HIP;
+  }
+
+  // ---- grow-only named workspace
+  int get(const char* name, size_t bytes, void** out);
+  template <typename T>
+  int get(const char* name, size_t count, T** out) {
+    return get(name, count * sizeof(T), reinterpret_cast<void**>(out));
+  }
+  void release_all();
+  uint64_t held_bytes() const;
+
+  // ---- timing: bracket [begin, end) launches of one kernel class with events when profiling
+  hipEvent_t take_event();
+  void prof_begin(const char* name);
+  void prof_end(const char* name, uint64_t launches, uint64_t bytes);
+  void prof_collect();  // after a stream sync: fold pending events into kstats
+  hipEvent_t cur_e0_ = nullptr;
+};
+
+#define SWZ_HIP(ctx, expr)                                                \
+  do {                                                                    \
+    hipError_t _e = (expr);                                               \
+    if (_e != hipSuccess) return (ctx)->hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define SWZ_TRY(expr)            \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != SWZ_OK) return _s; \
+  } while (0)
+
+// checks the launch itself (configuration errors); execution errors surface at the next sync
+#define SWZ_LAUNCH_CHECK(ctx) SWZ_HIP(ctx, hipGetLastError())
+
+namespace swz {
+
+inline uint32_t div_up(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// RAII-less helper: time one kernel class
+struct ProfScope {
+  swz_ctx* c;
+  const char* name;
+  uint64_t launches, bytes;
+  ProfScope(swz_ctx* ctx, const char* n, uint64_t b, uint64_t l = 1) : c(ctx), name(n), launches(l), bytes(b) {
+    c->prof_begin(name);
+  }
+  ~ProfScope() { c->prof_end(name, launches, bytes); }
+};
+
+// ---- stage entry points (each in its own .hip file) -------------------------------------------
+int encode_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
+                  uint64_t* d_keys);
+int generate_uniform_device(swz_ctx* c, uint64_t seed, uint64_t first, uint64_t n, double* d_xyz);
+
+// Stable LSD radix sort of (key, value) pairs.  Sorts d_keys_a/d_vals_a in place using the _b
+// buffers as the other half of the ping-pong (8 passes end in the _a buffers).  When
+// vals_identity is true the first pass synthesises value = element index instead of reading.
+int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_a, uint32_t* d_vals_a, uint64_t* d_keys_b,
+                     uint32_t* d_vals_b, uint32_t n, bool vals_identity);
+
+// Device-wide exclusive scan of a u32 array (in place allowed).  *d_total receives the sum.
+int scan_exclusive_u32(swz_ctx* c, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint32_t* d_total,
+                       const char* tag);
+
+// Gather positions into Morton order, SoA: X[i] = xyz[3*perm[i]] ...
+int gather_positions(swz_ctx* c, const double* d_xyz, const uint32_t* d_perm, uint32_t n, double* d_x,
+                     double* d_y, double* d_z);
+
+struct TileDeviceOut {
+  uint64_t* keys;   // sorted keys (n)
+  uint32_t* perm;   // original index (n)
+  int8_t* level;    // taken level per sorted position (n)
+  uint32_t* dup;    // may be null
+};
+
+int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
+                const swz_tile_params& p, const TileDeviceOut& out, swz_tile_stats* stats);
+
+int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uint64_t* d_keys,
+                         const uint32_t* d_idx, uint32_t n, const double* d_xyz, uint64_t node_key,
+                         int32_t node_level, const double rmin[3], const double rmax[3], float spacing,
+                         int behaviour, uint8_t* d_taken, uint64_t* num_taken);
+
+}  // namespace swz

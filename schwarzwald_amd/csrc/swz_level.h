@@ -1,0 +1,73 @@
+// swz_level.h -- per-level state shared between the level-synchronous tiler (swz_level.hip) and the
+// MIN_DISTANCE dependency sweep (swz_mindist.hip).
+#pragma once
+#include "swz_device.h"
+#include "swz_internal.h"
+
+namespace swz {
+
+enum : uint8_t { MODE_TAKE_ALL = 0, MODE_SAMPLE = 1 };
+
+// device counters of one level iteration
+enum {
+  CTR_NUM_NODES = 0,     // nodes at this level
+  CTR_SAMPLE_NODES = 1,  // nodes that run the sampler (count > max_points or forced)
+  CTR_SAMPLE_POINTS = 2, // points inside those nodes
+  CTR_ERROR = 3,         // SWZ_ERR_* raised by a kernel (0 = none)
+  CTR_REMAINING = 4,     // points handed to the next level
+  CTR_NUM_CELLS = 5,     // MIN_DISTANCE: cells
+  CTR_DONE_CELLS = 6,    // MIN_DISTANCE: cells finished
+  CTR_Q0 = 8,            // MIN_DISTANCE: three rotating queue counters
+  CTR_COUNT = 16
+};
+
+// The active set of one level: Morton-sorted survivors.  aidx == nullptr means identity (level -1).
+struct ActiveSet {
+  const uint64_t* akey = nullptr;  // key of every active point
+  const uint32_t* aidx = nullptr;  // its position in the fully sorted arrays (X/Y/Z/level)
+  uint32_t m = 0;
+};
+
+struct SortedPoints {
+  const double* X = nullptr;  // positions in Morton order, SoA
+  const double* Y = nullptr;
+  const double* Z = nullptr;
+};
+
+// What the host decides once per level (all float/libm corner cases of the reference live here,
+// evaluated with the host's glibc exactly like the reference evaluates them).
+struct LevelPlan {
+  int level = -1;           // node level (-1 = root)
+  uint32_t node_shift = 63; // key >> node_shift == node prefix
+  int sampler = 0;
+  uint64_t max_points = 0;
+  bool force_sample = false; // SamplingBehaviour::AlwaysAdhereToMinSpacing
+  bool terminal = false;     // tile_terminal_node: every node of this level keeps all its points
+  bool reroot = false;       // sampling this level would need Morton re-rooting
+  Box root;
+  // RANDOM_GRID / GRID_CENTER: candidate_level_in_octree (Sampling.h:223-229); -1 = first point only
+  int cand = -1;
+  // JITTERED / MIN_DISTANCE
+  double spacing_node = 0.0; // spacing_at_root / pow(2, level + 1)
+  uint32_t jitter_start = 0; // (3 * (level + 1)) % 16
+  // MIN_DISTANCE
+  double sq_spacing = 0.0;   // (double)((float)spacing_node * (float)spacing_node)
+  int cell_levels_geo = 0;   // finest cell subdivision (levels below the node) whose cells are >= spacing
+};
+
+struct LevelBuffers {
+  uint32_t* flags = nullptr;   // m
+  uint32_t* nid = nullptr;     // m
+  uint32_t* nstart = nullptr;  // m + 1
+  uint8_t* nmode = nullptr;    // m
+  uint8_t* taken = nullptr;    // m
+  uint32_t* counters = nullptr; // CTR_COUNT (device)
+};
+
+// MIN_DISTANCE for one level; fills lb.taken for the points of MODE_SAMPLE nodes (take-all points
+// are flagged by the caller).  rounds_out accumulates the dependency rounds executed.
+int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+                       const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes,
+                       uint32_t sample_points, uint32_t* rounds_out);
+
+}  // namespace swz

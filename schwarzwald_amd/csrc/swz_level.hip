@@ -1,0 +1,661 @@
+// swz_level.hip -- level-synchronous octree tiling (K3, K4a/b/d, K5) and the tiler drivers.
+//
+// The reference recurses top-down per node (TilingAlgorithmBase::do_tiling_for_node /
+// tile_node / tile_internal_node, core/tiling/TilingAlgorithms.cpp:499-561, 351-492, 247-349): sample
+// a node's Morton-sorted points (stable partition), persist the taken ones, split the rest into the
+// <= 8 child octants (:116-162) and recurse.  Here all nodes of one level are processed together:
+// the "active set" is the Morton-sorted array of points not yet taken; a node is a run of equal key
+// prefix, a sampling-grid cell a run of a longer prefix; taken points get their level recorded and
+// the survivors are stream-compacted (stable) into the next level's active set.
+#include <cmath>
+
+#include "swz_level.h"
+
+namespace swz {
+
+#define SWZ_JITTER_TABLE(W) __constant__ uint8_t PERMUTATIONS_##W[16 * W]
+#include "jitter_tables.inc"
+#undef SWZ_JITTER_TABLE
+
+__device__ __forceinline__ uint32_t spos_of(const uint32_t* aidx, uint32_t i) { return aidx ? aidx[i] : i; }
+
+// ----------------------------------------------------------------------------- node segmentation
+__global__ __launch_bounds__(256) void node_head_kernel(const uint64_t* __restrict__ akey, uint32_t m,
+                                                        uint32_t nsh, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  flags[i] = (i == 0) ? 1u : (uint32_t)((akey[i] >> nsh) != (akey[i - 1] >> nsh));
+}
+
+__global__ __launch_bounds__(256) void node_finish_kernel(const uint32_t* __restrict__ flags,
+                                                          uint32_t* __restrict__ nid, uint32_t m,
+                                                          uint32_t* __restrict__ nstart) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t f = flags[i];
+  const uint32_t id = nid[i] + f - 1u;  // exclusive count of heads before i -> node index of i
+  nid[i] = id;
+  if (f) nstart[id] = i;
+  if (i == m - 1) nstart[id + 1] = m;
+}
+
+// tile_node / tile_internal_node decisions per node: terminal nodes and nodes with <= max_points
+// points (SamplingBehaviour::TakeAllWhenCountBelowMaxPoints, Sampling.h:201-208) keep everything.
+__global__ __launch_bounds__(256) void node_mode_kernel(const uint32_t* __restrict__ nstart,
+                                                        uint8_t* __restrict__ nmode, uint32_t* __restrict__ counters,
+                                                        uint64_t max_points, int force_sample, int terminal,
+                                                        int reroot) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= counters[CTR_NUM_NODES]) return;
+  const uint32_t cnt = nstart[j + 1] - nstart[j];
+  const bool sample = !terminal && (force_sample || (uint64_t)cnt > max_points);
+  nmode[j] = sample ? MODE_SAMPLE : MODE_TAKE_ALL;
+  if (sample) {
+    if (reroot) atomicMax(&counters[CTR_ERROR], (uint32_t)SWZ_ERR_REROOT_UNSUPPORTED);
+    atomicAdd(&counters[CTR_SAMPLE_NODES], 1u);
+    atomicAdd(&counters[CTR_SAMPLE_POINTS], cnt);
+  }
+}
+
+// ----------------------------------------------------------------------------- RANDOM_GRID (K4a)
+// RandomSortedGridSampling::sample_points, Sampling.h:187-308: the first point of every run of equal
+// truncate_to_level(candidate_level) is taken.  candidate_level == -1 takes the first point only.
+__global__ __launch_bounds__(256) void random_grid_kernel(const uint64_t* __restrict__ akey, uint32_t m,
+                                                          const uint32_t* __restrict__ nid,
+                                                          const uint8_t* __restrict__ nmode, uint32_t csh,
+                                                          uint8_t* __restrict__ taken) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  uint8_t t = 1;
+  if (nmode[nid[i]] == MODE_SAMPLE) t = (i == 0) || ((akey[i] >> csh) != (akey[i - 1] >> csh));
+  taken[i] = t;
+}
+
+__global__ __launch_bounds__(256) void take_all_kernel(uint32_t m, const uint32_t* __restrict__ nid,
+                                                       const uint8_t* __restrict__ nmode,
+                                                       uint8_t* __restrict__ taken) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  if (nmode[nid[i]] == MODE_TAKE_ALL) taken[i] = 1;
+}
+
+// ----------------------------------------------------------------------------- GRID_CENTER / JITTERED (K4b, K4d)
+// Both pick, per run of equal grid-cell prefix, the first point with the smallest squared distance
+// to a per-cell target (std::min_element, Sampling.h:392-403 / :741-750): a segmented arg-min.
+constexpr int GA_THREADS = 256;
+constexpr int GA_IPT = 4;
+constexpr int GA_TILE = GA_THREADS * GA_IPT;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+struct Agg {
+  double d;    // smallest squared distance since the last run start (or since the range began)
+  uint32_t i;  // active index of the first point attaining it
+  uint32_t f;  // 1 when a run start lies inside the covered range
+};
+__device__ __forceinline__ bool agg_less(double d1, uint32_t i1, double d2, uint32_t i2) {
+  return d1 < d2 || (d1 == d2 && i1 < i2);
+}
+__device__ __forceinline__ Agg agg_combine(const Agg& a, const Agg& b) {  // a covers earlier points than b
+  if (b.f) return b;
+  Agg r;
+  r.f = a.f;
+  if (agg_less(b.d, b.i, a.d, a.i)) {
+    r.d = b.d;
+    r.i = b.i;
+  } else {
+    r.d = a.d;
+    r.i = a.i;
+  }
+  return r;
+}
+__device__ __forceinline__ Agg agg_shfl_up(const Agg& a, int delta) {
+  Agg r;
+  r.d = __shfl_up(a.d, delta, WAVE);
+  r.i = __shfl_up(a.i, delta, WAVE);
+  r.f = __shfl_up(a.f, delta, WAVE);
+  return r;
+}
+
+struct TileSummary {
+  double head_d;  // leading partial run (continues a run of the previous tile), if the first point is no start
+  double tail_d;  // trailing run that starts in this tile and continues into the next one
+  uint32_t head_i;
+  uint32_t tail_i;
+  uint32_t has_start;  // some run starts inside this tile
+  uint32_t last_open;  // the last run continues into the next tile
+};
+
+struct GridParams {
+  Box root;
+  int level;              // node level
+  int sampler;            // SWZ_GRID_CENTER or SWZ_JITTERED
+  int cand;               // GRID_CENTER candidate level (>= 0 here)
+  double spacing_node;    // JITTERED
+  uint32_t jitter_start;  // JITTERED
+};
+
+// get_prev_power_of_two -- core/util/stuff.cpp:340-349
+__device__ __forceinline__ uint32_t prev_pow2(uint32_t x) {
+  x = x | (x >> 1);
+  x = x | (x >> 2);
+  x = x | (x >> 4);
+  x = x | (x >> 8);
+  x = x | (x >> 16);
+  return x - (x >> 1);
+}
+
+// Cell prefix shift and sampling target of the cell that `key` falls in.  Returns an SWZ_ERR_* code
+// (JITTERED only) or 0.
+__device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, uint32_t& csh, double& tx,
+                                           double& ty, double& tz) {
+  if (g.sampler == SWZ_GRID_CENTER) {
+    // GridCenterSampling, Sampling.h:387-390: centre of get_bounds_from_morton_index(key, root, cand + 1)
+    csh = level_shift(g.cand);
+    const Box b = bounds_from_key(key, g.root, g.cand + 1);
+    tx = b.minx + (b.maxx - b.minx) / 2;  // AABB::getCenter, AABB.h:70
+    ty = b.miny + (b.maxy - b.miny) / 2;
+    tz = b.minz + (b.maxz - b.minz) / 2;
+    return 0;
+  }
+  // JitteredSampling, Sampling.h:621-739
+  const Box nb = bounds_from_key(key, g.root, g.level + 1);
+  const double ext_x = nb.maxx - nb.minx;
+  const double perfect = ext_x / g.spacing_node;
+  const uint32_t perfect_u = perfect >= 4294967295.0 ? 4294967295u : (uint32_t)perfect;
+  const uint32_t cells = prev_pow2(perfect_u);
+  if (cells < 16) return SWZ_ERR_JITTER_GRID_TOO_SMALL;
+  const uint32_t levels = 31u - (uint32_t)__clz((int)cells);  // (uint32_t)std::log2(power of two)
+  const uint32_t grid_level = (uint32_t)g.level + levels;
+  if (grid_level >= MAX_LEVELS) return SWZ_ERR_JITTER_NODE_TOO_DEEP;
+  csh = level_shift((int)grid_level);
+  const uint64_t rel = (key >> csh) & ((1ull << (3u * levels)) - 1ull);
+  const uint64_t mask = (1ull << levels) - 1ull;
+  const uint64_t gz = contract_bits_by_3(rel) & mask;  // OctreeNodeIndex64::to_grid_index, OctreeNodeIndex.h:357-363
+  const uint64_t gy = contract_bits_by_3(rel >> 1) & mask;
+  const uint64_t gx = contract_bits_by_3(rel >> 2) & mask;
+  const double cell_size = ext_x / cells;
+  const double perm_size = cell_size / cells;
+  const uint8_t* table;
+  uint32_t width;
+  if (cells <= 16) {
+    table = PERMUTATIONS_16;
+    width = 16;
+  } else if (cells <= 32) {
+    table = PERMUTATIONS_32;
+    width = 32;
+  } else {
+    table = PERMUTATIONS_64;
+    width = 64;
+  }
+  const uint32_t plen = cells < 64 ? cells : 64;
+  const uint32_t s0 = g.jitter_start, s1 = (g.jitter_start + 1) % 16, s2 = (g.jitter_start + 2) % 16;
+  const uint32_t px = (uint32_t)table[s0 * width + (uint32_t)((gy + gz) % plen)] - 1u;
+  const uint32_t py = (uint32_t)table[s1 * width + (uint32_t)((gx + gz) % plen)] - 1u;
+  const uint32_t pz = (uint32_t)table[s2 * width + (uint32_t)((gx + gy) % plen)] - 1u;
+  tx = nb.minx + ((double)gx * cell_size + (double)px * perm_size);
+  ty = nb.miny + ((double)gy * cell_size + (double)py * perm_size);
+  tz = nb.minz + ((double)gz * cell_size + (double)pz * perm_size);
+  return 0;
+}
+
+__global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
+  const uint64_t* __restrict__ akey, const uint32_t* __restrict__ aidx, uint32_t m, const uint32_t* __restrict__ nid,
+  const uint8_t* __restrict__ nmode, const double* __restrict__ X, const double* __restrict__ Y,
+  const double* __restrict__ Z, GridParams g, uint32_t node_shift, uint8_t* __restrict__ taken,
+  TileSummary* __restrict__ summaries, uint32_t* __restrict__ counters) {
+  __shared__ Agg wave_tot[GA_THREADS / WAVE];
+  const uint32_t tid = threadIdx.x, w = tid / WAVE, l = lane_id();
+  const uint32_t tile_base = blockIdx.x * GA_TILE;
+  const uint32_t tile_end = (m - tile_base) < (uint32_t)GA_TILE ? m : tile_base + GA_TILE;
+  const uint32_t last_valid = tile_end - 1;
+  const uint32_t first = tile_base + tid * GA_IPT;
+
+  double dist[GA_IPT];
+  bool head[GA_IPT];
+  uint64_t prev_key = 0;
+  bool have_prev = false;
+  if (first < tile_end && first > 0) {
+    prev_key = akey[first - 1];
+    have_prev = true;
+  }
+  uint32_t last_csh = node_shift;  // shift of the last valid item (for the last_open test)
+  uint64_t last_key = 0;
+  bool any_head = false;
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gi = first + j;
+    dist[j] = __builtin_inf();
+    head[j] = false;
+    if (gi < tile_end) {
+      const uint64_t key = akey[gi];
+      uint32_t csh = node_shift;
+      if (nmode[nid[gi]] == MODE_SAMPLE) {
+        double tx, ty, tz;
+        const int err = cell_target(g, key, csh, tx, ty, tz);
+        if (err) {
+          atomicMax(&counters[CTR_ERROR], (uint32_t)err);
+          csh = node_shift;
+        } else {
+          const uint32_t p = spos_of(aidx, gi);
+          dist[j] = sq_dist(X[p], Y[p], Z[p], tx, ty, tz);
+        }
+      } else {
+        taken[gi] = 1;  // take-all node
+      }
+      head[j] = !have_prev || ((key >> csh) != (prev_key >> csh));
+      any_head |= head[j];
+      prev_key = key;
+      have_prev = true;
+      last_csh = csh;
+      last_key = key;
+    }
+  }
+
+  // thread aggregate over its items, then block-wide exclusive segmented scan
+  Agg a{__builtin_inf(), NONE, 0};
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gi = first + j;
+    if (gi < tile_end) {
+      if (head[j]) {
+        a.d = dist[j];
+        a.i = gi;
+        a.f = 1;
+      } else if (agg_less(dist[j], gi, a.d, a.i)) {
+        a.d = dist[j];
+        a.i = gi;
+      }
+    }
+  }
+  Agg incl = a;
+#pragma unroll
+  for (int delta = 1; delta < WAVE; delta <<= 1) {
+    const Agg o = agg_shfl_up(incl, delta);
+    if (l >= (uint32_t)delta) incl = agg_combine(o, incl);
+  }
+  if (l == WAVE - 1) wave_tot[w] = incl;
+  Agg excl = agg_shfl_up(incl, 1);
+  if (l == 0) excl = Agg{__builtin_inf(), NONE, 0};
+  const int tile_has_start = __syncthreads_or(any_head ? 1 : 0);
+  Agg carry{__builtin_inf(), NONE, 0};
+  for (uint32_t i = 0; i < w; ++i) carry = agg_combine(carry, wave_tot[i]);
+  carry = agg_combine(carry, excl);
+
+  // second pass: close runs, emit winners / partial aggregates
+  bool started = carry.f != 0;
+  double rd = carry.d;
+  uint32_t ri = carry.i;
+  TileSummary* sum = &summaries[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gi = first + j;
+    if (gi < tile_end) {
+      if (head[j]) {
+        if (gi != tile_base) {  // the run ending at gi-1 closes inside this tile
+          if (started) {
+            if (ri != NONE) taken[ri] = 1;
+          } else {
+            sum->head_d = rd;
+            sum->head_i = ri;
+          }
+        }
+        rd = dist[j];
+        ri = gi;
+        started = true;
+      } else if (agg_less(dist[j], gi, rd, ri)) {
+        rd = dist[j];
+        ri = gi;
+      }
+      if (gi == last_valid) {
+        const bool last_open = (tile_end < m) && ((akey[tile_end] >> last_csh) == (last_key >> last_csh));
+        if (!last_open) {
+          if (started) {
+            if (ri != NONE) taken[ri] = 1;
+          } else {
+            sum->head_d = rd;
+            sum->head_i = ri;
+          }
+        } else if (started) {
+          sum->tail_d = rd;
+          sum->tail_i = ri;
+        } else {
+          sum->head_d = rd;
+          sum->head_i = ri;
+        }
+        sum->has_start = (uint32_t)tile_has_start;
+        sum->last_open = last_open ? 1u : 0u;
+      }
+    }
+  }
+}
+
+// runs that cross tile borders: the thread of the tile in which the run starts walks forward
+__global__ __launch_bounds__(256) void grid_resolve_kernel(const TileSummary* __restrict__ summaries,
+                                                           uint32_t ntiles, uint8_t* __restrict__ taken) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  const TileSummary s = summaries[t];
+  if (!(s.has_start && s.last_open)) return;
+  double d = s.tail_d;
+  uint32_t i = s.tail_i;
+  for (uint32_t u = t + 1; u < ntiles; ++u) {
+    const TileSummary h = summaries[u];
+    if (agg_less(h.head_d, h.head_i, d, i)) {
+      d = h.head_d;
+      i = h.head_i;
+    }
+    if (h.has_start || !h.last_open) break;
+  }
+  if (i != NONE) taken[i] = 1;
+}
+
+// ----------------------------------------------------------------------------- compaction (K5)
+__global__ __launch_bounds__(256) void keep_flags_kernel(const uint8_t* __restrict__ taken, uint32_t m,
+                                                         uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) flags[i] = taken[i] ? 0u : 1u;
+}
+
+__global__ __launch_bounds__(256) void compact_kernel(const uint64_t* __restrict__ akey,
+                                                      const uint32_t* __restrict__ aidx, uint32_t m,
+                                                      const uint8_t* __restrict__ taken,
+                                                      const uint32_t* __restrict__ pos, int8_t level,
+                                                      int8_t* __restrict__ level_out, uint64_t* __restrict__ okey,
+                                                      uint32_t* __restrict__ oidx) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t p = spos_of(aidx, i);
+  if (taken[i]) {
+    level_out[p] = level;
+  } else {
+    const uint32_t o = pos[i];
+    okey[o] = akey[i];
+    oidx[o] = p;
+  }
+}
+
+// ----------------------------------------------------------------------------- host: level plans
+// candidate_level_in_octree -- Sampling.h:210-229 (std::log2f on the double ratio narrowed to float)
+static int candidate_level_host(double root_extent_x, float spacing_at_root, int node_level) {
+  const auto spacing_at_this_node = spacing_at_root / std::pow(2, node_level + 1);
+  return std::max(-1, (int)std::floor(std::log2f(root_extent_x / spacing_at_this_node)) - 1);
+}
+// get_node_level_to_sample_from / first_node_level_obeying_spacing -- core/tiling/Node.cpp:37-57
+static int node_level_to_sample_from_host(double root_extent_x, float root_max_spacing, int node_level) {
+  const auto spacing_at_target_node = root_max_spacing / std::pow(2, node_level + 1);
+  const float target_spacing = (float)spacing_at_target_node;
+  return std::max(-1, (int)std::floor(std::log2f(root_extent_x / target_spacing)) - 1);
+}
+static uint32_t prev_pow2_host(uint32_t x) {
+  x = x | (x >> 1);
+  x = x | (x >> 2);
+  x = x | (x >> 4);
+  x = x | (x >> 8);
+  x = x | (x >> 16);
+  return x - (x >> 1);
+}
+// required_morton_index_depth -- core/tiling/Sampling.cpp:29-62
+static int required_depth_host(int sampler, int node_level, double root_extent_x, float root_max_spacing) {
+  switch (sampler) {
+    case SWZ_RANDOM_GRID:
+    case SWZ_GRID_CENTER:
+      return node_level_to_sample_from_host(root_extent_x, root_max_spacing, node_level);
+    case SWZ_MIN_DISTANCE:
+      return node_level;
+    default: {
+      const auto spacing_at_this_node = root_max_spacing / std::pow(2, node_level + 1);
+      const auto perfect_cell_count = (root_extent_x / std::pow(2, node_level + 1)) / spacing_at_this_node;
+      const double clamped = perfect_cell_count >= 4294967295.0 ? 4294967295.0 : perfect_cell_count;
+      const auto actual_cell_count = prev_pow2_host(static_cast<uint32_t>(clamped));
+      const uint32_t levels = static_cast<uint32_t>(std::log2(actual_cell_count));
+      return static_cast<int32_t>(static_cast<uint32_t>(node_level + levels));
+    }
+  }
+}
+
+static LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_at_root, uint32_t max_depth,
+                           const double bmin[3], const double bmax[3], bool force_sample, bool tiler_rules) {
+  LevelPlan p;
+  p.level = level;
+  p.node_shift = level < 0 ? 63u : level_shift(level);
+  p.sampler = sampler;
+  p.max_points = max_points;
+  p.force_sample = force_sample;
+  p.root = Box{bmin[0], bmin[1], bmin[2], bmax[0], bmax[1], bmax[2]};
+  const double ext_x = bmax[0] - bmin[0];
+  if (tiler_rules) {
+    // tile_node, TilingAlgorithms.cpp:408-444
+    const int req = required_depth_host(sampler, level, ext_x, spacing_at_root);
+    const bool deeper = req > level;
+    const int max_level = (int)std::min<uint32_t>(MAX_LEVELS - 1, max_depth);
+    if (!deeper) {
+      p.terminal = req >= max_level;
+    } else {
+      p.terminal = level >= max_level;
+      p.reroot = !p.terminal && req >= (int)MAX_LEVELS;
+    }
+  }
+  p.cand = candidate_level_host(ext_x, spacing_at_root, level);
+  p.spacing_node = spacing_at_root / std::pow(2, level + 1);
+  p.jitter_start = (3u * static_cast<uint32_t>(level + 1)) % 16u;
+  const float sf = static_cast<float>(p.spacing_node);  // PoissonDiskSampling, Sampling.h:448-449
+  const float sq = sf * sf;                             // SparseGrid::SparseGrid, SparseGrid.cpp:13
+  p.sq_spacing = (double)sq;                            // widened at the compare, GridCell.cpp:44,52
+  // finest subdivision of a node whose cells are still at least one spacing wide on every axis (with
+  // a 2^-20 relative margin so that quantisation of the key never lets two points closer than the
+  // spacing sit in non-adjacent cells); node extent / spacing is the same at every level
+  double min_ext = std::min(bmax[0] - bmin[0], std::min(bmax[1] - bmin[1], bmax[2] - bmin[2]));
+  const double need = (double)spacing_at_root * (1.0 + 0x1.0p-20);
+  int mg = 0;
+  while (mg < 20 && min_ext / 2 >= need) {
+    min_ext /= 2;
+    ++mg;
+  }
+  p.cell_levels_geo = std::min(mg, 20 - level);
+  return p;
+}
+
+// ----------------------------------------------------------------------------- one level
+struct LevelResult {
+  uint32_t remaining = 0;
+  uint32_t num_nodes = 0;
+  uint32_t md_rounds = 0;
+};
+
+// Samples every node of the level.  When okey/oidx are given the survivors are compacted into them
+// and level_out receives plan.level for the taken points; otherwise only lb.taken is produced.
+static int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+                      const LevelBuffers& lb, int8_t* level_out, uint64_t* okey, uint32_t* oidx,
+                      LevelResult* res) {
+  const uint32_t m = as.m;
+  const uint32_t nb = div_up(m, 256);
+  SWZ_HIP(c, hipMemsetAsync(lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
+  {
+    ProfScope ps(c, "level_nodes", (uint64_t)m * 8ull, 4);
+    hipLaunchKernelGGL(node_head_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, plan.node_shift, lb.flags);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(scan_exclusive_u32(c, lb.flags, lb.nid, m, lb.counters + CTR_NUM_NODES, "lvl"));
+    hipLaunchKernelGGL(node_finish_kernel, dim3(nb), dim3(256), 0, c->stream, lb.flags, lb.nid, m, lb.nstart);
+    SWZ_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(node_mode_kernel, dim3(nb), dim3(256), 0, c->stream, lb.nstart, lb.nmode, lb.counters,
+                       plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0);
+    SWZ_LAUNCH_CHECK(c);
+  }
+
+  const bool first_only = (plan.sampler == SWZ_RANDOM_GRID || plan.sampler == SWZ_GRID_CENTER) && plan.cand < 0;
+  if (plan.sampler == SWZ_RANDOM_GRID || first_only) {
+    // candidate level -1: "just take the first point" (Sampling.h:290-298, :346-348)
+    const uint32_t csh = first_only ? plan.node_shift : level_shift(plan.cand);
+    if (!first_only && plan.cand >= (int)MAX_LEVELS) return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, "candidate level >= 21");
+    ProfScope ps(c, "sample_random_grid", (uint64_t)m * 9ull);
+    hipLaunchKernelGGL(random_grid_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, lb.nid, lb.nmode, csh,
+                       lb.taken);
+    SWZ_LAUNCH_CHECK(c);
+  } else if (plan.sampler == SWZ_GRID_CENTER || plan.sampler == SWZ_JITTERED) {
+    if (plan.sampler == SWZ_GRID_CENTER && plan.cand >= (int)MAX_LEVELS)
+      return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, "candidate level >= 21");
+    const uint32_t ntiles = div_up(m, GA_TILE);
+    TileSummary* d_sum = nullptr;
+    SWZ_TRY(c->get("grid_summaries", (size_t)ntiles, &d_sum));
+    SWZ_HIP(c, hipMemsetAsync(lb.taken, 0, m, c->stream));
+    GridParams g;
+    g.root = plan.root;
+    g.level = plan.level;
+    g.sampler = plan.sampler;
+    g.cand = plan.cand;
+    g.spacing_node = plan.spacing_node;
+    g.jitter_start = plan.jitter_start;
+    ProfScope ps(c, plan.sampler == SWZ_GRID_CENTER ? "sample_grid_center" : "sample_jittered", (uint64_t)m * 33ull,
+                 2);
+    hipLaunchKernelGGL(grid_argmin_kernel, dim3(ntiles), dim3(GA_THREADS), 0, c->stream, as.akey, as.aidx, m, lb.nid,
+                       lb.nmode, sp.X, sp.Y, sp.Z, g, plan.node_shift, lb.taken, d_sum, lb.counters);
+    SWZ_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(grid_resolve_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, c->stream, d_sum, ntiles,
+                       lb.taken);
+    SWZ_LAUNCH_CHECK(c);
+  } else {  // MIN_DISTANCE
+    SWZ_HIP(c, hipMemsetAsync(lb.taken, 0, m, c->stream));
+    hipLaunchKernelGGL(take_all_kernel, dim3(nb), dim3(256), 0, c->stream, m, lb.nid, lb.nmode, lb.taken);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t h[CTR_COUNT];
+    SWZ_HIP(c, hipMemcpyAsync(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (h[CTR_ERROR]) return c->fail((int)h[CTR_ERROR], "node needs Morton re-rooting (unsupported)");
+    if (h[CTR_SAMPLE_NODES] > 0)
+      SWZ_TRY(min_distance_level(c, plan, as, sp, lb, h[CTR_NUM_NODES], h[CTR_SAMPLE_NODES], h[CTR_SAMPLE_POINTS],
+                                 &res->md_rounds));
+  }
+
+  if (okey) {
+    ProfScope ps(c, "level_compact", (uint64_t)m * 14ull, 4);
+    hipLaunchKernelGGL(keep_flags_kernel, dim3(nb), dim3(256), 0, c->stream, lb.taken, m, lb.flags);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(scan_exclusive_u32(c, lb.flags, lb.flags, m, lb.counters + CTR_REMAINING, "lvl"));
+    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, as.aidx, m, lb.taken, lb.flags,
+                       (int8_t)plan.level, level_out, okey, oidx);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  uint32_t h[CTR_COUNT];
+  SWZ_HIP(c, hipMemcpyAsync(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  c->prof_collect();
+  if (h[CTR_ERROR]) {
+    const int code = (int)h[CTR_ERROR];
+    const char* msg = code == SWZ_ERR_JITTER_GRID_TOO_SMALL
+                        ? "Grids smaller than 16x16 are not supported currently!"
+                        : code == SWZ_ERR_JITTER_NODE_TOO_DEEP ? "node is too small to be sampled with JITTERED"
+                                                               : "node needs Morton re-rooting (unsupported)";
+    return c->fail(code, msg);
+  }
+  res->remaining = h[CTR_REMAINING];
+  res->num_nodes = h[CTR_NUM_NODES];
+  return SWZ_OK;
+}
+
+static int alloc_level_buffers(swz_ctx* c, uint32_t m, LevelBuffers* lb) {
+  SWZ_TRY(c->get("lvl_flags", (size_t)m, &lb->flags));
+  SWZ_TRY(c->get("lvl_nid", (size_t)m, &lb->nid));
+  SWZ_TRY(c->get("lvl_nstart", (size_t)m + 1, &lb->nstart));
+  SWZ_TRY(c->get("lvl_nmode", (size_t)m, &lb->nmode));
+  SWZ_TRY(c->get("lvl_taken", (size_t)m, &lb->taken));
+  SWZ_TRY(c->get("lvl_counters", (size_t)CTR_COUNT, &lb->counters));
+  return SWZ_OK;
+}
+
+// ----------------------------------------------------------------------------- drivers
+int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
+                const swz_tile_params& p, const TileDeviceOut& out, swz_tile_stats* stats) {
+  if (p.strategy == SWZ_FAST) return c->fail(SWZ_ERR_BAD_ARG, "FAST strategy is not implemented yet");
+  // K1 + K2: index, sort (the output buffers double as the sort's primary buffers)
+  uint64_t* keys_b = nullptr;
+  uint32_t* vals_b = nullptr;
+  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
+  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vals_b));
+  SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, out.keys));
+  SWZ_TRY(radix_sort_pairs(c, out.keys, out.perm, keys_b, vals_b, n, true));
+  double *X = nullptr, *Y = nullptr, *Z = nullptr;
+  SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
+  SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));
+  SWZ_TRY(c->get("sorted_z", (size_t)n, &Z));
+  SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
+  if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
+  SortedPoints sp{X, Y, Z};
+
+  LevelBuffers lb;
+  SWZ_TRY(alloc_level_buffers(c, n, &lb));
+  // survivors ping-pong between the sort's secondary buffers and one extra pair
+  uint64_t* key_buf[2] = {keys_b, nullptr};
+  uint32_t* idx_buf[2] = {vals_b, nullptr};
+  ActiveSet as{out.keys, nullptr, n};
+  uint64_t visited = 0, nodes = 0;
+  uint32_t rounds = 0, nlevels = 0;
+  int max_level = -1;
+  int which = 0;
+  for (int level = -1; as.m > 0; ++level) {
+    if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
+    if (!key_buf[which]) {
+      SWZ_TRY(c->get("active_keys_2", (size_t)as.m, &key_buf[which]));
+      SWZ_TRY(c->get("active_idx_2", (size_t)as.m, &idx_buf[which]));
+    }
+    const LevelPlan plan =
+      make_plan(level, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
+    LevelResult r;
+    SWZ_TRY(level_step(c, plan, as, sp, lb, out.level, key_buf[which], idx_buf[which], &r));
+    visited += as.m;
+    nodes += r.num_nodes;
+    rounds += r.md_rounds;
+    max_level = level;
+    ++nlevels;
+    as = ActiveSet{key_buf[which], idx_buf[which], r.remaining};
+    which ^= 1;
+  }
+  if (stats) {
+    stats->num_nodes = nodes;
+    stats->points_visited = visited;
+    stats->max_level = max_level;
+    stats->fast_start_levels = -1;
+    stats->num_levels = nlevels;
+    stats->min_distance_rounds = rounds;
+  }
+  return SWZ_OK;
+}
+
+__global__ __launch_bounds__(256) void count_taken_kernel(const uint8_t* __restrict__ taken, uint32_t n,
+                                                          uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool t = (i < n) && taken[i];
+  const uint64_t b = __ballot(t);
+  if (lane_id() == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+}
+
+int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uint64_t* d_keys, const uint32_t* d_idx,
+                         uint32_t n, const double* d_xyz, uint64_t /*node_key*/, int32_t node_level,
+                         const double rmin[3], const double rmax[3], float spacing, int behaviour, uint8_t* d_taken,
+                         uint64_t* num_taken) {
+  double *X = nullptr, *Y = nullptr, *Z = nullptr;
+  SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
+  SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));
+  SWZ_TRY(c->get("sorted_z", (size_t)n, &Z));
+  SWZ_TRY(gather_positions(c, d_xyz, d_idx, n, X, Y, Z));
+  LevelBuffers lb;
+  SWZ_TRY(alloc_level_buffers(c, n, &lb));
+  const LevelPlan plan = make_plan(node_level, sampler, max_points, spacing, 100, rmin, rmax,
+                                   behaviour == SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, false);
+  ActiveSet as{d_keys, nullptr, n};
+  SortedPoints sp{X, Y, Z};
+  LevelResult r;
+  SWZ_TRY(level_step(c, plan, as, sp, lb, nullptr, nullptr, nullptr, &r));
+  SWZ_HIP(c, hipMemcpyAsync(d_taken, lb.taken, n, hipMemcpyDeviceToDevice, c->stream));
+  if (num_taken) {
+    SWZ_HIP(c, hipMemsetAsync(lb.counters, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(count_taken_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, lb.taken, n, lb.counters);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t cnt = 0;
+    SWZ_HIP(c, hipMemcpyAsync(&cnt, lb.counters, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    *num_taken = cnt;
+  }
+  return SWZ_OK;
+}
+
+}  // namespace swz

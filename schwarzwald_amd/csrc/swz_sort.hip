@@ -1,0 +1,280 @@
+// swz_sort.hip -- device-wide exclusive scan and the stable LSD radix sort by Morton key (K2).
+//
+// Replaces Range::sort = std::sort of IndexedPoint64 (util/containers/Range.h:62-66) called at
+// core/tiling/TilingAlgorithms.cpp:602 / :1292.  Keys are 63-bit, payload is the 32-bit point index;
+// 8 passes of 8-bit digits.  Per pass: per-tile digit histogram -> one device-wide scan over the
+// [digit][tile] table -> scatter.  The scatter ranks keys with wave64 ballots (match-any on the
+// digit), prefix-sums per-wave digit counts in LDS, exchanges the tile through LDS so that global
+// stores of one digit run are contiguous, and is stable (ties keep their input order), which makes
+// the final order (key, original index).
+#include "swz_device.h"
+#include "swz_internal.h"
+
+namespace swz {
+
+// ------------------------------------------------------------------------------------- scan
+constexpr int SC_THREADS = 256;
+constexpr int SC_IPT = 8;
+constexpr int SC_TILE = SC_THREADS * SC_IPT;
+
+__global__ __launch_bounds__(SC_THREADS) void scan_partial_kernel(const uint32_t* __restrict__ in, uint64_t n,
+                                                                  uint32_t* __restrict__ partial) {
+  __shared__ uint32_t lds[SC_THREADS / WAVE];
+  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SC_IPT; ++j)
+    if (base + j < n) s += in[base + j];
+  uint32_t total;
+  block_excl_sum<SC_THREADS>(s, lds, total);
+  if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of a short array (n <= a few thousand tiles), sequential over chunks
+__global__ __launch_bounds__(1024) void scan_small_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                          uint32_t n, uint32_t* __restrict__ total_out) {
+  __shared__ uint32_t lds[1024 / WAVE];
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < n; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = (i < n) ? in[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_excl_sum<1024>(v, lds, total);
+    if (i < n) out[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0 && total_out) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void scan_apply_kernel(const uint32_t* __restrict__ in,
+                                                                uint32_t* __restrict__ out, uint64_t n,
+                                                                const uint32_t* __restrict__ partial_scanned) {
+  __shared__ uint32_t lds[SC_THREADS / WAVE];
+  const uint64_t base = (uint64_t)blockIdx.x * SC_TILE + (uint64_t)threadIdx.x * SC_IPT;
+  uint32_t v[SC_IPT];
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < SC_IPT; ++j) {
+    v[j] = (base + j < n) ? in[base + j] : 0u;
+    s += v[j];
+  }
+  uint32_t total;
+  uint32_t ex = block_excl_sum<SC_THREADS>(s, lds, total) + partial_scanned[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < SC_IPT; ++j) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+static int scan_rec(swz_ctx* c, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint32_t* d_total,
+                    const std::string& tag, int depth) {
+  if (n <= 4096) {
+    hipLaunchKernelGGL(scan_small_kernel, dim3(1), dim3(1024), 0, c->stream, d_in, d_out, (uint32_t)n, d_total);
+    SWZ_LAUNCH_CHECK(c);
+    return SWZ_OK;
+  }
+  const uint32_t nb = div_up(n, SC_TILE);
+  uint32_t* d_partial = nullptr;
+  const std::string name = "scan_partial_" + tag + "_" + std::to_string(depth);
+  SWZ_TRY(c->get(name.c_str(), (size_t)nb, &d_partial));
+  hipLaunchKernelGGL(scan_partial_kernel, dim3(nb), dim3(SC_THREADS), 0, c->stream, d_in, n, d_partial);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(scan_rec(c, d_partial, d_partial, nb, d_total, tag, depth + 1));
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SC_THREADS), 0, c->stream, d_in, d_out, n, d_partial);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}
+
+int scan_exclusive_u32(swz_ctx* c, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint32_t* d_total,
+                       const char* tag) {
+  if (n == 0) {
+    if (d_total) SWZ_HIP(c, hipMemsetAsync(d_total, 0, sizeof(uint32_t), c->stream));
+    return SWZ_OK;
+  }
+  return scan_rec(c, d_in, d_out, n, d_total, tag, 0);
+}
+
+// ------------------------------------------------------------------------------------- radix sort
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = RS_THREADS / WAVE;
+constexpr int RS_KPT = 16;                      // keys per thread
+constexpr int RS_TILE = RS_THREADS * RS_KPT;    // 4096 keys per workgroup
+constexpr int RS_WAVE_SPAN = WAVE * RS_KPT;     // 1024 consecutive keys per wave
+constexpr int RADIX = 256;
+
+// per-tile digit histogram -> hist[digit * ntiles + tile]
+__global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                                int shift, uint32_t* __restrict__ hist,
+                                                                uint32_t ntiles) {
+  __shared__ uint32_t h[RS_WAVES][RADIX];
+  const uint32_t tid = threadIdx.x, w = tid / WAVE;
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) h[i][tid] = 0;
+  __syncthreads();
+  const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint64_t i = base + (uint64_t)k * RS_THREADS + tid;
+    if (i < n) atomicAdd(&h[w][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) s += h[i][tid];
+  hist[(uint64_t)tid * ntiles + blockIdx.x] = s;
+}
+
+// wave64 match-any on an 8-bit digit among the lanes set in `valid`
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid) {
+  uint64_t peers = valid;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const bool bit = (d >> b) & 1u;
+    const uint64_t m = __ballot(bit);
+    peers &= bit ? m : ~m;
+  }
+  return peers;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in,
+                                                                   uint64_t* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out, uint32_t n,
+                                                                   int shift, const uint32_t* __restrict__ offs,
+                                                                   uint32_t ntiles) {
+  __shared__ uint32_t whist[RS_WAVES][RADIX];  // per-wave digit counts, then exclusive wave bases
+  __shared__ uint32_t dstart[RADIX];           // start of each digit run inside the LDS-sorted tile
+  __shared__ uint32_t gbase[RADIX];            // global offset of this tile's run of each digit
+  __shared__ uint32_t scan_lds[RS_WAVES];
+  __shared__ uint64_t xkeys[RS_TILE];
+  __shared__ uint32_t xvals[RS_TILE];
+
+  const uint32_t tid = threadIdx.x, w = tid / WAVE, l = lane_id();
+  const uint64_t tile_base = (uint64_t)blockIdx.x * RS_TILE;
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)RS_TILE ? (n - tile_base) : RS_TILE);
+
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) whist[i][tid] = 0;
+  gbase[tid] = offs[(uint64_t)tid * ntiles + blockIdx.x];
+
+  // wave-blocked arrangement: wave w owns keys [w*1024, (w+1)*1024) of the tile, item k of lane l is
+  // element w*1024 + k*64 + l, so the order inside the tile is (wave, item, lane)
+  uint64_t key[RS_KPT];
+  uint32_t val[RS_KPT];
+  uint32_t rank[RS_KPT];
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+    if (e < tile_n) {
+      key[k] = keys_in[tile_base + e];
+      val[k] = vals_in ? vals_in[tile_base + e] : (uint32_t)(tile_base + e);
+    } else {
+      key[k] = ~0ull;
+      val[k] = 0;
+    }
+  }
+  __syncthreads();
+
+  // rank of every key among the equal-digit keys of its own wave, in (item, lane) order.  The
+  // per-wave counters are read and written by different lanes in successive items: volatile keeps
+  // every access a real, in-order LDS operation.
+  volatile uint32_t* wh = whist[w];
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+    const bool ok = e < tile_n;
+    const uint64_t valid = __ballot(ok);
+    const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+    const uint64_t peers = match_digit(d, valid);
+    uint32_t pre = 0;
+    if (ok) {
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+      if (l == leader) {
+        pre = wh[d];
+        wh[d] = pre + (uint32_t)__popcll(peers);
+      }
+      pre = __shfl(pre, leader, WAVE);
+      rank[k] = pre + (uint32_t)__popcll(peers & lanemask_lt());
+    } else {
+      rank[k] = 0;
+    }
+  }
+  __syncthreads();
+
+  // thread t owns digit t: exclusive prefix over the waves, tile total, then exclusive scan over digits
+  uint32_t s = 0;
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) {
+    const uint32_t t = whist[i][tid];
+    whist[i][tid] = s;
+    s += t;
+  }
+  uint32_t total;
+  const uint32_t ds = block_excl_sum<RS_THREADS>(s, scan_lds, total);
+  dstart[tid] = ds;
+  __syncthreads();
+
+  // exchange through LDS: position inside the digit-sorted tile
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+    if (e < tile_n) {
+      const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+      const uint32_t p = dstart[d] + whist[w][d] + rank[k];
+      xkeys[p] = key[k];
+      xvals[p] = val[k];
+    }
+  }
+  __syncthreads();
+
+  // contiguous stores per digit run
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t j = k * RS_THREADS + tid;
+    if (j < tile_n) {
+      const uint64_t kk = xkeys[j];
+      const uint32_t d = (uint32_t)(kk >> shift) & 255u;
+      const uint32_t dst = gbase[d] + (j - dstart[d]);
+      keys_out[dst] = kk;
+      vals_out[dst] = xvals[j];
+    }
+  }
+}
+
+int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_a, uint32_t* d_vals_a, uint64_t* d_keys_b, uint32_t* d_vals_b,
+                     uint32_t n, bool vals_identity) {
+  if (n == 0) return SWZ_OK;
+  const uint32_t ntiles = div_up(n, RS_TILE);
+  uint32_t* d_hist = nullptr;
+  SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
+  uint64_t* kin = d_keys_a;
+  uint32_t* vin = d_vals_a;
+  uint64_t* kout = d_keys_b;
+  uint32_t* vout = d_vals_b;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = pass * 8;
+    {
+      ProfScope ps(c, "radix_hist", (uint64_t)n * 8ull);
+      hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, kin, n, shift, d_hist,
+                         ntiles);
+      SWZ_LAUNCH_CHECK(c);
+    }
+    {
+      ProfScope ps(c, "radix_scan", (uint64_t)ntiles * RADIX * 8ull);
+      SWZ_TRY(scan_exclusive_u32(c, d_hist, d_hist, (uint64_t)ntiles * RADIX, nullptr, "radix"));
+    }
+    {
+      ProfScope ps(c, "radix_scatter", (uint64_t)n * 24ull);
+      hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, kin,
+                         (pass == 0 && vals_identity) ? (const uint32_t*)nullptr : vin, kout, vout, n, shift,
+                         d_hist, ntiles);
+      SWZ_LAUNCH_CHECK(c);
+    }
+    uint64_t* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+  }
+  return SWZ_OK;
+}
+
+}  // namespace swz

@@ -1,0 +1,236 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/swz_gpu.h), against the CPU oracle
+on the same seeded inputs.  Integer/byte/index work must be bit-exact; the only floating-point output is
+the in-place clamp, also compared bit-exactly."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import schwarzwald_amd as swz
+    c = swz.Context(0)
+    yield c
+    c.close()
+
+
+def _clustered(rng, n):
+    """Surface-like clustered points (real LAS is far from uniform): a few planes + blobs + duplicates."""
+    parts = []
+    k = n // 4
+    parts.append(np.column_stack([rng.random(k), rng.random(k), 0.3 + 0.001 * rng.standard_normal(k)]))
+    parts.append(np.column_stack([rng.random(k), 0.7 + 0.0005 * rng.standard_normal(k), rng.random(k)]))
+    parts.append(0.5 + 0.02 * rng.standard_normal((k, 3)))
+    rest = n - 3 * k
+    base = rng.random((max(rest // 8, 1), 3))
+    parts.append(base[rng.integers(0, base.shape[0], rest)])  # exact duplicates
+    return np.clip(np.vstack(parts), 0.0, 1.0)
+
+
+# ----------------------------------------------------------------------------------------- encode
+@pytest.mark.parametrize("n", [0, 1, 255, 256, 257, 100003])
+def test_morton_encode_matches_oracle(ctx, n):
+    rng = np.random.default_rng(n + 1)
+    xyz = rng.random((n, 3)) * 3.0 - 1.0  # a third of the points are outliers that must be clamped
+    bmin, bmax = [-0.25, 0.0, 0.1], [1.25, 1.0, 0.9]
+    keys, clamped = ctx.morton_encode(xyz, bmin, bmax)
+    okeys, oclamped = O.index_points(xyz, bmin, bmax)
+    assert np.array_equal(keys, okeys)
+    assert np.array_equal(clamped.view(np.uint64), oclamped.view(np.uint64))
+
+
+def test_morton_encode_known_answers(ctx):
+    pts = np.array([[0, 0, 0], [1, 1, 1], [.5, .5, .5], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0.3, 0.6, 0.9],
+                    [0.999999999, 1e-9, 0.25]], dtype=np.float64)
+    exp = [0x0, 0x7FFFFFFFFFFFFFFF, 0x7000000000000000, 0x4924924924924924, 0x2492492492492492,
+           0x1249249249249249, 0x3A56A56A56A56A56, 0x4B24924924924924]
+    keys, _ = ctx.morton_encode(pts, *UNIT)
+    assert [int(k) for k in keys] == exp
+    mn = [-512.25, 1000.5, -3.125]
+    mx = [v + 777.7 for v in mn]
+    keys, _ = ctx.morton_encode(np.array([[-100, 1500.123456789, 400]]), mn, mx)
+    assert int(keys[0]) == 0x7080F255F85E7F48
+
+
+def test_morton_encode_reference_lattice(ctx):
+    """test/TestOctreeIndexing.cpp:102-130 with 21 levels: every octant digit of the key is exact."""
+    b = ([0, 0, 0], [1 << 21] * 3)
+    rng = np.random.default_rng(3)
+    cells = rng.integers(0, 1 << 21, size=(5000, 3))
+    xyz = cells.astype(np.float64) + 0.5
+    keys, _ = ctx.morton_encode(xyz, *b)
+    for c, k in zip(cells[:200], keys[:200]):
+        x, y, z = (int(v) for v in c)
+        exp = 0
+        for bit in range(21):
+            exp |= ((z >> bit) & 1) << (3 * bit) | ((y >> bit) & 1) << (3 * bit + 1) | ((x >> bit) & 1) << (3 * bit + 2)
+        assert int(k) == exp
+    assert np.array_equal(keys, O.index_points(xyz, *b)[0])
+
+
+# ----------------------------------------------------------------------------------------- sort
+@pytest.mark.parametrize("n", [1, 2, 4095, 4096, 4097, 300001])
+def test_sort_matches_oracle(ctx, n):
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+    perm, ks = ctx.sort_by_key(keys)
+    assert np.array_equal(perm, O.sort_by_key(keys))
+    assert np.array_equal(ks, keys[perm])
+
+
+def test_sort_is_stable_on_ties(ctx):
+    rng = np.random.default_rng(11)
+    keys = rng.integers(0, 50, size=200000, dtype=np.uint64) << np.uint64(40)  # few distinct keys, high digits
+    keys[::7] = 0
+    keys[1::13] = (1 << 63) - 1
+    perm, ks = ctx.sort_by_key(keys)
+    assert np.array_equal(perm, O.sort_by_key(keys))
+    assert np.all(np.diff(ks.astype(np.float64)) >= 0)
+
+
+# ----------------------------------------------------------------------------------------- sample_points
+def _sorted_cloud(xyz, bmin, bmax):
+    keys, clamped = O.index_points(xyz, bmin, bmax)
+    order = O.sort_by_key(keys)
+    return keys[order], order, clamped
+
+
+def _flags_from_oracle(sampler, max_pts, ks, order, xyz, node_level, bmin, bmax, spacing, behaviour):
+    taken, k2, i2 = O.sample_points(sampler, max_pts, ks, order, xyz, 0, node_level, bmin, bmax, spacing, behaviour)
+    if taken < 0:
+        return taken, None
+    flags = np.zeros(len(order), dtype=np.uint8)
+    pos = {int(v): j for j, v in enumerate(order)}
+    for v in i2[:taken]:
+        flags[pos[int(v)]] = 1
+    return taken, flags
+
+
+def test_random_grid_reference_known_answer(ctx):
+    """test/TestOctreeIndexing.cpp:169-252 (32^3 lattice, spacing 32, node level 0) on 21-level keys."""
+    side = 32
+    g = np.arange(side, dtype=np.float64) + 0.5
+    xyz = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=-1).reshape(-1, 3)
+    bmin, bmax = [0, 0, 0], [side] * 3
+    ks, order, _ = _sorted_cloud(xyz, bmin, bmax)
+    import schwarzwald_amd as swz
+    flags = ctx.sample_points(swz.RANDOM_GRID, 16, ks, order, xyz, 0, 0, bmin, bmax, float(side))
+    assert int(flags.sum()) == 8
+    expected = [[0.5, 0.5, 0.5], [0.5, 0.5, 16.5], [0.5, 16.5, 0.5], [0.5, 16.5, 16.5],
+                [16.5, 0.5, 0.5], [16.5, 0.5, 16.5], [16.5, 16.5, 0.5], [16.5, 16.5, 16.5]]
+    assert xyz[order[flags == 1]].tolist() == expected
+
+
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+@pytest.mark.parametrize("spacing,behaviour", [(0.05, O.ALWAYS_ADHERE), (0.011, O.ALWAYS_ADHERE),
+                                               (0.03, O.TAKE_ALL_WHEN_BELOW_MAX)])
+def test_sample_points_root_matches_oracle(ctx, sampler, kind, spacing, behaviour):
+    rng = np.random.default_rng(17)
+    n = 60000
+    xyz = rng.random((n, 3)) if kind == "uniform" else _clustered(rng, n)
+    ks, order, clamped = _sorted_cloud(xyz, *UNIT)
+    taken, oflags = _flags_from_oracle(sampler, 1000, ks, order, clamped, -1, *UNIT, spacing, behaviour)
+    flags = ctx.sample_points(sampler, 1000, ks, order, clamped, 0, -1, *UNIT, spacing, behaviour)
+    assert int(flags.sum()) == taken
+    assert np.array_equal(flags, oflags)
+
+
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+def test_sample_points_inner_node_matches_oracle(ctx, sampler):
+    """A node at level 1 (two octants below the root): node-relative spacing, bounds and jitter tables."""
+    rng = np.random.default_rng(23)
+    lo, hi = np.array([0.25, 0.5, 0.75]), np.array([0.5, 0.75, 1.0])
+    xyz = lo + rng.random((40000, 3)) * (hi - lo) * 0.999999
+    ks, order, clamped = _sorted_cloud(xyz, *UNIT)
+    node_key = int(ks[0]) >> (3 * 19) << (3 * 19)
+    assert np.all((ks >> np.uint64(3 * 19)) == (ks[0] >> np.uint64(3 * 19)))
+    taken, k2, i2 = O.sample_points(sampler, 100, ks, order, clamped, node_key, 1, *UNIT, 0.04, O.ALWAYS_ADHERE)
+    assert taken > 0
+    oflags = np.zeros(len(order), dtype=np.uint8)
+    pos = {int(v): j for j, v in enumerate(order)}
+    for v in i2[:taken]:
+        oflags[pos[int(v)]] = 1
+    flags = ctx.sample_points(sampler, 100, ks, order, clamped, node_key, 1, *UNIT, 0.04, O.ALWAYS_ADHERE)
+    assert np.array_equal(flags, oflags)
+
+
+def test_jittered_small_grid_is_an_error(ctx):
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(5)
+    xyz = rng.random((5000, 3))
+    ks, order, clamped = _sorted_cloud(xyz, *UNIT)
+    taken, _, _ = O.sample_points(O.JITTERED, 10, ks, order, clamped, 0, -1, *UNIT, 0.2, O.ALWAYS_ADHERE)
+    assert taken == O.ERR_JITTER_GRID_TOO_SMALL
+    with pytest.raises(swz.SwzError) as e:
+        ctx.sample_points(swz.JITTERED, 10, ks, order, clamped, 0, -1, *UNIT, 0.2, swz.ALWAYS_ADHERE_TO_MIN_SPACING)
+    assert e.value.code == 3
+
+
+# ----------------------------------------------------------------------------------------- whole tiler
+def _tile_both(ctx, xyz, bmin, bmax, sampler, max_pts, spacing, max_depth=100):
+    import schwarzwald_amd as swz
+    o = O.tile(xyz, bmin, bmax, sampler, max_pts, spacing, max_depth=max_depth)
+    p = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing, max_depth=max_depth)
+    g = ctx.tile(xyz, bmin, bmax, p)
+    return o, g
+
+
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("kind,n,max_pts,d", [("uniform", 200000, 2000, 250), ("uniform", 65536, 64, 32),
+                                               ("clustered", 150000, 500, 250)])
+def test_tile_accurate_matches_oracle(ctx, sampler, kind, n, max_pts, d):
+    rng = np.random.default_rng(n + d)
+    xyz = rng.random((n, 3)) if kind == "uniform" else _clustered(rng, n)
+    spacing = O.spacing_from_diagonal(*UNIT, d)
+    o, g = _tile_both(ctx, xyz, *UNIT, sampler, max_pts, spacing)
+    assert o["status"] == 0
+    assert np.array_equal(g.keys, o["keys"])
+    assert np.array_equal(g.perm, o["perm"])
+    assert np.array_equal(g.level, o["level"])
+    assert g.stats["num_nodes"] == o["stats"]["num_nodes"]
+    assert g.stats["points_visited"] == o["stats"]["points_visited"]
+    assert g.stats["max_level"] == o["stats"]["max_level"]
+
+
+def test_tile_max_depth_makes_terminal_nodes(ctx):
+    rng = np.random.default_rng(8)
+    xyz = rng.random((100000, 3))
+    spacing = 0.2  # coarse: 64 grid cells at the root, so most points reach the terminal level
+    for sampler in (O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE):
+        o, g = _tile_both(ctx, xyz, *UNIT, sampler, 100, spacing, max_depth=2)
+        assert o["status"] == 0 and o["stats"]["max_level"] == 2
+        assert np.array_equal(g.level, o["level"])
+
+
+def test_tile_outliers_and_small_inputs(ctx):
+    rng = np.random.default_rng(4)
+    for n in (1, 2, 63, 1000):
+        xyz = rng.random((n, 3)) * 1.4 - 0.2
+        o, g = _tile_both(ctx, xyz, *UNIT, O.GRID_CENTER, 10, 0.05)
+        assert np.array_equal(g.keys, o["keys"]) and np.array_equal(g.perm, o["perm"])
+        assert np.array_equal(g.level, o["level"])
+        assert np.array_equal(g.xyz_clamped.view(np.uint64), o["xyz_clamped"].view(np.uint64))
+
+
+def test_node_lists_group_points_by_node(ctx):
+    rng = np.random.default_rng(6)
+    xyz = rng.random((50000, 3))
+    import schwarzwald_amd as swz
+    p = swz.TileParams(sampler=swz.RANDOM_GRID, max_points_per_node=500,
+                       spacing_at_root=O.spacing_from_diagonal(*UNIT, 250))
+    g = ctx.tile(xyz, *UNIT, p)
+    order, nodes = ctx.build_node_lists(g.keys, g.level)
+    assert sorted(order.tolist()) == list(range(50000))
+    assert len(nodes["level"]) == g.stats["num_nodes"]
+    for lvl, key, off, cnt in zip(nodes["level"], nodes["key"], nodes["offset"], nodes["count"]):
+        members = order[int(off):int(off + cnt)]
+        assert np.all(g.level[members] == lvl)
+        sh = 63 if lvl < 0 else 3 * (20 - int(lvl))
+        assert np.all((g.keys[members] >> np.uint64(sh)) == (np.uint64(key) >> np.uint64(sh)))
+        assert np.all(np.diff(members.astype(np.int64)) > 0)  # Morton order inside the node
