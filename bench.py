@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpoints/s of the tiler hot path (Morton encode + radix sort + octree partition + LOD
+sampling) on synthetic uniform points, per BASELINE.json.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic points that already sit in HBM when
+the timed region starts.  N=1 runs BASELINE.json's headline configuration (1 B points, MIN_DISTANCE,
+spacing = diagonal/250, ACCURATE strategy) on one MI355X.  For N>1 (launched by torch.distributed.run,
+one rank per GPU) every rank owns the same number of points (weak scaling); points are exchanged once
+after the encode by their top Morton bits (RCCL all-to-all) and every rank then tiles its own octants.
+
+Rank 0 prints ONE JSON line with the metric, the roofline of the dominant kernel (HIP-event timing taken
+inside the timed region) and, at N=1, a CPU baseline (the oracle, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SEED = 0x5C4A72A1D
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--points", type=int, default=1_000_000_000, help="points per GPU")
+    ap.add_argument("--sampler", default="MIN_DISTANCE", choices=["RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED"])
+    ap.add_argument("--diagonal-fraction", type=float, default=250.0)
+    ap.add_argument("--max-points-per-node", type=int, default=20000)
+    ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_point(sampler, visit_factor):
+    """encode 32 + sort 200 + per visited level 33 (RANDOM_GRID) or 57."""
+    per_level = 33.0 if sampler == "RANDOM_GRID" else 57.0
+    return 32.0 + 200.0 + per_level * visit_factor
+
+
+def cpu_baseline(args, spacing):
+    """The oracle (CPU restatement of the reference path, single thread) on a bounded sample of the same
+    workload: same generator, bounds, spacing and parameters, fewer points."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+
+    n = args.cpu_sample
+    xyz = O.generate_uniform(SEED + 3, n)
+    t0 = time.perf_counter()
+    r = O.tile(xyz, [0, 0, 0], [1, 1, 1], getattr(O, args.sampler), args.max_points_per_node, spacing)
+    dt = time.perf_counter() - t0
+    assert r["status"] == 0
+    return {"value": round(n / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
+            "sample": "%d uniform points, %s, d=%g, max_points_per_node=%d, ACCURATE, one batch (%.1f s)" % (
+                n, args.sampler, args.diagonal_fraction, args.max_points_per_node, dt)}
+
+
+def main():
+    args = parse_args()
+    import torch
+
+    import schwarzwald_amd as swz
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if distributed else 0)
+
+    n = args.points
+    bmin, bmax = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    spacing = swz.spacing_from_diagonal(bmin, bmax, args.diagonal_fraction)
+    params = swz.TileParams(sampler=swz.SAMPLERS[args.sampler], max_points_per_node=args.max_points_per_node,
+                            spacing_at_root=spacing, max_depth=100, strategy=swz.ACCURATE)
+    ctx = swz.Context(dev.index)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+
+    # synthetic input, resident in HBM before the timed region
+    xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    ctx.generate_uniform_device(SEED + 3, rank * n, n, xyz.data_ptr())
+
+    if distributed:
+        from schwarzwald_amd import sharded
+        runner = sharded.ShardedTiler(ctx, dev, bmin, bmax, params)
+
+        def step():
+            return runner.tile(xyz)
+    else:
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        level = torch.empty(n, dtype=torch.int8, device=dev)
+
+        def step():
+            return ctx.tile_device(xyz.data_ptr(), n, bmin, bmax, params, keys.data_ptr(), perm.data_ptr(),
+                                   level.data_ptr())
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    stats = None
+    for _ in range(args.steps):
+        stats = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    prof = {} if args.no_profile else ctx.profile_get()
+    total_points = n * world
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = total_points / (elapsed / args.steps) / 1e6
+    visit = stats["points_visited"] / float(n) if stats else 0.0
+
+    if rank == 0:
+        roofline = None
+        if prof:
+            name, k = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+            avg_ms = k["total_ms"] / max(k["launches"], 1)
+            alg_per_launch = k["algorithmic_bytes"] / max(k["launches"], 1)
+            achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "launches": k["launches"], "avg_launch_ms": round(avg_ms, 4)}
+        alg = algorithmic_bytes_per_point(args.sampler, visit)
+        out = {
+            "metric": "Mpoints/s end-to-end tile (Morton+sort+sample)", "value": round(value, 3),
+            "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64 keys / f64 positions", "data": "synthetic",
+            "config": {"workload": "%d uniform points per GPU in the unit cube, %s sampling, spacing = diagonal/%g, "
+                                   "max_points_per_node=%d, ACCURATE strategy, one batch" % (
+                                       n, args.sampler, args.diagonal_fraction, args.max_points_per_node),
+                       "points_per_gpu": n, "sampler": args.sampler, "strategy": "ACCURATE",
+                       "min_distance_mode": "exact" if args.sampler == "MIN_DISTANCE" else None,
+                       "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
+            "visit_factor": round(visit, 4),
+            "hbm_frac_end_to_end": round(alg * total_points / world / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
+            "algorithmic_bytes_per_point": round(alg, 1),
+            "tile_stats": stats,
+            "roofline": roofline,
+            "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+        }
+        if world == 1 and args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args, spacing)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
