@@ -18,6 +18,10 @@ enum {
   CTR_NUM_CELLS = 5,     // MIN_DISTANCE: cells
   CTR_DONE_CELLS = 6,    // MIN_DISTANCE: cells finished
   CTR_Q0 = 8,            // MIN_DISTANCE: three rotating queue counters
+  CTR_DBG_ACT = 11,      // MIN_DISTANCE statistics (SWZ_DEBUG=1): cell activations,
+  CTR_DBG_SCAN = 12,     //   64-point chunks read by blocker scans,
+  CTR_DBG_RTEST = 13,    //   accepted points tested per chunk by the rejection pass,
+  CTR_DBG_STALL = 14,    //   activations that ended stalled
   CTR_COUNT = 16
 };
 

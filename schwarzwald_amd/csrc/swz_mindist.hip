@@ -7,17 +7,23 @@
 // hash grid there is only an accelerator; the result is the lexicographically-first maximal
 // independent set in Morton order:  accept(i) <=> for all accepted j < i : d2(i, j) >= s2.
 //
-// Exact parallel form used here.  Cut every sampled node into octree cells at least one spacing
-// wide, so a point can only conflict with points of its own and the 26 adjacent cells.  Cells are
-// runs of the sorted keys, and every point of a cell with a smaller Morton code precedes every point
-// of a cell with a larger one.  Hence a cell's outcome depends only on the accepted points of its
-// adjacent cells with smaller code: a dependency DAG, processed in topological rounds (Kahn): a
-// cell becomes ready when all its earlier neighbours are final; one wavefront then runs the greedy
-// for the cell (all points against the neighbours' accepted points in parallel, then the in-cell
-// sequential part with wave ballots) and releases its later neighbours.  Every distance compare is
-// the reference's, so the accepted set is bit-identical.
+// Exact parallel form used here ("frontier sweep").  Every sampled node is cut into octree cells at
+// least one spacing wide, so a point can only conflict with points of its own and the 26 adjacent
+// cells; cells are runs of the sorted keys and all points of a cell with a smaller Morton code
+// precede all points of a cell with a larger one.  Each cell owns a frontier `pos`: its points before
+// pos are decided.  In every round a wavefront advances the frontier of an active cell:
+//   (R) a point closer than the spacing to an already accepted earlier point is rejected;
+//   (A) a surviving point is accepted once no possibly-undecided earlier point (a point at or behind
+//       the frontier of an earlier adjacent cell) is closer than the spacing -- otherwise the cell
+//       stalls on that point and sleeps on the blocking cell's wait list until its frontier passed it.
+// Rounds read only state committed by earlier launches (pos/acc_cnt are published by a commit kernel),
+// so a stale view is merely conservative.  Decisions follow exactly the reference's distance compares,
+// hence the accepted set is bit-identical; the number of rounds is the true dependency depth of the
+// greedy sweep instead of the length of the cell adjacency chains.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 #include "swz_level.h"
 
@@ -26,7 +32,10 @@ namespace swz {
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr int MD_THREADS = 256;
 constexpr int MD_WAVES = MD_THREADS / WAVE;
-constexpr int MD_OWN_CAP = 128;  // accepted points of the current cell cached in LDS per wave
+constexpr int MD_EXT_CAP = 256;   // accepted points of the neighbourhood cached in LDS per wave (window)
+constexpr int MD_FRESH_CAP = 64;  // points a cell may accept per activation
+
+enum : uint32_t { ST_STALLED = 0, ST_FINISHED = 1, ST_YIELD = 2 };
 
 struct MdArgs {
   const uint64_t* akey;
@@ -45,16 +54,30 @@ struct MdArgs {
   uint32_t* cend;
   uint32_t* crel;
   uint32_t* csnode;
-  uint32_t* ndeps;
-  uint32_t* acc_cnt;
-  uint32_t* acc_list;   // per cell: sorted positions of its accepted points, at [cstart, cstart+acc_cnt)
-  uint32_t* gridmap;    // [sample node][cell code] -> cell index
+  uint32_t* pos;       // committed frontier (active index)
+  uint32_t* acc_cnt;   // committed number of accepted points
+  uint32_t* npos;      // pending frontier / count / status written by the sweep kernel
+  uint32_t* ncnt;
+  uint32_t* status;
+  uint32_t* blk_p;     // stalled candidate and where its blocker scan stopped
+  uint32_t* blk_slot;
+  uint32_t* blk_q;
+  uint32_t* blk_cell;
+  uint32_t* whead;     // wait list of cells sleeping on this cell
+  uint32_t* wnext;
+  uint32_t* acc_list;  // per cell: sorted positions of its accepted points, at [cstart, cstart+acc_cnt)
+  uint32_t* gridmap;   // [sample node][cell code] -> cell index
   uint32_t* queue[2];
   const uint32_t* snode_of;  // node -> compact index among sampled nodes
   uint32_t cell_shift;
   uint32_t cell_levels;      // octree levels between node and cell (cells per axis = 2^cell_levels)
   uint64_t cells_per_node;   // 8^cell_levels
   double sq_spacing;
+  // blocker-scan culling: a cell is cut into 2^sub_levels slabs per axis; usq[a] = squared slab width
+  uint32_t sub_levels;
+  uint32_t batch_blockers;   // very sparse level: test all surviving lanes in one pass over the neighbours
+  double usq[3];
+  double cull_sq;            // sq_spacing with a safety margin
 };
 
 __device__ __forceinline__ uint32_t md_spos(const uint32_t* aidx, uint32_t i) { return aidx ? aidx[i] : i; }
@@ -83,6 +106,9 @@ __global__ __launch_bounds__(256) void md_cell_build_kernel(MdArgs a, const uint
   a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
   a.csnode[c] = a.snode_of[a.nid[i]];
   a.acc_cnt[c] = 0;
+  a.pos[c] = i;
+  a.whead[c] = NONE32;
+  a.blk_p[c] = NONE32;
 }
 
 __global__ __launch_bounds__(256) void md_cell_end_kernel(MdArgs a, uint32_t ncells) {
@@ -108,147 +134,356 @@ __device__ __forceinline__ bool md_neighbour_code(uint32_t rel, uint32_t cell_le
   return true;
 }
 
-// dependency count = existing adjacent cells with a smaller code; cells without any start round 0
-__global__ __launch_bounds__(256) void md_deps_kernel(MdArgs a, uint32_t ncells) {
-  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncells) return;
-  const uint32_t rel = a.crel[c];
-  const uint64_t base = (uint64_t)a.csnode[c] * a.cells_per_node;
-  uint32_t deps = 0;
-  for (int k = 0; k < 27; ++k) {
-    if (k == 13) continue;
-    uint32_t nrel;
-    if (!md_neighbour_code(rel, a.cell_levels, k, nrel)) continue;
-    if (nrel < rel && a.gridmap[base + nrel] != NONE32) ++deps;
-  }
-  a.ndeps[c] = deps;
-  if (deps == 0) {
-    const uint32_t slot = atomicAdd(&a.counters[CTR_Q0], 1u);
-    a.queue[0][slot] = c;
-  }
-}
-
 __device__ __forceinline__ double bcast_f64(double v, int src) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, src);
   hi = __builtin_amdgcn_readlane(hi, src);
   return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+}
 
-// One wavefront runs the reference's greedy for one ready cell.
-__device__ void md_process_cell(const MdArgs& a, uint32_t c, uint32_t* qout, uint32_t* qout_count, double* own_x,
-                                double* own_y, double* own_z) {
+struct MdLds {
+  double ex[MD_EXT_CAP], ey[MD_EXT_CAP], ez[MD_EXT_CAP];
+  double fx[MD_FRESH_CAP], fy[MD_FRESH_CAP], fz[MD_FRESH_CAP];
+  uint32_t esp[MD_EXT_CAP];
+};
+
+// Fills the LDS window [base, base + MD_EXT_CAP) of the flattened list of accepted points of the
+// neighbourhood (lane k < 27 owns the n_cnt entries of adjacent cell k starting at list offset off).
+__device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, uint32_t base, uint32_t T,
+                                                   uint32_t maxcnt, uint32_t n_cnt, uint32_t n_start, uint32_t off) {
   const uint32_t l = lane_id();
-  const uint32_t s = a.cstart[c], e = a.cend[c], rel = a.crel[c];
-  const uint64_t gbase = (uint64_t)a.csnode[c] * a.cells_per_node;
-  const double t = a.sq_spacing;
-
-  // lanes 0..26 look up the adjacent cells
-  uint32_t nb = NONE32;
-  bool earlier = false, later = false;
-  if (l < 27 && l != 13) {
-    uint32_t nrel;
-    if (md_neighbour_code(rel, a.cell_levels, (int)l, nrel)) {
-      nb = a.gridmap[gbase + nrel];
-      earlier = nb != NONE32 && nrel < rel;
-      later = nb != NONE32 && nrel > rel;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = 0; j < maxcnt; ++j) {
+    if (j < n_cnt) {
+      const uint32_t ti = off + j;
+      if (ti >= base && ti < base + MD_EXT_CAP) lds.esp[ti - base] = a.acc_list[n_start + j];
     }
   }
-  const uint64_t emask = __ballot(earlier);
-  uint32_t own_cnt = 0;
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t wn = (T - base) < (uint32_t)MD_EXT_CAP ? (T - base) : (uint32_t)MD_EXT_CAP;
+  for (uint32_t ti = l; ti < wn; ti += WAVE) {
+    const uint32_t q = lds.esp[ti];
+    lds.ex[ti] = a.X[q];
+    lds.ey[ti] = a.Y[q];
+    lds.ez[ti] = a.Z[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+  return wn;
+}
 
-  for (uint32_t p0 = s; p0 < e; p0 += WAVE) {
-    const uint32_t p = p0 + l;
+// squared slab distance from a point with slab coordinates (sx,sy,sz) to the adjacent cell in slot k
+__device__ __forceinline__ bool md_culled(const MdArgs& a, int k, int sx, int sy, int sz) {
+  const int smax = (1 << a.sub_levels) - 1;
+  const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
+  const double gx = (double)(dx < 0 ? sx : (dx > 0 ? smax - sx : 0));
+  const double gy = (double)(dy < 0 ? sy : (dy > 0 ? smax - sy : 0));
+  const double gz = (double)(dz < 0 ? sz : (dz > 0 ? smax - sz : 0));
+  return gx * gx * a.usq[0] + gy * gy * a.usq[1] + gz * gz * a.usq[2] >= a.cull_sq;
+}
+
+// One wavefront advances the frontier of one active cell as far as it can.
+__device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
+  const uint32_t l = lane_id();
+  const uint32_t s0 = a.cstart[c], e = a.cend[c], rel = a.crel[c];
+  const uint64_t gbase = (uint64_t)a.csnode[c] * a.cells_per_node;
+  const double t = a.sq_spacing;
+  const uint32_t P = a.pos[c], CNT = a.acc_cnt[c];
+
+  // lanes 0..26: the adjacent cells (13 = this cell); committed state of the earlier ones
+  uint32_t nb = NONE32, n_cnt = 0, n_start = 0, n_pos = 0, n_end = 0;
+  bool earlier = false;
+  if (l < 27) {
+    if (l == 13) {
+      nb = c;
+      n_cnt = CNT;
+      n_start = s0;
+    } else {
+      uint32_t nrel;
+      if (md_neighbour_code(rel, a.cell_levels, (int)l, nrel) && nrel < rel) {
+        nb = a.gridmap[gbase + nrel];
+        if (nb != NONE32) {
+          earlier = true;
+          n_cnt = a.acc_cnt[nb];
+          n_start = a.cstart[nb];
+          n_pos = a.pos[nb];
+          n_end = a.cend[nb];
+        }
+      }
+    }
+  }
+  const uint64_t emask = __ballot(earlier && n_pos < n_end);  // neighbours that may still hold undecided points
+  const uint32_t incl = wave_incl_sum(n_cnt);
+  const uint32_t off = incl - n_cnt;
+  const uint32_t T = bcast_u32(incl, WAVE - 1);  // accepted points of the neighbourhood (incl. own committed)
+  uint32_t maxcnt = n_cnt;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(maxcnt, d, WAVE);
+    maxcnt = o > maxcnt ? o : maxcnt;
+  }
+  uint32_t wn0 = 0;
+  if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
+
+  const bool resume = a.blk_p[c] == P;
+  const uint32_t r_slot = resume ? a.blk_slot[c] : 0u;
+  const uint32_t r_q = resume ? a.blk_q[c] : 0u;
+
+  uint32_t fresh = 0;
+#ifdef SWZ_MD_STATS
+  uint32_t dbg_scan = 0, dbg_rtest = 0;
+#endif
+  uint32_t cur = P;
+  uint32_t out_pos = e, out_status = ST_FINISHED;
+  uint32_t b_slot = 0, b_q = 0, b_cell = 0;
+  bool stop = false;
+
+  while (cur < e && !stop) {
+    const uint32_t p = cur + l;
     const bool valid = p < e;
     uint32_t sp = 0;
+    int sx = 0, sy = 0, sz = 0;
     double px = 0, py = 0, pz = 0;
     if (valid) {
       sp = md_spos(a.aidx, p);
       px = a.X[sp];
       py = a.Y[sp];
       pz = a.Z[sp];
+      // slab coordinates inside the cell (culling of blocker scans)
+      const uint64_t sub = (a.akey[p] >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+      sx = (int)contract_bits_by_3(sub >> 2);
+      sy = (int)contract_bits_by_3(sub >> 1);
+      sz = (int)contract_bits_by_3(sub);
     }
     bool rej = !valid;
-    // accepted points of the earlier adjacent cells (final: those cells finished in earlier rounds)
-    uint64_t mm = emask;
-    while (mm) {
-      const int k = __ffsll((unsigned long long)mm) - 1;
-      mm &= mm - 1;
-      const uint32_t nbc = (uint32_t)__builtin_amdgcn_readlane((int)nb, k);
-      const uint32_t cnt = a.acc_cnt[nbc];
-      const uint32_t st = a.cstart[nbc];
-      for (uint32_t a0 = 0; a0 < cnt; a0 += WAVE) {
-        double qx = 0, qy = 0, qz = 0;
-        if (a0 + l < cnt) {
-          const uint32_t q = a.acc_list[st + a0 + l];
-          qx = a.X[q];
-          qy = a.Y[q];
-          qz = a.Z[q];
-        }
-        const int nchunk = (int)((cnt - a0) < (uint32_t)WAVE ? (cnt - a0) : WAVE);
-        for (int j = 0; j < nchunk; ++j) {
-          const double bx = bcast_f64(qx, j), by = bcast_f64(qy, j), bz = bcast_f64(qz, j);
-          if (sq_dist(px, py, pz, bx, by, bz) < t) rej = true;
-        }
-      }
+    // (R) against the committed accepted points of the neighbourhood, window by window
+    for (uint32_t base = 0; base < T; base += MD_EXT_CAP) {
+      const uint32_t wn = (base == 0 && T <= (uint32_t)MD_EXT_CAP && cur == P)
+                            ? wn0
+                            : ((T <= (uint32_t)MD_EXT_CAP) ? wn0 : md_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off));
+#ifdef SWZ_MD_STATS
+      dbg_rtest += wn;
+#endif
+      for (uint32_t ti = 0; ti < wn; ++ti)
+        if (sq_dist(px, py, pz, lds.ex[ti], lds.ey[ti], lds.ez[ti]) < t) rej = true;
       if (!__ballot(!rej)) break;
     }
-    // accepted points of this cell from earlier chunks
-    if (__ballot(!rej)) {
-      const uint32_t in_lds = own_cnt < (uint32_t)MD_OWN_CAP ? own_cnt : (uint32_t)MD_OWN_CAP;
-      for (uint32_t j = 0; j < in_lds; ++j)
-        if (sq_dist(px, py, pz, own_x[j], own_y[j], own_z[j]) < t) rej = true;
-      for (uint32_t j = MD_OWN_CAP; j < own_cnt; ++j) {  // overflow: read back what this wave published
-        const uint32_t q = __hip_atomic_load(&a.acc_list[s + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (sq_dist(px, py, pz, a.X[q], a.Y[q], a.Z[q]) < t) rej = true;
-      }
-    }
-    // sequential greedy inside the chunk: the first surviving lane is accepted and rejects the
-    // later lanes closer than the spacing
+    // ... and against the points accepted earlier in this activation
+    for (uint32_t ti = 0; ti < fresh; ++ti)
+      if (sq_dist(px, py, pz, lds.fx[ti], lds.fy[ti], lds.fz[ti]) < t) rej = true;
+
     uint64_t alive = __ballot(!rej);
-    while (alive) {
-      const int j = __ffsll((unsigned long long)alive) - 1;
-      const double bx = bcast_f64(px, j), by = bcast_f64(py, j), bz = bcast_f64(pz, j);
-      if ((int)l == j) {
-        a.taken[p] = 1;
-        __hip_atomic_store(&a.acc_list[s + own_cnt], sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (own_cnt < (uint32_t)MD_OWN_CAP) {
-          own_x[own_cnt] = bx;
-          own_y[own_cnt] = by;
-          own_z[own_cnt] = bz;
+    // (A) for many survivors at once: one pass over the possibly-undecided points of the earlier
+    // adjacent cells, every surviving lane testing its own point against the broadcast one
+    bool pre = false;          // blocker flags of this chunk were precomputed for all lanes
+    bool blk = false;          // lane: an undecided earlier point is closer than the spacing
+    uint32_t blk_slot_l = 0, blk_q_l = 0;
+    const int first_alive = alive ? __ffsll((unsigned long long)alive) - 1 : 0;
+    bool still = false;  // the stalled candidate of the last activation is still blocked by the same point
+    if (resume && cur == P && (alive & 1ull) && ((emask >> r_slot) & 1ull) && bcast_u32(n_pos, (int)r_slot) <= r_q) {
+      still = true;
+      blk = (l == 0);
+      blk_slot_l = r_slot;
+      blk_q_l = r_q;
+      pre = true;
+    }
+    if (!still && a.batch_blockers && __popcll(alive) > 8) {
+      pre = true;
+      uint64_t mm = emask;
+      bool first_blocked = false;
+      while (mm && !first_blocked) {
+        const int k = __ffsll((unsigned long long)mm) - 1;
+        mm &= mm - 1;
+        const bool need = !rej && !blk && !md_culled(a, k, sx, sy, sz);
+        if (!__ballot(need)) continue;
+        const uint32_t qs = bcast_u32(n_pos, k), qe = bcast_u32(n_end, k);
+        for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
+#ifdef SWZ_MD_STATS
+          ++dbg_scan;
+#endif
+          double qx = 0, qy = 0, qz = 0;
+          if (q0 + l < qe) {
+            const uint32_t sq = md_spos(a.aidx, q0 + l);
+            qx = a.X[sq];
+            qy = a.Y[sq];
+            qz = a.Z[sq];
+          }
+          const int nq = (int)((qe - q0) < (uint32_t)WAVE ? (qe - q0) : WAVE);
+          for (int j = 0; j < nq; ++j) {
+            const double bx = bcast_f64(qx, j), by = bcast_f64(qy, j), bz = bcast_f64(qz, j);
+            if (need && !blk && sq_dist(px, py, pz, bx, by, bz) < t) {
+              blk = true;
+              blk_slot_l = (uint32_t)k;
+              blk_q_l = q0 + (uint32_t)j;
+            }
+          }
+          first_blocked = __builtin_amdgcn_readlane((int)blk, first_alive) != 0;
+          if (first_blocked || !__ballot(need && !blk)) break;
         }
       }
-      ++own_cnt;
+    }
+
+    // surviving lanes in order: accept or stall
+    while (alive) {
+      const int j = __ffsll((unsigned long long)alive) - 1;
+      const uint32_t cand = cur + (uint32_t)j;
+      const double bx = bcast_f64(px, j), by = bcast_f64(py, j), bz = bcast_f64(pz, j);
+      bool blocked = false;
+      if (pre) {
+        blocked = __builtin_amdgcn_readlane((int)blk, j) != 0;
+        if (blocked) {
+          b_slot = bcast_u32(blk_slot_l, j);
+          b_q = bcast_u32(blk_q_l, j);
+          b_cell = bcast_u32(nb, (int)b_slot);
+        }
+      } else {
+        // few survivors: scan the earlier adjacent cells for this candidate, 64 points at a time
+        const int csx = __builtin_amdgcn_readlane(sx, j), csy = __builtin_amdgcn_readlane(sy, j),
+                  csz = __builtin_amdgcn_readlane(sz, j);
+        uint64_t mm = emask;
+        const bool res = resume && cand == P;
+        if (res) mm &= ~((1ull << r_slot) - 1ull);  // slots before r_slot were scanned clean already
+        while (mm && !blocked) {
+          const int k = __ffsll((unsigned long long)mm) - 1;
+          mm &= mm - 1;
+          if (md_culled(a, k, csx, csy, csz)) continue;
+          uint32_t qs = bcast_u32(n_pos, k);
+          const uint32_t qe = bcast_u32(n_end, k);
+          if (res && (uint32_t)k == r_slot && r_q > qs) qs = r_q;
+          for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
+#ifdef SWZ_MD_STATS
+            ++dbg_scan;
+#endif
+            const uint32_t q = q0 + l;
+            bool hit = false;
+            if (q < qe) {
+              const uint32_t sq = md_spos(a.aidx, q);
+              hit = sq_dist(bx, by, bz, a.X[sq], a.Y[sq], a.Z[sq]) < t;
+            }
+            const uint64_t hb = __ballot(hit);
+            if (hb) {
+              blocked = true;
+              b_slot = (uint32_t)k;
+              b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
+              b_cell = bcast_u32(nb, k);
+              break;
+            }
+          }
+        }
+      }
+      if (blocked) {
+        out_pos = cand;
+        out_status = ST_STALLED;
+        stop = true;
+        break;
+      }
+      // accepted
+      if ((int)l == j) {
+        a.taken[cand] = 1;
+        a.acc_list[s0 + CNT + fresh] = sp;
+        lds.fx[fresh] = px;
+        lds.fy[fresh] = py;
+        lds.fz[fresh] = pz;
+      }
+      ++fresh;
       if ((int)l > j && !rej && sq_dist(px, py, pz, bx, by, bz) < t) rej = true;
       alive = __ballot(!rej && (int)l > j);
+      __builtin_amdgcn_wave_barrier();
+      if (fresh == (uint32_t)MD_FRESH_CAP) {  // LDS list full: publish and continue in the next round
+        const uint32_t next = alive ? cur + (uint32_t)__ffsll((unsigned long long)alive) - 1u
+                                    : ((cur + WAVE) < e ? cur + WAVE : e);
+        if (next < e) {
+          out_pos = next;
+          out_status = ST_YIELD;
+          stop = true;
+        }
+        break;
+      }
     }
-    __builtin_amdgcn_wave_barrier();
+    if (!stop) cur += WAVE;
   }
   if (l == 0) {
-    a.acc_cnt[c] = own_cnt;
-    atomicAdd(&a.counters[CTR_DONE_CELLS], 1u);
-  }
-  // release the later adjacent cells
-  if (later) {
-    const uint32_t old = atomicSub(&a.ndeps[nb], 1u);
-    if (old == 1u) {
-      const uint32_t slot = atomicAdd(qout_count, 1u);
-      qout[slot] = nb;
+#ifdef SWZ_MD_STATS
+    atomicAdd(&a.counters[CTR_DBG_ACT], 1u);
+    atomicAdd(&a.counters[CTR_DBG_SCAN], dbg_scan);
+    atomicAdd(&a.counters[CTR_DBG_RTEST], dbg_rtest);
+    if (out_status == ST_STALLED) atomicAdd(&a.counters[CTR_DBG_STALL], 1u);
+#endif
+    a.npos[c] = out_pos;
+    a.ncnt[c] = CNT + fresh;
+    a.status[c] = out_status;
+    if (out_status == ST_STALLED) {
+      a.blk_p[c] = out_pos;
+      a.blk_slot[c] = b_slot;
+      a.blk_q[c] = b_q;
+      a.blk_cell[c] = b_cell;
     }
   }
 }
 
-__global__ __launch_bounds__(MD_THREADS) void md_round_kernel(MdArgs a, uint32_t round) {
-  __shared__ double own[MD_WAVES][3][MD_OWN_CAP];
+__global__ __launch_bounds__(MD_THREADS) void md_sweep_kernel(MdArgs a, uint32_t round) {
+  __shared__ MdLds lds[MD_WAVES];
   const uint32_t w = threadIdx.x / WAVE;
-  uint32_t* cin = &a.counters[CTR_Q0 + round % 3];
-  uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (round + 2) % 3] = 0;
-  const uint32_t nq = *cin;
+  const uint32_t nq = a.counters[CTR_Q0 + round % 3];
+  const uint32_t* qin = a.queue[round & 1];
+  for (uint32_t i = blockIdx.x * MD_WAVES + w; i < nq; i += gridDim.x * MD_WAVES) md_sweep_cell(a, qin[i], lds[w]);
+}
+
+// publish the new frontiers; a cell whose frontier moved wakes the cells sleeping on it
+__global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round) {
+  const uint32_t nq = a.counters[CTR_Q0 + round % 3];
+  uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   const uint32_t* qin = a.queue[round & 1];
   uint32_t* qout = a.queue[(round + 1) & 1];
-  for (uint32_t e = blockIdx.x * MD_WAVES + w; e < nq; e += gridDim.x * MD_WAVES)
-    md_process_cell(a, qin[e], qout, cout, own[w][0], own[w][1], own[w][2]);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+    const uint32_t c = qin[i];
+    const uint32_t old = a.pos[c], np = a.npos[c];
+    a.pos[c] = np;
+    a.acc_cnt[c] = a.ncnt[c];
+    const bool fin = a.status[c] == ST_FINISHED;
+    if (fin) atomicAdd(&a.counters[CTR_DONE_CELLS], 1u);
+    if (np > old || fin) {
+      uint32_t w = a.whead[c];
+      a.whead[c] = NONE32;
+      while (w != NONE32) {
+        const uint32_t nx = a.wnext[w];
+        qout[atomicAdd(cout, 1u)] = w;
+        w = nx;
+      }
+    }
+  }
+}
+
+// stalled cells go to sleep on their blocker's wait list (or straight back into the queue when the
+// blocker's frontier has already passed the blocking point); yielded cells are re-queued
+__global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t round) {
+  const uint32_t nq = a.counters[CTR_Q0 + round % 3];
+  uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
+  const uint32_t* qin = a.queue[round & 1];
+  uint32_t* qout = a.queue[(round + 1) & 1];
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
+    const uint32_t c = qin[i];
+    const uint32_t st = a.status[c];
+    if (st == ST_YIELD) {
+      qout[atomicAdd(cout, 1u)] = c;
+    } else if (st == ST_STALLED) {
+      const uint32_t b = a.blk_cell[c];
+      if (a.pos[b] > a.blk_q[c]) {
+        qout[atomicAdd(cout, 1u)] = c;
+      } else {
+        a.wnext[c] = atomicExch(&a.whead[b], c);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void md_fill_queue_kernel(uint32_t* q, uint32_t n, uint32_t* counter) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) q[i] = i;
+  if (i == 0) *counter = n;
 }
 
 int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
@@ -279,9 +514,23 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   a.counters = lb.counters;
   a.cell_levels = (uint32_t)cl;
   a.cells_per_node = cells_per_node;
-  a.cell_shift = plan.node_shift == 63u ? level_shift(cl - 1) : plan.node_shift - 3u * (uint32_t)cl;
-  if (plan.node_shift == 63u && cl == 0) a.cell_shift = 63u;
+  a.cell_shift = (plan.node_shift == 63u ? 63u : plan.node_shift) - 3u * (uint32_t)cl;
   a.sq_spacing = plan.sq_spacing;
+  {
+    // absolute octree level of a cell is level + cl; up to 4 further levels of the key give the slabs
+    const int cell_abs = plan.level + cl;
+    const int sub = std::max(0, std::min(4, 20 - cell_abs));
+    a.sub_levels = (uint32_t)sub;
+    const double ext[3] = {plan.root.maxx - plan.root.minx, plan.root.maxy - plan.root.miny,
+                           plan.root.maxz - plan.root.minz};
+    for (int ax = 0; ax < 3; ++ax) {
+      const double u = std::ldexp(ext[ax], -(plan.level + 1 + cl + sub));
+      a.usq[ax] = u * u;
+    }
+    a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
+    // expected points per spacing-sized cell; far below one almost every candidate is accepted
+    a.batch_blockers = (avg / std::pow(8.0, plan.cell_levels_geo) < 0.25) ? 1u : 0u;
+  }
 
   uint32_t* snode = nullptr;
   SWZ_TRY(c->get("md_snode", (size_t)nnodes, &snode));
@@ -301,12 +550,11 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   if (ncells == 0) return SWZ_OK;
 
-  SWZ_TRY(c->get("md_cstart", (size_t)ncells, &a.cstart));
-  SWZ_TRY(c->get("md_cend", (size_t)ncells, &a.cend));
-  SWZ_TRY(c->get("md_crel", (size_t)ncells, &a.crel));
-  SWZ_TRY(c->get("md_csnode", (size_t)ncells, &a.csnode));
-  SWZ_TRY(c->get("md_ndeps", (size_t)ncells, &a.ndeps));
-  SWZ_TRY(c->get("md_acc_cnt", (size_t)ncells, &a.acc_cnt));
+  uint32_t* cellbuf = nullptr;  // 15 per-cell arrays
+  SWZ_TRY(c->get("md_cells", (size_t)ncells * 15, &cellbuf));
+  uint32_t** fields[] = {&a.cstart, &a.cend,     &a.crel,    &a.csnode,   &a.pos,   &a.acc_cnt, &a.npos, &a.ncnt,
+                         &a.status, &a.blk_p,    &a.blk_slot, &a.blk_q,   &a.blk_cell, &a.whead, &a.wnext};
+  for (size_t f = 0; f < 15; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
   SWZ_TRY(c->get("md_acc_list", (size_t)m, &a.acc_list));
   SWZ_TRY(c->get("md_queue0", (size_t)ncells, &a.queue[0]));
   SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
@@ -319,24 +567,50 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(md_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
-  hipLaunchKernelGGL(md_deps_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
+  hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, a.queue[0], ncells,
+                     lb.counters + CTR_Q0);
   SWZ_LAUNCH_CHECK(c);
 
-  // topological rounds; the host only looks at the done counter every `batch` launches
-  const uint32_t grid = std::min<uint32_t>(2048u, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
+  // rounds; the host only looks at the done counter every `batch` rounds
+  const bool dbg = getenv("SWZ_DEBUG") != nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (dbg) {
+    ev0 = c->take_event();
+    ev1 = c->take_event();
+    (void)hipEventRecord(ev0, c->stream);
+  }
+  const uint32_t sweep_grid = std::min<uint32_t>(2048u, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
+  const uint32_t commit_grid = std::min<uint32_t>(1024u, std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
-  const uint32_t batch = 256;
-  const uint64_t max_rounds = (uint64_t)ncells + batch;
+  const uint32_t batch = 32;
+  const uint64_t max_rounds = 4ull * m + 1024;
   while (done < ncells) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
-      hipLaunchKernelGGL(md_round_kernel, dim3(grid), dim3(MD_THREADS), 0, c->stream, a, round);
+      hipLaunchKernelGGL(md_sweep_kernel, dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
+      hipLaunchKernelGGL(md_commit_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
+      hipLaunchKernelGGL(md_requeue_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
     }
     SWZ_LAUNCH_CHECK(c);
     SWZ_HIP(c, hipMemcpyAsync(&done, lb.counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    if (round > max_rounds) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE dependency sweep did not terminate");
+    if (round > max_rounds) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE frontier sweep did not terminate");
   }
   if (rounds_out) *rounds_out += round;
+  if (dbg) {
+    float ms = 0.f;
+    (void)hipEventRecord(ev1, c->stream);
+    (void)hipEventSynchronize(ev1);
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    c->event_pool.push_back(ev0);
+    c->event_pool.push_back(ev1);
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d sweep: %.2f ms\n", plan.level, ms);
+    uint32_t h[CTR_COUNT];
+    SWZ_HIP(c, hipMemcpy(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d: %u pts in %u nodes, cell_levels %d, %u cells, %u rounds, %u activations "
+                    "(%u stalled), %u scan chunks, %u rtests\n",
+            plan.level, sample_points, sample_nodes, cl, ncells, round, h[CTR_DBG_ACT], h[CTR_DBG_STALL],
+            h[CTR_DBG_SCAN], h[CTR_DBG_RTEST]);
+  }
   return SWZ_OK;
 }
 
