@@ -137,6 +137,35 @@ int swz_build_node_lists(swz_ctx* ctx, const uint64_t* keys_sorted, const int8_t
                          uint64_t* node_key_out, uint64_t* node_offset_out, uint64_t* node_count_out,
                          uint64_t* num_nodes_out);
 
+/* ---- multi-GPU sharding: one context per GPU, points owned by their top
+ * Morton bits (level-0 octant, MortonIndex::get_octant_at_level(0), MortonIndex.h:133-138), so every
+ * node at level >= 0 lives on exactly one GPU.  The reference has no counterpart (it is a single
+ * process); the exchange itself (RCCL all-to-all) is done by the host driver, the library provides
+ * the device-side pieces:
+ *   swz_partition_by_octant_device: perm groups point indices by octant 0..7 (stable inside an
+ *     octant); counts_out[o] = points of octant o.
+ *   swz_shard_begin_device: indexes + sorts the shard's points and samples the ROOT node, whose
+ *     take-all/sample decision uses shard->global_points.  For MIN_DISTANCE the root couples the
+ *     shards: the points the root took on all lower octants are passed as ghosts (they sort first and
+ *     are accepted again, rejecting exactly what the single-GPU sweep would reject).
+ *   swz_shard_root_taken_device: positions (N x 3) of the LOCAL points the root took, Morton order:
+ *     the ghosts to hand to the shards owning higher octants.
+ *   swz_shard_finish_device: tiles levels >= 0 and writes the outputs of swz_tile_device for the n
+ *     local points (keys ascending, perm = index into the local xyz, level). */
+typedef struct {
+  uint64_t global_points;      /* points of the whole batch over all shards */
+  const double* d_ghost_xyz;   /* device, num_ghosts x 3; all ghosts must lie in lower octants */
+  uint64_t num_ghosts;
+} swz_shard_info;
+int swz_partition_by_octant_device(swz_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t* d_perm_out,
+                                   uint64_t counts_out[8]);
+int swz_shard_begin_device(swz_ctx* ctx, const double* d_xyz_local, uint64_t n, const double bounds_min[3],
+                           const double bounds_max[3], const swz_tile_params* params,
+                           const swz_shard_info* shard, uint64_t* num_root_taken_out);
+int swz_shard_root_taken_device(swz_ctx* ctx, double* d_xyz_out);
+int swz_shard_finish_device(swz_ctx* ctx, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
+                            swz_tile_stats* stats);
+
 /* ---- synthetic workload of BASELINE.json / SURVEY.md section 8(d): uniform points in the unit
  * cube from a counter-based splitmix64 stream (point i draws x,y,z = draws 3i..3i+2). */
 int swz_generate_uniform_device(swz_ctx* ctx, uint64_t seed, uint64_t first_point, uint64_t n,

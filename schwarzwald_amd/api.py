@@ -35,6 +35,10 @@ class _TileStats(C.Structure):
                 ("fast_start_levels", C.c_int32), ("num_levels", C.c_uint32), ("min_distance_rounds", C.c_uint32)]
 
 
+class _ShardInfo(C.Structure):
+    _fields_ = [("global_points", C.c_uint64), ("d_ghost_xyz", C.c_void_p), ("num_ghosts", C.c_uint64)]
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algorithmic_bytes", C.c_uint64)]
@@ -112,13 +116,19 @@ def load_library():
     L.swz_build_node_lists.argtypes = [vp, _u64p, _i8p, C.c_uint64, _u32p, C.c_uint64, _i8p, _u64p, _u64p, _u64p,
                                        _u64p]
     L.swz_generate_uniform_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    L.swz_partition_by_octant_device.argtypes = [vp, vp, C.c_uint64, vp, _u64p]
+    L.swz_shard_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.POINTER(_ShardInfo),
+                                         _u64p]
+    L.swz_shard_root_taken_device.argtypes = [vp, vp]
+    L.swz_shard_finish_device.argtypes = [vp, vp, vp, vp, C.POINTER(_TileStats)]
     L.swz_profile_enable.argtypes = [vp, C.c_int]
     L.swz_profile_reset.argtypes = [vp]
     L.swz_profile_get.argtypes = [vp, C.POINTER(_KernelStat), C.c_uint32, _u32p]
     for name in ("swz_create", "swz_destroy", "swz_set_stream", "swz_release_workspace", "swz_morton_encode",
                  "swz_morton_encode_device", "swz_sort_by_key", "swz_sort_by_key_device", "swz_sample_points",
                  "swz_tile", "swz_tile_device", "swz_build_node_lists", "swz_generate_uniform_device",
-                 "swz_profile_enable", "swz_profile_reset", "swz_profile_get"):
+                 "swz_profile_enable", "swz_profile_reset", "swz_profile_get", "swz_partition_by_octant_device",
+                 "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -274,4 +284,30 @@ class Context:
         self._check(self._lib.swz_tile_device(self._ctx, C.c_void_p(d_xyz), int(n), _vec3(bmin), _vec3(bmax),
                                               C.byref(p), C.c_void_p(d_keys), C.c_void_p(d_perm),
                                               C.c_void_p(d_level), C.c_void_p(d_dup), C.byref(stats)))
+        return _stats_dict(stats)
+
+    # ------------------------------------------------------------------ sharded batches (one context per GPU)
+    def partition_by_octant_device(self, d_keys, n, d_perm):
+        """Groups point indices by level-0 octant (stable).  Returns the 8 octant counts."""
+        counts = (C.c_uint64 * 8)()
+        self._check(self._lib.swz_partition_by_octant_device(self._ctx, C.c_void_p(d_keys), int(n),
+                                                             C.c_void_p(d_perm), counts))
+        return [int(v) for v in counts]
+
+    def shard_begin_device(self, d_xyz_local, n, bmin, bmax, params, global_points, d_ghost_xyz=None, num_ghosts=0):
+        """Indexes + sorts the shard and samples the root node.  Returns how many local points the root took."""
+        info = _ShardInfo(int(global_points), C.c_void_p(d_ghost_xyz), int(num_ghosts))
+        p = params._c()
+        taken = C.c_uint64()
+        self._check(self._lib.swz_shard_begin_device(self._ctx, C.c_void_p(d_xyz_local), int(n), _vec3(bmin),
+                                                     _vec3(bmax), C.byref(p), C.byref(info), C.byref(taken)))
+        return int(taken.value)
+
+    def shard_root_taken_device(self, d_xyz_out):
+        self._check(self._lib.swz_shard_root_taken_device(self._ctx, C.c_void_p(d_xyz_out)))
+
+    def shard_finish_device(self, d_keys, d_perm, d_level):
+        stats = _TileStats()
+        self._check(self._lib.swz_shard_finish_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_perm),
+                                                      C.c_void_p(d_level), C.byref(stats)))
         return _stats_dict(stats)

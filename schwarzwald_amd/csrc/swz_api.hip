@@ -85,6 +85,7 @@ void swz_ctx::prof_collect() {
 }
 
 static std::string g_create_error;
+static int check_params(swz_ctx* c, const swz_tile_params* p);
 
 namespace {
 
@@ -157,6 +158,7 @@ int swz_create(swz_ctx** ctx_out, int device) {
 int swz_destroy(swz_ctx* c) {
   if (!c) return SWZ_OK;
   (void)hipSetDevice(c->device);
+  swz::shard_free(c);
   c->release_all();
   c->prof_collect();
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
@@ -363,6 +365,60 @@ int swz_tile(swz_ctx* c, double* xyz, uint64_t n, const double bmin[3], const do
   if (dup_mask_out) SWZ_TRY(download(c, dup_mask_out, d_dup, (size_t)n * 4));
   SWZ_TRY(download(c, xyz, d_xyz, (size_t)n * 24));
   return sync(c);
+}
+
+// ------------------------------------------------------------------------------ sharded batches
+int swz_partition_by_octant_device(swz_ctx* c, const uint64_t* d_keys, uint64_t n, uint32_t* d_perm_out,
+                                   uint64_t counts_out[8]) {
+  if (!c || !counts_out) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  for (int o = 0; o < 8; ++o) counts_out[o] = 0;
+  if (n == 0) return SWZ_OK;
+  if (!d_keys || !d_perm_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_partition_by_octant_device: NULL buffer");
+  uint64_t hist[256];
+  SWZ_TRY(swz::partition_top_digit(c, d_keys, (uint32_t)n, d_perm_out, hist));
+  for (int d = 0; d < 256; ++d) counts_out[(d >> 4) & 7] += hist[d];  // digit = key bits 56..63, octant = bits 60..62
+  return sync(c);
+}
+
+int swz_shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint64_t n, const double bmin[3],
+                           const double bmax[3], const swz_tile_params* params, const swz_shard_info* shard,
+                           uint64_t* num_root_taken_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (!shard) return c->fail(SWZ_ERR_BAD_ARG, "shard info must not be NULL");
+  SWZ_TRY(check_n(c, n + shard->num_ghosts));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  SWZ_TRY(check_params(c, params));
+  if ((n && !d_xyz_local) || (shard->num_ghosts && !shard->d_ghost_xyz))
+    return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_begin_device: NULL buffer");
+  if (n + shard->num_ghosts == 0) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_begin_device: empty shard");
+  int st = swz::shard_begin_device(c, d_xyz_local, (uint32_t)n, bmin, bmax, *params, shard->global_points,
+                                   shard->d_ghost_xyz, (uint32_t)shard->num_ghosts, num_root_taken_out);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
+}
+
+int swz_shard_root_taken_device(swz_ctx* c, double* d_xyz_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(swz::shard_root_taken_device(c, d_xyz_out));
+  return sync(c);
+}
+
+int swz_shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
+                            swz_tile_stats* stats) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->max_level = -1;
+    stats->fast_start_levels = -1;
+  }
+  int st = swz::shard_finish_device(c, d_keys_out, d_perm_out, d_level_out, stats);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
 }
 
 // ------------------------------------------------------------------------------ sample_points

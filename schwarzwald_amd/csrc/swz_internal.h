@@ -71,6 +71,7 @@ struct swz_ctx {
   void prof_end(const char* name, uint64_t launches, uint64_t bytes);
   void prof_collect();  // after a stream sync: fold pending events into kstats
   hipEvent_t cur_e0_ = nullptr;
+  void* shard = nullptr;  // swz::ShardState of an open sharded batch (swz_level.hip)
 };
 
 #define SWZ_HIP(ctx, expr)                                                \
@@ -131,6 +132,17 @@ struct TileDeviceOut {
 
 int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
                 const swz_tile_params& p, const TileDeviceOut& out, swz_tile_stats* stats);
+
+int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3],
+                       const double bmax[3], const swz_tile_params& p, uint64_t global_points,
+                       const double* d_ghost_xyz, uint32_t ghosts, uint64_t* num_root_taken);
+int shard_root_taken_device(swz_ctx* c, double* d_xyz_out);
+int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
+                        swz_tile_stats* stats);
+void shard_free(swz_ctx* c);
+// One radix pass on the top 8 key bits: perm groups the points by octant (stable); hist256 (host)
+// receives the digit counts.
+int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t hist256[256]);
 
 int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uint64_t* d_keys,
                          const uint32_t* d_idx, uint32_t n, const double* d_xyz, uint64_t node_key,

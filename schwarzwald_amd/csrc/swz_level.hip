@@ -7,7 +7,9 @@
 // the "active set" is the Morton-sorted array of points not yet taken; a node is a run of equal key
 // prefix, a sampling-grid cell a run of a longer prefix; taken points get their level recorded and
 // the survivors are stream-compacted (stable) into the next level's active set.
+#include <algorithm>
 #include <cmath>
+#include <vector>
 
 #include "swz_level.h"
 
@@ -563,10 +565,44 @@ static int alloc_level_buffers(swz_ctx* c, uint32_t m, LevelBuffers* lb) {
 }
 
 // ----------------------------------------------------------------------------- drivers
-int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
-                const swz_tile_params& p, const TileDeviceOut& out, swz_tile_stats* stats) {
-  if (p.strategy == SWZ_FAST) return c->fail(SWZ_ERR_BAD_ARG, "FAST strategy is not implemented yet");
-  // K1 + K2: index, sort (the output buffers double as the sort's primary buffers)
+// State of one batch between "indexed + sorted" and "all levels done".  Held in the context while a
+// sharded batch waits for its neighbours' root samples (swz_shard_begin / swz_shard_finish).
+struct TileSession {
+  uint32_t n = 0;
+  double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+  swz_tile_params params{};
+  uint64_t* keys = nullptr;  // sorted keys
+  uint32_t* perm = nullptr;  // original index per sorted position
+  int8_t* level = nullptr;
+  uint32_t* dup = nullptr;
+  SortedPoints sp;
+  LevelBuffers lb;
+  uint64_t* key_buf[2] = {nullptr, nullptr};
+  uint32_t* idx_buf[2] = {nullptr, nullptr};
+  int which = 0;
+  ActiveSet as;
+  int next_level = -1;
+  uint64_t visited = 0, nodes = 0;
+  uint32_t rounds = 0, nlevels = 0;
+  int max_level = -1;
+  int fast_start = -1;
+  uint32_t ghosts = 0;  // leading points that belong to other shards (sharded batches only)
+};
+
+// K1 + K2 + gather: index, sort, positions into Morton order
+static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n, const double bmin[3],
+                           const double bmax[3], const swz_tile_params& p, const TileDeviceOut& out) {
+  t = TileSession{};
+  t.n = n;
+  for (int a = 0; a < 3; ++a) {
+    t.bmin[a] = bmin[a];
+    t.bmax[a] = bmax[a];
+  }
+  t.params = p;
+  t.keys = out.keys;
+  t.perm = out.perm;
+  t.level = out.level;
+  t.dup = out.dup;
   uint64_t* keys_b = nullptr;
   uint32_t* vals_b = nullptr;
   SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
@@ -579,44 +615,299 @@ int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], con
   SWZ_TRY(c->get("sorted_z", (size_t)n, &Z));
   SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
-  SortedPoints sp{X, Y, Z};
-
-  LevelBuffers lb;
-  SWZ_TRY(alloc_level_buffers(c, n, &lb));
+  SWZ_HIP(c, hipMemsetAsync(out.level, 0x80, (size_t)n, c->stream));  // -128 = not persisted yet
+  t.sp = SortedPoints{X, Y, Z};
+  SWZ_TRY(alloc_level_buffers(c, n, &t.lb));
   // survivors ping-pong between the sort's secondary buffers and one extra pair
-  uint64_t* key_buf[2] = {keys_b, nullptr};
-  uint32_t* idx_buf[2] = {vals_b, nullptr};
-  ActiveSet as{out.keys, nullptr, n};
-  uint64_t visited = 0, nodes = 0;
-  uint32_t rounds = 0, nlevels = 0;
-  int max_level = -1;
-  int which = 0;
-  for (int level = -1; as.m > 0; ++level) {
+  t.key_buf[0] = keys_b;
+  t.idx_buf[0] = vals_b;
+  t.as = ActiveSet{out.keys, nullptr, n};
+  return SWZ_OK;
+}
+
+// Runs the level loop from t.next_level while points remain and level <= last_level.
+// root_mode: -1 = decide per node from its count; 0/1 force take-all/sample for the FIRST level run
+// (sharded batches decide the root from the global point count).
+static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int first_mode) {
+  for (int level = t.next_level; t.as.m > 0 && level <= last_level; ++level) {
     if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
-    if (!key_buf[which]) {
-      SWZ_TRY(c->get("active_keys_2", (size_t)as.m, &key_buf[which]));
-      SWZ_TRY(c->get("active_idx_2", (size_t)as.m, &idx_buf[which]));
+    if (!t.key_buf[t.which]) {
+      SWZ_TRY(c->get("active_keys_2", (size_t)t.as.m, &t.key_buf[t.which]));
+      SWZ_TRY(c->get("active_idx_2", (size_t)t.as.m, &t.idx_buf[t.which]));
     }
-    const LevelPlan plan =
-      make_plan(level, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
+    LevelPlan plan = make_plan(level, t.params.sampler, t.params.max_points_per_node, t.params.spacing_at_root,
+                               t.params.max_depth, t.bmin, t.bmax, false, true);
+    if (first_mode >= 0 && level == t.next_level && !plan.terminal) {
+      if (first_mode == 1) {
+        plan.force_sample = true;
+      } else {
+        plan.max_points = ~0ull;
+      }
+    }
     LevelResult r;
-    SWZ_TRY(level_step(c, plan, as, sp, lb, out.level, key_buf[which], idx_buf[which], &r));
-    visited += as.m;
-    nodes += r.num_nodes;
-    rounds += r.md_rounds;
-    max_level = level;
-    ++nlevels;
-    as = ActiveSet{key_buf[which], idx_buf[which], r.remaining};
-    which ^= 1;
+    SWZ_TRY(level_step(c, plan, t.as, t.sp, t.lb, t.level, t.key_buf[t.which], t.idx_buf[t.which], &r));
+    t.visited += t.as.m;
+    t.nodes += r.num_nodes;
+    t.rounds += r.md_rounds;
+    t.max_level = level;
+    ++t.nlevels;
+    t.as = ActiveSet{t.key_buf[t.which], t.idx_buf[t.which], r.remaining};
+    t.which ^= 1;
+    t.next_level = level + 1;
   }
-  if (stats) {
-    stats->num_nodes = nodes;
-    stats->points_visited = visited;
-    stats->max_level = max_level;
-    stats->fast_start_levels = -1;
-    stats->num_levels = nlevels;
-    stats->min_distance_rounds = rounds;
+  return SWZ_OK;
+}
+
+static void session_stats(const TileSession& t, swz_tile_stats* stats) {
+  if (!stats) return;
+  stats->num_nodes = t.nodes;
+  stats->points_visited = t.visited;
+  stats->max_level = t.max_level;
+  stats->fast_start_levels = t.fast_start;
+  stats->num_levels = t.nlevels;
+  stats->min_distance_rounds = t.rounds;
+}
+
+// ---- FAST (TilingAlgorithmV3) -------------------------------------------------------------------
+// first index whose 6-octant prefix is >= bin, for every bin of the 8^6 grid (+ the end sentinel)
+__global__ __launch_bounds__(256) void prefix_bounds_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                            uint32_t* __restrict__ starts, uint32_t nbins) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b > nbins) return;
+  if (b == nbins) {
+    starts[b] = n;
+    return;
   }
+  const uint64_t target = (uint64_t)b << 45;  // 63 - 6*3
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (keys[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  starts[b] = lo;
+}
+
+// estimate_start_node_level_in_octree -- TilingAlgorithms.cpp:1473-1535, from the 6-level prefix counts
+static size_t estimate_start_level_host(const std::vector<uint32_t>& starts6, size_t concurrency) {
+  constexpr uint32_t MIN_LEVEL = 3, MAX_LEVEL = 6;
+  constexpr float MIN_SCORE = 1.f;
+  for (uint32_t level = 0; level < MAX_LEVEL; ++level) {
+    const uint32_t digits = level + 1;
+    const uint32_t group = 1u << (3 * (6 - digits));  // 6-digit bins per range at this level
+    size_t ranges = 0, large = 0;
+    for (uint32_t b = 0; b < (1u << 18); b += group) {
+      const uint32_t cnt = starts6[b + group] - starts6[b];
+      if (cnt > 0) ++ranges;
+      if (cnt >= 100000) ++large;
+    }
+    float score = 0.f;
+    if (!(ranges <= concurrency / 2)) score = static_cast<float>(large) / static_cast<float>(concurrency);
+    if (score >= MIN_SCORE) return std::max(level + 1, MIN_LEVEL);
+  }
+  return MAX_LEVEL;
+}
+
+// children's persisted points of the nodes being reconstructed: taken at level S-1 (start nodes) or
+// flagged as stored in the reconstructed node one level below
+__global__ __launch_bounds__(256) void recon_select_kernel(const int8_t* __restrict__ level,
+                                                           const uint32_t* __restrict__ dup, uint32_t n,
+                                                           int start_node_level, uint32_t child_bit,
+                                                           uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  flags[i] = child_bit ? ((dup[i] & child_bit) ? 1u : 0u) : (level[i] == (int8_t)start_node_level ? 1u : 0u);
+}
+__global__ __launch_bounds__(256) void recon_gather_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                           const uint32_t* __restrict__ flags_in_scanned,
+                                                           const int8_t* __restrict__ level,
+                                                           const uint32_t* __restrict__ dup, int start_node_level,
+                                                           uint32_t child_bit, uint64_t* __restrict__ okey,
+                                                           uint32_t* __restrict__ oidx) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool sel = child_bit ? ((dup[i] & child_bit) != 0) : (level[i] == (int8_t)start_node_level);
+  if (sel) {
+    const uint32_t o = flags_in_scanned[i];
+    okey[o] = keys[i];
+    oidx[o] = i;
+  }
+}
+__global__ __launch_bounds__(256) void recon_mark_kernel(const uint32_t* __restrict__ aidx, uint32_t m,
+                                                         const uint8_t* __restrict__ taken, uint32_t bit,
+                                                         uint32_t* __restrict__ dup) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m && taken[i]) dup[aidx[i]] |= bit;
+}
+
+int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
+                const swz_tile_params& p, const TileDeviceOut& out_in, swz_tile_stats* stats) {
+  TileDeviceOut out = out_in;
+  if (p.strategy == SWZ_FAST && !out.dup) SWZ_TRY(c->get("fast_dup", (size_t)n, &out.dup));
+  TileSession t;
+  SWZ_TRY(session_prepare(c, t, d_xyz, n, bmin, bmax, p, out));
+  if (p.strategy == SWZ_ACCURATE) {
+    SWZ_TRY(session_run_levels(c, t, 20, -1));
+    session_stats(t, stats);
+    return SWZ_OK;
+  }
+  // ---- FAST: TilingAlgorithmV3 first iteration (:1250-1360) + finalize (:1717-1784)
+  const uint32_t nbins = 1u << 18;
+  uint32_t* d_starts = nullptr;
+  SWZ_TRY(c->get("fast_starts", (size_t)nbins + 1, &d_starts));
+  hipLaunchKernelGGL(prefix_bounds_kernel, dim3(div_up(nbins + 1, 256)), dim3(256), 0, c->stream, t.keys, n, d_starts,
+                     nbins);
+  SWZ_LAUNCH_CHECK(c);
+  std::vector<uint32_t> starts(nbins + 1);
+  SWZ_HIP(c, hipMemcpyAsync(starts.data(), d_starts, (nbins + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  const int S = (int)estimate_start_level_host(starts, p.fast_concurrency);
+  t.fast_start = S;
+  // every point starts in the node made of its first S octants (split_indexed_points_into_subranges)
+  t.next_level = S - 1;
+  SWZ_TRY(session_run_levels(c, t, 20, -1));
+  // reconstruct the skipped levels, deepest first: a node with lv octants samples the points persisted
+  // by its (up to) 8 children with AlwaysAdhereToMinSpacing (reconstruct_single_node :1661-1715)
+  uint64_t* rkey = nullptr;
+  uint32_t* ridx = nullptr;
+  SWZ_TRY(c->get("recon_keys", (size_t)n, &rkey));
+  SWZ_TRY(c->get("recon_idx", (size_t)n, &ridx));
+  const uint32_t nb = div_up(n, 256);
+  for (int lv = S - 1; lv >= 0; --lv) {
+    const uint32_t child_bit = (lv + 1 == S) ? 0u : (1u << (lv + 1));
+    hipLaunchKernelGGL(recon_select_kernel, dim3(nb), dim3(256), 0, c->stream, t.level, t.dup, n, S - 1, child_bit,
+                       t.lb.flags);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_HIP(c, hipMemsetAsync(t.lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
+    SWZ_TRY(scan_exclusive_u32(c, t.lb.flags, t.lb.flags, n, t.lb.counters + CTR_REMAINING, "rec"));
+    hipLaunchKernelGGL(recon_gather_kernel, dim3(nb), dim3(256), 0, c->stream, t.keys, n, t.lb.flags, t.level, t.dup,
+                       S - 1, child_bit, rkey, ridx);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t m = 0;
+    SWZ_HIP(c, hipMemcpyAsync(&m, t.lb.counters + CTR_REMAINING, 4, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (m == 0) continue;
+    const LevelPlan plan = make_plan(lv - 1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin,
+                                     bmax, true, false);
+    ActiveSet as{rkey, ridx, m};
+    LevelResult r;
+    SWZ_TRY(level_step(c, plan, as, t.sp, t.lb, nullptr, nullptr, nullptr, &r));
+    hipLaunchKernelGGL(recon_mark_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, ridx, m, t.lb.taken,
+                       1u << lv, t.dup);
+    SWZ_LAUNCH_CHECK(c);
+    t.nodes += r.num_nodes;
+    t.rounds += r.md_rounds;
+  }
+  session_stats(t, stats);
+  return SWZ_OK;
+}
+
+// ---- sharded batches ------------------------------------------------------------------------------
+struct ShardState {
+  TileSession t;
+  uint32_t n_local = 0;
+  bool open = false;
+};
+
+static ShardState* shard_state(swz_ctx* c) {
+  if (!c->shard) c->shard = new ShardState();
+  return static_cast<ShardState*>(c->shard);
+}
+void shard_free(swz_ctx* c) {
+  delete static_cast<ShardState*>(c->shard);
+  c->shard = nullptr;
+}
+
+__global__ __launch_bounds__(256) void root_taken_count_kernel(const int8_t* __restrict__ level, uint32_t first,
+                                                               uint32_t n, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flags[i] = (i >= first && level[i] == (int8_t)-1) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void root_taken_gather_kernel(const int8_t* __restrict__ level, uint32_t first,
+                                                                uint32_t n, const uint32_t* __restrict__ pos,
+                                                                const double* __restrict__ X,
+                                                                const double* __restrict__ Y,
+                                                                const double* __restrict__ Z,
+                                                                double* __restrict__ out_xyz) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || i < first || level[i] != (int8_t)-1) return;
+  const uint64_t o = pos[i];
+  out_xyz[3 * o] = X[i];
+  out_xyz[3 * o + 1] = Y[i];
+  out_xyz[3 * o + 2] = Z[i];
+}
+__global__ __launch_bounds__(256) void shard_strip_kernel(const uint64_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ perm,
+                                                          const int8_t* __restrict__ level, uint32_t ghosts,
+                                                          uint32_t n_local, uint64_t* __restrict__ okeys,
+                                                          uint32_t* __restrict__ operm, int8_t* __restrict__ olevel) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_local) return;
+  okeys[i] = keys[ghosts + i];
+  operm[i] = perm[ghosts + i] - ghosts;
+  olevel[i] = level[ghosts + i];
+}
+
+int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3],
+                       const double bmax[3], const swz_tile_params& p, uint64_t global_points,
+                       const double* d_ghost_xyz, uint32_t ghosts, uint64_t* num_root_taken) {
+  if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  ShardState* s = shard_state(c);
+  s->open = false;
+  const uint32_t total = n + ghosts;
+  double* xyz = nullptr;
+  SWZ_TRY(c->get("shard_xyz", (size_t)total * 3, &xyz));
+  if (ghosts) SWZ_HIP(c, hipMemcpyAsync(xyz, d_ghost_xyz, (size_t)ghosts * 24, hipMemcpyDeviceToDevice, c->stream));
+  SWZ_HIP(c, hipMemcpyAsync(xyz + (size_t)ghosts * 3, d_xyz_local, (size_t)n * 24, hipMemcpyDeviceToDevice, c->stream));
+  TileDeviceOut out{};
+  SWZ_TRY(c->get("shard_keys", (size_t)total, &out.keys));
+  SWZ_TRY(c->get("shard_perm", (size_t)total, &out.perm));
+  SWZ_TRY(c->get("shard_level", (size_t)total, &out.level));
+  SWZ_TRY(session_prepare(c, s->t, xyz, total, bmin, bmax, p, out));
+  s->t.ghosts = ghosts;
+  s->n_local = n;
+  // the root node spans all shards: its take-all / sample decision uses the global point count
+  const LevelPlan root_plan =
+    make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
+  if ((p.sampler == SWZ_RANDOM_GRID || p.sampler == SWZ_GRID_CENTER) && root_plan.cand < 0 &&
+      global_points > p.max_points_per_node)
+    return c->fail(SWZ_ERR_BAD_ARG, "sharded root with candidate level -1 (spacing >= half the extent) is unsupported");
+  SWZ_TRY(session_run_levels(c, s->t, -1, global_points > p.max_points_per_node ? 1 : 0));
+  // how many LOCAL points the root took (their positions become the next shard's ghosts)
+  const uint32_t nb = div_up(total, 256);
+  SWZ_HIP(c, hipMemsetAsync(s->t.lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(root_taken_count_kernel, dim3(nb), dim3(256), 0, c->stream, s->t.level, ghosts, total,
+                     s->t.lb.flags);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(scan_exclusive_u32(c, s->t.lb.flags, s->t.lb.flags, total, s->t.lb.counters + CTR_REMAINING, "shr"));
+  uint32_t cnt = 0;
+  SWZ_HIP(c, hipMemcpyAsync(&cnt, s->t.lb.counters + CTR_REMAINING, 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  if (num_root_taken) *num_root_taken = cnt;
+  s->open = true;
+  return SWZ_OK;
+}
+
+int shard_root_taken_device(swz_ctx* c, double* d_xyz_out) {
+  ShardState* s = shard_state(c);
+  if (!s->open) return c->fail(SWZ_ERR_BAD_ARG, "no sharded batch is open");
+  const uint32_t total = s->t.n;
+  // lb.flags still holds the exclusive scan of the root-taken flags of swz_shard_begin
+  hipLaunchKernelGGL(root_taken_gather_kernel, dim3(div_up(total, 256)), dim3(256), 0, c->stream, s->t.level,
+                     s->t.ghosts, total, s->t.lb.flags, s->t.sp.X, s->t.sp.Y, s->t.sp.Z, d_xyz_out);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}
+
+int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
+                        swz_tile_stats* stats) {
+  ShardState* s = shard_state(c);
+  if (!s->open) return c->fail(SWZ_ERR_BAD_ARG, "no sharded batch is open");
+  s->open = false;
+  SWZ_TRY(session_run_levels(c, s->t, 20, -1));
+  hipLaunchKernelGGL(shard_strip_kernel, dim3(div_up(s->n_local, 256)), dim3(256), 0, c->stream, s->t.keys, s->t.perm,
+                     s->t.level, s->t.ghosts, s->n_local, d_keys_out, d_perm_out, d_level_out);
+  SWZ_LAUNCH_CHECK(c);
+  session_stats(s->t, stats);
   return SWZ_OK;
 }
 

@@ -277,4 +277,34 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_a, uint32_t* d_vals_a, uint64_
   return SWZ_OK;
 }
 
+__global__ __launch_bounds__(256) void digit_starts_kernel(const uint32_t* __restrict__ offs, uint32_t ntiles,
+                                                           uint32_t* __restrict__ out) {
+  out[threadIdx.x] = offs[(uint64_t)threadIdx.x * ntiles];
+}
+
+int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t hist256[256]) {
+  for (int d = 0; d < 256; ++d) hist256[d] = 0;
+  if (n == 0) return SWZ_OK;
+  const uint32_t ntiles = div_up(n, RS_TILE);
+  uint32_t *d_hist = nullptr, *d_starts = nullptr;
+  uint64_t* d_keys_tmp = nullptr;
+  SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
+  SWZ_TRY(c->get("part_starts", (size_t)RADIX, &d_starts));
+  SWZ_TRY(c->get("part_keys", (size_t)n, &d_keys_tmp));
+  const int shift = 56;
+  hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, d_keys, n, shift, d_hist, ntiles);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(scan_exclusive_u32(c, d_hist, d_hist, (uint64_t)ntiles * RADIX, nullptr, "radix"));
+  hipLaunchKernelGGL(digit_starts_kernel, dim3(1), dim3(256), 0, c->stream, d_hist, ntiles, d_starts);
+  SWZ_LAUNCH_CHECK(c);
+  hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, d_keys,
+                     (const uint32_t*)nullptr, d_keys_tmp, d_perm_out, n, shift, d_hist, ntiles);
+  SWZ_LAUNCH_CHECK(c);
+  uint32_t starts[256];
+  SWZ_HIP(c, hipMemcpyAsync(starts, d_starts, sizeof(starts), hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  for (int d = 0; d < 256; ++d) hist256[d] = (uint64_t)((d == 255 ? n : starts[d + 1]) - starts[d]);
+  return SWZ_OK;
+}
+
 }  // namespace swz

@@ -234,3 +234,43 @@ def test_node_lists_group_points_by_node(ctx):
         sh = 63 if lvl < 0 else 3 * (20 - int(lvl))
         assert np.all((g.keys[members] >> np.uint64(sh)) == (np.uint64(key) >> np.uint64(sh)))
         assert np.all(np.diff(members.astype(np.int64)) > 0)  # Morton order inside the node
+
+
+# ----------------------------------------------------------------------------------------- FAST (TilingAlgorithmV3)
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("n,concurrency,max_pts", [(400000, 2, 2000), (150000, 8, 300)])
+def test_tile_fast_matches_oracle(ctx, sampler, n, concurrency, max_pts):
+    """FAST = start below the root (level chosen from the point distribution and the thread count), then
+    reconstruct the skipped levels from the children's samples; dup marks the duplicated points."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(n + concurrency)
+    xyz = rng.random((n, 3))
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    o = O.tile(xyz, *UNIT, sampler, max_pts, spacing, strategy=O.FAST, fast_concurrency=concurrency)
+    assert o["status"] == 0
+    p = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing, strategy=swz.FAST,
+                       fast_concurrency=concurrency)
+    g = ctx.tile(xyz, *UNIT, p)
+    assert g.stats["fast_start_levels"] == o["stats"]["fast_start_levels"]
+    assert np.array_equal(g.keys, o["keys"]) and np.array_equal(g.perm, o["perm"])
+    assert np.array_equal(g.level, o["level"])
+    assert np.array_equal(g.dup, o["dup"])
+    assert g.stats["num_nodes"] == o["stats"]["num_nodes"]
+    assert g.level.min() >= o["stats"]["fast_start_levels"] - 1  # nothing is persisted above the start level
+
+
+def test_tile_fast_start_level_depends_on_concurrency(ctx):
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(77)
+    xyz = rng.random((1_000_000, 3))
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    seen = set()
+    for conc in (1, 4, 64):
+        o = O.tile(xyz, *UNIT, O.RANDOM_GRID, 20000, spacing, strategy=O.FAST, fast_concurrency=conc)
+        p = swz.TileParams(sampler=swz.RANDOM_GRID, max_points_per_node=20000, spacing_at_root=spacing,
+                           strategy=swz.FAST, fast_concurrency=conc)
+        g = ctx.tile(xyz, *UNIT, p)
+        assert g.stats["fast_start_levels"] == o["stats"]["fast_start_levels"]
+        assert np.array_equal(g.level, o["level"]) and np.array_equal(g.dup, o["dup"])
+        seen.add(g.stats["fast_start_levels"])
+    assert len(seen) > 1

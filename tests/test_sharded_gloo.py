@@ -1,0 +1,154 @@
+"""world_size-2 tests of the multi-GPU path over gloo.
+
+CPU part (no GPU needed): the exchange plumbing -- owner map, send counts, all_to_all of row blocks -- moves
+every point to the rank that owns its level-0 octant, keeping the order inside each (source, octant) block.
+GPU part (-m gpu): both ranks share cuda:0 (collectives over gloo on CPU tensors), run the full sharded
+tiler and the union of their shards must equal the oracle's single-process result bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import oracle_lib as O  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _init(rank, world, port):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _cloud(n, seed):
+    return O.generate_uniform(seed, n)
+
+
+# ------------------------------------------------------------------ CPU: exchange plumbing
+def _exchange_worker(rank, world, port, n, q):
+    _init(rank, world, port)
+    from schwarzwald_amd import sharded
+    xyz = _cloud(n, 100 + rank)
+    keys, _ = O.index_points(xyz, [0, 0, 0], [1, 1, 1])
+    octant = (keys >> np.uint64(60)).astype(np.int64)
+    order = np.argsort(octant, kind="stable")  # what swz_partition_by_octant_device produces
+    counts = np.bincount(octant, minlength=8).tolist()
+    send_counts = sharded.rank_send_counts(counts, world)
+    rows = torch.from_numpy(xyz[order])
+    recv, recv_counts = sharded.exchange_rows(rows, send_counts)
+    q.put((rank, recv.numpy(), recv_counts))
+    dist.destroy_process_group()
+
+
+def test_exchange_moves_points_to_octant_owner():
+    world, n = 2, 5000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, recv, rc = q.get(timeout=120)
+        got[r] = (recv, rc)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from schwarzwald_amd import sharded
+    clouds = [_cloud(n, 100 + r) for r in range(world)]
+    for r in range(world):
+        recv, rc = got[r]
+        keys, _ = O.index_points(recv, [0, 0, 0], [1, 1, 1])
+        owners = np.array([sharded.owner_of_octant(int(k >> np.uint64(60)), world) for k in keys])
+        assert np.all(owners == r)
+        # block from source s = that source's points owned by r, in (octant, original index) order
+        off = 0
+        for s in range(world):
+            k, _ = O.index_points(clouds[s], [0, 0, 0], [1, 1, 1])
+            octant = (k >> np.uint64(60)).astype(np.int64)
+            order = np.argsort(octant, kind="stable")
+            mine = order[np.array([sharded.owner_of_octant(int(o), world) == r for o in octant[order]])]
+            assert rc[s] == len(mine)
+            assert np.array_equal(recv[off:off + rc[s]], clouds[s][mine])
+            off += rc[s]
+    assert sum(len(got[r][0]) for r in range(world)) == world * n
+
+
+def test_owner_map_is_monotone_and_balanced():
+    from schwarzwald_amd import sharded
+    for world in (1, 2, 4, 8):
+        owners = [sharded.owner_of_octant(o, world) for o in range(8)]
+        assert owners == sorted(owners) and set(owners) == set(range(world))
+        assert sharded.rank_send_counts([1] * 8, world) == [8 // world] * world
+
+
+# ------------------------------------------------------------------ GPU: full sharded tiler, 2 ranks on one GPU
+def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q):
+    _init(rank, world, port)
+    import schwarzwald_amd as swz
+    from schwarzwald_amd import sharded
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ctx = swz.Context(0)
+    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
+    xyz = torch.from_numpy(_cloud(n, 300 + rank)).to(dev)
+    tiler = sharded.ShardedTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
+    stats = tiler.tile(xyz)
+    recv, keys, perm, level = tiler.result
+    q.put((rank, recv.cpu().numpy(), keys.cpu().numpy().view(np.uint64), perm.cpu().numpy().view(np.uint32),
+           level.cpu().numpy(), stats))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+def test_sharded_tile_matches_oracle(sampler):
+    world, n, max_pts = 2, 60000, 500
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process oracle on the union of all points
+    union = np.vstack([_cloud(n, 300 + r) for r in range(world)])
+    ref = O.tile(union, [0, 0, 0], [1, 1, 1], sampler, max_pts, spacing)
+    assert ref["status"] == 0
+    ref_xyz = ref["xyz_clamped"][ref["perm"]]  # positions in Morton order
+    # concatenating the shards in rank order gives the global Morton order (ties aside: compare as multisets
+    # of (key, level, position) which is order independent)
+    keys = np.concatenate([got[r][1] for r in range(world)])
+    level = np.concatenate([got[r][3] for r in range(world)])
+    pos = np.vstack([got[r][0][got[r][2]] for r in range(world)])
+    assert np.array_equal(keys, ref["keys"])
+
+    def canon(k, lv, p):
+        rec = np.rec.fromarrays([k, lv, p[:, 0], p[:, 1], p[:, 2]], names="k,l,x,y,z")
+        return np.sort(rec, order=["k", "x", "y", "z", "l"])
+
+    a, b = canon(keys, level, pos), canon(ref["keys"], ref["level"], ref_xyz)
+    assert np.array_equal(a, b)
+    assert sum(got[r][4]["num_nodes"] for r in range(world)) - (world - 1) == ref["stats"]["num_nodes"]

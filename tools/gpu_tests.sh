@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 1200 python -m pytest tests -x -q -m gpu 2>&1 | tail -25
