@@ -1,0 +1,258 @@
+// swz_tiling.hpp -- host-side C++17 mirror of the reference's tiler/sampling interface on top of the
+// C ABI (include/swz_gpu.h).  Header only, no dependency besides the C++ standard library and
+// libswz_gpu.so.  Names, argument meaning and error behaviour follow the reference seams so that the
+// adapter a maintainer writes inside Schwarzwald is a thin forwarding layer:
+//
+//   reference (schwarzwald/core/...)                         here (namespace swz_host)
+//   ------------------------------------------------------   -----------------------------------------
+//   Vector3<double>, AABB            math/Vector3.h, AABB.h   Vector3d, AABB
+//   MortonIndex64                    MortonIndex.h:80-169     MortonIndex64 (uint64_t) + helpers
+//   IndexedPoint64                   tiling/Sampling.h:147    IndexedPoint64 {point_index, morton_index}
+//   OutlierPointsBehaviour           OctreeAlgorithms.h:20    OutlierPointsBehaviour
+//   index_points<21>                 OctreeAlgorithms.h:181   index_points
+//   Range::sort                      containers/Range.h:62    sort_indexed_points
+//   SamplingStrategy + factory       Sampling.h:761-791       SamplingStrategy, make_sampling_strategy_from_name
+//   SamplingBehaviour                Sampling.h:170-181       SamplingBehaviour
+//   sample_points                    Sampling.h:799-821       sample_points (returns the partition point)
+//   TilerMetaParameters              process/Tiler.h:64-75    TilerMetaParameters
+//   PointsPersistence::persist_points io/PointsPersistence.h  PointsSink::persist_points
+//   TilingAlgorithmBase              TilingAlgorithms.h:70    TilingAlgorithmGPU::tile_batch / finalize
+//   get_octant_bounds                OctreeAlgorithms.cpp:3   get_octant_bounds
+//
+// Errors: every failing ABI call becomes std::runtime_error carrying swz_last_error(), the way the
+// reference reports tiler failures (executable/main.cpp:599-602).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/swz_gpu.h"
+
+namespace swz_host {
+
+struct Vector3d {
+  double x = 0, y = 0, z = 0;
+};
+struct AABB {
+  Vector3d min, max;
+  Vector3d extent() const { return {max.x - min.x, max.y - min.y, max.z - min.z}; }
+};
+
+using MortonIndex64 = uint64_t;
+constexpr unsigned MortonIndex64Levels = 21;
+
+struct IndexedPoint64 {
+  uint32_t point_index;  // stands for PointBuffer::PointReference: row of the position array
+  MortonIndex64 morton_index;
+};
+
+enum class OutlierPointsBehaviour { ClampToBounds, Abort };
+enum class SamplingBehaviour { TakeAllWhenCountBelowMaxPoints, AlwaysAdhereToMinSpacing };
+enum class TilingStrategy { Accurate, Fast };
+
+struct SamplingStrategy {
+  int kind;  // SWZ_RANDOM_GRID ...
+  size_t max_points_per_node;
+};
+// make_sampling_strategy_from_name -- core/tiling/Sampling.h:774-791 (MIN_DISTANCE_FAST is out of scope)
+inline SamplingStrategy make_sampling_strategy_from_name(const std::string& name, size_t max_points_per_node) {
+  if (name == "RANDOM_GRID") return {SWZ_RANDOM_GRID, max_points_per_node};
+  if (name == "GRID_CENTER") return {SWZ_GRID_CENTER, max_points_per_node};
+  if (name == "MIN_DISTANCE") return {SWZ_MIN_DISTANCE, max_points_per_node};
+  if (name == "JITTERED") return {SWZ_JITTERED, max_points_per_node};
+  throw std::runtime_error{"Unrecognized sampling strategy name \"" + name + "\""};
+}
+
+struct TilerMetaParameters {  // core/process/Tiler.h:64-75
+  float spacing_at_root = 0.f;
+  uint32_t max_depth = 100;
+  size_t max_points_per_node = 20000;
+  TilingStrategy tiling_strategy = TilingStrategy::Accurate;
+  uint32_t num_indexing_threads = 8;  // FAST: decides the start level
+};
+
+// get_octant_bounds -- core/tiling/OctreeAlgorithms.cpp:3-18
+inline AABB get_octant_bounds(uint8_t octant, const AABB& parent) {
+  const Vector3d e = parent.extent();
+  const double min_z = (octant & 1) ? (parent.min.z + e.z / 2) : parent.min.z;
+  const double min_y = ((octant >> 1) & 1) ? (parent.min.y + e.y / 2) : parent.min.y;
+  const double min_x = ((octant >> 2) & 1) ? (parent.min.x + e.x / 2) : parent.min.x;
+  return {{min_x, min_y, min_z}, {min_x + e.x / 2, min_y + e.y / 2, min_z + e.z / 2}};
+}
+inline uint8_t get_octant_at_level(MortonIndex64 key, uint32_t level) {
+  return static_cast<uint8_t>((key >> ((MortonIndex64Levels - level - 1) * 3)) & 0b111);
+}
+
+// One swz_ctx, owned.  Not thread-safe (one call in flight per context).
+class Context {
+public:
+  explicit Context(int device = 0) {
+    if (swz_create(&_ctx, device) != SWZ_OK) throw std::runtime_error{swz_last_error(nullptr)};
+  }
+  ~Context() { swz_destroy(_ctx); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  swz_ctx* get() const { return _ctx; }
+  void check(int status) const {
+    if (status != SWZ_OK) throw std::runtime_error{swz_last_error(_ctx)};
+  }
+
+private:
+  swz_ctx* _ctx = nullptr;
+};
+
+// index_points<21> -- OctreeAlgorithms.h:181-197.  positions: n x 3 doubles (PointBuffer::positions().data());
+// outliers are clamped in place, like index_point does.
+inline void index_points(Context& ctx, double* positions, size_t n, IndexedPoint64* indexed_points_begin,
+                         const AABB& bounds, OutlierPointsBehaviour behaviour) {
+  if (behaviour != OutlierPointsBehaviour::ClampToBounds)
+    throw std::runtime_error{"only OutlierPointsBehaviour::ClampToBounds is implemented (the tiler never uses Abort)"};
+  std::vector<uint64_t> keys(n);
+  const double mn[3] = {bounds.min.x, bounds.min.y, bounds.min.z}, mx[3] = {bounds.max.x, bounds.max.y, bounds.max.z};
+  ctx.check(swz_morton_encode(ctx.get(), positions, n, mn, mx, keys.data()));
+  for (size_t i = 0; i < n; ++i) indexed_points_begin[i] = {static_cast<uint32_t>(i), keys[i]};
+}
+
+// Range<IndexedPointsIter>::sort -- containers/Range.h:62-66; ties keep their input order
+inline void sort_indexed_points(Context& ctx, IndexedPoint64* begin, IndexedPoint64* end) {
+  const size_t n = static_cast<size_t>(end - begin);
+  std::vector<uint64_t> keys(n);
+  for (size_t i = 0; i < n; ++i) keys[i] = begin[i].morton_index;
+  std::vector<uint32_t> perm(n);
+  ctx.check(swz_sort_by_key(ctx.get(), keys.data(), n, perm.data(), nullptr));
+  std::vector<IndexedPoint64> tmp(begin, end);
+  for (size_t i = 0; i < n; ++i) begin[i] = tmp[perm[i]];
+}
+
+// sample_points -- Sampling.h:799-821: stable partition of [begin, end) into [taken | rest], returns the
+// partition point.  positions: the PointBuffer's position array the point indices refer to.
+inline IndexedPoint64* sample_points(Context& ctx, const SamplingStrategy& strategy, IndexedPoint64* begin,
+                                     IndexedPoint64* end, MortonIndex64 node_key, int32_t node_level,
+                                     const AABB& root_bounds, float spacing_at_root, SamplingBehaviour behaviour,
+                                     const double* positions, size_t num_positions) {
+  const size_t n = static_cast<size_t>(end - begin);
+  std::vector<uint64_t> keys(n);
+  std::vector<uint32_t> idx(n);
+  for (size_t i = 0; i < n; ++i) {
+    keys[i] = begin[i].morton_index;
+    idx[i] = begin[i].point_index;
+  }
+  std::vector<uint8_t> taken(n);
+  uint64_t num_taken = 0;
+  const double mn[3] = {root_bounds.min.x, root_bounds.min.y, root_bounds.min.z};
+  const double mx[3] = {root_bounds.max.x, root_bounds.max.y, root_bounds.max.z};
+  ctx.check(swz_sample_points(ctx.get(), strategy.kind, strategy.max_points_per_node, keys.data(), idx.data(), n,
+                              positions, num_positions, node_key, node_level, mn, mx, spacing_at_root,
+                              behaviour == SamplingBehaviour::AlwaysAdhereToMinSpacing
+                                ? SWZ_ALWAYS_ADHERE_TO_MIN_SPACING
+                                : SWZ_TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS,
+                              taken.data(), &num_taken));
+  std::vector<IndexedPoint64> tmp(begin, end);
+  IndexedPoint64* front = begin;
+  IndexedPoint64* back = begin + num_taken;
+  for (size_t i = 0; i < n; ++i) *(taken[i] ? front++ : back++) = tmp[i];
+  return begin + num_taken;
+}
+
+// What the adapter needs from PointsPersistence (core/io/PointsPersistence.h:23-53).
+struct PointsSink {
+  virtual ~PointsSink() = default;
+  // points of one node, in Morton order; indices are rows of the batch's position array
+  virtual void persist_points(const uint32_t* indices_begin, const uint32_t* indices_end, const AABB& node_bounds,
+                              const std::string& node_name) = 0;
+};
+
+// The shape of TilingAlgorithmBase (core/tiling/TilingAlgorithms.h:70-116): one object per Tiler, fed one
+// batch at a time.  tile_batch() is what the single task emitted by build_execution_graph() runs:
+// upload -> kernels -> download -> one persist_points() call per node.
+class TilingAlgorithmGPU {
+public:
+  TilingAlgorithmGPU(SamplingStrategy sampling_strategy, PointsSink& persistence, TilerMetaParameters meta,
+                     int device = 0)
+    : _ctx(device), _sampling_strategy(sampling_strategy), _persistence(persistence), _meta(meta) {}
+
+  struct BatchResult {
+    swz_tile_stats stats;
+    size_t nodes_persisted;
+  };
+
+  // positions: n x 3 doubles of this batch (clamped in place); bounds: the octree's (cubic) root bounds
+  BatchResult tile_batch(double* positions, size_t n, const AABB& bounds) {
+    swz_tile_params p{};
+    p.sampler = _sampling_strategy.kind;
+    p.max_points_per_node = _sampling_strategy.max_points_per_node;
+    p.spacing_at_root = _meta.spacing_at_root;
+    p.max_depth = _meta.max_depth;
+    p.strategy = _meta.tiling_strategy == TilingStrategy::Fast ? SWZ_FAST : SWZ_ACCURATE;
+    p.fast_concurrency = _meta.num_indexing_threads;
+    std::vector<uint64_t> keys(n);
+    std::vector<uint32_t> perm(n), dup(n), order(n);
+    std::vector<int8_t> level(n);
+    swz_tile_stats stats{};
+    const double mn[3] = {bounds.min.x, bounds.min.y, bounds.min.z}, mx[3] = {bounds.max.x, bounds.max.y, bounds.max.z};
+    _ctx.check(swz_tile(_ctx.get(), positions, n, mn, mx, &p, keys.data(), perm.data(), level.data(), dup.data(),
+                        &stats));
+    // group the points by node and hand every node to the persistence
+    const uint64_t cap = n ? n : 1;
+    std::vector<int8_t> nl(cap);
+    std::vector<uint64_t> nk(cap), no(cap), nc(cap);
+    uint64_t nn = 0;
+    _ctx.check(swz_build_node_lists(_ctx.get(), keys.data(), level.data(), n, order.data(), cap, nl.data(), nk.data(),
+                                    no.data(), nc.data(), &nn));
+    size_t persisted = 0;
+    std::vector<uint32_t> indices;
+    for (uint64_t j = 0; j < nn; ++j) {
+      indices.resize(nc[j]);
+      for (uint64_t q = 0; q < nc[j]; ++q) indices[q] = perm[order[no[j] + q]];
+      persist_node(nl[j], nk[j], indices, bounds);
+      ++persisted;
+    }
+    // FAST: the reconstructed ancestors hold copies of some of their descendants' points
+    if (p.strategy == SWZ_FAST) {
+      for (int lv = stats.fast_start_levels - 1; lv >= 0; --lv) {
+        const uint32_t bit = 1u << lv;
+        const uint32_t sh = lv == 0 ? 63u : (MortonIndex64Levels - static_cast<uint32_t>(lv)) * 3u;
+        size_t i = 0;
+        while (i < n) {
+          if (!(dup[i] & bit)) {
+            ++i;
+            continue;
+          }
+          const uint64_t prefix = keys[i] >> sh;
+          indices.clear();
+          size_t j = i;
+          for (; j < n && (keys[j] >> sh) == prefix; ++j)
+            if (dup[j] & bit) indices.push_back(perm[j]);
+          persist_node(static_cast<int8_t>(lv - 1), lv == 0 ? 0 : (prefix << sh), indices, bounds);
+          ++persisted;
+          i = j;
+        }
+      }
+    }
+    return {stats, persisted};
+  }
+
+  void finalize(const AABB&) {}  // FAST's reconstruction already happened inside tile_batch (single batch)
+
+private:
+  void persist_node(int8_t level, uint64_t key, const std::vector<uint32_t>& indices, const AABB& root) {
+    std::string name = "r";  // node names: "r" + octant digits, TilingAlgorithms.cpp:139
+    AABB b = root;
+    for (int l = 0; l <= level; ++l) {
+      const uint8_t o = get_octant_at_level(key, static_cast<uint32_t>(l));
+      name.push_back(static_cast<char>('0' + o));
+      b = get_octant_bounds(o, b);
+    }
+    _persistence.persist_points(indices.data(), indices.data() + indices.size(), b, name);
+  }
+
+  Context _ctx;
+  SamplingStrategy _sampling_strategy;
+  PointsSink& _persistence;
+  TilerMetaParameters _meta;
+};
+
+}  // namespace swz_host
