@@ -32,7 +32,7 @@ namespace swz {
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
 constexpr int MD_THREADS = 256;
 constexpr int MD_WAVES = MD_THREADS / WAVE;
-constexpr int MD_EXT_CAP = 256;   // accepted points of the neighbourhood cached in LDS per wave (window)
+constexpr int MD_EXT_CAP = 128;   // accepted points of the neighbourhood cached in LDS per wave (window)
 constexpr int MD_FRESH_CAP = 64;  // points a cell may accept per activation
 
 enum : uint32_t { ST_STALLED = 0, ST_FINISHED = 1, ST_YIELD = 2 };
@@ -50,12 +50,10 @@ struct MdArgs {
   uint8_t* taken;
   uint32_t* counters;
   // cells
-  uint32_t* cstart;
-  uint32_t* cend;
+  uint4* cell;         // per cell {start, end, pos, cnt}: point range, committed frontier (active index),
+                       // committed number of accepted points -- one 16-byte load per adjacent cell
   uint32_t* crel;
   uint32_t* csnode;
-  uint32_t* pos;       // committed frontier (active index)
-  uint32_t* acc_cnt;   // committed number of accepted points
   uint32_t* npos;      // pending frontier / count / status written by the sweep kernel
   uint32_t* ncnt;
   uint32_t* status;
@@ -65,7 +63,7 @@ struct MdArgs {
   uint32_t* blk_cell;
   uint32_t* whead;     // wait list of cells sleeping on this cell
   uint32_t* wnext;
-  uint32_t* acc_list;  // per cell: sorted positions of its accepted points, at [cstart, cstart+acc_cnt)
+  double* acc_xyz;     // per cell: positions of its accepted points, 3 doubles each, at slots [start, start+cnt)
   uint32_t* gridmap;   // [sample node][cell code] -> cell index
   uint32_t* queue[2];
   const uint32_t* snode_of;  // node -> compact index among sampled nodes
@@ -102,11 +100,9 @@ __global__ __launch_bounds__(256) void md_cell_build_kernel(MdArgs a, const uint
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.m || !md_is_head(a, i)) return;
   const uint32_t c = excl[i];
-  a.cstart[c] = i;
+  a.cell[c] = make_uint4(i, 0u, i, 0u);
   a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
   a.csnode[c] = a.snode_of[a.nid[i]];
-  a.acc_cnt[c] = 0;
-  a.pos[c] = i;
   a.whead[c] = NONE32;
   a.blk_p[c] = NONE32;
 }
@@ -114,10 +110,10 @@ __global__ __launch_bounds__(256) void md_cell_build_kernel(MdArgs a, const uint
 __global__ __launch_bounds__(256) void md_cell_end_kernel(MdArgs a, uint32_t ncells) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ncells) return;
-  const uint32_t s = a.cstart[c];
+  const uint32_t s = a.cell[c].x;
   const uint32_t node_end = a.nstart[a.nid[s] + 1];
-  const uint32_t next = (c + 1 < ncells) ? a.cstart[c + 1] : a.m;
-  a.cend[c] = next < node_end ? next : node_end;
+  const uint32_t next = (c + 1 < ncells) ? a.cell[c + 1].x : a.m;
+  a.cell[c].y = next < node_end ? next : node_end;
   a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + a.crel[c]] = c;
 }
 
@@ -147,31 +143,26 @@ __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) {
 struct MdLds {
   double ex[MD_EXT_CAP], ey[MD_EXT_CAP], ez[MD_EXT_CAP];
   double fx[MD_FRESH_CAP], fy[MD_FRESH_CAP], fz[MD_FRESH_CAP];
-  uint32_t esp[MD_EXT_CAP];
 };
 
 // Fills the LDS window [base, base + MD_EXT_CAP) of the flattened list of accepted points of the
 // neighbourhood (lane k < 27 owns the n_cnt entries of adjacent cell k starting at list offset off).
 __device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, uint32_t base, uint32_t T,
                                                    uint32_t maxcnt, uint32_t n_cnt, uint32_t n_start, uint32_t off) {
-  const uint32_t l = lane_id();
   __builtin_amdgcn_wave_barrier();
+  const double* src = a.acc_xyz + (size_t)n_start * 3;
   for (uint32_t j = 0; j < maxcnt; ++j) {
     if (j < n_cnt) {
       const uint32_t ti = off + j;
-      if (ti >= base && ti < base + MD_EXT_CAP) lds.esp[ti - base] = a.acc_list[n_start + j];
+      if (ti >= base && ti < base + MD_EXT_CAP) {
+        lds.ex[ti - base] = src[3 * j];
+        lds.ey[ti - base] = src[3 * j + 1];
+        lds.ez[ti - base] = src[3 * j + 2];
+      }
     }
   }
   __builtin_amdgcn_wave_barrier();
-  const uint32_t wn = (T - base) < (uint32_t)MD_EXT_CAP ? (T - base) : (uint32_t)MD_EXT_CAP;
-  for (uint32_t ti = l; ti < wn; ti += WAVE) {
-    const uint32_t q = lds.esp[ti];
-    lds.ex[ti] = a.X[q];
-    lds.ey[ti] = a.Y[q];
-    lds.ez[ti] = a.Z[q];
-  }
-  __builtin_amdgcn_wave_barrier();
-  return wn;
+  return (T - base) < (uint32_t)MD_EXT_CAP ? (T - base) : (uint32_t)MD_EXT_CAP;
 }
 
 // squared slab distance from a point with slab coordinates (sx,sy,sz) to the adjacent cell in slot k
@@ -187,10 +178,11 @@ __device__ __forceinline__ bool md_culled(const MdArgs& a, int k, int sx, int sy
 // One wavefront advances the frontier of one active cell as far as it can.
 __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t l = lane_id();
-  const uint32_t s0 = a.cstart[c], e = a.cend[c], rel = a.crel[c];
+  const uint4 me = a.cell[c];
+  const uint32_t s0 = me.x, e = me.y, rel = a.crel[c];
   const uint64_t gbase = (uint64_t)a.csnode[c] * a.cells_per_node;
   const double t = a.sq_spacing;
-  const uint32_t P = a.pos[c], CNT = a.acc_cnt[c];
+  const uint32_t P = me.z, CNT = me.w;
 
   // lanes 0..26: the adjacent cells (13 = this cell); committed state of the earlier ones
   uint32_t nb = NONE32, n_cnt = 0, n_start = 0, n_pos = 0, n_end = 0;
@@ -206,10 +198,11 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
         nb = a.gridmap[gbase + nrel];
         if (nb != NONE32) {
           earlier = true;
-          n_cnt = a.acc_cnt[nb];
-          n_start = a.cstart[nb];
-          n_pos = a.pos[nb];
-          n_end = a.cend[nb];
+          const uint4 o = a.cell[nb];
+          n_start = o.x;
+          n_end = o.y;
+          n_pos = o.z;
+          n_cnt = o.w;
         }
       }
     }
@@ -382,7 +375,10 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       // accepted
       if ((int)l == j) {
         a.taken[cand] = 1;
-        a.acc_list[s0 + CNT + fresh] = sp;
+        double* dst = a.acc_xyz + (size_t)(s0 + CNT + fresh) * 3;
+        dst[0] = px;
+        dst[1] = py;
+        dst[2] = pz;
         lds.fx[fresh] = px;
         lds.fy[fresh] = py;
         lds.fz[fresh] = pz;
@@ -440,19 +436,25 @@ __global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round
   uint32_t* qout = a.queue[(round + 1) & 1];
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
     const uint32_t c = qin[i];
-    const uint32_t old = a.pos[c], np = a.npos[c];
-    a.pos[c] = np;
-    a.acc_cnt[c] = a.ncnt[c];
+    const uint32_t old = a.cell[c].z, np = a.npos[c];
+    a.cell[c].z = np;
+    a.cell[c].w = a.ncnt[c];
     const bool fin = a.status[c] == ST_FINISHED;
     if (fin) atomicAdd(&a.counters[CTR_DONE_CELLS], 1u);
     if (np > old || fin) {
-      uint32_t w = a.whead[c];
-      a.whead[c] = NONE32;
+      // wake the sleepers whose blocking point the frontier has passed; the others stay on the list
+      uint32_t w = a.whead[c], keep = NONE32;
       while (w != NONE32) {
         const uint32_t nx = a.wnext[w];
-        qout[atomicAdd(cout, 1u)] = w;
+        if (fin || a.blk_q[w] < np) {
+          qout[atomicAdd(cout, 1u)] = w;
+        } else {
+          a.wnext[w] = keep;
+          keep = w;
+        }
         w = nx;
       }
+      a.whead[c] = keep;
     }
   }
 }
@@ -471,7 +473,7 @@ __global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t roun
       qout[atomicAdd(cout, 1u)] = c;
     } else if (st == ST_STALLED) {
       const uint32_t b = a.blk_cell[c];
-      if (a.pos[b] > a.blk_q[c]) {
+      if (a.cell[b].z > a.blk_q[c]) {
         qout[atomicAdd(cout, 1u)] = c;
       } else {
         a.wnext[c] = atomicExch(&a.whead[b], c);
@@ -550,12 +552,13 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   if (ncells == 0) return SWZ_OK;
 
-  uint32_t* cellbuf = nullptr;  // 15 per-cell arrays
-  SWZ_TRY(c->get("md_cells", (size_t)ncells * 15, &cellbuf));
-  uint32_t** fields[] = {&a.cstart, &a.cend,     &a.crel,    &a.csnode,   &a.pos,   &a.acc_cnt, &a.npos, &a.ncnt,
-                         &a.status, &a.blk_p,    &a.blk_slot, &a.blk_q,   &a.blk_cell, &a.whead, &a.wnext};
-  for (size_t f = 0; f < 15; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
-  SWZ_TRY(c->get("md_acc_list", (size_t)m, &a.acc_list));
+  uint32_t* cellbuf = nullptr;  // 11 per-cell u32 arrays + the packed {start,end,pos,cnt} records
+  SWZ_TRY(c->get("md_cells", (size_t)ncells * 11, &cellbuf));
+  uint32_t** fields[] = {&a.crel,     &a.csnode, &a.npos,     &a.ncnt,  &a.status, &a.blk_p,
+                         &a.blk_slot, &a.blk_q,  &a.blk_cell, &a.whead, &a.wnext};
+  for (size_t f = 0; f < 11; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
+  SWZ_TRY(c->get("md_cell4", (size_t)ncells, &a.cell));
+  SWZ_TRY(c->get("md_acc_xyz", (size_t)m * 3, &a.acc_xyz));
   SWZ_TRY(c->get("md_queue0", (size_t)ncells, &a.queue[0]));
   SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
   const uint64_t grid_entries = (uint64_t)sample_nodes * cells_per_node;
