@@ -44,7 +44,7 @@ struct MdArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* nstart;
-  const double* X;
+  const double* X;     // positions in ACTIVE order (X[i] belongs to active point i)
   const double* Y;
   const double* Z;
   uint8_t* taken;
@@ -143,26 +143,37 @@ __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) {
 struct MdLds {
   double ex[MD_EXT_CAP], ey[MD_EXT_CAP], ez[MD_EXT_CAP];
   double fx[MD_FRESH_CAP], fy[MD_FRESH_CAP], fz[MD_FRESH_CAP];
+  uint8_t owner[MD_EXT_CAP];
 };
 
 // Fills the LDS window [base, base + MD_EXT_CAP) of the flattened list of accepted points of the
 // neighbourhood (lane k < 27 owns the n_cnt entries of adjacent cell k starting at list offset off).
 __device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, uint32_t base, uint32_t T,
                                                    uint32_t maxcnt, uint32_t n_cnt, uint32_t n_start, uint32_t off) {
+  const uint32_t l = lane_id();
+  const uint32_t wn = (T - base) < (uint32_t)MD_EXT_CAP ? (T - base) : (uint32_t)MD_EXT_CAP;
+  // which adjacent cell owns list entry ti: lane k marks its entries, then every lane fetches whole
+  // entries independently (all loads of the window are in flight together)
   __builtin_amdgcn_wave_barrier();
-  const double* src = a.acc_xyz + (size_t)n_start * 3;
   for (uint32_t j = 0; j < maxcnt; ++j) {
     if (j < n_cnt) {
       const uint32_t ti = off + j;
-      if (ti >= base && ti < base + MD_EXT_CAP) {
-        lds.ex[ti - base] = src[3 * j];
-        lds.ey[ti - base] = src[3 * j + 1];
-        lds.ez[ti - base] = src[3 * j + 2];
-      }
+      if (ti >= base && ti < base + MD_EXT_CAP) lds.owner[ti - base] = (uint8_t)l;
     }
   }
   __builtin_amdgcn_wave_barrier();
-  return (T - base) < (uint32_t)MD_EXT_CAP ? (T - base) : (uint32_t)MD_EXT_CAP;
+  for (uint32_t ti = l; ti < ((wn + WAVE - 1) / WAVE) * WAVE; ti += WAVE) {
+    const uint32_t k = ti < wn ? lds.owner[ti] : 0u;
+    const uint32_t ks = __shfl(n_start, (int)k, WAVE), ko = __shfl(off, (int)k, WAVE);
+    if (ti < wn) {
+      const double* src = a.acc_xyz + (size_t)(ks + (base + ti - ko)) * 3;
+      lds.ex[ti] = src[0];
+      lds.ey[ti] = src[1];
+      lds.ez[ti] = src[2];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return wn;
 }
 
 // squared slab distance from a point with slab coordinates (sx,sy,sz) to the adjacent cell in slot k
@@ -221,7 +232,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
 
   const bool resume = a.blk_p[c] == P;
-  const uint32_t r_slot = resume ? a.blk_slot[c] : 0u;
+  const uint32_t r_packed = resume ? a.blk_slot[c] : 0u;
+  const uint32_t r_slot = r_packed & 0xFFu;   // slot of the blocking cell
+  const uint32_t r_group = r_packed >> 8;    // first slot of the group that was being scanned
   const uint32_t r_q = resume ? a.blk_q[c] : 0u;
 
   uint32_t fresh = 0;
@@ -236,19 +249,31 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   while (cur < e && !stop) {
     const uint32_t p = cur + l;
     const bool valid = p < e;
-    uint32_t sp = 0;
     int sx = 0, sy = 0, sz = 0;
     double px = 0, py = 0, pz = 0;
     if (valid) {
-      sp = md_spos(a.aidx, p);
-      px = a.X[sp];
-      py = a.Y[sp];
-      pz = a.Z[sp];
+      px = a.X[p];
+      py = a.Y[p];
+      pz = a.Z[p];
       // slab coordinates inside the cell (culling of blocker scans)
       const uint64_t sub = (a.akey[p] >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
       sx = (int)contract_bits_by_3(sub >> 2);
       sy = (int)contract_bits_by_3(sub >> 1);
       sz = (int)contract_bits_by_3(sub);
+    }
+    // adjacent cells that can hold a point closer than the spacing to this lane's point: squared slab
+    // gaps per axis and direction, summed per slot (once per chunk, all lanes in parallel)
+    uint32_t needmask = 0;
+    {
+      const int smax = (1 << a.sub_levels) - 1;
+      const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
+                   lz = (double)sz, hz = (double)(smax - sz);
+      const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
+      const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
+      const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) needmask |= 1u << k;
     }
     bool rej = !valid;
     // (R) against the committed accepted points of the neighbourhood, window by window
@@ -289,7 +314,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       while (mm && !first_blocked) {
         const int k = __ffsll((unsigned long long)mm) - 1;
         mm &= mm - 1;
-        const bool need = !rej && !blk && !md_culled(a, k, sx, sy, sz);
+        const bool need = !rej && !blk && ((needmask >> k) & 1u);
         if (!__ballot(need)) continue;
         const uint32_t qs = bcast_u32(n_pos, k), qe = bcast_u32(n_end, k);
         for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
@@ -298,10 +323,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 #endif
           double qx = 0, qy = 0, qz = 0;
           if (q0 + l < qe) {
-            const uint32_t sq = md_spos(a.aidx, q0 + l);
-            qx = a.X[sq];
-            qy = a.Y[sq];
-            qz = a.Z[sq];
+            qx = a.X[q0 + l];
+            qy = a.Y[q0 + l];
+            qz = a.Z[q0 + l];
           }
           const int nq = (int)((qe - q0) < (uint32_t)WAVE ? (qe - q0) : WAVE);
           for (int j = 0; j < nq; ++j) {
@@ -327,21 +351,19 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       if (pre) {
         blocked = __builtin_amdgcn_readlane((int)blk, j) != 0;
         if (blocked) {
-          b_slot = bcast_u32(blk_slot_l, j);
+          const uint32_t hs = bcast_u32(blk_slot_l, j);
           b_q = bcast_u32(blk_q_l, j);
-          b_cell = bcast_u32(nb, (int)b_slot);
+          b_cell = bcast_u32(nb, (int)hs);
+          b_slot = hs | (still ? (r_group << 8) : 0u);
         }
       } else {
         // few survivors: scan the earlier adjacent cells for this candidate, 64 points at a time
-        const int csx = __builtin_amdgcn_readlane(sx, j), csy = __builtin_amdgcn_readlane(sy, j),
-                  csz = __builtin_amdgcn_readlane(sz, j);
-        uint64_t mm = emask;
         const bool res = resume && cand == P;
-        if (res) mm &= ~((1ull << r_slot) - 1ull);  // slots before r_slot were scanned clean already
-        while (mm && !blocked) {
-          const int k = __ffsll((unsigned long long)mm) - 1;
-          mm &= mm - 1;
-          if (md_culled(a, k, csx, csy, csz)) continue;
+        uint64_t nm = emask & (uint64_t)bcast_u32(needmask, j);
+        if (res) nm &= ~((1ull << r_group) - 1ull);  // slots before the stalled one were scanned clean
+        while (nm && !blocked) {
+          const int k = __ffsll((unsigned long long)nm) - 1;
+          nm &= nm - 1;
           uint32_t qs = bcast_u32(n_pos, k);
           const uint32_t qe = bcast_u32(n_end, k);
           if (res && (uint32_t)k == r_slot && r_q > qs) qs = r_q;
@@ -350,15 +372,11 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
             ++dbg_scan;
 #endif
             const uint32_t q = q0 + l;
-            bool hit = false;
-            if (q < qe) {
-              const uint32_t sq = md_spos(a.aidx, q);
-              hit = sq_dist(bx, by, bz, a.X[sq], a.Y[sq], a.Z[sq]) < t;
-            }
+            const bool hit = q < qe && sq_dist(bx, by, bz, a.X[q], a.Y[q], a.Z[q]) < t;
             const uint64_t hb = __ballot(hit);
             if (hb) {
               blocked = true;
-              b_slot = (uint32_t)k;
+              b_slot = (uint32_t)k | ((uint32_t)k << 8);
               b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
               b_cell = bcast_u32(nb, k);
               break;
@@ -419,7 +437,10 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   }
 }
 
-__global__ __launch_bounds__(MD_THREADS) void md_sweep_kernel(MdArgs a, uint32_t round) {
+#ifndef SWZ_MD_MIN_WAVES
+#define SWZ_MD_MIN_WAVES 5
+#endif
+__global__ __launch_bounds__(MD_THREADS, SWZ_MD_MIN_WAVES) void md_sweep_kernel(MdArgs a, uint32_t round) {
   __shared__ MdLds lds[MD_WAVES];
   const uint32_t w = threadIdx.x / WAVE;
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (round + 2) % 3] = 0;
@@ -428,34 +449,56 @@ __global__ __launch_bounds__(MD_THREADS) void md_sweep_kernel(MdArgs a, uint32_t
   for (uint32_t i = blockIdx.x * MD_WAVES + w; i < nq; i += gridDim.x * MD_WAVES) md_sweep_cell(a, qin[i], lds[w]);
 }
 
+// append `value` of every lane with want == true to the queue: one atomic per wavefront
+__device__ __forceinline__ void md_wave_push(bool want, uint32_t value, uint32_t* qout, uint32_t* cout) {
+  const uint64_t m = __ballot(want);
+  if (!m) return;
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane_id() == leader) base = atomicAdd(cout, (uint32_t)__popcll(m));
+  base = __shfl(base, leader, WAVE);
+  if (want) qout[base + (uint32_t)__popcll(m & lanemask_lt())] = value;
+}
+
 // publish the new frontiers; a cell whose frontier moved wakes the cells sleeping on it
 __global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round) {
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   const uint32_t* qin = a.queue[round & 1];
   uint32_t* qout = a.queue[(round + 1) & 1];
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
-    const uint32_t c = qin[i];
-    const uint32_t old = a.cell[c].z, np = a.npos[c];
-    a.cell[c].z = np;
-    a.cell[c].w = a.ncnt[c];
-    const bool fin = a.status[c] == ST_FINISHED;
-    if (fin) atomicAdd(&a.counters[CTR_DONE_CELLS], 1u);
-    if (np > old || fin) {
-      // wake the sleepers whose blocking point the frontier has passed; the others stay on the list
-      uint32_t w = a.whead[c], keep = NONE32;
-      while (w != NONE32) {
+  for (uint32_t i0 = blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < nq; i0 += gridDim.x * 256) {  // wave-uniform
+    const uint32_t i = i0 + lane_id();
+    const bool valid = i < nq;
+    uint32_t c = 0, np = 0, w = NONE32, keep = NONE32;
+    bool fin = false;
+    if (valid) {
+      c = qin[i];
+      const uint32_t old = a.cell[c].z;
+      np = a.npos[c];
+      a.cell[c].z = np;
+      a.cell[c].w = a.ncnt[c];
+      fin = a.status[c] == ST_FINISHED;
+      if (np > old || fin) w = a.whead[c];
+    }
+    const uint64_t fm = __ballot(fin);
+    if (fm && lane_id() == 0) atomicAdd(&a.counters[CTR_DONE_CELLS], (uint32_t)__popcll(fm));
+    const bool walk = valid && w != NONE32;
+    // wake the sleepers whose blocking point the frontier has passed; the others stay on the list
+    while (__ballot(w != NONE32)) {
+      bool wake = false;
+      uint32_t cur = w;
+      if (w != NONE32) {
         const uint32_t nx = a.wnext[w];
-        if (fin || a.blk_q[w] < np) {
-          qout[atomicAdd(cout, 1u)] = w;
-        } else {
+        wake = fin || a.blk_q[w] < np;
+        if (!wake) {
           a.wnext[w] = keep;
           keep = w;
         }
         w = nx;
       }
-      a.whead[c] = keep;
+      md_wave_push(wake, cur, qout, cout);
     }
+    if (walk) a.whead[c] = keep;
   }
 }
 
@@ -466,20 +509,39 @@ __global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t roun
   uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   const uint32_t* qin = a.queue[round & 1];
   uint32_t* qout = a.queue[(round + 1) & 1];
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256) {
-    const uint32_t c = qin[i];
-    const uint32_t st = a.status[c];
-    if (st == ST_YIELD) {
-      qout[atomicAdd(cout, 1u)] = c;
-    } else if (st == ST_STALLED) {
-      const uint32_t b = a.blk_cell[c];
-      if (a.cell[b].z > a.blk_q[c]) {
-        qout[atomicAdd(cout, 1u)] = c;
-      } else {
-        a.wnext[c] = atomicExch(&a.whead[b], c);
+  for (uint32_t i0 = blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < nq; i0 += gridDim.x * 256) {  // wave-uniform
+    const uint32_t i = i0 + lane_id();
+    bool push = false;
+    uint32_t c = 0;
+    if (i < nq) {
+      c = qin[i];
+      const uint32_t st = a.status[c];
+      if (st == ST_YIELD) {
+        push = true;
+      } else if (st == ST_STALLED) {
+        const uint32_t b = a.blk_cell[c];
+        if (a.cell[b].z > a.blk_q[c]) {
+          push = true;
+        } else {
+          a.wnext[c] = atomicExch(&a.whead[b], c);
+        }
       }
     }
+    md_wave_push(push, c, qout, cout);
   }
+}
+
+__global__ __launch_bounds__(256) void md_gather_active_kernel(const uint32_t* __restrict__ aidx, uint32_t m,
+                                                               const double* __restrict__ X,
+                                                               const double* __restrict__ Y,
+                                                               const double* __restrict__ Z, double* __restrict__ ax,
+                                                               double* __restrict__ ay, double* __restrict__ az) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t s = aidx[i];
+  ax[i] = X[s];
+  ay[i] = Y[s];
+  az[i] = Z[s];
 }
 
 __global__ __launch_bounds__(256) void md_fill_queue_kernel(uint32_t* q, uint32_t n, uint32_t* counter) {
@@ -498,7 +560,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   int cl = plan.cell_levels_geo;
   const double avg = (double)sample_points / (double)sample_nodes;
   int cl_density = 0;
-  while (cl_density < 10 && std::pow(8.0, cl_density + 1) * 8.0 <= avg) ++cl_density;
+  double per_cell = 8.0;
+  if (const char* e = getenv("SWZ_MD_DENSITY")) per_cell = atof(e);
+  while (cl_density < 10 && std::pow(8.0, cl_density + 1) * per_cell <= avg) ++cl_density;
   cl = std::max(0, std::min(cl, cl_density));
   const uint64_t cells_per_node = 1ull << (3 * cl);
 
@@ -512,6 +576,18 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   a.X = sp.X;
   a.Y = sp.Y;
   a.Z = sp.Z;
+  if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
+    double *ax = nullptr, *ay = nullptr, *az = nullptr;
+    SWZ_TRY(c->get("md_ax", (size_t)m, &ax));
+    SWZ_TRY(c->get("md_ay", (size_t)m, &ay));
+    SWZ_TRY(c->get("md_az", (size_t)m, &az));
+    hipLaunchKernelGGL(md_gather_active_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.aidx, m, sp.X, sp.Y,
+                       sp.Z, ax, ay, az);
+    SWZ_LAUNCH_CHECK(c);
+    a.X = ax;
+    a.Y = ay;
+    a.Z = az;
+  }
   a.taken = lb.taken;
   a.counters = lb.counters;
   a.cell_levels = (uint32_t)cl;
