@@ -253,17 +253,18 @@ int swz_sort_by_key_device(swz_ctx* c, const uint64_t* d_keys, uint64_t n, uint3
   SWZ_TRY(check_n(c, n));
   if (n == 0) return SWZ_OK;
   if (!d_keys || !d_perm_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_sort_by_key_device: NULL buffer");
-  uint64_t *ka = nullptr, *kb = nullptr;
-  uint32_t* vb = nullptr;
-  if (d_keys_sorted_out) {
-    ka = d_keys_sorted_out;
+  uint64_t *kin = nullptr, *kout = d_keys_sorted_out;
+  uint32_t* vtmp = nullptr;
+  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &kin));
+  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vtmp));
+  if (!kout) SWZ_TRY(c->get("sort_keys_a", (size_t)n, &kout));
+  if (swz::radix_result_in_second()) {
+    SWZ_HIP(c, hipMemcpyAsync(kin, d_keys, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_TRY(swz::radix_sort_pairs(c, kin, vtmp, kout, d_perm_out, (uint32_t)n, true));
   } else {
-    SWZ_TRY(c->get("sort_keys_a", (size_t)n, &ka));
+    SWZ_HIP(c, hipMemcpyAsync(kout, d_keys, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_TRY(swz::radix_sort_pairs(c, kout, d_perm_out, kin, vtmp, (uint32_t)n, true));
   }
-  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &kb));
-  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vb));
-  SWZ_HIP(c, hipMemcpyAsync(ka, d_keys, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
-  SWZ_TRY(swz::radix_sort_pairs(c, ka, d_perm_out, kb, vb, (uint32_t)n, true));
   return sync(c);
 }
 
@@ -279,8 +280,13 @@ int swz_sort_by_key(swz_ctx* c, const uint64_t* keys, uint64_t n, uint32_t* perm
   SWZ_TRY(c->get("sort_keys_b", (size_t)n, &kb));
   SWZ_TRY(c->get("sort_vals_a", (size_t)n, &va));
   SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vb));
-  SWZ_TRY(upload(c, ka, keys, (size_t)n * 8));
-  SWZ_TRY(swz::radix_sort_pairs(c, ka, va, kb, vb, (uint32_t)n, true));
+  if (swz::radix_result_in_second()) {
+    SWZ_TRY(upload(c, kb, keys, (size_t)n * 8));
+    SWZ_TRY(swz::radix_sort_pairs(c, kb, vb, ka, va, (uint32_t)n, true));
+  } else {
+    SWZ_TRY(upload(c, ka, keys, (size_t)n * 8));
+    SWZ_TRY(swz::radix_sort_pairs(c, ka, va, kb, vb, (uint32_t)n, true));
+  }
   SWZ_TRY(download(c, perm_out, va, (size_t)n * 4));
   if (keys_sorted_out) SWZ_TRY(download(c, keys_sorted_out, ka, (size_t)n * 8));
   return sync(c);
@@ -376,9 +382,7 @@ int swz_partition_by_octant_device(swz_ctx* c, const uint64_t* d_keys, uint64_t 
   for (int o = 0; o < 8; ++o) counts_out[o] = 0;
   if (n == 0) return SWZ_OK;
   if (!d_keys || !d_perm_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_partition_by_octant_device: NULL buffer");
-  uint64_t hist[256];
-  SWZ_TRY(swz::partition_top_digit(c, d_keys, (uint32_t)n, d_perm_out, hist));
-  for (int d = 0; d < 256; ++d) counts_out[(d >> 4) & 7] += hist[d];  // digit = key bits 56..63, octant = bits 60..62
+  SWZ_TRY(swz::partition_top_digit(c, d_keys, (uint32_t)n, d_perm_out, counts_out));
   return sync(c);
 }
 

@@ -109,11 +109,14 @@ int encode_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], c
                   uint64_t* d_keys);
 int generate_uniform_device(swz_ctx* c, uint64_t seed, uint64_t first, uint64_t n, double* d_xyz);
 
-// Stable LSD radix sort of (key, value) pairs.  Sorts d_keys_a/d_vals_a in place using the _b
-// buffers as the other half of the ping-pong (8 passes end in the _a buffers).  When
-// vals_identity is true the first pass synthesises value = element index instead of reading.
-int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_a, uint32_t* d_vals_a, uint64_t* d_keys_b,
-                     uint32_t* d_vals_b, uint32_t n, bool vals_identity);
+// Stable LSD radix sort of (key, value) pairs.  The keys in the FIRST pair (d_keys_in, and
+// d_vals_tmp unless vals_identity) are the input; both pairs are clobbered by the ping-pong and the
+// sorted result ends in the first pair for an even number of passes, in the second pair for an odd
+// one (radix_result_in_second()).  With vals_identity the first pass synthesises value = element
+// index instead of reading the values.
+bool radix_result_in_second();
+int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint64_t* d_keys_out,
+                     uint32_t* d_vals_out, uint32_t n, bool vals_identity);
 
 // Device-wide exclusive scan of a u32 array (in place allowed).  *d_total receives the sum.
 int scan_exclusive_u32(swz_ctx* c, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint32_t* d_total,
@@ -140,9 +143,9 @@ int shard_root_taken_device(swz_ctx* c, double* d_xyz_out);
 int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
                         swz_tile_stats* stats);
 void shard_free(swz_ctx* c);
-// One radix pass on the top 8 key bits: perm groups the points by octant (stable); hist256 (host)
-// receives the digit counts.
-int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t hist256[256]);
+// One radix pass on the top key digit: perm groups the points by octant (stable); octants (host)
+// receives the eight counts.
+int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t octants[8]);
 
 int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uint64_t* d_keys,
                          const uint32_t* d_idx, uint32_t n, const double* d_xyz, uint64_t node_key,

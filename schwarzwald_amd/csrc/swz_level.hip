@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "swz_level.h"
+#include "swz_scan.h"
 
 namespace swz {
 
@@ -22,6 +23,48 @@ namespace swz {
 __device__ __forceinline__ uint32_t spos_of(const uint32_t* aidx, uint32_t i) { return aidx ? aidx[i] : i; }
 
 // ----------------------------------------------------------------------------- node segmentation
+// fused form: node-head flag computed from the keys inside the scan, node id / node start written by it
+struct NodeHeadF {
+  const uint64_t* akey;
+  uint32_t nsh;
+  __device__ uint32_t operator()(uint32_t i) const {
+    return (i == 0) ? 1u : (uint32_t)((akey[i] >> nsh) != (akey[i - 1] >> nsh));
+  }
+};
+struct NodeAssignG {
+  uint32_t* nid;
+  uint32_t* nstart;
+  uint32_t m;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t head) const {
+    const uint32_t id = excl + head - 1u;
+    nid[i] = id;
+    if (head) nstart[id] = i;
+    if (i == m - 1) nstart[id + 1] = m;
+  }
+};
+// fused stable compaction: survivors move to the next level's active set, taken points get their level
+struct KeepF {
+  const uint8_t* taken;
+  __device__ uint32_t operator()(uint32_t i) const { return taken[i] ? 0u : 1u; }
+};
+struct CompactG {
+  const uint64_t* akey;
+  const uint32_t* aidx;
+  int8_t level;
+  int8_t* level_out;
+  uint64_t* okey;
+  uint32_t* oidx;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t keep) const {
+    const uint32_t p = aidx ? aidx[i] : i;
+    if (keep) {
+      okey[excl] = akey[i];
+      oidx[excl] = p;
+    } else {
+      level_out[p] = level;
+    }
+  }
+};
+
 __global__ __launch_bounds__(256) void node_head_kernel(const uint64_t* __restrict__ akey, uint32_t m,
                                                         uint32_t nsh, uint32_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -473,12 +516,9 @@ static int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, co
   const uint32_t nb = div_up(m, 256);
   SWZ_HIP(c, hipMemsetAsync(lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
   {
-    ProfScope ps(c, "level_nodes", (uint64_t)m * 8ull, 4);
-    hipLaunchKernelGGL(node_head_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, plan.node_shift, lb.flags);
-    SWZ_LAUNCH_CHECK(c);
-    SWZ_TRY(scan_exclusive_u32(c, lb.flags, lb.nid, m, lb.counters + CTR_NUM_NODES, "lvl"));
-    hipLaunchKernelGGL(node_finish_kernel, dim3(nb), dim3(256), 0, c->stream, lb.flags, lb.nid, m, lb.nstart);
-    SWZ_LAUNCH_CHECK(c);
+    ProfScope ps(c, "level_nodes", (uint64_t)m * 8ull, 3);
+    SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
+                       lb.counters + CTR_NUM_NODES, "lvl"));
     hipLaunchKernelGGL(node_mode_kernel, dim3(nb), dim3(256), 0, c->stream, lb.nstart, lb.nmode, lb.counters,
                        plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0);
     SWZ_LAUNCH_CHECK(c);
@@ -529,13 +569,9 @@ static int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, co
   }
 
   if (okey) {
-    ProfScope ps(c, "level_compact", (uint64_t)m * 14ull, 4);
-    hipLaunchKernelGGL(keep_flags_kernel, dim3(nb), dim3(256), 0, c->stream, lb.taken, m, lb.flags);
-    SWZ_LAUNCH_CHECK(c);
-    SWZ_TRY(scan_exclusive_u32(c, lb.flags, lb.flags, m, lb.counters + CTR_REMAINING, "lvl"));
-    hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, as.aidx, m, lb.taken, lb.flags,
-                       (int8_t)plan.level, level_out, okey, oidx);
-    SWZ_LAUNCH_CHECK(c);
+    ProfScope ps(c, "level_compact", (uint64_t)m * 14ull, 2);
+    SWZ_TRY(fused_scan(c, KeepF{lb.taken}, CompactG{as.akey, as.aidx, (int8_t)plan.level, level_out, okey, oidx}, m,
+                       lb.counters + CTR_REMAINING, "lvl"));
   }
   uint32_t h[CTR_COUNT];
   SWZ_HIP(c, hipMemcpyAsync(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
@@ -607,8 +643,13 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   uint32_t* vals_b = nullptr;
   SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
   SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vals_b));
-  SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, out.keys));
-  SWZ_TRY(radix_sort_pairs(c, out.keys, out.perm, keys_b, vals_b, n, true));
+  if (radix_result_in_second()) {  // place the input so that the sorted result lands in the output buffers
+    SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, keys_b));
+    SWZ_TRY(radix_sort_pairs(c, keys_b, vals_b, out.keys, out.perm, n, true));
+  } else {
+    SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, out.keys));
+    SWZ_TRY(radix_sort_pairs(c, out.keys, out.perm, keys_b, vals_b, n, true));
+  }
   double *X = nullptr, *Y = nullptr, *Z = nullptr;
   SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
   SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));

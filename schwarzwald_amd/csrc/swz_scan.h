@@ -1,0 +1,71 @@
+// swz_scan.h -- fused device-wide exclusive scan: the scanned value of element i is COMPUTED by a
+// functor (no flag array is materialised) and the result is CONSUMED by a second functor (node ids,
+// stream compaction, ...), so a "flag + scan + scatter" sequence costs two passes over the inputs
+// instead of five.  Three phases: per-tile sums -> scan of the tile sums (swz_sort.hip) -> apply.
+#pragma once
+#include <string>
+
+#include "swz_device.h"
+#include "swz_internal.h"
+
+namespace swz {
+
+constexpr int FS_THREADS = 256;
+constexpr int FS_IPT = 2;  // 2 x u64 = one 16-byte access per lane: loads and the compacted stores stay coalesced
+constexpr int FS_TILE = FS_THREADS * FS_IPT;
+
+template <typename F>
+__global__ __launch_bounds__(FS_THREADS) void fscan_partial_kernel(F f, uint32_t n, uint32_t* __restrict__ partial) {
+  __shared__ uint32_t lds[FS_THREADS / WAVE];
+  const uint32_t base = blockIdx.x * FS_TILE + threadIdx.x * FS_IPT;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < FS_IPT; ++j)
+    if (base + j < n) s += f(base + j);
+  uint32_t total;
+  block_excl_sum<FS_THREADS>(s, lds, total);
+  if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+template <typename F, typename G>
+__global__ __launch_bounds__(FS_THREADS) void fscan_apply_kernel(F f, G g, uint32_t n,
+                                                                 const uint32_t* __restrict__ partial_scanned) {
+  __shared__ uint32_t lds[FS_THREADS / WAVE];
+  const uint32_t base = blockIdx.x * FS_TILE + threadIdx.x * FS_IPT;
+  uint32_t v[FS_IPT];
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < FS_IPT; ++j) {
+    v[j] = (base + j < n) ? f(base + j) : 0u;
+    s += v[j];
+  }
+  uint32_t total;
+  uint32_t ex = block_excl_sum<FS_THREADS>(s, lds, total) + partial_scanned[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < FS_IPT; ++j) {
+    if (base + j < n) g(base + j, ex, v[j]);
+    ex += v[j];
+  }
+}
+
+// f: uint32_t(uint32_t i)   g: void(uint32_t i, uint32_t exclusive_prefix, uint32_t value)
+template <typename F, typename G>
+int fused_scan(swz_ctx* c, F f, G g, uint32_t n, uint32_t* d_total, const char* tag) {
+  if (n == 0) {
+    if (d_total) SWZ_HIP(c, hipMemsetAsync(d_total, 0, sizeof(uint32_t), c->stream));
+    return SWZ_OK;
+  }
+  const uint32_t nb = div_up(n, FS_TILE);
+  uint32_t* d_partial = nullptr;
+  const std::string name = std::string("fscan_partial_") + tag;
+  SWZ_TRY(c->get(name.c_str(), (size_t)nb, &d_partial));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fscan_partial_kernel<F>), dim3(nb), dim3(FS_THREADS), 0, c->stream, f, n, d_partial);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(scan_exclusive_u32(c, d_partial, d_partial, nb, d_total, tag));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fscan_apply_kernel<F, G>), dim3(nb), dim3(FS_THREADS), 0, c->stream, f, g, n,
+                     d_partial);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}
+
+}  // namespace swz

@@ -2,7 +2,8 @@
 //
 // Replaces Range::sort = std::sort of IndexedPoint64 (util/containers/Range.h:62-66) called at
 // core/tiling/TilingAlgorithms.cpp:602 / :1292.  Keys are 63-bit, payload is the 32-bit point index;
-// 8 passes of 8-bit digits.  Per pass: per-tile digit histogram -> one device-wide scan over the
+// 8 passes of 8-bit digits (9-bit digits / 7 passes were measured: the shorter digit runs of a
+// 4096-key tile store less contiguously and the saved pass is lost again).  Per pass: per-tile digit histogram -> one device-wide scan over the
 // [digit][tile] table -> scatter.  The scatter ranks keys with wave64 ballots (match-any on the
 // digit), prefix-sums per-wave digit counts in LDS, exchanges the tile through LDS so that global
 // stores of one digit run are contiguous, and is stable (ties keep their input order), which makes
@@ -101,7 +102,10 @@ constexpr int RS_WAVES = RS_THREADS / WAVE;
 constexpr int RS_KPT = 16;                      // keys per thread
 constexpr int RS_TILE = RS_THREADS * RS_KPT;    // 4096 keys per workgroup
 constexpr int RS_WAVE_SPAN = WAVE * RS_KPT;     // 1024 consecutive keys per wave
-constexpr int RADIX = 256;
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;         // 256 bins
+constexpr int RADIX_PASSES = 8;                // 8 * 8 = 64 >= 63 key bits
+constexpr int DPT = RADIX / RS_THREADS;        // digits owned by one thread
 
 // per-tile digit histogram -> hist[digit * ntiles + tile]
 __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
@@ -110,26 +114,32 @@ __global__ __launch_bounds__(RS_THREADS) void radix_hist_kernel(const uint64_t* 
   __shared__ uint32_t h[RS_WAVES][RADIX];
   const uint32_t tid = threadIdx.x, w = tid / WAVE;
 #pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) h[i][tid] = 0;
+  for (int i = 0; i < RS_WAVES; ++i)
+#pragma unroll
+    for (int d = 0; d < DPT; ++d) h[i][tid * DPT + d] = 0;
   __syncthreads();
   const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
 #pragma unroll
   for (int k = 0; k < RS_KPT; ++k) {
     const uint64_t i = base + (uint64_t)k * RS_THREADS + tid;
-    if (i < n) atomicAdd(&h[w][(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    if (i < n) atomicAdd(&h[w][(uint32_t)(keys[i] >> shift) & (RADIX - 1)], 1u);
   }
   __syncthreads();
-  uint32_t s = 0;
 #pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) s += h[i][tid];
-  hist[(uint64_t)tid * ntiles + blockIdx.x] = s;
+  for (int d = 0; d < DPT; ++d) {
+    const uint32_t dg = tid * DPT + d;
+    uint32_t s = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) s += h[i][dg];
+    hist[(uint64_t)dg * ntiles + blockIdx.x] = s;
+  }
 }
 
-// wave64 match-any on an 8-bit digit among the lanes set in `valid`
+// wave64 match-any on a digit among the lanes set in `valid`
 __device__ __forceinline__ uint64_t match_digit(uint32_t d, uint64_t valid) {
   uint64_t peers = valid;
 #pragma unroll
-  for (int b = 0; b < 8; ++b) {
+  for (int b = 0; b < RADIX_BITS; ++b) {
     const bool bit = (d >> b) & 1u;
     const uint64_t m = __ballot(bit);
     peers &= bit ? m : ~m;
@@ -155,8 +165,12 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
   const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)RS_TILE ? (n - tile_base) : RS_TILE);
 
 #pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) whist[i][tid] = 0;
-  gbase[tid] = offs[(uint64_t)tid * ntiles + blockIdx.x];
+  for (int d = 0; d < DPT; ++d) {
+    const uint32_t dg = tid * DPT + d;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) whist[i][dg] = 0;
+    gbase[dg] = offs[(uint64_t)dg * ntiles + blockIdx.x];
+  }
 
   // wave-blocked arrangement: wave w owns keys [w*1024, (w+1)*1024) of the tile, item k of lane l is
   // element w*1024 + k*64 + l, so the order inside the tile is (wave, item, lane)
@@ -185,7 +199,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
     const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
     const bool ok = e < tile_n;
     const uint64_t valid = __ballot(ok);
-    const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+    const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
     const uint64_t peers = match_digit(d, valid);
     uint32_t pre = 0;
     if (ok) {
@@ -202,17 +216,29 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
   }
   __syncthreads();
 
-  // thread t owns digit t: exclusive prefix over the waves, tile total, then exclusive scan over digits
+  // thread t owns digits t*DPT ..: exclusive prefix over the waves, tile totals, then exclusive scan over digits
+  uint32_t cnt[DPT];
   uint32_t s = 0;
 #pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) {
-    const uint32_t t = whist[i][tid];
-    whist[i][tid] = s;
-    s += t;
+  for (int d = 0; d < DPT; ++d) {
+    const uint32_t dg = tid * DPT + d;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) {
+      const uint32_t t = whist[i][dg];
+      whist[i][dg] = acc;
+      acc += t;
+    }
+    cnt[d] = acc;
+    s += acc;
   }
   uint32_t total;
-  const uint32_t ds = block_excl_sum<RS_THREADS>(s, scan_lds, total);
-  dstart[tid] = ds;
+  uint32_t ds = block_excl_sum<RS_THREADS>(s, scan_lds, total);
+#pragma unroll
+  for (int d = 0; d < DPT; ++d) {
+    dstart[tid * DPT + d] = ds;
+    ds += cnt[d];
+  }
   __syncthreads();
 
   // exchange through LDS: position inside the digit-sorted tile
@@ -220,7 +246,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
   for (int k = 0; k < RS_KPT; ++k) {
     const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
     if (e < tile_n) {
-      const uint32_t d = (uint32_t)(key[k] >> shift) & 255u;
+      const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
       const uint32_t p = dstart[d] + whist[w][d] + rank[k];
       xkeys[p] = key[k];
       xvals[p] = val[k];
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
     const uint32_t j = k * RS_THREADS + tid;
     if (j < tile_n) {
       const uint64_t kk = xkeys[j];
-      const uint32_t d = (uint32_t)(kk >> shift) & 255u;
+      const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
       const uint32_t dst = gbase[d] + (j - dstart[d]);
       keys_out[dst] = kk;
       vals_out[dst] = xvals[j];
@@ -242,18 +268,21 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
   }
 }
 
-int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_a, uint32_t* d_vals_a, uint64_t* d_keys_b, uint32_t* d_vals_b,
-                     uint32_t n, bool vals_identity) {
+bool radix_result_in_second() { return (RADIX_PASSES & 1) != 0; }
+
+int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint64_t* d_keys_out,
+                     uint32_t* d_vals_out, uint32_t n, bool vals_identity) {
   if (n == 0) return SWZ_OK;
   const uint32_t ntiles = div_up(n, RS_TILE);
   uint32_t* d_hist = nullptr;
   SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
-  uint64_t* kin = d_keys_a;
-  uint32_t* vin = d_vals_a;
-  uint64_t* kout = d_keys_b;
-  uint32_t* vout = d_vals_b;
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = pass * 8;
+  // the data ping-pongs first -> second -> first ...; radix_result_in_second() tells where it ends
+  uint64_t* kin = d_keys_in;
+  uint32_t* vin = d_vals_tmp;
+  uint64_t* kout = d_keys_out;
+  uint32_t* vout = d_vals_out;
+  for (int pass = 0; pass < RADIX_PASSES; ++pass) {
+    const int shift = pass * RADIX_BITS;
     {
       ProfScope ps(c, "radix_hist", (uint64_t)n * 8ull);
       hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, kin, n, shift, d_hist,
@@ -277,13 +306,13 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_a, uint32_t* d_vals_a, uint64_
   return SWZ_OK;
 }
 
-__global__ __launch_bounds__(256) void digit_starts_kernel(const uint32_t* __restrict__ offs, uint32_t ntiles,
-                                                           uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(RADIX) void digit_starts_kernel(const uint32_t* __restrict__ offs, uint32_t ntiles,
+                                                             uint32_t* __restrict__ out) {
   out[threadIdx.x] = offs[(uint64_t)threadIdx.x * ntiles];
 }
 
-int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t hist256[256]) {
-  for (int d = 0; d < 256; ++d) hist256[d] = 0;
+int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t octants[8]) {
+  for (int o = 0; o < 8; ++o) octants[o] = 0;
   if (n == 0) return SWZ_OK;
   const uint32_t ntiles = div_up(n, RS_TILE);
   uint32_t *d_hist = nullptr, *d_starts = nullptr;
@@ -291,19 +320,20 @@ int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t
   SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
   SWZ_TRY(c->get("part_starts", (size_t)RADIX, &d_starts));
   SWZ_TRY(c->get("part_keys", (size_t)n, &d_keys_tmp));
-  const int shift = 56;
+  const int shift = 64 - RADIX_BITS;  // top digit; the octant (key bits 60..62) is its bits below the unused bit 63
   hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, d_keys, n, shift, d_hist, ntiles);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, d_hist, d_hist, (uint64_t)ntiles * RADIX, nullptr, "radix"));
-  hipLaunchKernelGGL(digit_starts_kernel, dim3(1), dim3(256), 0, c->stream, d_hist, ntiles, d_starts);
+  hipLaunchKernelGGL(digit_starts_kernel, dim3(1), dim3(RADIX), 0, c->stream, d_hist, ntiles, d_starts);
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, d_keys,
                      (const uint32_t*)nullptr, d_keys_tmp, d_perm_out, n, shift, d_hist, ntiles);
   SWZ_LAUNCH_CHECK(c);
-  uint32_t starts[256];
+  uint32_t starts[RADIX];
   SWZ_HIP(c, hipMemcpyAsync(starts, d_starts, sizeof(starts), hipMemcpyDeviceToHost, c->stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
-  for (int d = 0; d < 256; ++d) hist256[d] = (uint64_t)((d == 255 ? n : starts[d + 1]) - starts[d]);
+  for (int d = 0; d < RADIX; ++d)
+    octants[(d >> (RADIX_BITS - 4)) & 7] += (uint64_t)((d == RADIX - 1 ? n : starts[d + 1]) - starts[d]);
   return SWZ_OK;
 }
 
