@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void take_all_kernel(uint32_t m, const uint32_
 // Both pick, per run of equal grid-cell prefix, the first point with the smallest squared distance
 // to a per-cell target (std::min_element, Sampling.h:392-403 / :741-750): a segmented arg-min.
 constexpr int GA_THREADS = 256;
-constexpr int GA_IPT = 4;
+constexpr int GA_IPT = 1;
 constexpr int GA_TILE = GA_THREADS * GA_IPT;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
