@@ -144,7 +144,8 @@ int swz_build_node_lists(swz_ctx* ctx, const uint64_t* keys_sorted, const int8_t
  * the device-side pieces:
  *   swz_partition_by_octant_device: perm groups point indices by octant 0..7 (stable inside an
  *     octant); counts_out[o] = points of octant o.
- *   swz_shard_begin_device: indexes + sorts the shard's points and samples the ROOT node, whose
+ *   swz_shard_begin_device: indexes + sorts the shard's points (d_xyz_local stays referenced until
+ *     swz_shard_finish_device returns and may be clamped in place) and samples the ROOT node, whose
  *     take-all/sample decision uses shard->global_points.  For MIN_DISTANCE the root couples the
  *     shards: the points the root took on all lower octants are passed as ghosts (they sort first and
  *     are accepted again, rejecting exactly what the single-GPU sweep would reject).
@@ -154,7 +155,8 @@ int swz_build_node_lists(swz_ctx* ctx, const uint64_t* keys_sorted, const int8_t
  *     local points (keys ascending, perm = index into the local xyz, level). */
 typedef struct {
   uint64_t global_points;      /* points of the whole batch over all shards */
-  const double* d_ghost_xyz;   /* device, num_ghosts x 3; all ghosts must lie in lower octants */
+  const double* d_ghost_xyz;   /* device, num_ghosts x 3; all ghosts must lie in lower octants.  When the
+                                  ghosts end exactly where d_xyz_local starts, no staging copy is made */
   uint64_t num_ghosts;
 } swz_shard_info;
 int swz_partition_by_octant_device(swz_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t* d_perm_out,

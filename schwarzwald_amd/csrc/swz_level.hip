@@ -896,9 +896,16 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   s->open = false;
   const uint32_t total = n + ghosts;
   double* xyz = nullptr;
-  SWZ_TRY(c->get("shard_xyz", (size_t)total * 3, &xyz));
-  if (ghosts) SWZ_HIP(c, hipMemcpyAsync(xyz, d_ghost_xyz, (size_t)ghosts * 24, hipMemcpyDeviceToDevice, c->stream));
-  SWZ_HIP(c, hipMemcpyAsync(xyz + (size_t)ghosts * 3, d_xyz_local, (size_t)n * 24, hipMemcpyDeviceToDevice, c->stream));
+  if (ghosts == 0) {
+    xyz = const_cast<double*>(d_xyz_local);  // already inside the bounds (it was encoded before the exchange)
+  } else if (d_ghost_xyz + (size_t)ghosts * 3 == d_xyz_local) {
+    xyz = const_cast<double*>(d_ghost_xyz);  // caller laid the ghosts out right in front of its points
+  } else {
+    SWZ_TRY(c->get("shard_xyz", (size_t)total * 3, &xyz));
+    SWZ_HIP(c, hipMemcpyAsync(xyz, d_ghost_xyz, (size_t)ghosts * 24, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_HIP(c, hipMemcpyAsync(xyz + (size_t)ghosts * 3, d_xyz_local, (size_t)n * 24, hipMemcpyDeviceToDevice,
+                              c->stream));
+  }
   TileDeviceOut out{};
   SWZ_TRY(c->get("shard_keys", (size_t)total, &out.keys));
   SWZ_TRY(c->get("shard_perm", (size_t)total, &out.perm));

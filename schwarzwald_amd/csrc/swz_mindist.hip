@@ -74,6 +74,8 @@ struct MdArgs {
   // blocker-scan culling: a cell is cut into 2^sub_levels slabs per axis; usq[a] = squared slab width
   uint32_t sub_levels;
   uint32_t batch_blockers;   // very sparse level: test all surviving lanes in one pass over the neighbours
+  uint32_t early_recheck;    // re-activated cells first continue the stalled candidate's blocker scan
+  uint32_t ablate;           // debugging only (SWZ_MD_ABLATE): 1 = never blocked, 2 = no rejection tests
   double usq[3];
   double cull_sq;            // sq_spacing with a safety margin
 };
@@ -228,14 +230,71 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     const uint32_t o = __shfl_xor(maxcnt, d, WAVE);
     maxcnt = o > maxcnt ? o : maxcnt;
   }
-  uint32_t wn0 = 0;
-  if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
-
   const bool resume = a.blk_p[c] == P;
   const uint32_t r_packed = resume ? a.blk_slot[c] : 0u;
   const uint32_t r_slot = r_packed & 0xFFu;   // slot of the blocking cell
   const uint32_t r_group = r_packed >> 8;    // first slot of the group that was being scanned
   const uint32_t r_q = resume ? a.blk_q[c] : 0u;
+
+  // Re-activation of a stalled cell: before paying for the accepted-points window and the rejection
+  // tests of the whole chunk, continue the blocker scan of the stalled candidate P where it stopped.
+  // Going back to sleep on a new blocker is always safe (a rejection of P is simply found later).
+  bool p_clear = false;  // P has no possibly-undecided earlier neighbour in this activation's snapshot
+  if (resume && a.early_recheck && !(a.ablate & 1u)) {
+    const double bx = a.X[P], by = a.Y[P], bz = a.Z[P];
+    uint32_t pmask = 0;
+    {
+      const uint64_t sub = (a.akey[P] >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+      const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1),
+                sz = (int)contract_bits_by_3(sub);
+      const int smax = (1 << a.sub_levels) - 1;
+      const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
+                   lz = (double)sz, hz = (double)(smax - sz);
+      const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
+      const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
+      const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) pmask |= 1u << k;
+    }
+    uint64_t nm = emask & (uint64_t)pmask & ~((1ull << r_group) - 1ull);
+    bool blocked = false;
+    uint32_t b_slot = 0, b_q = 0, b_cell = 0;
+    while (nm && !blocked) {
+      const int k = __ffsll((unsigned long long)nm) - 1;
+      nm &= nm - 1;
+      uint32_t qs = bcast_u32(n_pos, k);
+      const uint32_t qe = bcast_u32(n_end, k);
+      if ((uint32_t)k == r_slot && r_q > qs) qs = r_q;
+      for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
+        const uint32_t q = q0 + l;
+        const bool hit = q < qe && sq_dist(bx, by, bz, a.X[q], a.Y[q], a.Z[q]) < t;
+        const uint64_t hb = __ballot(hit);
+        if (hb) {
+          blocked = true;
+          b_slot = (uint32_t)k | ((uint32_t)k << 8);
+          b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
+          b_cell = bcast_u32(nb, k);
+          break;
+        }
+      }
+    }
+    if (blocked && !(a.ablate & 4u)) {
+      if (l == 0) {
+        a.npos[c] = P;
+        a.ncnt[c] = CNT;
+        a.status[c] = ST_STALLED;
+        a.blk_slot[c] = b_slot;
+        a.blk_q[c] = b_q;
+        a.blk_cell[c] = b_cell;
+      }
+      return;
+    }
+    p_clear = true;
+  }
+
+  uint32_t wn0 = 0;
+  if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
 
   uint32_t fresh = 0;
 #ifdef SWZ_MD_STATS
@@ -277,7 +336,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     }
     bool rej = !valid;
     // (R) against the committed accepted points of the neighbourhood, window by window
-    for (uint32_t base = 0; base < T; base += MD_EXT_CAP) {
+    for (uint32_t base = 0; base < T && !(a.ablate & 2u); base += MD_EXT_CAP) {
       const uint32_t wn = (base == 0 && T <= (uint32_t)MD_EXT_CAP && cur == P)
                             ? wn0
                             : ((T <= (uint32_t)MD_EXT_CAP) ? wn0 : md_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off));
@@ -300,7 +359,8 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     uint32_t blk_slot_l = 0, blk_q_l = 0;
     const int first_alive = alive ? __ffsll((unsigned long long)alive) - 1 : 0;
     bool still = false;  // the stalled candidate of the last activation is still blocked by the same point
-    if (resume && cur == P && (alive & 1ull) && ((emask >> r_slot) & 1ull) && bcast_u32(n_pos, (int)r_slot) <= r_q) {
+    if (!p_clear && resume && cur == P && (alive & 1ull) && ((emask >> r_slot) & 1ull) &&
+        bcast_u32(n_pos, (int)r_slot) <= r_q) {
       still = true;
       blk = (l == 0);
       blk_slot_l = r_slot;
@@ -360,6 +420,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
         // few survivors: scan the earlier adjacent cells for this candidate, 64 points at a time
         const bool res = resume && cand == P;
         uint64_t nm = emask & (uint64_t)bcast_u32(needmask, j);
+        if ((a.ablate & 1u) || (p_clear && cand == P)) nm = 0;
         if (res) nm &= ~((1ull << r_group) - 1ull);  // slots before the stalled one were scanned clean
         while (nm && !blocked) {
           const int k = __ffsll((unsigned long long)nm) - 1;
@@ -384,6 +445,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
           }
         }
       }
+      if (a.ablate & 4u) blocked = false;
       if (blocked) {
         out_pos = cand;
         out_status = ST_STALLED;
@@ -606,6 +668,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       a.usq[ax] = u * u;
     }
     a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
+    a.ablate = getenv("SWZ_MD_ABLATE") ? (uint32_t)atoi(getenv("SWZ_MD_ABLATE")) : 0u;
     // expected points per spacing-sized cell; far below one almost every candidate is accepted
     a.batch_blockers = (avg / std::pow(8.0, plan.cell_levels_geo) < 0.25) ? 1u : 0u;
   }
@@ -649,6 +712,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, a.queue[0], ncells,
                      lb.counters + CTR_Q0);
   SWZ_LAUNCH_CHECK(c);
+
+  // With many small cells a round is bound by activation throughput: futile re-activations must be
+  // cheap.  With few large cells it is bound by the latency of one activation: no extra scan.
+  a.early_recheck = (ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0) ? 1u : 0u;
 
   // rounds; the host only looks at the done counter every `batch` rounds
   const bool dbg = getenv("SWZ_DEBUG") != nullptr;

@@ -32,9 +32,13 @@ def rank_send_counts(octant_counts, world):
     return out
 
 
-def exchange_rows(rows, send_counts, group=None):
+GHOST_HEADROOM = 4 << 20  # rows reserved in front of the received points for MIN_DISTANCE root ghosts
+
+
+def exchange_rows(rows, send_counts, group=None, headroom=0):
     """all_to_all_single of row blocks.  rows: [n, k] tensor already grouped by destination rank;
-    send_counts[r] rows go to rank r.  Returns (received rows, recv_counts)."""
+    send_counts[r] rows go to rank r.  Returns (buffer, recv_counts): the received rows are buffer[headroom:]
+    (the first `headroom` rows are left free so that a few rows can later be put right in front)."""
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = rows.device
@@ -43,10 +47,17 @@ def exchange_rows(rows, send_counts, group=None):
     rc = torch.empty(world, dtype=torch.int64, device=comm_dev)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(v) for v in rc.tolist()]
-    send = rows if rows.device == comm_dev else rows.to(comm_dev)
-    recv = torch.empty((sum(recv_counts),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=comm_dev)
-    dist.all_to_all_single(recv, send.contiguous(), recv_counts, [int(v) for v in send_counts], group=group)
-    return (recv if recv.device == dev else recv.to(dev)), recv_counts
+    m = sum(recv_counts)
+    buf = torch.empty((headroom + m,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
+    if comm_dev == dev:
+        dist.all_to_all_single(buf[headroom:], rows.contiguous(), recv_counts, [int(v) for v in send_counts],
+                               group=group)
+    else:
+        recv = torch.empty((m,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=comm_dev)
+        dist.all_to_all_single(recv, rows.to(comm_dev).contiguous(), recv_counts, [int(v) for v in send_counts],
+                               group=group)
+        buf[headroom:].copy_(recv)
+    return buf, recv_counts
 
 
 class ShardedTiler:
@@ -85,14 +96,18 @@ class ShardedTiler:
         send = xyz.index_select(0, perm.long())
         del perm
         # 2. the one exchange step
-        recv, _ = exchange_rows(send, send_counts, self.group)
-        del send
-        m = recv.shape[0]
         total = torch.tensor([n], dtype=torch.int64, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(total, group=self.group)
         global_points = int(total.item())
-        # 3. root node
         sequential_root = self.params.sampler == api.MIN_DISTANCE and global_points > self.params.max_points_per_node
+        headroom = GHOST_HEADROOM if (sequential_root and self.rank > 0) else 0
+        buf, _ = exchange_rows(send, send_counts, self.group, headroom)
+        del send
+        if dev.type == "cuda":
+            torch.cuda.empty_cache()  # hand the freed send buffers back: the context allocates with hipMalloc
+        recv = buf[headroom:]
+        m = recv.shape[0]
+        # 3. root node
         if not sequential_root:
             ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points)
         else:
@@ -101,9 +116,17 @@ class ShardedTiler:
                 cnt = torch.zeros(1, dtype=torch.int64, device=dev)
                 mine = None
                 if r == self.rank:
-                    g = torch.cat(ghosts) if ghosts else torch.empty((0, 3), dtype=torch.float64, device=dev)
+                    g = sum(t.shape[0] for t in ghosts)
+                    if g == 0:
+                        gptr = None
+                    elif g <= headroom:  # ghosts go right in front of the received points: no staging copy
+                        torch.cat(ghosts, out=buf[headroom - g:headroom])
+                        gptr = buf[headroom - g:].data_ptr()
+                    else:
+                        gbuf = torch.cat(ghosts)
+                        gptr = gbuf.data_ptr()
                     taken = ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points,
-                                                   g.data_ptr() if g.shape[0] else None, g.shape[0])
+                                                   gptr, g)
                     mine = torch.empty((taken, 3), dtype=torch.float64, device=dev)
                     if taken:
                         ctx.shard_root_taken_device(mine.data_ptr())
@@ -111,16 +134,17 @@ class ShardedTiler:
                 if r == world - 1:
                     break  # nobody owns higher octants
                 self._bcast(cnt, r)
-                buf = mine if r == self.rank else torch.empty((int(cnt.item()), 3), dtype=torch.float64, device=dev)
-                if buf.shape[0]:
-                    self._bcast(buf, r)
+                b = mine if r == self.rank else torch.empty((int(cnt.item()), 3), dtype=torch.float64, device=dev)
+                if b.shape[0]:
+                    self._bcast(b, r)
                 if self.rank > r:
-                    ghosts.append(buf)
+                    ghosts.append(b)
         # 4. everything below the root is local
         okeys = torch.empty(m, dtype=torch.int64, device=dev)
         operm = torch.empty(m, dtype=torch.int32, device=dev)
         olevel = torch.empty(m, dtype=torch.int8, device=dev)
         stats = ctx.shard_finish_device(okeys.data_ptr(), operm.data_ptr(), olevel.data_ptr())
         self.result = (recv, okeys, operm, olevel)
+        self._keepalive = buf  # the context reads the points until shard_finish returned
         stats["shard_points"] = m
         return stats

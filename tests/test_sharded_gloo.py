@@ -47,8 +47,8 @@ def _exchange_worker(rank, world, port, n, q):
     counts = np.bincount(octant, minlength=8).tolist()
     send_counts = sharded.rank_send_counts(counts, world)
     rows = torch.from_numpy(xyz[order])
-    recv, recv_counts = sharded.exchange_rows(rows, send_counts)
-    q.put((rank, recv.numpy(), recv_counts))
+    buf, recv_counts = sharded.exchange_rows(rows, send_counts, headroom=3)
+    q.put((rank, buf[3:].numpy(), recv_counts))
     dist.destroy_process_group()
 
 
