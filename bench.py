@@ -46,6 +46,20 @@ def algorithmic_bytes_per_point(sampler, visit_factor):
     return 32.0 + 200.0 + per_level * visit_factor
 
 
+def measured_traffic(kernel_class, n, sampler):
+    """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
+    (profiles/r01/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
+    command, corrected as MI355X_MICROARCH.md prescribes).  None when no matching profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None
+    if t.get("points") != n or t.get("sampler") != sampler:
+        return None
+    return t.get("bytes_per_launch", {}).get(kernel_class)
+
+
 def cpu_baseline(args, spacing):
     """The oracle (CPU restatement of the reference path, single thread) on a bounded sample of the same
     workload: same generator, bounds, spacing and parameters, fewer points."""
@@ -144,7 +158,8 @@ def main():
             alg_per_launch = k["algorithmic_bytes"] / max(k["launches"], 1)
             achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": measured_traffic(name, n, args.sampler),
                         "launches": k["launches"], "avg_launch_ms": round(avg_ms, 4)}
         alg = algorithmic_bytes_per_point(args.sampler, visit)
         out = {

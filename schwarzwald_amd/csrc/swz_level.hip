@@ -651,10 +651,12 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
     SWZ_TRY(radix_sort_pairs(c, out.keys, out.perm, keys_b, vals_b, n, true));
   }
   double *X = nullptr, *Y = nullptr, *Z = nullptr;
-  SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
-  SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));
-  SWZ_TRY(c->get("sorted_z", (size_t)n, &Z));
-  SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
+  if (p.sampler != SWZ_RANDOM_GRID) {  // RANDOM_GRID decides on the keys alone
+    SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
+    SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));
+    SWZ_TRY(c->get("sorted_z", (size_t)n, &Z));
+    SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
+  }
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(out.level, 0x80, (size_t)n, c->stream));  // -128 = not persisted yet
   t.sp = SortedPoints{X, Y, Z};

@@ -1,0 +1,33 @@
+# Collects this round's evidence into gpurun_out/profile/: the bench line, the rocprofv3 kernel summary of
+# the same command, and HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate --pmc passes).
+cd $GRAFT_REPO_ROOT
+OUT=$GRAFT_REPO_ROOT/gpurun_out/profile
+rm -rf $OUT; mkdir -p $OUT
+python bench.py > $OUT/bench_1B_min_distance.json 2> $OUT/bench.err
+python bench.py --points 100000000 --sampler GRID_CENTER --steps 5 --warmup 2 --cpu-sample 2000000 > $OUT/bench_100M_grid_center.json 2>> $OUT/bench.err
+for s in RANDOM_GRID GRID_CENTER JITTERED; do
+  python bench.py --sampler $s --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_$s.json 2>> $OUT/bench.err
+done
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/stats_run.json 2>/dev/null
+find $OUT/stats -name "*kernel_trace*" -delete
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+python3 - <<'PY'
+import csv, glob, collections, os
+out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profile")
+for tag in ("fetch", "write"):
+    for f in glob.glob(os.path.join(out, "pmc_%s" % tag, "**", "*counter_collection.csv"), recursive=True):
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                k = row.get("Kernel_Name", "?").split("(")[0]
+                agg[k][0] += 1
+                agg[k][1] += float(row.get("Counter_Value", 0) or 0)
+        with open(os.path.join(out, "pmc_%s_SIZE_by_kernel.csv" % tag.upper()), "w") as o:
+            o.write("kernel,dispatches,sum_counter_value_KiB\n")
+            for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                o.write("%s,%d,%.1f\n" % (k, n, v))
+        os.remove(f)
+PY
+ls -la $OUT; head -c 600 $OUT/bench_1B_min_distance.json; echo; cat $OUT/bench.err | tail -3
