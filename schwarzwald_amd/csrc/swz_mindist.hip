@@ -221,6 +221,29 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     }
   }
   const uint64_t emask = __ballot(earlier && n_pos < n_end);  // neighbours that may still hold undecided points
+  // Blocker scans visit the earlier adjacent cells LATEST FIRST (largest Morton code first): decisions
+  // arrive roughly in Morton order, so the blocker found first tends to be the one decided last and one
+  // sleep covers the others.  rank 0 = latest; slot_of_rank lives in lane r; masks below are in rank space.
+  uint32_t nrel_key = 0;
+  if (earlier) {
+    uint32_t nrel;
+    md_neighbour_code(rel, a.cell_levels, (int)l, nrel);
+    nrel_key = nrel + 1u;
+  }
+  uint32_t rank = 0;
+  for (int jj = 0; jj < 27; ++jj) {
+    const uint32_t kj = bcast_u32(nrel_key, jj);
+    rank += (kj > nrel_key) ? 1u : 0u;
+  }
+  uint32_t slot_of_rank = 0;
+  uint32_t emask_r = 0;
+  for (int r = 0; r < 27; ++r) {
+    const uint64_t bm = __ballot(earlier && rank == (uint32_t)r);
+    if (!bm) break;
+    const uint32_t k = (uint32_t)__ffsll((unsigned long long)bm) - 1u;
+    if ((int)l == r) slot_of_rank = k;
+    if ((emask >> k) & 1ull) emask_r |= 1u << r;
+  }
   const uint32_t incl = wave_incl_sum(n_cnt);
   const uint32_t off = incl - n_cnt;
   const uint32_t T = bcast_u32(incl, WAVE - 1);  // accepted points of the neighbourhood (incl. own committed)
@@ -233,7 +256,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const bool resume = a.blk_p[c] == P;
   const uint32_t r_packed = resume ? a.blk_slot[c] : 0u;
   const uint32_t r_slot = r_packed & 0xFFu;   // slot of the blocking cell
-  const uint32_t r_group = r_packed >> 8;    // first slot of the group that was being scanned
+  const uint32_t r_group = r_packed >> 8;    // rank (scan position) of that cell: earlier ranks were scanned clean
   const uint32_t r_q = resume ? a.blk_q[c] : 0u;
 
   // Re-activation of a stalled cell: before paying for the accepted-points window and the rejection
@@ -257,12 +280,16 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       for (int k = 0; k < 27; ++k)
         if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) pmask |= 1u << k;
     }
-    uint64_t nm = emask & (uint64_t)pmask & ~((1ull << r_group) - 1ull);
+    uint32_t nm = 0;
+    for (int r = 0; r < 27; ++r)
+      if ((emask_r >> r) & 1u) nm |= ((pmask >> bcast_u32(slot_of_rank, r)) & 1u) << r;
+    nm &= ~((1u << r_group) - 1u);
     bool blocked = false;
     uint32_t b_slot = 0, b_q = 0, b_cell = 0;
     while (nm && !blocked) {
-      const int k = __ffsll((unsigned long long)nm) - 1;
+      const int r = __ffs((int)nm) - 1;
       nm &= nm - 1;
+      const int k = (int)bcast_u32(slot_of_rank, r);
       uint32_t qs = bcast_u32(n_pos, k);
       const uint32_t qe = bcast_u32(n_end, k);
       if ((uint32_t)k == r_slot && r_q > qs) qs = r_q;
@@ -272,7 +299,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
         const uint64_t hb = __ballot(hit);
         if (hb) {
           blocked = true;
-          b_slot = (uint32_t)k | ((uint32_t)k << 8);
+          b_slot = (uint32_t)k | ((uint32_t)r << 8);
           b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
           b_cell = bcast_u32(nb, k);
           break;
@@ -334,6 +361,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       for (int k = 0; k < 27; ++k)
         if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) needmask |= 1u << k;
     }
+    uint32_t needrank = 0;  // the same in scan order, restricted to cells that may hold undecided points
+    for (int r = 0; r < 27; ++r)
+      if ((emask_r >> r) & 1u) needrank |= ((needmask >> bcast_u32(slot_of_rank, r)) & 1u) << r;
     bool rej = !valid;
     // (R) against the committed accepted points of the neighbourhood, window by window
     for (uint32_t base = 0; base < T && !(a.ablate & 2u); base += MD_EXT_CAP) {
@@ -419,12 +449,13 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       } else {
         // few survivors: scan the earlier adjacent cells for this candidate, 64 points at a time
         const bool res = resume && cand == P;
-        uint64_t nm = emask & (uint64_t)bcast_u32(needmask, j);
+        uint32_t nm = bcast_u32(needrank, j);
         if ((a.ablate & 1u) || (p_clear && cand == P)) nm = 0;
-        if (res) nm &= ~((1ull << r_group) - 1ull);  // slots before the stalled one were scanned clean
+        if (res) nm &= ~((1u << r_group) - 1u);  // cells scanned before the stalled one were clean
         while (nm && !blocked) {
-          const int k = __ffsll((unsigned long long)nm) - 1;
+          const int r = __ffs((int)nm) - 1;
           nm &= nm - 1;
+          const int k = (int)bcast_u32(slot_of_rank, r);
           uint32_t qs = bcast_u32(n_pos, k);
           const uint32_t qe = bcast_u32(n_end, k);
           if (res && (uint32_t)k == r_slot && r_q > qs) qs = r_q;
@@ -437,7 +468,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
             const uint64_t hb = __ballot(hit);
             if (hb) {
               blocked = true;
-              b_slot = (uint32_t)k | ((uint32_t)k << 8);
+              b_slot = (uint32_t)k | ((uint32_t)r << 8);
               b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
               b_cell = bcast_u32(nb, k);
               break;
