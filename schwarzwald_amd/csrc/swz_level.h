@@ -74,4 +74,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
                        const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes,
                        uint32_t sample_points, uint32_t* rounds_out);
 
+// Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
+// qualify.  ax/ay/az: positions in active order; snode_of: node -> index among the sampled nodes.
+int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const double* ax,
+                              const double* ay, const double* az, const LevelBuffers& lb, const uint32_t* snode_of,
+                              uint32_t sample_nodes, uint32_t sample_points, uint32_t* rounds_out, bool* used);
+
 }  // namespace swz

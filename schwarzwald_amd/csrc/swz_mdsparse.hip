@@ -1,0 +1,241 @@
+// swz_mdsparse.hip -- MIN_DISTANCE for SPARSE levels: one thread per point.
+//
+// Same result as the frontier sweep of swz_mindist.hip (the lexicographically-first maximal
+// independent set in Morton order, PoissonDiskSampling / SparseGrid::add, core/tiling/Sampling.h:421-471,
+// core/datastructures/SparseGrid.cpp:116-146), computed the other way round.  When a spacing-sized cell
+// holds about one point, nearly every point is accepted and a wavefront per cell idles 63 lanes, so:
+//   1. every point looks up its 27 adjacent cells once (dense [node][cell] table of run starts) and
+//      records its EARLIER neighbours closer than the spacing (exact compare, usually 0-3 of them);
+//   2. fixpoint rounds over the still undecided points: rejected when a recorded neighbour is accepted,
+//      accepted when all of them are rejected, otherwise wait.  States only move undecided -> final, so a
+//      stale read is conservative; the number of rounds is the dependency depth (tens).
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "swz_level.h"
+
+namespace swz {
+
+constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
+constexpr int SP_K = 12;  // recorded neighbours per point; more -> the point re-searches every round
+enum : uint8_t { SP_U = 0, SP_A = 1, SP_R = 2 };
+
+struct SpArgs {
+  const uint64_t* akey;
+  const uint32_t* nid;
+  const uint8_t* nmode;
+  const uint32_t* snode_of;
+  const double* X;  // active order
+  const double* Y;
+  const double* Z;
+  uint32_t m;
+  uint32_t cell_shift;      // key >> cell_shift = node prefix + cell code
+  uint32_t cell_levels;
+  uint64_t cells_per_node;
+  double sq_spacing;
+  uint32_t* table;          // [sample node][cell code] -> first active index of the cell's run
+  uint32_t* nbr;            // [point][SP_K]
+  uint8_t* ncount;          // recorded neighbours, SP_K + 1 = overflow
+  uint8_t* state;
+  uint8_t* taken;
+};
+
+__device__ __forceinline__ bool sp_sampled(const SpArgs& a, uint32_t i) { return a.nmode[a.nid[i]] == MODE_SAMPLE; }
+
+__global__ __launch_bounds__(256) void sp_table_kernel(SpArgs a) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.m || !sp_sampled(a, i)) return;
+  const uint64_t pre = a.akey[i] >> a.cell_shift;
+  if (i > 0 && (a.akey[i - 1] >> a.cell_shift) == pre) return;  // not the first point of its cell
+  const uint64_t code = pre & (a.cells_per_node - 1ull);
+  a.table[(uint64_t)a.snode_of[a.nid[i]] * a.cells_per_node + code] = i;
+}
+
+// Visits every EARLIER point closer than the spacing to point p.  f(q) returns false to stop.
+template <typename F>
+__device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F f) {
+  const uint64_t key = a.akey[p];
+  const uint64_t pre = key >> a.cell_shift;
+  const uint32_t code = (uint32_t)(pre & (a.cells_per_node - 1ull));
+  const uint64_t base = (uint64_t)a.snode_of[a.nid[p]] * a.cells_per_node;
+  const double px = a.X[p], py = a.Y[p], pz = a.Z[p];
+  const int cx = (int)contract_bits_by_3((uint64_t)code >> 2), cy = (int)contract_bits_by_3((uint64_t)code >> 1),
+            cz = (int)contract_bits_by_3((uint64_t)code);
+  const int lim = 1 << a.cell_levels;
+  for (int k = 0; k < 27; ++k) {
+    const int x = cx + k % 3 - 1, y = cy + (k / 3) % 3 - 1, z = cz + k / 9 - 1;
+    if (x < 0 || y < 0 || z < 0 || x >= lim || y >= lim || z >= lim) continue;
+    const uint32_t ncode =
+      (uint32_t)(expand_bits_by_3((uint64_t)z) | (expand_bits_by_3((uint64_t)y) << 1) | (expand_bits_by_3((uint64_t)x) << 2));
+    if (ncode > code) continue;  // all its points come later in Morton order
+    uint32_t q = a.table[base + ncode];
+    if (q == SP_NONE) continue;
+    const uint64_t npre = (pre - code) + ncode;  // same node prefix, neighbour's cell code
+    for (; q < p && (a.akey[q] >> a.cell_shift) == npre; ++q) {
+      if (sq_dist(px, py, pz, a.X[q], a.Y[q], a.Z[q]) < a.sq_spacing) {
+        if (!f(q)) return;
+      }
+    }
+  }
+}
+
+// phase 1: record the earlier neighbours; points without any are accepted right away
+__global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ ulist,
+                                                            uint32_t* __restrict__ ucount) {
+  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+  bool undecided = false;
+  if (p < a.m && sp_sampled(a, p)) {
+    uint32_t cnt = 0;
+    uint32_t* mine = a.nbr + (size_t)p * SP_K;
+    sp_visit_earlier(a, p, [&](uint32_t q) {
+      if (cnt < (uint32_t)SP_K) mine[cnt] = q;
+      ++cnt;
+      return cnt <= (uint32_t)SP_K;  // one past the capacity marks the overflow, then stop
+    });
+    a.ncount[p] = (uint8_t)cnt;
+    if (cnt == 0) {
+      a.state[p] = SP_A;
+      a.taken[p] = 1;
+    } else {
+      a.state[p] = SP_U;
+      undecided = true;
+    }
+  }
+  const uint64_t bm = __ballot(undecided);
+  if (bm) {
+    const int leader = __ffsll((unsigned long long)bm) - 1;
+    uint32_t off = 0;
+    if ((int)lane_id() == leader) off = atomicAdd(ucount, (uint32_t)__popcll(bm));
+    off = __shfl(off, leader, WAVE);
+    if (undecided) ulist[off + (uint32_t)__popcll(bm & lanemask_lt())] = p;
+  }
+}
+
+// phase 2: one fixpoint round over the undecided points
+__global__ __launch_bounds__(256) void sp_round_kernel(SpArgs a, const uint32_t* __restrict__ uin, const uint32_t* __restrict__ nin,
+                                                       uint32_t* __restrict__ uout, uint32_t* __restrict__ nout) {
+  const uint32_t n = *nin;
+  for (uint32_t i0 = blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * 256) {  // wave-uniform
+    const uint32_t i = i0 + lane_id();
+    bool again = false;
+    uint32_t p = 0;
+    if (i < n) {
+      p = uin[i];
+      const uint32_t cnt = a.ncount[p];
+      bool rej = false, wait = false;
+      if (cnt <= (uint32_t)SP_K) {
+        const uint32_t* mine = a.nbr + (size_t)p * SP_K;
+        for (uint32_t j = 0; j < cnt; ++j) {
+          const uint8_t s = a.state[mine[j]];
+          rej |= s == SP_A;
+          wait |= s == SP_U;
+        }
+      } else {  // too many neighbours to record: search again
+        sp_visit_earlier(a, p, [&](uint32_t q) {
+          const uint8_t s = a.state[q];
+          rej |= s == SP_A;
+          wait |= s == SP_U;
+          return !rej;
+        });
+      }
+      if (rej) {
+        a.state[p] = SP_R;
+      } else if (!wait) {
+        a.state[p] = SP_A;
+        a.taken[p] = 1;
+      } else {
+        again = true;
+      }
+    }
+    const uint64_t bm = __ballot(again);
+    if (bm) {
+      const int leader = __ffsll((unsigned long long)bm) - 1;
+      uint32_t off = 0;
+      if ((int)lane_id() == leader) off = atomicAdd(nout, (uint32_t)__popcll(bm));
+      off = __shfl(off, leader, WAVE);
+      if (again) uout[off + (uint32_t)__popcll(bm & lanemask_lt())] = p;
+    }
+  }
+}
+
+__global__ void sp_zero_kernel(uint32_t* p) { *p = 0; }
+
+// positions already in active order (X/Y/Z); snode_of already scanned.  Returns SWZ_OK and sets *used
+// to false when the level does not qualify (the caller then runs the frontier sweep).
+int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const double* ax,
+                              const double* ay, const double* az, const LevelBuffers& lb, const uint32_t* snode_of,
+                              uint32_t sample_nodes, uint32_t sample_points, uint32_t* rounds_out, bool* used) {
+  *used = false;
+  const double avg = (double)sample_points / (double)sample_nodes;
+  int cl = plan.cell_levels_geo;
+  // the table must stay addressable and affordable: at most 2^31 entries
+  while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
+  const double per_cell = avg / std::pow(8.0, cl);
+  double limit = 1.5;
+  if (const char* e = getenv("SWZ_MD_SPARSE_LIMIT")) limit = atof(e);
+  if (!(per_cell < limit)) return SWZ_OK;
+  const uint32_t m = as.m;
+
+  SpArgs a{};
+  a.akey = as.akey;
+  a.nid = lb.nid;
+  a.nmode = lb.nmode;
+  a.snode_of = snode_of;
+  a.X = ax;
+  a.Y = ay;
+  a.Z = az;
+  a.m = m;
+  a.cell_levels = (uint32_t)cl;
+  a.cells_per_node = 1ull << (3 * cl);
+  a.cell_shift = (plan.node_shift == 63u ? 63u : plan.node_shift) - 3u * (uint32_t)cl;
+  a.sq_spacing = plan.sq_spacing;
+  a.taken = lb.taken;
+  const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
+  SWZ_TRY(c->get("sp_table", (size_t)entries, &a.table));
+  SWZ_TRY(c->get("sp_nbr", (size_t)m * SP_K, &a.nbr));
+  SWZ_TRY(c->get("sp_ncount", (size_t)m, &a.ncount));
+  SWZ_TRY(c->get("sp_state", (size_t)m, &a.state));
+  uint32_t *u0 = nullptr, *u1 = nullptr, *cnt = nullptr;
+  SWZ_TRY(c->get("sp_ulist0", (size_t)m, &u0));
+  SWZ_TRY(c->get("sp_ulist1", (size_t)m, &u1));
+  SWZ_TRY(c->get("sp_counts", (size_t)4, &cnt));
+  ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
+  SWZ_HIP(c, hipMemsetAsync(a.table, 0xFF, (size_t)entries * 4, c->stream));
+  SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
+  const uint32_t nb = div_up(m, 256);
+  hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
+  SWZ_LAUNCH_CHECK(c);
+  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(nb), dim3(256), 0, c->stream, a, u0, cnt);
+  SWZ_LAUNCH_CHECK(c);
+  uint32_t* uin = u0;
+  uint32_t* uout = u1;
+  uint32_t cur = 0;  // index of the counter of uin
+  uint32_t rounds = 0;
+  for (;;) {
+    uint32_t h[2] = {0, 0};
+    SWZ_HIP(c, hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    const uint32_t left = h[cur];
+    if (left == 0) break;
+    if (rounds > m + 16) return c->fail(SWZ_ERR_INTERNAL, "sparse MIN_DISTANCE fixpoint did not terminate");
+    // a few rounds per host look; an empty list makes the remaining launches no-ops
+    for (int r = 0; r < 4; ++r, ++rounds) {
+      hipLaunchKernelGGL(sp_zero_kernel, dim3(1), dim3(1), 0, c->stream, cnt + (cur ^ 1));
+      hipLaunchKernelGGL(sp_round_kernel, dim3(std::min<uint32_t>(4096u, std::max(1u, div_up(left, 256)))), dim3(256), 0,
+                         c->stream, a, uin, cnt + cur, uout, cnt + (cur ^ 1));
+      SWZ_LAUNCH_CHECK(c);
+      std::swap(uin, uout);
+      cur ^= 1;
+    }
+  }
+  if (rounds_out) *rounds_out += rounds;
+  if (getenv("SWZ_DEBUG"))
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d sparse path: %u pts, cell_levels %d (%.2f pts/cell), %u rounds\n", plan.level,
+            sample_points, cl, per_cell, rounds);
+  *used = true;
+  return SWZ_OK;
+}
+
+}  // namespace swz

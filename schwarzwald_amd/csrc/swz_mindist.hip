@@ -715,10 +715,17 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_TRY(c->get("md_snode", (size_t)nnodes, &snode));
   a.snode_of = snode;
   const uint32_t nb = div_up(m, 256);
-  ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
   hipLaunchKernelGGL(md_node_flag_kernel, dim3(div_up(nnodes, 256)), dim3(256), 0, c->stream, lb.nmode, nnodes, snode);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, snode, snode, nnodes, nullptr, "mdn"));
+  {
+    // sparse levels (about one point per spacing-sized cell or fewer): one thread per point
+    bool used = false;
+    SWZ_TRY(min_distance_sparse_level(c, plan, as, a.X, a.Y, a.Z, lb, snode, sample_nodes, sample_points, rounds_out,
+                                      &used));
+    if (used) return SWZ_OK;
+  }
+  ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
 
   // cells = runs of the cell prefix inside sampled nodes
   hipLaunchKernelGGL(md_cell_head_kernel, dim3(nb), dim3(256), 0, c->stream, a, lb.flags);
