@@ -274,3 +274,18 @@ def test_tile_fast_start_level_depends_on_concurrency(ctx):
         assert np.array_equal(g.level, o["level"]) and np.array_equal(g.dup, o["dup"])
         seen.add(g.stats["fast_start_levels"])
     assert len(seen) > 1
+
+
+def test_min_distance_sparse_path_and_its_fallback(ctx, monkeypatch):
+    """Sparse levels use a thread-per-point fixpoint; when the data is locally dense it gives up and the frontier
+    sweep takes over.  Both must give the oracle's set (SWZ_MD_SPARSE_LIMIT forces the sparse path onto denser data)."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(321)
+    xyz = np.vstack([rng.random((120000, 3)), 0.5 + 0.004 * rng.standard_normal((30000, 3))])  # a dense blob inside
+    xyz = np.clip(xyz, 0.0, 1.0)
+    for limit, d in (("1000", 250), ("1000", 60), ("0", 250)):
+        monkeypatch.setenv("SWZ_MD_SPARSE_LIMIT", limit)
+        spacing = O.spacing_from_diagonal(*UNIT, d)
+        o = O.tile(xyz, *UNIT, O.MIN_DISTANCE, 300, spacing)
+        g = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=300, spacing_at_root=spacing))
+        assert np.array_equal(g.level, o["level"])
