@@ -42,6 +42,25 @@ struct SpArgs {
   uint8_t* taken;
 };
 
+// states are polled while other wavefronts publish them: agent-scope relaxed atomics (served by L2)
+__device__ __forceinline__ uint8_t sp_load(const uint8_t* st, uint32_t i) {
+  return __hip_atomic_load(st + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sp_store(uint8_t* st, uint32_t i, uint8_t v) {
+  __hip_atomic_store(st + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one evaluation of point p from its recorded neighbours: 0 = still waiting, SP_A, SP_R
+__device__ __forceinline__ uint8_t sp_eval(const uint8_t* st, const uint32_t* mine, uint32_t cnt) {
+  bool rej = false, wait = false;
+  for (uint32_t j = 0; j < cnt; ++j) {
+    const uint8_t s = sp_load(st, mine[j]);
+    rej |= s == SP_A;
+    wait |= s == SP_U;
+  }
+  return rej ? SP_R : (wait ? SP_U : SP_A);
+}
+
 __device__ __forceinline__ bool sp_sampled(const SpArgs& a, uint32_t i) { return a.nmode[a.nid[i]] == MODE_SAMPLE; }
 
 __global__ __launch_bounds__(256) void sp_table_kernel(SpArgs a) {
@@ -98,11 +117,23 @@ __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* 
     a.ncount[p] = (uint8_t)cnt;
     if (cnt > (uint32_t)SP_K) atomicAdd(overflow, 1u);
     if (cnt == 0) {
-      a.state[p] = SP_A;
+      sp_store(a.state, p, SP_A);
       a.taken[p] = 1;
     } else {
-      a.state[p] = SP_U;
       undecided = true;
+    }
+  }
+  // A few fixpoint iterations right here: workgroups run roughly in Morton order, so most earlier
+  // neighbours are already final (or become final in this wavefront within an iteration or two).
+  for (int it = 0; it < 4; ++it) {
+    if (!__ballot(undecided)) break;
+    if (undecided && a.ncount[p] <= (uint8_t)SP_K) {
+      const uint8_t r = sp_eval(a.state, a.nbr + (size_t)p * SP_K, a.ncount[p]);
+      if (r != SP_U) {
+        sp_store(a.state, p, r);
+        if (r == SP_A) a.taken[p] = 1;
+        undecided = false;
+      }
     }
   }
   const uint64_t bm = __ballot(undecided);
@@ -126,29 +157,25 @@ __global__ __launch_bounds__(256) void sp_round_kernel(SpArgs a, const uint32_t*
     if (i < n) {
       p = uin[i];
       const uint32_t cnt = a.ncount[p];
-      bool rej = false, wait = false;
+      uint8_t r = SP_U;
       if (cnt <= (uint32_t)SP_K) {
         const uint32_t* mine = a.nbr + (size_t)p * SP_K;
-        for (uint32_t j = 0; j < cnt; ++j) {
-          const uint8_t s = a.state[mine[j]];
-          rej |= s == SP_A;
-          wait |= s == SP_U;
-        }
+        for (int it = 0; it < 4 && r == SP_U; ++it) r = sp_eval(a.state, mine, cnt);
       } else {  // too many neighbours to record: search again
+        bool rej = false, wait = false;
         sp_visit_earlier(a, p, [&](uint32_t q) {
-          const uint8_t s = a.state[q];
+          const uint8_t s = sp_load(a.state, q);
           rej |= s == SP_A;
           wait |= s == SP_U;
           return !rej;
         });
+        r = rej ? SP_R : (wait ? SP_U : SP_A);
       }
-      if (rej) {
-        a.state[p] = SP_R;
-      } else if (!wait) {
-        a.state[p] = SP_A;
-        a.taken[p] = 1;
-      } else {
+      if (r == SP_U) {
         again = true;
+      } else {
+        sp_store(a.state, p, r);
+        if (r == SP_A) a.taken[p] = 1;
       }
     }
     const uint64_t bm = __ballot(again);
@@ -206,6 +233,7 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
   SWZ_HIP(c, hipMemsetAsync(a.table, 0xFF, (size_t)entries * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
+  SWZ_HIP(c, hipMemsetAsync(a.state, SP_U, (size_t)m, c->stream));
   const uint32_t nb = div_up(m, 256);
   hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
   SWZ_LAUNCH_CHECK(c);
