@@ -5,7 +5,11 @@
 // core/datastructures/SparseGrid.cpp:116-146), computed the other way round.  When a spacing-sized cell
 // holds about one point, nearly every point is accepted and a wavefront per cell idles 63 lanes, so:
 //   1. every point looks up its 27 adjacent cells once (dense [node][cell] table of run starts) and
-//      records its EARLIER neighbours closer than the spacing (exact compare, usually 0-3 of them);
+//      records its EARLIER neighbours closer than the spacing (exact compare, usually 0-3 of them).
+//      The search is a chain of dependent loads (table -> points), so it is laid out for latency: the
+//      table holds {first, end} of every cell's run, the active points are gathered into 32-byte
+//      records, and the 27 cells are taken nine at a time with all nine table lookups, then the j-th
+//      record of all nine runs, in flight together;
 //   2. fixpoint rounds over the still undecided points: rejected when a recorded neighbour is accepted,
 //      accepted when all of them are rejected, otherwise wait.  States only move undecided -> final, so a
 //      stale read is conservative; the number of rounds is the dependency depth (tens).
@@ -27,15 +31,13 @@ struct SpArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* snode_of;
-  const double* X;  // active order
-  const double* Y;
-  const double* Z;
+  const double4* rec;  // active order: {x, y, z, key bits}
   uint32_t m;
   uint32_t cell_shift;      // key >> cell_shift = node prefix + cell code
   uint32_t cell_levels;
   uint64_t cells_per_node;
   double sq_spacing;
-  uint32_t* table;          // [sample node][cell code] -> first active index of the cell's run
+  uint2* table;             // [sample node][cell code] -> {first, end} active index of the cell's run
   uint32_t* nbr;            // [point][SP_K]
   uint8_t* ncount;          // recorded neighbours, SP_K + 1 = overflow
   uint8_t* state;
@@ -67,34 +69,87 @@ __global__ __launch_bounds__(256) void sp_table_kernel(SpArgs a) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= a.m || !sp_sampled(a, i)) return;
   const uint64_t pre = a.akey[i] >> a.cell_shift;
-  if (i > 0 && (a.akey[i - 1] >> a.cell_shift) == pre) return;  // not the first point of its cell
+  const bool head = i == 0 || (a.akey[i - 1] >> a.cell_shift) != pre;
+  const bool tail = i + 1 == a.m || (a.akey[i + 1] >> a.cell_shift) != pre;
+  if (!head && !tail) return;
   const uint64_t code = pre & (a.cells_per_node - 1ull);
-  a.table[(uint64_t)a.snode_of[a.nid[i]] * a.cells_per_node + code] = i;
+  uint2* e = a.table + ((uint64_t)a.snode_of[a.nid[i]] * a.cells_per_node + code);
+  if (head) e->x = i;
+  if (tail) e->y = i + 1u;
 }
+
+__global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t* __restrict__ aidx, const uint64_t* __restrict__ akey,
+                                                        uint32_t m, const double* __restrict__ X, const double* __restrict__ Y,
+                                                        const double* __restrict__ Z, double4* __restrict__ rec) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t s = aidx ? aidx[i] : i;
+  rec[i] = make_double4(X[s], Y[s], Z[s], __longlong_as_double((long long)akey[i]));
+}
+
+__device__ __forceinline__ uint64_t sp_key(const double4& r) { return (uint64_t)__double_as_longlong(r.w); }
 
 // Visits every EARLIER point closer than the spacing to point p.  f(q) returns false to stop.
 template <typename F>
 __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F f) {
-  const uint64_t key = a.akey[p];
-  const uint64_t pre = key >> a.cell_shift;
+  const double4 me = a.rec[p];
+  const uint64_t pre = sp_key(me) >> a.cell_shift;
   const uint32_t code = (uint32_t)(pre & (a.cells_per_node - 1ull));
   const uint64_t base = (uint64_t)a.snode_of[a.nid[p]] * a.cells_per_node;
-  const double px = a.X[p], py = a.Y[p], pz = a.Z[p];
-  const int cx = (int)contract_bits_by_3((uint64_t)code >> 2), cy = (int)contract_bits_by_3((uint64_t)code >> 1),
-            cz = (int)contract_bits_by_3((uint64_t)code);
-  const int lim = 1 << a.cell_levels;
-  for (int k = 0; k < 27; ++k) {
-    const int x = cx + k % 3 - 1, y = cy + (k / 3) % 3 - 1, z = cz + k / 9 - 1;
-    if (x < 0 || y < 0 || z < 0 || x >= lim || y >= lim || z >= lim) continue;
-    const uint32_t ncode =
-      (uint32_t)(expand_bits_by_3((uint64_t)z) | (expand_bits_by_3((uint64_t)y) << 1) | (expand_bits_by_3((uint64_t)x) << 2));
-    if (ncode > code) continue;  // all its points come later in Morton order
-    uint32_t q = a.table[base + ncode];
-    if (q == SP_NONE) continue;
-    const uint64_t npre = (pre - code) + ncode;  // same node prefix, neighbour's cell code
-    for (; q < p && (a.akey[q] >> a.cell_shift) == npre; ++q) {
-      if (sq_dist(px, py, pz, a.X[q], a.Y[q], a.Z[q]) < a.sq_spacing) {
-        if (!f(q)) return;
+  // neighbour cell codes by arithmetic on the dilated coordinates (code = x bits | y bits | z bits, every
+  // third bit): minus one = (v - 1) & mask, plus one = ((v | ~mask) + 1) & mask; out of the node when the
+  // coordinate is already 0 / all ones
+  const uint32_t all = (uint32_t)(a.cells_per_node - 1ull);
+  const uint32_t mz = all & 0x09249249u, my = mz << 1, mx = mz << 2;
+  const uint32_t vx = code & mx, vy = code & my, vz = code & mz;
+  // index 0: minus one, 1: same, 2: plus one; SP_NONE marks "outside"
+  const uint32_t dx[3] = {vx ? ((vx - 1u) & mx) : SP_NONE, vx, vx != mx ? (((vx | ~mx) + 1u) & mx) : SP_NONE};
+  const uint32_t dy[3] = {vy ? ((vy - 1u) & my) : SP_NONE, vy, vy != my ? (((vy | ~my) + 1u) & my) : SP_NONE};
+  const uint32_t dz[3] = {vz ? ((vz - 1u) & mz) : SP_NONE, vz, vz != mz ? (((vz | ~mz) + 1u) & mz) : SP_NONE};
+  // nine cells (one z slab) at a time: their table entries, then the j-th record of every run, are
+  // requested together, so a slab costs 1 + (longest run) memory round trips instead of one per record
+  const uint2* __restrict__ tab = a.table + base;
+  const uint64_t npre0 = pre - code;
+  (void)npre0;
+  for (int zs = 0; zs < 3; ++zs) {
+    const uint32_t Z = zs == 0 ? dz[0] : (zs == 1 ? dz[1] : dz[2]);
+    if (Z == SP_NONE) continue;
+    uint32_t q[9], qe[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+      const uint32_t X = dx[i % 3], Y = dy[i / 3];
+      const uint32_t ncode = X | Y | Z;
+      // a cell with a larger code holds later points only
+      const bool want = X != SP_NONE && Y != SP_NONE && ncode <= code;
+      uint2 e = make_uint2(0u, 0u);
+      if (want) e = tab[ncode];
+      q[i] = e.x;
+      qe[i] = (want && e.x != SP_NONE) ? min(e.y, p) : 0u;  // own cell: earlier points only; empty: {NONE, NONE}
+      if (qe[i] == 0u) q[i] = 0u;
+    }
+    for (;;) {
+      double rx[9], ry[9], rz[9];
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        if (q[i] < qe[i]) {
+          const double4* r = a.rec + q[i];
+          const double2 xy = *reinterpret_cast<const double2*>(r);
+          rx[i] = xy.x;
+          ry[i] = xy.y;
+          rz[i] = r->z;
+          any = true;
+        }
+      }
+      if (!any) break;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) {
+        if (q[i] < qe[i]) {
+          if (sq_dist(me.x, me.y, me.z, rx[i], ry[i], rz[i]) < a.sq_spacing) {
+            if (!f(q[i])) return;
+          }
+          ++q[i];
+        }
       }
     }
   }
@@ -103,8 +158,11 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
 // phase 1: record the earlier neighbours; points without any are accepted right away
 __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ ulist,
                                                             uint32_t* __restrict__ ucount,
-                                                            uint32_t* __restrict__ overflow) {
-  const uint32_t p = blockIdx.x * 256 + threadIdx.x;
+                                                            uint32_t* __restrict__ overflow, uint32_t xcd) {
+  // workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the points, so the
+  // neighbourhoods a workgroup reads were mostly fetched into the same L2 by the workgroups just before it
+  const uint32_t blk = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const uint32_t p = blk * 256 + threadIdx.x;
   bool undecided = false;
   if (p < a.m && sp_sampled(a, p)) {
     uint32_t cnt = 0;
@@ -193,9 +251,9 @@ __global__ void sp_zero_kernel(uint32_t* p) { *p = 0; }
 
 // positions already in active order (X/Y/Z); snode_of already scanned.  Returns SWZ_OK and sets *used
 // to false when the level does not qualify (the caller then runs the frontier sweep).
-int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const double* ax,
-                              const double* ay, const double* az, const LevelBuffers& lb, const uint32_t* snode_of,
-                              uint32_t sample_nodes, uint32_t sample_points, uint32_t* rounds_out, bool* used) {
+int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+                              const LevelBuffers& lb, const uint32_t* snode_of, uint32_t sample_nodes,
+                              uint32_t sample_points, uint32_t* rounds_out, bool* used) {
   *used = false;
   const double avg = (double)sample_points / (double)sample_nodes;
   int cl = plan.cell_levels_geo;
@@ -212,9 +270,6 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.nid = lb.nid;
   a.nmode = lb.nmode;
   a.snode_of = snode_of;
-  a.X = ax;
-  a.Y = ay;
-  a.Z = az;
   a.m = m;
   a.cell_levels = (uint32_t)cl;
   a.cells_per_node = 1ull << (3 * cl);
@@ -223,6 +278,9 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.taken = lb.taken;
   const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
   SWZ_TRY(c->get("sp_table", (size_t)entries, &a.table));
+  double4* rec = nullptr;
+  SWZ_TRY(c->get("sp_rec", (size_t)m, &rec));
+  a.rec = rec;
   SWZ_TRY(c->get("sp_nbr", (size_t)m * SP_K, &a.nbr));
   SWZ_TRY(c->get("sp_ncount", (size_t)m, &a.ncount));
   SWZ_TRY(c->get("sp_state", (size_t)m, &a.state));
@@ -231,14 +289,27 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_TRY(c->get("sp_ulist1", (size_t)m, &u1));
   SWZ_TRY(c->get("sp_counts", (size_t)4, &cnt));
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
-  SWZ_HIP(c, hipMemsetAsync(a.table, 0xFF, (size_t)entries * 4, c->stream));
+  SWZ_HIP(c, hipMemsetAsync(a.table, 0xFF, (size_t)entries * sizeof(uint2), c->stream));
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
   SWZ_HIP(c, hipMemsetAsync(a.state, SP_U, (size_t)m, c->stream));
   const uint32_t nb = div_up(m, 256);
+  hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, rec);
+  SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
   SWZ_LAUNCH_CHECK(c);
-  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2);
+  const uint32_t xcd = getenv("SWZ_MD_XCD") ? ((uint32_t)atoi(getenv("SWZ_MD_XCD")) >> 1) & 1u : 1u;
+  const bool dbg = getenv("SWZ_DEBUG") != nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  if (dbg) {
+    ev0 = c->take_event();
+    ev1 = c->take_event();
+    ev2 = c->take_event();
+    (void)hipEventRecord(ev0, c->stream);
+  }
+  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nb, 8) * 8 : nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2,
+                     xcd);
   SWZ_LAUNCH_CHECK(c);
+  if (dbg) (void)hipEventRecord(ev1, c->stream);
   uint32_t* uin = u0;
   uint32_t* uout = u1;
   uint32_t cur = 0;  // index of the counter of uin
@@ -269,9 +340,16 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     }
   }
   if (rounds_out) *rounds_out += rounds;
-  if (getenv("SWZ_DEBUG"))
-    fprintf(stderr, "[swz] MIN_DISTANCE level %d sparse path: %u pts, cell_levels %d (%.2f pts/cell), %u rounds\n", plan.level,
-            sample_points, cl, per_cell, rounds);
+  if (dbg) {
+    float t1 = 0.f, t2 = 0.f;
+    (void)hipEventRecord(ev2, c->stream);
+    (void)hipEventSynchronize(ev2);
+    (void)hipEventElapsedTime(&t1, ev0, ev1);
+    (void)hipEventElapsedTime(&t2, ev1, ev2);
+    c->event_pool.insert(c->event_pool.end(), {ev0, ev1, ev2});
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d sparse path: %u pts, cell_levels %d (%.2f pts/cell), %u rounds, %.1f + %.1f ms\n",
+            plan.level, sample_points, cl, per_cell, rounds, t1, t2);
+  }
   *used = true;
   return SWZ_OK;
 }

@@ -79,6 +79,7 @@ struct MdArgs {
   uint32_t batch_blockers;   // very sparse level: test all surviving lanes in one pass over the neighbours
   uint32_t early_recheck;    // re-activated cells first continue the stalled candidate's blocker scan
   uint32_t latest_first;     // blocker scans visit the latest adjacent cell first (else the earliest)
+  uint32_t xcd_chunks;       // 1 = each XCD sweeps a contiguous eighth of the queue
   uint32_t ablate;           // debugging only (SWZ_MD_ABLATE): 1 = never blocked, 2 = no rejection tests
   double usq[3];
   double cull_sq;            // sq_spacing with a safety margin
@@ -232,6 +233,51 @@ __device__ __forceinline__ bool md_culled(const MdArgs& a, int k, int sx, int sy
   return gx * gx * a.usq[0] + gy * gy * a.usq[1] + gz * gz * a.usq[2] >= a.cull_sq;
 }
 
+// First LIVE point of [qs, qe) closer than the spacing to (bx, by, bz), or NONE32.  A point that is closer
+// than the spacing to one of the wn accepted points in the LDS window is dead: it will be rejected whenever
+// its cell gets to it (accepted sets only grow, and an accepted neighbour of an undecided point is always
+// the earlier of the two), so it cannot keep anybody waiting.  The scan is a chain of dependent load
+// latencies, so long ranges go four chunks (256 points) per step with all loads in flight.
+__device__ __forceinline__ uint64_t md_live_hits(const MdArgs& a, const MdLds& lds, uint32_t wn, bool hit, double x,
+                                                 double y, double z) {
+  uint64_t hb = __ballot(hit);
+  if (hb && wn) {
+    for (uint32_t ti = 0; ti < wn; ++ti)
+      if (sq_dist(x, y, z, lds.ex[ti], lds.ey[ti], lds.ez[ti]) < a.sq_spacing) hit = false;
+    hb = __ballot(hit);
+  }
+  return hb;
+}
+
+__device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& lds, uint32_t wn, uint32_t qs, uint32_t qe,
+                                                 double bx, double by, double bz) {
+  const uint32_t l = lane_id();
+  const double t = a.sq_spacing;
+  uint32_t q0 = qs;
+  while (qe - q0 > (uint32_t)WAVE) {  // qe > q0 always
+    double x[4], y[4], z[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t q = min(q0 + (uint32_t)u * WAVE + l, qe - 1u);
+      x[u] = a.X[q];
+      y[u] = a.Y[q];
+      z[u] = a.Z[q];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t q = q0 + (uint32_t)u * WAVE + l;
+      const uint64_t hb = md_live_hits(a, lds, wn, q < qe && sq_dist(bx, by, bz, x[u], y[u], z[u]) < t, x[u], y[u], z[u]);
+      if (hb) return q0 + (uint32_t)u * WAVE + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
+    }
+    if (qe - q0 <= 4u * WAVE) return NONE32;
+    q0 += 4u * WAVE;
+  }
+  const uint32_t q = min(q0 + l, qe - 1u);
+  const double x = a.X[q], y = a.Y[q], z = a.Z[q];
+  const uint64_t hb = md_live_hits(a, lds, wn, q0 + l < qe && sq_dist(bx, by, bz, x, y, z) < t, x, y, z);
+  return hb ? q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u : NONE32;
+}
+
 // One wavefront advances the frontier of one active cell as far as it can.
 __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t l = lane_id();
@@ -304,17 +350,12 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       nm &= ~(1u << r);
       const uint32_t qs = bcast_u32(n_pos, r);
       const uint32_t qe = bcast_u32(n_end, r);
-      for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
-        const uint32_t q = q0 + l;
-        const bool hit = q < qe && sq_dist(bx, by, bz, a.X[q], a.Y[q], a.Z[q]) < t;
-        const uint64_t hb = __ballot(hit);
-        if (hb) {
-          blocked = true;
-          b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
-          b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
-          b_cell = bcast_u32(nb, r);
-          break;
-        }
+      const uint32_t hq = md_first_hit(a, lds, 0u, qs, qe, bx, by, bz);
+      if (hq != NONE32) {
+        blocked = true;
+        b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
+        b_q = hq;
+        b_cell = bcast_u32(nb, r);
       }
     }
     if (blocked && !(a.ablate & 4u)) {
@@ -334,6 +375,8 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   uint32_t wn0 = 0;
   if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
 
+  // the whole list of accepted points is resident in LDS: blocker scans can tell dead points
+  const uint32_t live_wn = (T <= (uint32_t)MD_EXT_CAP && !(a.ablate & 8u)) ? wn0 : 0u;
   uint32_t fresh = 0;
 #ifdef SWZ_MD_STATS
   uint32_t dbg_scan = 0, dbg_rtest = 0;
@@ -466,20 +509,12 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
           nm &= ~(1u << r);
           const uint32_t qs = bcast_u32(n_pos, r);
           const uint32_t qe = bcast_u32(n_end, r);
-          for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
-#ifdef SWZ_MD_STATS
-            ++dbg_scan;
-#endif
-            const uint32_t q = q0 + l;
-            const bool hit = q < qe && sq_dist(bx, by, bz, a.X[q], a.Y[q], a.Z[q]) < t;
-            const uint64_t hb = __ballot(hit);
-            if (hb) {
-              blocked = true;
-              b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
-              b_q = q0 + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
-              b_cell = bcast_u32(nb, r);
-              break;
-            }
+          const uint32_t hq = md_first_hit(a, lds, live_wn, qs, qe, bx, by, bz);
+          if (hq != NONE32) {
+            blocked = true;
+            b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
+            b_q = hq;
+            b_cell = bcast_u32(nb, r);
           }
         }
       }
@@ -546,6 +581,15 @@ __global__ __launch_bounds__(MD_THREADS, SWZ_MD_MIN_WAVES) void md_sweep_kernel(
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (round + 2) % 3] = 0;
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   const uint32_t* qin = a.queue[round & 1];
+  if (a.xcd_chunks && (gridDim.x & 7u) == 0) {
+    // workgroups go round-robin over the 8 XCDs: give every XCD one contiguous eighth of the queue so that
+    // neighbouring cells (which read each other's records and accepted points) share an L2
+    const uint32_t seg = (nq + 7u) / 8u, x = blockIdx.x & 7u;
+    const uint32_t end = min(nq, (x + 1u) * seg);
+    for (uint32_t i = x * seg + (blockIdx.x >> 3) * MD_WAVES + w; i < end; i += (gridDim.x >> 3) * MD_WAVES)
+      md_sweep_cell(a, qin[i], lds[w]);
+    return;
+  }
   for (uint32_t i = blockIdx.x * MD_WAVES + w; i < nq; i += gridDim.x * MD_WAVES) md_sweep_cell(a, qin[i], lds[w]);
 }
 
@@ -664,6 +708,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   if (const char* e = getenv("SWZ_MD_DENSITY")) per_cell = atof(e);
   while (cl_density < 10 && std::pow(8.0, cl_density + 1) * per_cell <= avg) ++cl_density;
   cl = std::max(0, std::min(cl, cl_density));
+  if (const char* e = getenv("SWZ_MD_COARSEN")) {
+    const double thr = getenv("SWZ_MD_COARSEN_MIN") ? atof(getenv("SWZ_MD_COARSEN_MIN")) : 32.0;
+    if (avg / std::pow(8.0, cl) >= thr) cl = std::max(0, cl - atoi(e));
+  }
   const uint64_t cells_per_node = 1ull << (3 * cl);
 
   MdArgs a{};
@@ -676,18 +724,6 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   a.X = sp.X;
   a.Y = sp.Y;
   a.Z = sp.Z;
-  if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
-    double *ax = nullptr, *ay = nullptr, *az = nullptr;
-    SWZ_TRY(c->get("md_ax", (size_t)m, &ax));
-    SWZ_TRY(c->get("md_ay", (size_t)m, &ay));
-    SWZ_TRY(c->get("md_az", (size_t)m, &az));
-    hipLaunchKernelGGL(md_gather_active_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.aidx, m, sp.X, sp.Y,
-                       sp.Z, ax, ay, az);
-    SWZ_LAUNCH_CHECK(c);
-    a.X = ax;
-    a.Y = ay;
-    a.Z = az;
-  }
   a.taken = lb.taken;
   a.counters = lb.counters;
   a.cell_levels = (uint32_t)cl;
@@ -706,6 +742,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       a.usq[ax] = u * u;
     }
     a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
+    a.xcd_chunks = getenv("SWZ_MD_XCD") ? (uint32_t)atoi(getenv("SWZ_MD_XCD")) & 1u : 0u;
     a.ablate = getenv("SWZ_MD_ABLATE") ? (uint32_t)atoi(getenv("SWZ_MD_ABLATE")) : 0u;
     // expected points per spacing-sized cell; far below one almost every candidate is accepted
     a.batch_blockers = (avg / std::pow(8.0, plan.cell_levels_geo) < 0.25) ? 1u : 0u;
@@ -721,9 +758,20 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   {
     // sparse levels (about one point per spacing-sized cell or fewer): one thread per point
     bool used = false;
-    SWZ_TRY(min_distance_sparse_level(c, plan, as, a.X, a.Y, a.Z, lb, snode, sample_nodes, sample_points, rounds_out,
-                                      &used));
+    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes, sample_points, rounds_out, &used));
     if (used) return SWZ_OK;
+  }
+  if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
+    double *ax = nullptr, *ay = nullptr, *az = nullptr;
+    SWZ_TRY(c->get("md_ax", (size_t)m, &ax));
+    SWZ_TRY(c->get("md_ay", (size_t)m, &ay));
+    SWZ_TRY(c->get("md_az", (size_t)m, &az));
+    hipLaunchKernelGGL(md_gather_active_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.aidx, m, sp.X, sp.Y,
+                       sp.Z, ax, ay, az);
+    SWZ_LAUNCH_CHECK(c);
+    a.X = ax;
+    a.Y = ay;
+    a.Z = az;
   }
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
 
@@ -766,6 +814,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   // cheap.  With few large cells it is bound by the latency of one activation: no extra scan.
   a.early_recheck = (ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0) ? 1u : 0u;
   a.latest_first = a.early_recheck;
+  if (const char* e = getenv("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
   if (const char* e = getenv("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
 
   // rounds; the host only looks at the done counter every `batch` rounds
@@ -790,6 +839,15 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     SWZ_LAUNCH_CHECK(c);
     SWZ_HIP(c, hipMemcpyAsync(&done, lb.counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (dbg && getenv("SWZ_MD_TIMELINE")) {
+      float t = 0.f;
+      hipEvent_t e = c->take_event();
+      (void)hipEventRecord(e, c->stream);
+      (void)hipEventSynchronize(e);
+      (void)hipEventElapsedTime(&t, ev0, e);
+      c->event_pool.push_back(e);
+      fprintf(stderr, " r%u:%.1fms:%.3f%%", round, t, 100.0 * done / ncells);
+    }
     if (round > max_rounds) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE frontier sweep did not terminate");
   }
   if (rounds_out) *rounds_out += round;

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Derives profiles/rNN/traffic.json from the two per-kernel PMC summaries tools/profile_round.sh writes
+(FETCH_SIZE and WRITE_SIZE, KiB, separate --pmc passes of `bench.py --steps 1 --warmup 0`).
+bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half the bytes on gfx950
+(/opt/skills/guides/MI355X_MICROARCH.md); the factor is re-checked on radix_hist_kernel, which reads
+8 passes x 8 B x points and nothing else."""
+import csv, json, sys, os
+
+d = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01"
+points = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
+levels = int(sys.argv[3]) if len(sys.argv) > 3 else 5  # sampled levels per step (root .. 3)
+
+
+def load(name):
+    out = {}
+    with open(os.path.join(d, name)) as f:
+        next(f)
+        for line in f:
+            k, n, v = line.rstrip("\n").rsplit(",", 2)
+            out[k] = (int(n), float(v))
+    return out
+
+
+fetch, write = load("pmc_FETCH_SIZE_by_kernel.csv"), load("pmc_WRITE_SIZE_by_kernel.csv")
+
+
+def bytes_of(pred):
+    ks = sorted(k for k in set(fetch) | set(write) if pred(k))
+    b = sum((2.0 * fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1]) * 1024.0 for k in ks)
+    return ks, b
+
+
+calib = 2.0 * fetch["swz::radix_hist_kernel"][1] * 1024.0 / (8 * 8.0 * points)
+md_k, md_b = bytes_of(lambda k: k.startswith("swz::md_") or k.startswith("swz::sp_"))
+rs_k, rs_b = bytes_of(lambda k: k == "swz::radix_scatter_kernel")
+out = {
+    "points": points, "sampler": "MIN_DISTANCE",
+    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0`; "
+              "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md); "
+              "check: corrected radix_hist_kernel reads / (64 B x points) = %.4f" % calib,
+    "bytes_per_launch": {"sample_min_distance": md_b / levels, "radix_scatter": rs_b / 8},
+    "detail": {
+        "sample_min_distance": {"kernels": md_k, "launches_per_step": levels, "bytes_per_step": md_b},
+        "radix_scatter": {"kernels": rs_k, "launches_per_step": 8, "bytes_per_step": rs_b},
+    },
+}
+json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
+print(json.dumps(out["bytes_per_launch"]), "calibration", calib)
