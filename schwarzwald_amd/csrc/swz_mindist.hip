@@ -124,51 +124,52 @@ __global__ __launch_bounds__(256) void md_cell_end_kernel(MdArgs a, uint32_t nce
   a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + a.crel[c]] = c;
 }
 
-// neighbour k (0..26, 13 = self) of the cell with Morton code rel; returns false when outside the node
-__device__ __forceinline__ bool md_neighbour_code(uint32_t rel, uint32_t cell_levels, int k, uint32_t& nrel) {
-  const int dx = k % 3 - 1, dy = (k / 3) % 3 - 1, dz = k / 9 - 1;
-  const int lim = 1 << cell_levels;
-  const int x = (int)contract_bits_by_3((uint64_t)rel >> 2) + dx;
-  const int y = (int)contract_bits_by_3((uint64_t)rel >> 1) + dy;
-  const int z = (int)contract_bits_by_3((uint64_t)rel) + dz;
-  if (x < 0 || y < 0 || z < 0 || x >= lim || y >= lim || z >= lim) return false;
-  nrel = (uint32_t)(expand_bits_by_3((uint64_t)z) | (expand_bits_by_3((uint64_t)y) << 1) |
-                    (expand_bits_by_3((uint64_t)x) << 2));
-  return true;
-}
-
 // earlier adjacent cells of every cell, sorted latest first (a cell's blocker scans and accepted-point
-// pulls walk this list; it never changes during the sweep)
+// pulls walk this list; it never changes during the sweep).  Half a wavefront per cell: lane k looks up
+// adjacent cell k, its rank is the number of found cells with a larger code.
 __global__ __launch_bounds__(256) void md_nbr_build_kernel(MdArgs a, uint32_t ncells) {
-  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= ncells) return;
-  const uint32_t rel = a.crel[c];
-  const uint64_t base = (uint64_t)a.csnode[c] * a.cells_per_node;
-  uint32_t ids[27], codes[27];
-  uint8_t slots[27];
-  int cnt = 0;
-  for (int k = 0; k < 27; ++k) {
-    if (k == 13) continue;
-    uint32_t nrel;
-    if (!md_neighbour_code(rel, a.cell_levels, k, nrel) || nrel >= rel) continue;
-    const uint32_t nb = a.gridmap[base + nrel];
-    if (nb == NONE32) continue;
-    int p = cnt++;
-    while (p > 0 && codes[p - 1] < nrel) {  // insertion sort, descending code
-      ids[p] = ids[p - 1];
-      codes[p] = codes[p - 1];
-      slots[p] = slots[p - 1];
-      --p;
+  const uint32_t c = blockIdx.x * 8u + threadIdx.x / 32u;
+  const uint32_t k = threadIdx.x & 31u;
+  uint32_t nrel = 0, nb = NONE32;
+  bool have = false;
+  if (c < ncells && k < 27u && k != 13u) {
+    const uint32_t rel = a.crel[c];
+    // codes of the adjacent cells by arithmetic on the dilated coordinates (every third bit)
+    const uint32_t all = (uint32_t)(a.cells_per_node - 1ull);
+    const uint32_t mz = all & 0x09249249u, my = mz << 1, mx = mz << 2;
+    const uint32_t v[3] = {rel & mx, rel & my, rel & mz};
+    const uint32_t mk[3] = {mx, my, mz};
+    const uint32_t d[3] = {k % 3u, (k / 3u) % 3u, k / 9u};  // 0: minus one, 1: same, 2: plus one
+    bool inside = true;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      uint32_t w = v[ax];
+      if (d[ax] == 0u) {
+        inside &= w != 0u;
+        w = (w - 1u) & mk[ax];
+      } else if (d[ax] == 2u) {
+        inside &= w != mk[ax];
+        w = ((w | ~mk[ax]) + 1u) & mk[ax];
+      }
+      nrel |= w;
     }
-    ids[p] = nb;
-    codes[p] = nrel;
-    slots[p] = (uint8_t)k;
+    if (inside && nrel < rel) {
+      nb = a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + nrel];
+      have = nb != NONE32;
+    }
   }
-  for (int r = 0; r < cnt; ++r) {
-    a.nbr_id[(size_t)c * 27 + r] = ids[r];
-    a.nbr_slot[(size_t)c * 32 + r] = slots[r];
+  const uint32_t half = lane_id() & 32u;
+  const uint32_t found = (uint32_t)(__ballot(have) >> half);
+  uint32_t rank = 0;
+  for (uint32_t j = 0; j < 27u; ++j) {
+    const uint32_t other = (uint32_t)__shfl((int)nrel, (int)(half + j), WAVE);
+    rank += (((found >> j) & 1u) && other > nrel) ? 1u : 0u;
   }
-  a.nbr_slot[(size_t)c * 32 + 31] = (uint8_t)cnt;
+  if (have) {
+    a.nbr_id[(size_t)c * 27 + rank] = nb;
+    a.nbr_slot[(size_t)c * 32 + rank] = (uint8_t)k;
+  }
+  if (k == 31u && c < ncells) a.nbr_slot[(size_t)c * 32 + 31] = (uint8_t)__popc(found);
 }
 
 // next cell (rank) of a blocker scan: latest first when the level is throughput bound, earliest first when
@@ -804,7 +805,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(md_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
-  hipLaunchKernelGGL(md_nbr_build_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
+  hipLaunchKernelGGL(md_nbr_build_kernel, dim3(div_up(ncells, 8)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, a.queue[0], ncells,
                      lb.counters + CTR_Q0);
