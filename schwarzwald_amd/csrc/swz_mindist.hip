@@ -79,6 +79,8 @@ struct MdArgs {
   uint32_t batch_blockers;   // very sparse level: test all surviving lanes in one pass over the neighbours
   uint32_t early_recheck;    // re-activated cells first continue the stalled candidate's blocker scan
   uint32_t latest_first;     // blocker scans visit the latest adjacent cell first (else the earliest)
+  uint32_t patient;          // 1 = a stalled cell sleeps until the blocking CELL is finished, not just the blocking point
+  float lazy_frac;           // lazy start: sleep until this fraction of the latest earlier neighbour is decided
   uint32_t xcd_chunks;       // 1 = each XCD sweeps a contiguous eighth of the queue
   uint32_t ablate;           // debugging only (SWZ_MD_ABLATE): 1 = never blocked, 2 = no rejection tests
   double usq[3];
@@ -355,7 +357,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       if (hq != NONE32) {
         blocked = true;
         b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
-        b_q = hq;
+        b_q = a.patient ? qe - 1u : hq;
         b_cell = bcast_u32(nb, r);
       }
     }
@@ -514,7 +516,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
           if (hq != NONE32) {
             blocked = true;
             b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
-            b_q = hq;
+            b_q = a.patient ? qe - 1u : hq;
             b_cell = bcast_u32(nb, r);
           }
         }
@@ -695,6 +697,28 @@ __global__ __launch_bounds__(256) void md_fill_queue_kernel(uint32_t* q, uint32_
   if (i == 0) *counter = n;
 }
 
+// Patient levels start lazily: only the cells without an earlier adjacent cell are queued, every other cell
+// sleeps until its latest earlier neighbour is finished (sleeping on a blocker that is not the real one is
+// always safe, the cell looks again when it wakes up).  This replaces a first round in which every cell
+// would scan its neighbourhood just to find out that it has to wait.
+__global__ __launch_bounds__(256) void md_lazy_start_kernel(MdArgs a, uint32_t ncells, uint32_t* q, uint32_t* counter) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  bool push = false;
+  if (c < ncells) {
+    if (a.nbr_slot[(size_t)c * 32 + 31] == 0) {
+      push = true;
+    } else {
+      const uint32_t b = a.nbr_id[(size_t)c * 27];
+      a.blk_cell[c] = b;
+      const uint4 o = a.cell[b];
+      a.blk_q[c] = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
+      a.status[c] = ST_STALLED;
+      a.wnext[c] = atomicExch(&a.whead[b], c);
+    }
+  }
+  md_wave_push(push, c, q, counter);
+}
+
 int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                        const LevelBuffers& lb, uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points,
                        uint32_t* rounds_out) {
@@ -807,16 +831,28 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(md_nbr_build_kernel, dim3(div_up(ncells, 8)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
-  hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, a.queue[0], ncells,
-                     lb.counters + CTR_Q0);
-  SWZ_LAUNCH_CHECK(c);
-
   // With many small cells a round is bound by activation throughput: futile re-activations must be
-  // cheap.  With few large cells it is bound by the latency of one activation: no extra scan.
+  // cheap, and a stalled cell sleeps until the whole blocking cell is finished (fewer, later wake-ups:
+  // measured at 1 B points, level 1: 302 -> 259 ms).  With few large cells a round is bound by the latency
+  // of one activation and the level by the number of rounds: no extra scan, wake up as early as possible.
   a.early_recheck = (ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0) ? 1u : 0u;
   a.latest_first = a.early_recheck;
+  a.patient = a.early_recheck;
   if (const char* e = getenv("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
+  if (const char* e = getenv("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
   if (const char* e = getenv("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
+  bool lazy = a.early_recheck != 0;
+  if (const char* e = getenv("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
+  a.lazy_frac = getenv("SWZ_MD_LAZY_FRAC") ? (float)atof(getenv("SWZ_MD_LAZY_FRAC")) : 0.5f;
+  if (lazy) {
+    SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_Q0, 0, 4, c->stream));
+    hipLaunchKernelGGL(md_lazy_start_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, a.queue[0],
+                       lb.counters + CTR_Q0);
+  } else {
+    hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, a.queue[0], ncells,
+                       lb.counters + CTR_Q0);
+  }
+  SWZ_LAUNCH_CHECK(c);
 
   // rounds; the host only looks at the done counter every `batch` rounds
   const bool dbg = getenv("SWZ_DEBUG") != nullptr;
