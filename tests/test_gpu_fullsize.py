@@ -1,0 +1,158 @@
+"""Full-size checks of the HIP path through properties that do not need the oracle to run at that size.
+
+The greedy MIN_DISTANCE sample of a node (PoissonDiskSampling / SparseGrid::add, Sampling.h:421-471,
+SparseGrid.cpp:116-146) is characterised point by point:
+
+    taken(p)  <=>  no point taken EARLIER (Morton order) in the same node is closer than the spacing to p
+
+(induction over the order), so any subset of points can be verified independently against the set of taken points
+around it.  The test tiles BASELINE's MIN_DISTANCE workload (uniform points, d = 250, 20000 points per node) at
+SWZ_FULLSIZE_POINTS points (default 100 M; 1000000000 is the bench configuration), then verifies every point of a
+random box per level that way, with the exact arithmetic of the reference ((dx*dx + dy*dy) + dz*dz < float spacing
+squared in float).  Sortedness, the permutation and the keys are checked on the whole output.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+N = int(os.environ.get("SWZ_FULLSIZE_POINTS", "100000000"))
+MAX_POINTS = 20000
+SEED = 0x5C4A72A1D + 3
+
+
+@pytest.fixture(scope="module")
+def tiled():
+    import torch
+    import schwarzwald_amd as swz
+    dev = torch.device("cuda:0")
+    ctx = swz.Context(0)
+    xyz = torch.empty((N, 3), dtype=torch.float64, device=dev)
+    ctx.generate_uniform_device(SEED, 0, N, xyz.data_ptr())
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    out = {}
+    for sampler in (swz.MIN_DISTANCE, swz.RANDOM_GRID):
+        keys = torch.empty(N, dtype=torch.int64, device=dev)
+        perm = torch.empty(N, dtype=torch.int32, device=dev)
+        level = torch.empty(N, dtype=torch.int8, device=dev)
+        params = swz.TileParams(sampler=sampler, max_points_per_node=MAX_POINTS, spacing_at_root=spacing)
+        stats = ctx.tile_device(xyz.data_ptr(), N, UNIT[0], UNIT[1], params, keys.data_ptr(), perm.data_ptr(),
+                                level.data_ptr())
+        torch.cuda.synchronize()
+        out[sampler] = (keys, perm, level, stats)
+    ctx.release_workspace()
+    yield {"xyz": xyz, "spacing": spacing, "out": out, "torch": torch, "swz": swz}
+    ctx.close()
+
+
+def test_output_is_a_sorted_permutation_with_matching_keys(tiled):
+    torch, swz = tiled["torch"], tiled["swz"]
+    keys, perm, level, stats = tiled["out"][swz.MIN_DISTANCE]
+    assert bool((keys[1:] >= keys[:-1]).all())
+    ties = keys[1:] == keys[:-1]
+    assert bool((perm[1:][ties] > perm[:-1][ties]).all())  # canonical order: (key, original index)
+    seen = torch.zeros(N, dtype=torch.bool, device=keys.device)
+    seen[perm.long()] = True
+    assert bool(seen.all())
+    del seen
+    # keys against the oracle's encoder on a random sample
+    rng = np.random.default_rng(5)
+    pick = torch.from_numpy(np.sort(rng.choice(N, size=min(N, 1_000_000), replace=False))).to(keys.device)
+    pts = tiled["xyz"][perm[pick].long()].cpu().numpy()
+    want = O.index_points(pts, *UNIT)[0]
+    assert np.array_equal(keys[pick].cpu().numpy().view(np.uint64), want)
+    # every point was stored exactly once, on a level the statistics know about
+    assert int(level.min()) >= -1 and int(level.max()) == stats["max_level"]
+    assert stats["points_visited"] >= N
+
+
+def _check_level(tiled, L, rng, target_points=1_500_000):
+    """Verifies taken(p) <=> no earlier taken point of the same node within the spacing, for all points of a random
+    box that are active at level L.  Returns (#points checked, #taken among them)."""
+    from scipy.spatial import cKDTree
+    torch, swz = tiled["torch"], tiled["swz"]
+    keys, perm, level, _ = tiled["out"][swz.MIN_DISTANCE]
+    s = np.float32(tiled["spacing"]) / np.float32(2.0 ** (L + 1))   # exact in float (power of two)
+    sq = float(np.float32(s) * np.float32(s))                        # SparseGrid.cpp:18: float product
+    active = level >= L
+    n_active = int(active.sum())
+    if n_active == 0:
+        return 0, 0
+    shift = 63 - 3 * (L + 1)
+    node = (keys >> shift) if shift < 63 else torch.zeros_like(keys)
+    # nodes that sample (more than MAX_POINTS arrive) -- the others take everything
+    uniq, counts = torch.unique_consecutive(node[active], return_counts=True)
+    sampling_nodes = uniq[counts > MAX_POINTS]
+    if sampling_nodes.numel() == 0:
+        return 0, 0
+    in_sampling = active & torch.isin(node, sampling_nodes)
+    # a box holding about target_points of them
+    frac = min(1.0, target_points / max(1, int(in_sampling.sum())))
+    h = 0.5 * frac ** (1.0 / 3.0)
+    c = rng.random(3) * (1.0 - 2.0 * h) + h
+    idx_all = torch.nonzero(in_sampling).squeeze(1)
+    pos = tiled["xyz"][perm[idx_all].long()]
+    lo = torch.tensor(c - h - float(s) * 1.01, device=pos.device)
+    hi = torch.tensor(c + h + float(s) * 1.01, device=pos.device)
+    near = ((pos >= lo) & (pos <= hi)).all(dim=1)
+    idx = idx_all[near]
+    P = pos[near].cpu().numpy()
+    sorted_index = idx.cpu().numpy()
+    node_h = node[idx].cpu().numpy()
+    taken = (level[idx] == L).cpu().numpy()
+    del pos, near, idx_all, in_sampling, active, node
+    inner = np.all((P >= c - h) & (P <= c + h), axis=1)              # the points to verify
+    Q, Qi = P[inner], np.nonzero(inner)[0]
+    T, Ti = P[taken], np.nonzero(taken)[0]
+    pairs = cKDTree(Q).sparse_distance_matrix(cKDTree(T), float(s) * (1.0 + 1e-9), output_type="ndarray")
+    qi, ti = Qi[pairs["i"]], Ti[pairs["j"]]
+    d = P[qi] - P[ti]
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]  # Vector3.h:55-62 order of operations
+    hit = (d2 < sq) & (sorted_index[ti] < sorted_index[qi]) & (node_h[ti] == node_h[qi])
+    has_earlier = np.zeros(P.shape[0], dtype=bool)
+    has_earlier[qi[hit]] = True
+    bad = np.nonzero(inner & (taken == has_earlier))[0]
+    assert bad.size == 0, "level %d: %d of %d points decided differently from the greedy rule, first sorted index %d" % (
+        L, bad.size, int(inner.sum()), int(sorted_index[bad[0]]))
+    return int(inner.sum()), int((taken & inner).sum())
+
+
+def test_min_distance_levels_obey_the_greedy_rule(tiled):
+    swz = tiled["swz"]
+    stats = tiled["out"][swz.MIN_DISTANCE][3]
+    rng = np.random.default_rng(11)
+    checked = 0
+    for L in range(-1, stats["max_level"] + 1):
+        for _ in range(2):
+            n, t = _check_level(tiled, L, rng)
+            print("level %d: %d points verified, %d of them taken" % (L, n, t))
+            checked += n
+    assert checked > 1_000_000
+
+
+def test_random_grid_takes_the_first_point_of_every_cell(tiled):
+    """RandomSortedGridSampling (Sampling.h:187-308): in a sampling node at level L the taken points are exactly
+    the first points of the runs of equal key prefix at level L + 7 (d = 250 on a cube: 128 cells per axis)."""
+    torch, swz = tiled["torch"], tiled["swz"]
+    keys, perm, level, stats = tiled["out"][swz.RANDOM_GRID]
+    for L in range(-1, stats["max_level"] + 1):
+        active = level >= L
+        k = keys[active]
+        lv = level[active]
+        shift = 63 - 3 * (L + 1)
+        node = (k >> shift) if shift < 63 else torch.zeros_like(k)
+        uniq, inv, counts = torch.unique_consecutive(node, return_inverse=True, return_counts=True)
+        sampling = (counts > MAX_POINTS)[inv]
+        cand = L + 7
+        if cand > 20:
+            continue
+        cell = k >> (3 * (20 - cand))
+        head = torch.ones_like(cell, dtype=torch.bool)
+        head[1:] = cell[1:] != cell[:-1]
+        want_taken = torch.where(sampling, head, torch.ones_like(head))
+        assert bool(((lv == L) == want_taken).all()), "level %d" % L
