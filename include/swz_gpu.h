@@ -137,6 +137,71 @@ int swz_build_node_lists(swz_ctx* ctx, const uint64_t* keys_sorted, const int8_t
                          uint64_t* node_key_out, uint64_t* node_offset_out, uint64_t* node_count_out,
                          uint64_t* num_nodes_out);
 
+/* Same on the device: d_keys_sorted / d_level are swz_tile_device's outputs, d_order_out[n] is device
+ * memory; the node table (at most max_nodes entries) is written to the host arrays. */
+int swz_build_node_lists_device(swz_ctx* ctx, const uint64_t* d_keys_sorted, const int8_t* d_level, uint64_t n,
+                                uint32_t* d_order_out, uint64_t max_nodes, int8_t* node_level_out,
+                                uint64_t* node_key_out, uint64_t* node_offset_out, uint64_t* node_count_out,
+                                uint64_t* num_nodes_out);
+
+/* ---- node payload: what a lossless PointsPersistence stores for a node.
+ * The attribute columns of a point batch, SoA like PointBuffer (core/datastructures/PointBuffer.h:109-121,
+ * 292-304); a NULL column is absent.  Indices double as bit numbers of BinaryPersistence's properties
+ * bitmask (core/io/BinaryPersistence.h:24-35) and give the order of the arrays in a node file. */
+enum {
+  SWZ_ATTR_RGB = 0,                 /* 3 x uint8  */
+  SWZ_ATTR_NORMAL = 1,              /* 3 x float  */
+  SWZ_ATTR_INTENSITY = 2,           /* uint16     */
+  SWZ_ATTR_CLASSIFICATION = 3,      /* uint8      */
+  SWZ_ATTR_EDGE_OF_FLIGHT_LINE = 4, /* uint8      */
+  SWZ_ATTR_GPS_TIME = 5,            /* double     */
+  SWZ_ATTR_NUMBER_OF_RETURNS = 6,   /* uint8      */
+  SWZ_ATTR_RETURN_NUMBER = 7,       /* uint8      */
+  SWZ_ATTR_POINT_SOURCE_ID = 8,     /* uint16     */
+  SWZ_ATTR_SCAN_DIRECTION_FLAG = 9, /* uint8      */
+  SWZ_ATTR_SCAN_ANGLE_RANK = 10,    /* int8       */
+  SWZ_ATTR_USER_DATA = 11,          /* uint8      */
+  SWZ_ATTR_COUNT = 12
+};
+typedef struct {
+  void* column[SWZ_ATTR_COUNT];
+} swz_attribute_columns;
+/* bytes per point of attribute a (0 for an invalid index) */
+uint32_t swz_attribute_row_bytes(int attribute);
+
+/* Permuted gather into node order: row i of every output column = row d_perm[d_order[i]] of the input
+ * column (positions N x 3 doubles plus every attribute present in BOTH column sets).  d_perm and d_order
+ * are swz_tile_device's perm and swz_build_node_lists_device's order.  After this the points of node k
+ * are rows [node_offset[k], node_offset[k] + node_count[k]) of every column, in Morton order -- exactly
+ * the iterator range tile_node hands to persist_points (TilingAlgorithms.cpp:232-236, 316-322). */
+int swz_gather_payload_device(swz_ctx* ctx, const uint32_t* d_perm, const uint32_t* d_order, uint64_t n,
+                              const double* d_xyz, const swz_attribute_columns* d_in, double* d_xyz_out,
+                              const swz_attribute_columns* d_out);
+
+/* BinaryPersistence node files (core/io/BinaryPersistence.h:45-193, BinaryPersistence.cpp:200-375):
+ * uint32 properties bitmask, uint64 point count, positions (24 B each), then every present attribute
+ * array in the order RGB, normal, intensity, classification, edge of flight line, GPS time, number of
+ * returns, return number, point source id, scan angle rank, scan direction flag, user data (bit order
+ * except that the reference writes bit 10 before bit 9); little-endian, no padding.  compressed != 0 wraps the same bytes in one zlib stream (level 1,
+ * "<name>.binz"), else "<name>.bin".  Host functions, no GPU involved; ctx only carries the error text
+ * and may be NULL.
+ *   swz_bin_write_node: columns point at the node's first row.  count == 0 writes nothing (like
+ *     persist_points).
+ *   swz_bin_read_header / swz_bin_read_node: retrieve_points; read_node fills xyz_out (count x 3) and
+ *     every non-NULL column whose bit is set in the file.
+ *   swz_bin_persist_nodes: one file per node of a node table, named "r" + octant digits
+ *     (TilingAlgorithms.cpp:139) in directory dir; xyz / columns are the gathered payload of the batch. */
+int swz_bin_write_node(swz_ctx* ctx, const char* path, uint64_t count, const double* xyz,
+                       const swz_attribute_columns* columns, int compressed);
+int swz_bin_read_header(swz_ctx* ctx, const char* path, int compressed, uint32_t* bitmask_out, uint64_t* count_out);
+int swz_bin_read_node(swz_ctx* ctx, const char* path, int compressed, double* xyz_out,
+                      const swz_attribute_columns* columns_out);
+int swz_bin_persist_nodes(swz_ctx* ctx, const char* dir, uint64_t num_nodes, const int8_t* node_level,
+                          const uint64_t* node_key, const uint64_t* node_offset, const uint64_t* node_count,
+                          const double* xyz, const swz_attribute_columns* columns, int compressed);
+/* "r" + octant digits of a node; name_out must hold 23 bytes */
+int swz_node_name(int8_t node_level, uint64_t node_key, char* name_out);
+
 /* ---- multi-GPU sharding: one context per GPU, points owned by their top
  * Morton bits (level-0 octant, MortonIndex::get_octant_at_level(0), MortonIndex.h:133-138), so every
  * node at level >= 0 lives on exactly one GPU.  The reference has no counterpart (it is a single

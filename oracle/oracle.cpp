@@ -19,6 +19,7 @@
 #include <cassert>
 #include <cmath>
 #include <cstddef>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -858,6 +859,60 @@ void orc_merge_ranges_i32(const int32_t* const* ranges, const int64_t* sizes, in
     if (lowest < 0) return;
     out[o] = *heads[(size_t)lowest].first++;
   }
+}
+
+/* ---- BinaryPersistence, uncompressed --------------------------------------------------------------- */
+namespace {
+const size_t kAttrBytes[12] = {3, 12, 2, 1, 1, 8, 1, 1, 2, 1, 1, 1};
+/* persist_points writes, after the positions: colors, normals, intensities, classifications, edge of
+ * flight lines, gps times, number of returns, return numbers, point source ids, scan angle ranks, scan
+ * direction flags, user data (BinaryPersistence.h:120-190); retrieve_points reads in the same order
+ * (BinaryPersistence.cpp:270-360). */
+const int kFileOrder[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 9, 11};
+}  // namespace
+
+int32_t orc_bin_persist_points(const char* path, const uint32_t* point_refs, uint64_t count, const double* xyz,
+                               const void* const columns[12]) {
+  if (count == 0) return ORC_OK; /* BinaryPersistence.h:51-53 */
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return ORC_ERR_BAD_ARG;
+  uint32_t bitmask = 0;
+  for (int a = 0; a < 12; ++a)
+    if (columns && columns[a]) bitmask |= 1u << a; /* has_attribute && pointer != nullptr, :73-112 */
+  std::fwrite(&bitmask, sizeof(bitmask), 1, f); /* write_binary, util/io/io_util.h:15-18 */
+  std::fwrite(&count, sizeof(count), 1, f);
+  for (uint64_t i = 0; i < count; ++i) std::fwrite(xyz + 3 * (size_t)point_refs[i], 24, 1, f); /* :117-118 */
+  for (int k = 0; k < 12; ++k) {
+    const int a = kFileOrder[k];
+    if (!(bitmask & (1u << a))) continue;
+    const unsigned char* col = static_cast<const unsigned char*>(columns[a]);
+    for (uint64_t i = 0; i < count; ++i) std::fwrite(col + kAttrBytes[a] * (size_t)point_refs[i], kAttrBytes[a], 1, f);
+  }
+  return std::fclose(f) == 0 ? ORC_OK : ORC_ERR_BAD_ARG;
+}
+
+int32_t orc_bin_retrieve_points(const char* path, uint32_t* bitmask_out, uint64_t* count_out, double* xyz_out,
+                                void* const columns_out[12]) {
+  FILE* f = std::fopen(path, "rb");
+  if (!f) return ORC_ERR_BAD_ARG;
+  uint32_t bitmask = 0;
+  uint64_t count = 0;
+  bool ok = std::fread(&bitmask, 4, 1, f) == 1 && std::fread(&count, 8, 1, f) == 1; /* BinaryPersistence.cpp:230-234 */
+  if (ok && xyz_out) {
+    ok = count == 0 || std::fread(xyz_out, 24, count, f) == count;
+    for (int k = 0; ok && k < 12; ++k) {
+      const int a = kFileOrder[k];
+      if (!(bitmask & (1u << a))) continue;
+      if (columns_out && columns_out[a])
+        ok = count == 0 || std::fread(columns_out[a], kAttrBytes[a], count, f) == count;
+      else
+        ok = std::fseek(f, (long)(kAttrBytes[a] * count), SEEK_CUR) == 0;
+    }
+  }
+  std::fclose(f);
+  if (bitmask_out) *bitmask_out = bitmask;
+  if (count_out) *count_out = count;
+  return ok ? ORC_OK : ORC_ERR_BAD_ARG;
 }
 
 void orc_generate_uniform(uint64_t seed, uint64_t first_point, uint64_t n, double* xyz) {

@@ -120,6 +120,22 @@ int64_t orc_stable_partition_take_multiples(int32_t* values, int64_t n, int32_t 
 void orc_merge_ranges_i32(const int32_t* const* ranges, const int64_t* sizes, int64_t num_ranges,
                           int32_t* out);
 
+/* BinaryPersistence with Compressed::No (core/io/BinaryPersistence.h:45-193 persist_points,
+ * core/io/BinaryPersistence.cpp:212-375 retrieve_points).  The points of the node are given the way the
+ * tiler gives them: references (indices) into the SoA columns of the batch's PointBuffer
+ * (PointBuffer.h:292-304); columns[a] == NULL means the attribute is absent.  Column index = bit number
+ * of the properties bitmask (BinaryPersistence.h:24-35): 0 RGB (3 x u8), 1 normal (3 x f32), 2 intensity
+ * (u16), 3 classification, 4 edge of flight line, 5 GPS time (f64), 6 number of returns, 7 return number,
+ * 8 point source id (u16), 9 scan direction flag, 10 scan angle rank (i8), 11 user data.
+ * PARITY UNPINNED beyond the reference's own round-trip test (test/TestBinaryPersistence.cpp:52-108), which
+ * tests/test_bin_persistence.py reproduces: the reference ships no golden node file. */
+int32_t orc_bin_persist_points(const char* path, const uint32_t* point_refs, uint64_t count, const double* xyz,
+                               const void* const columns[12]);
+/* Reads the header (and, when xyz_out != NULL, the arrays; buffers must hold *count_out points, so call
+ * twice).  columns_out[a] may be NULL to skip an attribute. */
+int32_t orc_bin_retrieve_points(const char* path, uint32_t* bitmask_out, uint64_t* count_out, double* xyz_out,
+                                void* const columns_out[12]);
+
 /* splitmix64 synthetic workload of SURVEY.md section 8(d): point i draws x,y,z consecutively. */
 void orc_generate_uniform(uint64_t seed, uint64_t first_point, uint64_t n, double* xyz);
 

@@ -74,6 +74,78 @@ def spacing_from_diagonal(bmin, bmax, diagonal_fraction):
     return float(np.float32(np.sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]) / diagonal_fraction))
 
 
+# attribute columns of a point batch: name -> (index = bit of BinaryPersistence's bitmask, numpy dtype, row width)
+ATTRIBUTES = {
+    "rgb": (0, np.uint8, 3), "normal": (1, np.float32, 3), "intensity": (2, np.uint16, 1),
+    "classification": (3, np.uint8, 1), "edge_of_flight_line": (4, np.uint8, 1), "gps_time": (5, np.float64, 1),
+    "number_of_returns": (6, np.uint8, 1), "return_number": (7, np.uint8, 1), "point_source_id": (8, np.uint16, 1),
+    "scan_direction_flag": (9, np.uint8, 1), "scan_angle_rank": (10, np.int8, 1), "user_data": (11, np.uint8, 1),
+}
+
+
+class _AttributeColumns(C.Structure):
+    _fields_ = [("column", C.c_void_p * 12)]
+
+
+def _host_columns(attrs, n=None):
+    """dict name -> array  =>  (swz_attribute_columns, keep-alive list of contiguous arrays)"""
+    cols, keep = _AttributeColumns(), {}
+    for name, arr in (attrs or {}).items():
+        idx, dt, width = ATTRIBUTES[name]
+        a = np.ascontiguousarray(arr, dtype=dt).reshape(-1, width) if width > 1 else np.ascontiguousarray(arr, dtype=dt).reshape(-1)
+        if n is not None and a.shape[0] != n:
+            raise ValueError("attribute %s has %d rows, expected %d" % (name, a.shape[0], n))
+        keep[name] = a
+        cols.column[idx] = a.ctypes.data
+    return cols, keep
+
+
+def device_columns(ptrs):
+    """dict name -> device pointer  =>  swz_attribute_columns"""
+    cols = _AttributeColumns()
+    for name, ptr in (ptrs or {}).items():
+        cols.column[ATTRIBUTES[name][0]] = int(ptr)
+    return cols
+
+
+def node_name(level, key):
+    """"r" + octant digits of a node (TilingAlgorithms.cpp:139)."""
+    buf = C.create_string_buffer(24)
+    if load_library().swz_node_name(int(level), int(key), buf) != 0:
+        raise ValueError("bad node level %d" % level)
+    return buf.value.decode()
+
+
+def bin_write_node(path, xyz, attrs=None, compressed=False):
+    """BinaryPersistence::persist_points for one node (host only, no GPU needed)."""
+    x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+    cols, keep = _host_columns(attrs, x.shape[0])
+    st = load_library().swz_bin_write_node(None, os.fsencode(path), x.shape[0], x.ctypes.data_as(_dp), C.byref(cols),
+                                           int(bool(compressed)))
+    if st != 0:
+        raise SwzError(st, "swz_bin_write_node(%s) failed" % path)
+
+
+def bin_read_node(path, compressed=False):
+    """BinaryPersistence::retrieve_points: returns (xyz, dict of attribute arrays)."""
+    L = load_library()
+    mask, count = C.c_uint32(), C.c_uint64()
+    st = L.swz_bin_read_header(None, os.fsencode(path), int(bool(compressed)), C.byref(mask), C.byref(count))
+    if st != 0:
+        raise SwzError(st, "swz_bin_read_header(%s) failed" % path)
+    n = int(count.value)
+    xyz = np.empty((n, 3), dtype=np.float64)
+    out = {}
+    for name, (idx, dt, width) in ATTRIBUTES.items():
+        if mask.value & (1 << idx):
+            out[name] = np.empty((n, width) if width > 1 else n, dtype=dt)
+    cols, keep = _host_columns(out, n)
+    st = L.swz_bin_read_node(None, os.fsencode(path), int(bool(compressed)), xyz.ctypes.data_as(_dp), C.byref(cols))
+    if st != 0:
+        raise SwzError(st, "swz_bin_read_node(%s) failed" % path)
+    return xyz, keep
+
+
 def library_path():
     return os.environ.get("SWZ_GPU_LIBRARY", os.path.join(_HERE, "lib", "libswz_gpu.so"))
 
@@ -116,6 +188,16 @@ def load_library():
     L.swz_build_node_lists.argtypes = [vp, _u64p, _i8p, C.c_uint64, _u32p, C.c_uint64, _i8p, _u64p, _u64p, _u64p,
                                        _u64p]
     L.swz_generate_uniform_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    L.swz_build_node_lists_device.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint64, _i8p, _u64p, _u64p, _u64p, _u64p]
+    L.swz_attribute_row_bytes.restype = C.c_uint32
+    L.swz_attribute_row_bytes.argtypes = [C.c_int]
+    cols = C.POINTER(_AttributeColumns)
+    L.swz_gather_payload_device.argtypes = [vp, vp, vp, C.c_uint64, vp, cols, vp, cols]
+    L.swz_bin_write_node.argtypes = [vp, C.c_char_p, C.c_uint64, _dp, cols, C.c_int]
+    L.swz_bin_read_header.argtypes = [vp, C.c_char_p, C.c_int, _u32p, _u64p]
+    L.swz_bin_read_node.argtypes = [vp, C.c_char_p, C.c_int, _dp, cols]
+    L.swz_bin_persist_nodes.argtypes = [vp, C.c_char_p, C.c_uint64, _i8p, _u64p, _u64p, _u64p, _dp, cols, C.c_int]
+    L.swz_node_name.argtypes = [C.c_int8, C.c_uint64, C.c_char_p]
     L.swz_partition_by_octant_device.argtypes = [vp, vp, C.c_uint64, vp, _u64p]
     L.swz_shard_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.POINTER(_ShardInfo),
                                          _u64p]
@@ -128,7 +210,9 @@ def load_library():
                  "swz_morton_encode_device", "swz_sort_by_key", "swz_sort_by_key_device", "swz_sample_points",
                  "swz_tile", "swz_tile_device", "swz_build_node_lists", "swz_generate_uniform_device",
                  "swz_profile_enable", "swz_profile_reset", "swz_profile_get", "swz_partition_by_octant_device",
-                 "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device"):
+                 "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device",
+                 "swz_build_node_lists_device", "swz_gather_payload_device", "swz_bin_write_node",
+                 "swz_bin_read_header", "swz_bin_read_node", "swz_bin_persist_nodes", "swz_node_name"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -285,6 +369,41 @@ class Context:
                                               C.byref(p), C.c_void_p(d_keys), C.c_void_p(d_perm),
                                               C.c_void_p(d_level), C.c_void_p(d_dup), C.byref(stats)))
         return _stats_dict(stats)
+
+    def build_node_lists_device(self, d_keys_sorted, d_level, n, d_order):
+        """Device version of build_node_lists: d_order (u32 x n, device) receives the order; returns the node table."""
+        cap = max(int(n), 1)
+        nl = np.empty(cap, dtype=np.int8)
+        nk = np.empty(cap, dtype=np.uint64)
+        no = np.empty(cap, dtype=np.uint64)
+        nc = np.empty(cap, dtype=np.uint64)
+        num = C.c_uint64()
+        self._check(self._lib.swz_build_node_lists_device(self._ctx, C.c_void_p(d_keys_sorted), C.c_void_p(d_level), int(n),
+                                                          C.c_void_p(d_order), cap, nl.ctypes.data_as(_i8p),
+                                                          nk.ctypes.data_as(_u64p), no.ctypes.data_as(_u64p),
+                                                          nc.ctypes.data_as(_u64p), C.byref(num)))
+        m = int(num.value)
+        return dict(level=nl[:m].copy(), key=nk[:m].copy(), offset=no[:m].copy(), count=nc[:m].copy())
+
+    def gather_payload_device(self, d_perm, d_order, n, d_xyz, d_attrs_in, d_xyz_out, d_attrs_out):
+        """Row i of every output column = row perm[order[i]] of the input column (dicts name -> device pointer)."""
+        cin, cout = device_columns(d_attrs_in), device_columns(d_attrs_out)
+        self._check(self._lib.swz_gather_payload_device(self._ctx, C.c_void_p(d_perm), C.c_void_p(d_order), int(n),
+                                                        C.c_void_p(d_xyz), C.byref(cin), C.c_void_p(d_xyz_out),
+                                                        C.byref(cout)))
+
+    def bin_persist_nodes(self, directory, nodes, xyz, attrs=None, compressed=False):
+        """One BinaryPersistence file per node of a node table from the gathered (host) payload."""
+        x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        cols, keep = _host_columns(attrs, x.shape[0])
+        nl = np.ascontiguousarray(nodes["level"], dtype=np.int8)
+        nk = np.ascontiguousarray(nodes["key"], dtype=np.uint64)
+        no = np.ascontiguousarray(nodes["offset"], dtype=np.uint64)
+        nc = np.ascontiguousarray(nodes["count"], dtype=np.uint64)
+        self._check(self._lib.swz_bin_persist_nodes(self._ctx, os.fsencode(directory), nl.shape[0], nl.ctypes.data_as(_i8p),
+                                                    nk.ctypes.data_as(_u64p), no.ctypes.data_as(_u64p),
+                                                    nc.ctypes.data_as(_u64p), x.ctypes.data_as(_dp), C.byref(cols),
+                                                    int(bool(compressed))))
 
     # ------------------------------------------------------------------ sharded batches (one context per GPU)
     def partition_by_octant_device(self, d_keys, n, d_perm):

@@ -146,6 +146,9 @@ void shard_free(swz_ctx* c);
 // One radix pass on the top key digit: perm groups the points by octant (stable); octants (host)
 // receives the eight counts.
 int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t octants[8]);
+// Stable partition by the top byte of the keys: d_perm_out[i] = index of the i-th element, starts[d] = first
+// position of byte value d.
+int partition_by_top_byte(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint32_t starts[256]);
 
 int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uint64_t* d_keys,
                          const uint32_t* d_idx, uint32_t n, const double* d_xyz, uint64_t node_key,

@@ -1,0 +1,335 @@
+// swz_payload.hip -- node lists on the device, the permuted payload gather, and BinaryPersistence node files
+// (reference: core/io/BinaryPersistence.h:45-193, BinaryPersistence.cpp:200-375,
+// core/tiling/TilingAlgorithms.cpp:139, 232-236).
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "swz_internal.h"
+#include "swz_device.h"
+
+namespace swz {
+
+static const uint32_t ATTR_BYTES[SWZ_ATTR_COUNT] = {3, 12, 2, 1, 1, 8, 1, 1, 2, 1, 1, 1};
+// order of the attribute arrays in a node file (BinaryPersistence.h:120-190: bit 10 before bit 9)
+static const int FILE_ORDER[SWZ_ATTR_COUNT] = {SWZ_ATTR_RGB, SWZ_ATTR_NORMAL, SWZ_ATTR_INTENSITY, SWZ_ATTR_CLASSIFICATION,
+                                               SWZ_ATTR_EDGE_OF_FLIGHT_LINE, SWZ_ATTR_GPS_TIME, SWZ_ATTR_NUMBER_OF_RETURNS,
+                                               SWZ_ATTR_RETURN_NUMBER, SWZ_ATTR_POINT_SOURCE_ID, SWZ_ATTR_SCAN_ANGLE_RANK,
+                                               SWZ_ATTR_SCAN_DIRECTION_FLAG, SWZ_ATTR_USER_DATA};
+
+// ---------------------------------------------------------------------------------- node lists
+__global__ __launch_bounds__(256) void level_key_kernel(const int8_t* __restrict__ level, uint32_t n, uint64_t* __restrict__ out,
+                                                        uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int l = level[i];
+  if (l < -1 || l > 20) atomicAdd(bad, 1u);
+  out[i] = (uint64_t)(uint8_t)(l + 1) << 56;  // the stable partition looks at the top byte only
+}
+
+// position i of the level-grouped order starts a node: first of its level, or another key prefix
+__global__ __launch_bounds__(256) void node_head_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
+                                                        const int8_t* __restrict__ level, uint32_t n, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = order[i];
+  const int l = level[p];
+  bool head = i == 0;
+  if (!head) {
+    const uint32_t q = order[i - 1];
+    head = level[q] != l || (l >= 0 && (keys[q] >> level_shift(l)) != (keys[p] >> level_shift(l)));
+  }
+  flags[i] = head ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void node_table_kernel(const uint32_t* __restrict__ order, const uint64_t* __restrict__ keys,
+                                                         const int8_t* __restrict__ level, uint32_t n,
+                                                         const uint32_t* __restrict__ excl, uint32_t max_nodes,
+                                                         int8_t* __restrict__ nlevel, uint64_t* __restrict__ nkey,
+                                                         uint64_t* __restrict__ noffset) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = order[i];
+  const int l = level[p];
+  bool head = i == 0;
+  if (!head) {
+    const uint32_t q = order[i - 1];
+    head = level[q] != l || (l >= 0 && (keys[q] >> level_shift(l)) != (keys[p] >> level_shift(l)));
+  }
+  if (!head) return;
+  const uint32_t k = excl[i];
+  if (k >= max_nodes) return;
+  nlevel[k] = (int8_t)l;
+  nkey[k] = l < 0 ? 0ull : ((keys[p] >> level_shift(l)) << level_shift(l));
+  noffset[k] = i;
+}
+
+// ---------------------------------------------------------------------------------- payload gather
+__global__ __launch_bounds__(256) void compose_kernel(const uint32_t* __restrict__ perm, const uint32_t* __restrict__ order,
+                                                      uint32_t n, uint32_t* __restrict__ src) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) src[i] = perm[order ? order[i] : i];
+}
+
+// rows of K elements of T; one thread per row (rows are at most 24 bytes)
+template <typename T, int K>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* __restrict__ in, const uint32_t* __restrict__ src, uint32_t n,
+                                                          T* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const T* r = in + (size_t)src[i] * K;
+  T v[K];
+#pragma unroll
+  for (int j = 0; j < K; ++j) v[j] = r[j];
+#pragma unroll
+  for (int j = 0; j < K; ++j) out[(size_t)i * K + j] = v[j];
+}
+
+template <typename T, int K>
+static void launch_gather(swz_ctx* c, const void* in, const uint32_t* src, uint32_t n, void* out) {
+  hipLaunchKernelGGL((gather_rows_kernel<T, K>), dim3(div_up(n, 256)), dim3(256), 0, c->stream, (const T*)in, src, n, (T*)out);
+}
+
+// ---------------------------------------------------------------------------------- node files
+struct ByteSink {
+  std::vector<unsigned char> buf;
+  void put(const void* p, size_t n) {
+    const unsigned char* b = (const unsigned char*)p;
+    buf.insert(buf.end(), b, b + n);
+  }
+};
+
+static int fail(swz_ctx* c, int code, const std::string& msg) {
+  if (c) return c->fail(code, msg.c_str());
+  return code;
+}
+
+static int read_file(swz_ctx* c, const char* path, int compressed, std::vector<unsigned char>& out, size_t want_at_most) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return fail(c, SWZ_ERR_BAD_ARG, std::string("cannot open ") + path);
+  std::vector<unsigned char> raw;
+  unsigned char tmp[1 << 16];
+  size_t got;
+  while ((got = fread(tmp, 1, sizeof(tmp), f)) > 0) raw.insert(raw.end(), tmp, tmp + got);
+  fclose(f);
+  if (!compressed) {
+    out.swap(raw);
+    return SWZ_OK;
+  }
+  z_stream zs;
+  memset(&zs, 0, sizeof(zs));
+  if (inflateInit(&zs) != Z_OK) return fail(c, SWZ_ERR_INTERNAL, "inflateInit failed");
+  zs.next_in = raw.data();
+  zs.avail_in = (uInt)raw.size();
+  int rc = Z_OK;
+  out.clear();
+  while (rc != Z_STREAM_END && out.size() < want_at_most) {
+    zs.next_out = tmp;
+    zs.avail_out = sizeof(tmp);
+    rc = inflate(&zs, Z_NO_FLUSH);
+    if (rc != Z_OK && rc != Z_STREAM_END) {
+      inflateEnd(&zs);
+      return fail(c, SWZ_ERR_BAD_ARG, std::string("corrupt zlib stream in ") + path);
+    }
+    out.insert(out.end(), tmp, tmp + (sizeof(tmp) - zs.avail_out));
+  }
+  inflateEnd(&zs);
+  return SWZ_OK;
+}
+
+}  // namespace swz
+
+using namespace swz;
+
+extern "C" {
+
+uint32_t swz_attribute_row_bytes(int attribute) {
+  return (attribute >= 0 && attribute < SWZ_ATTR_COUNT) ? ATTR_BYTES[attribute] : 0u;
+}
+
+int swz_build_node_lists_device(swz_ctx* c, const uint64_t* d_keys_sorted, const int8_t* d_level, uint64_t n,
+                                uint32_t* d_order_out, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
+                                uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out) {
+  if (!c || !num_nodes_out) return SWZ_ERR_BAD_ARG;
+  *num_nodes_out = 0;
+  if (n == 0) return SWZ_OK;
+  if (n > 0xFFFFFFFFull) return c->fail(SWZ_ERR_BAD_ARG, "more than 2^32-1 points in one batch");
+  if (!d_keys_sorted || !d_level || !d_order_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_build_node_lists_device: NULL buffer");
+  const uint32_t m = (uint32_t)n;
+  const uint32_t nb = div_up(m, 256);
+  uint64_t* lkeys = nullptr;
+  uint32_t *flags = nullptr, *cnt = nullptr;
+  SWZ_TRY(c->get("nl_keys", (size_t)m, &lkeys));
+  SWZ_TRY(c->get("nl_flags", (size_t)m, &flags));
+  SWZ_TRY(c->get("nl_cnt", (size_t)2, &cnt));
+  SWZ_HIP(c, hipMemsetAsync(cnt, 0, 8, c->stream));
+  hipLaunchKernelGGL(level_key_kernel, dim3(nb), dim3(256), 0, c->stream, d_level, m, lkeys, cnt);
+  SWZ_LAUNCH_CHECK(c);
+  uint32_t starts[256];
+  SWZ_TRY(partition_by_top_byte(c, lkeys, m, d_order_out, starts));
+  hipLaunchKernelGGL(node_head_kernel, dim3(nb), dim3(256), 0, c->stream, d_order_out, d_keys_sorted, d_level, m, flags);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(scan_exclusive_u32(c, flags, flags, m, cnt + 1, "nl"));
+  uint32_t h[2] = {0, 0};
+  SWZ_HIP(c, hipMemcpyAsync(h, cnt, 8, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  if (h[0]) return c->fail(SWZ_ERR_BAD_ARG, "level out of range");
+  const uint64_t nn = h[1];
+  *num_nodes_out = nn;
+  if (nn > max_nodes) return c->fail(SWZ_ERR_BAD_ARG, "max_nodes too small");
+  if (!node_level_out || !node_key_out || !node_offset_out || !node_count_out) return SWZ_OK;
+  int8_t* dl = nullptr;
+  uint64_t *dk = nullptr, *doff = nullptr;
+  SWZ_TRY(c->get("nl_level", (size_t)nn, &dl));
+  SWZ_TRY(c->get("nl_key", (size_t)nn, &dk));
+  SWZ_TRY(c->get("nl_off", (size_t)nn, &doff));
+  hipLaunchKernelGGL(node_table_kernel, dim3(nb), dim3(256), 0, c->stream, d_order_out, d_keys_sorted, d_level, m, flags,
+                     (uint32_t)nn, dl, dk, doff);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_HIP(c, hipMemcpyAsync(node_level_out, dl, nn, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipMemcpyAsync(node_key_out, dk, nn * 8, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipMemcpyAsync(node_offset_out, doff, nn * 8, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  for (uint64_t k = 0; k < nn; ++k) node_count_out[k] = (k + 1 < nn ? node_offset_out[k + 1] : n) - node_offset_out[k];
+  return SWZ_OK;
+}
+
+int swz_gather_payload_device(swz_ctx* c, const uint32_t* d_perm, const uint32_t* d_order, uint64_t n, const double* d_xyz,
+                              const swz_attribute_columns* d_in, double* d_xyz_out, const swz_attribute_columns* d_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  if (n == 0) return SWZ_OK;
+  if (n > 0xFFFFFFFFull) return c->fail(SWZ_ERR_BAD_ARG, "more than 2^32-1 points in one batch");
+  if (!d_perm) return c->fail(SWZ_ERR_BAD_ARG, "swz_gather_payload_device: NULL perm");
+  if ((d_xyz == nullptr) != (d_xyz_out == nullptr)) return c->fail(SWZ_ERR_BAD_ARG, "positions need input and output");
+  const uint32_t m = (uint32_t)n;
+  uint32_t* src = nullptr;
+  SWZ_TRY(c->get("payload_src", (size_t)m, &src));
+  uint64_t bytes = 12ull * n;  // perm + order read, composed index written
+  hipLaunchKernelGGL(compose_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, d_perm, d_order, m, src);
+  SWZ_LAUNCH_CHECK(c);
+  {
+    ProfScope ps(c, "payload_gather", 0, 1);
+    if (d_xyz) {
+      launch_gather<double, 3>(c, d_xyz, src, m, d_xyz_out);
+      bytes += 52ull * n;
+    }
+    for (int a = 0; a < SWZ_ATTR_COUNT; ++a) {
+      const void* in = d_in ? d_in->column[a] : nullptr;
+      void* out = d_out ? d_out->column[a] : nullptr;
+      if (!in || !out) continue;
+      switch (ATTR_BYTES[a]) {
+        case 3: launch_gather<uint8_t, 3>(c, in, src, m, out); break;
+        case 12: launch_gather<float, 3>(c, in, src, m, out); break;
+        case 2: launch_gather<uint16_t, 1>(c, in, src, m, out); break;
+        case 8: launch_gather<double, 1>(c, in, src, m, out); break;
+        default: launch_gather<uint8_t, 1>(c, in, src, m, out); break;
+      }
+      bytes += (4ull + 2ull * ATTR_BYTES[a]) * n;
+    }
+    SWZ_LAUNCH_CHECK(c);
+    ps.bytes = bytes;
+  }
+  return SWZ_OK;
+}
+
+int swz_node_name(int8_t node_level, uint64_t node_key, char* name_out) {
+  if (!name_out || node_level < -1 || node_level > 20) return SWZ_ERR_BAD_ARG;
+  int k = 0;
+  name_out[k++] = 'r';
+  for (int l = 0; l <= node_level; ++l) name_out[k++] = (char)('0' + ((node_key >> level_shift(l)) & 7u));
+  name_out[k] = 0;
+  return SWZ_OK;
+}
+
+int swz_bin_write_node(swz_ctx* c, const char* path, uint64_t count, const double* xyz, const swz_attribute_columns* columns,
+                       int compressed) {
+  if (!path) return fail(c, SWZ_ERR_BAD_ARG, "swz_bin_write_node: NULL path");
+  if (count == 0) return SWZ_OK;  // persist_points returns before opening the file
+  if (!xyz) return fail(c, SWZ_ERR_BAD_ARG, "swz_bin_write_node: NULL positions");
+  uint32_t bitmask = 0;
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (columns && columns->column[a]) bitmask |= 1u << a;
+  ByteSink sink;
+  sink.put(&bitmask, 4);
+  sink.put(&count, 8);
+  sink.put(xyz, (size_t)count * 24);
+  for (int k = 0; k < SWZ_ATTR_COUNT; ++k) {
+    const int a = FILE_ORDER[k];
+    if (bitmask & (1u << a)) sink.put(columns->column[a], (size_t)count * ATTR_BYTES[a]);
+  }
+  FILE* f = fopen(path, "wb");
+  if (!f) return fail(c, SWZ_ERR_BAD_ARG, std::string("cannot write ") + path);
+  bool ok = true;
+  if (!compressed) {
+    ok = fwrite(sink.buf.data(), 1, sink.buf.size(), f) == sink.buf.size();
+  } else {
+    uLongf cap = compressBound((uLong)sink.buf.size());
+    std::vector<unsigned char> z(cap);
+    ok = compress2(z.data(), &cap, sink.buf.data(), (uLong)sink.buf.size(), Z_BEST_SPEED) == Z_OK &&
+         fwrite(z.data(), 1, cap, f) == cap;
+  }
+  ok = (fclose(f) == 0) && ok;
+  return ok ? SWZ_OK : fail(c, SWZ_ERR_INTERNAL, std::string("short write to ") + path);
+}
+
+int swz_bin_read_header(swz_ctx* c, const char* path, int compressed, uint32_t* bitmask_out, uint64_t* count_out) {
+  if (!path || !bitmask_out || !count_out) return fail(c, SWZ_ERR_BAD_ARG, "swz_bin_read_header: NULL argument");
+  std::vector<unsigned char> data;
+  const int st = read_file(c, path, compressed, data, compressed ? 12 : (size_t)-1);
+  if (st != SWZ_OK) return st;
+  if (data.size() < 12) return fail(c, SWZ_ERR_BAD_ARG, std::string("truncated node file ") + path);
+  memcpy(bitmask_out, data.data(), 4);
+  memcpy(count_out, data.data() + 4, 8);
+  return SWZ_OK;
+}
+
+int swz_bin_read_node(swz_ctx* c, const char* path, int compressed, double* xyz_out, const swz_attribute_columns* columns_out) {
+  if (!path) return fail(c, SWZ_ERR_BAD_ARG, "swz_bin_read_node: NULL path");
+  std::vector<unsigned char> data;
+  const int st = read_file(c, path, compressed, data, (size_t)-1);
+  if (st != SWZ_OK) return st;
+  if (data.size() < 12) return fail(c, SWZ_ERR_BAD_ARG, std::string("truncated node file ") + path);
+  uint32_t bitmask;
+  uint64_t count;
+  memcpy(&bitmask, data.data(), 4);
+  memcpy(&count, data.data() + 4, 8);
+  size_t need = 12 + (size_t)count * 24;
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (bitmask & (1u << a)) need += (size_t)count * ATTR_BYTES[a];
+  if (data.size() < need) return fail(c, SWZ_ERR_BAD_ARG, std::string("truncated node file ") + path);
+  size_t at = 12;
+  if (xyz_out) memcpy(xyz_out, data.data() + at, (size_t)count * 24);
+  at += (size_t)count * 24;
+  for (int k = 0; k < SWZ_ATTR_COUNT; ++k) {
+    const int a = FILE_ORDER[k];
+    if (!(bitmask & (1u << a))) continue;
+    if (columns_out && columns_out->column[a]) memcpy(columns_out->column[a], data.data() + at, (size_t)count * ATTR_BYTES[a]);
+    at += (size_t)count * ATTR_BYTES[a];
+  }
+  return SWZ_OK;
+}
+
+int swz_bin_persist_nodes(swz_ctx* c, const char* dir, uint64_t num_nodes, const int8_t* node_level, const uint64_t* node_key,
+                          const uint64_t* node_offset, const uint64_t* node_count, const double* xyz,
+                          const swz_attribute_columns* columns, int compressed) {
+  if (!dir || (num_nodes && (!node_level || !node_key || !node_offset || !node_count || !xyz)))
+    return fail(c, SWZ_ERR_BAD_ARG, "swz_bin_persist_nodes: NULL argument");
+  for (uint64_t k = 0; k < num_nodes; ++k) {
+    char name[24];
+    if (swz_node_name(node_level[k], node_key[k], name) != SWZ_OK) return fail(c, SWZ_ERR_BAD_ARG, "bad node level");
+    const std::string path = std::string(dir) + "/" + name + (compressed ? ".binz" : ".bin");
+    swz_attribute_columns cols;
+    for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+      cols.column[a] = (columns && columns->column[a])
+                         ? (void*)((unsigned char*)columns->column[a] + (size_t)node_offset[k] * ATTR_BYTES[a])
+                         : nullptr;
+    const int st = swz_bin_write_node(c, path.c_str(), node_count[k], xyz + (size_t)node_offset[k] * 3, &cols, compressed);
+    if (st != SWZ_OK) return st;
+  }
+  return SWZ_OK;
+}
+
+}  // extern "C"

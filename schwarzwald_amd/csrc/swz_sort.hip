@@ -311,8 +311,9 @@ __global__ __launch_bounds__(RADIX) void digit_starts_kernel(const uint32_t* __r
   out[threadIdx.x] = offs[(uint64_t)threadIdx.x * ntiles];
 }
 
-int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t octants[8]) {
-  for (int o = 0; o < 8; ++o) octants[o] = 0;
+int partition_by_top_byte(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint32_t starts[256]) {
+  static_assert(RADIX == 256, "one radix digit is one byte");
+  for (int d = 0; d < RADIX; ++d) starts[d] = 0;
   if (n == 0) return SWZ_OK;
   const uint32_t ntiles = div_up(n, RS_TILE);
   uint32_t *d_hist = nullptr, *d_starts = nullptr;
@@ -320,7 +321,7 @@ int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t
   SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
   SWZ_TRY(c->get("part_starts", (size_t)RADIX, &d_starts));
   SWZ_TRY(c->get("part_keys", (size_t)n, &d_keys_tmp));
-  const int shift = 64 - RADIX_BITS;  // top digit; the octant (key bits 60..62) is its bits below the unused bit 63
+  const int shift = 64 - RADIX_BITS;
   hipLaunchKernelGGL(radix_hist_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, d_keys, n, shift, d_hist, ntiles);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, d_hist, d_hist, (uint64_t)ntiles * RADIX, nullptr, "radix"));
@@ -329,9 +330,17 @@ int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t
   hipLaunchKernelGGL(radix_scatter_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, d_keys,
                      (const uint32_t*)nullptr, d_keys_tmp, d_perm_out, n, shift, d_hist, ntiles);
   SWZ_LAUNCH_CHECK(c);
-  uint32_t starts[RADIX];
-  SWZ_HIP(c, hipMemcpyAsync(starts, d_starts, sizeof(starts), hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipMemcpyAsync(starts, d_starts, sizeof(uint32_t) * RADIX, hipMemcpyDeviceToHost, c->stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  return SWZ_OK;
+}
+
+// the octant (key bits 60..62) is the top digit's bits below the unused bit 63
+int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t octants[8]) {
+  for (int o = 0; o < 8; ++o) octants[o] = 0;
+  if (n == 0) return SWZ_OK;
+  uint32_t starts[RADIX];
+  SWZ_TRY(partition_by_top_byte(c, d_keys, n, d_perm_out, starts));
   for (int d = 0; d < RADIX; ++d)
     octants[(d >> (RADIX_BITS - 4)) & 7] += (uint64_t)((d == RADIX - 1 ? n : starts[d + 1]) - starts[d]);
   return SWZ_OK;

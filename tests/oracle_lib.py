@@ -90,6 +90,10 @@ def lib():
         L.orc_merge_ranges_i32.restype = None
         L.orc_merge_ranges_i32.argtypes = [C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int64), C.c_int64,
                                            C.POINTER(C.c_int32)]
+        L.orc_bin_persist_points.restype = C.c_int32
+        L.orc_bin_persist_points.argtypes = [C.c_char_p, _u32p, C.c_uint64, _dp, C.POINTER(C.c_void_p)]
+        L.orc_bin_retrieve_points.restype = C.c_int32
+        L.orc_bin_retrieve_points.argtypes = [C.c_char_p, _u32p, _u64p, _dp, C.POINTER(C.c_void_p)]
         L.orc_generate_uniform.restype = None
         L.orc_generate_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _dp]
         _lib = L
@@ -212,6 +216,52 @@ def tile(xyz, bmin, bmax, sampler, max_points_per_node, spacing_at_root, max_dep
     return dict(status=int(st), keys=keys, perm=perm, level=level, dup=dup, xyz_clamped=x,
                 stats=dict(num_nodes=int(stats.num_nodes), points_visited=int(stats.points_visited),
                            max_level=int(stats.max_level), fast_start_levels=int(stats.fast_start_levels)))
+
+
+# attribute columns: name -> (bit of BinaryPersistence's bitmask, dtype, row width)
+ATTRIBUTES = {
+    "rgb": (0, np.uint8, 3), "normal": (1, np.float32, 3), "intensity": (2, np.uint16, 1),
+    "classification": (3, np.uint8, 1), "edge_of_flight_line": (4, np.uint8, 1), "gps_time": (5, np.float64, 1),
+    "number_of_returns": (6, np.uint8, 1), "return_number": (7, np.uint8, 1), "point_source_id": (8, np.uint16, 1),
+    "scan_direction_flag": (9, np.uint8, 1), "scan_angle_rank": (10, np.int8, 1), "user_data": (11, np.uint8, 1),
+}
+
+
+def _columns(attrs):
+    cols = (C.c_void_p * 12)()
+    keep = {}
+    for name, arr in (attrs or {}).items():
+        idx, dt, width = ATTRIBUTES[name]
+        a = np.ascontiguousarray(arr, dtype=dt)
+        keep[name] = a
+        cols[idx] = a.ctypes.data
+    return cols, keep
+
+
+def bin_persist_points(path, point_refs, xyz, attrs=None):
+    """BinaryPersistence::persist_points (uncompressed) of the points `point_refs` of a batch."""
+    refs = np.ascontiguousarray(point_refs, dtype=np.uint32)
+    x = np.ascontiguousarray(xyz, dtype=np.float64)
+    cols, keep = _columns(attrs)
+    st = lib().orc_bin_persist_points(os.fsencode(path), _ptr(refs, _u32p), refs.shape[0], _ptr(x, _dp), cols)
+    assert st == 0, st
+
+
+def bin_retrieve_points(path):
+    """BinaryPersistence::retrieve_points: (bitmask, xyz, attrs)."""
+    mask, count = C.c_uint32(), C.c_uint64()
+    st = lib().orc_bin_retrieve_points(os.fsencode(path), C.byref(mask), C.byref(count), None, None)
+    assert st == 0, st
+    n = int(count.value)
+    xyz = np.empty((n, 3), dtype=np.float64)
+    out = {}
+    for name, (idx, dt, width) in ATTRIBUTES.items():
+        if mask.value & (1 << idx):
+            out[name] = np.empty((n, width) if width > 1 else n, dtype=dt)
+    cols, keep = _columns(out)
+    st = lib().orc_bin_retrieve_points(os.fsencode(path), C.byref(mask), C.byref(count), _ptr(xyz, _dp), cols)
+    assert st == 0, st
+    return int(mask.value), xyz, keep
 
 
 def generate_uniform(seed, n, first_point=0):

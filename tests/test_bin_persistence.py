@@ -1,0 +1,180 @@
+"""BinaryPersistence node files (core/io/BinaryPersistence.h:45-193,
+BinaryPersistence.cpp:212-375).
+
+CPU part: the oracle's restatement reproduces the reference's own test (test/TestBinaryPersistence.cpp:52-108:
+index, sort, split into the root's octants, persist every octant, retrieve, compare -- lossless), its byte layout
+is checked against a layout written out by hand here, and the library's host-side writer/reader (no GPU involved)
+must produce the same bytes.  GPU part: tile a batch with attributes on the device, build the node lists and
+gather the payload on the device, write every node file, and compare each file byte for byte with what the
+oracle pipeline (oracle tile -> per node point references -> oracle persist_points) writes.
+"""
+import os
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+
+
+def _attributes(rng, n, names):
+    out = {}
+    for name in names:
+        idx, dt, width = O.ATTRIBUTES[name]
+        shape = (n, width) if width > 1 else n
+        if np.issubdtype(dt, np.floating):
+            out[name] = rng.standard_normal(shape).astype(dt)
+        else:
+            info = np.iinfo(dt)
+            out[name] = rng.integers(info.min, info.max, size=shape, endpoint=True).astype(dt)
+    return out
+
+
+ALL = list(O.ATTRIBUTES)
+
+
+def test_oracle_round_trip_like_the_reference_test(tmp_path):
+    """test/TestBinaryPersistence.cpp:52-108 with 4096 random points, positions only."""
+    rng = np.random.default_rng(1)
+    xyz = rng.random((4096, 3))
+    keys, _ = O.index_points(xyz, *UNIT)
+    perm = O.sort_by_key(keys)
+    off = O.partition_child_octants(keys[perm], 0)
+    assert off[0] == 0 and off[8] == 4096
+    for b, e in zip(off[:-1], off[1:]):
+        if e == b:
+            continue
+        path = str(tmp_path / "_persistence_test_.bin")
+        O.bin_persist_points(path, perm[b:e], xyz)
+        mask, got, attrs = O.bin_retrieve_points(path)
+        assert mask == 0 and attrs == {}
+        assert np.array_equal(got, xyz[perm[b:e]])
+        os.remove(path)
+
+
+def _expected_bytes(refs, xyz, attrs):
+    """The layout written out by hand: u32 bitmask, u64 count, positions, then the arrays in the order
+    persist_points writes them (bit 10, scan angle rank, BEFORE bit 9, scan direction flag)."""
+    mask = 0
+    for name in attrs:
+        mask |= 1 << O.ATTRIBUTES[name][0]
+    out = struct.pack("<IQ", mask, len(refs)) + np.ascontiguousarray(xyz[refs], dtype="<f8").tobytes()
+    for name in ["rgb", "normal", "intensity", "classification", "edge_of_flight_line", "gps_time", "number_of_returns",
+                 "return_number", "point_source_id", "scan_angle_rank", "scan_direction_flag", "user_data"]:
+        if name in attrs:
+            out += np.ascontiguousarray(attrs[name][refs]).tobytes()
+    return out
+
+
+@pytest.mark.parametrize("names", [[], ["rgb", "intensity"], ALL, ["scan_angle_rank", "scan_direction_flag", "gps_time"]])
+def test_oracle_layout_and_library_writer_agree(tmp_path, names):
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(2)
+    n = 1000
+    xyz = rng.random((n, 3))
+    attrs = _attributes(rng, n, names)
+    refs = rng.permutation(n)[:333].astype(np.uint32)
+    p_orc = str(tmp_path / "orc.bin")
+    O.bin_persist_points(p_orc, refs, xyz, attrs)
+    want = _expected_bytes(refs, xyz, attrs)
+    assert open(p_orc, "rb").read() == want
+    # library (host-side, works without a GPU): the node's rows already gathered
+    p_lib = str(tmp_path / "lib.bin")
+    swz.bin_write_node(p_lib, xyz[refs], {k: v[refs] for k, v in attrs.items()})
+    assert open(p_lib, "rb").read() == want
+    # .binz = the same bytes in one zlib stream
+    p_z = str(tmp_path / "lib.binz")
+    swz.bin_write_node(p_z, xyz[refs], {k: v[refs] for k, v in attrs.items()}, compressed=True)
+    assert zlib.decompress(open(p_z, "rb").read()) == want
+    # both readers return what was written
+    for reader_xyz, reader_attrs in (swz.bin_read_node(p_lib), swz.bin_read_node(p_z, compressed=True),
+                                     O.bin_retrieve_points(p_lib)[1:]):
+        assert np.array_equal(reader_xyz, xyz[refs])
+        assert set(reader_attrs) == set(names)
+        for k in names:
+            assert np.array_equal(reader_attrs[k], attrs[k][refs])
+
+
+def test_empty_node_writes_no_file_and_names(tmp_path):
+    import schwarzwald_amd as swz
+    swz.bin_write_node(str(tmp_path / "none.bin"), np.empty((0, 3)))
+    O.bin_persist_points(str(tmp_path / "none2.bin"), np.empty(0, dtype=np.uint32), np.empty((0, 3)))
+    assert not (tmp_path / "none.bin").exists() and not (tmp_path / "none2.bin").exists()
+    assert swz.node_name(-1, 0) == "r"
+    key = int(O.morton_index([0.3, 0.6, 0.9], *UNIT))         # octants 351265126512651265126
+    assert swz.node_name(4, key) == "r35126"
+    for m in (swz.api.ATTRIBUTES, O.ATTRIBUTES):
+        for name, (idx, dt, width) in m.items():
+            assert swz.load_library().swz_attribute_row_bytes(idx) == np.dtype(dt).itemsize * width
+    assert swz.load_library().swz_attribute_row_bytes(12) == 0
+
+
+def _oracle_node_files(directory, xyz, attrs, tile):
+    """oracle tile result -> one file per node through the oracle's persist_points."""
+    keys, perm, level = tile["keys"], tile["perm"], tile["level"]
+    names = {}
+    order = np.lexsort((np.arange(len(keys)), level))   # stable by level; inside a level Morton order
+    i = 0
+    while i < len(order):
+        p = order[i]
+        L = int(level[p])
+        shift = 63 if L < 0 else 3 * (20 - L)
+        prefix = int(keys[p]) >> shift
+        j = i
+        while j < len(order) and level[order[j]] == L and (int(keys[order[j]]) >> shift) == prefix:
+            j += 1
+        name = "r" + "".join(str((int(keys[p]) >> (3 * (20 - l))) & 7) for l in range(L + 1))
+        O.bin_persist_points(os.path.join(directory, name + ".bin"), perm[order[i:j]], xyz, attrs)
+        names[name] = j - i
+        i = j
+    return names
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler,names", [(O.MIN_DISTANCE, ["rgb", "intensity"]), (O.GRID_CENTER, ALL), (O.RANDOM_GRID, [])])
+def test_gpu_node_files_match_the_oracle_pipeline(tmp_path, sampler, names):
+    import torch
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(3)
+    n = 150_000
+    xyz = rng.random((n, 3))
+    attrs = _attributes(rng, n, names)
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    o = O.tile(xyz, *UNIT, sampler, 2000, spacing)
+    d_orc = tmp_path / "orc"
+    d_gpu = tmp_path / "gpu"
+    d_orc.mkdir()
+    d_gpu.mkdir()
+    want = _oracle_node_files(str(d_orc), xyz, attrs, o)
+
+    dev = torch.device("cuda:0")
+    ctx = swz.Context(0)
+    d_xyz = torch.from_numpy(xyz).to(dev)
+    d_attr = {k: torch.from_numpy(v).to(dev) for k, v in attrs.items()}
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    level = torch.empty(n, dtype=torch.int8, device=dev)
+    ctx.tile_device(d_xyz.data_ptr(), n, *UNIT, swz.TileParams(sampler=sampler, max_points_per_node=2000, spacing_at_root=spacing),
+                    keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    nodes = ctx.build_node_lists_device(keys.data_ptr(), level.data_ptr(), n, order.data_ptr())
+    # the device node table equals the host one
+    h_order, h_nodes = ctx.build_node_lists(keys.cpu().numpy().view(np.uint64), level.cpu().numpy())
+    assert np.array_equal(order.cpu().numpy().view(np.uint32), h_order)
+    for k in ("level", "key", "offset", "count"):
+        assert np.array_equal(nodes[k], h_nodes[k])
+    out_xyz = torch.empty_like(d_xyz)
+    out_attr = {k: torch.empty_like(v) for k, v in d_attr.items()}
+    ctx.gather_payload_device(perm.data_ptr(), order.data_ptr(), n, d_xyz.data_ptr(), {k: v.data_ptr() for k, v in d_attr.items()},
+                              out_xyz.data_ptr(), {k: v.data_ptr() for k, v in out_attr.items()})
+    torch.cuda.synchronize()
+    ctx.bin_persist_nodes(str(d_gpu), nodes, out_xyz.cpu().numpy(), {k: v.cpu().numpy() for k, v in out_attr.items()})
+    ctx.close()
+    got = sorted(os.listdir(d_gpu))
+    assert got == sorted(f + ".bin" for f in want)
+    assert len(got) == o["stats"]["num_nodes"]
+    for f in got:
+        assert open(d_gpu / f, "rb").read() == open(d_orc / f, "rb").read(), f
