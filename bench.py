@@ -19,6 +19,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -37,6 +39,9 @@ def parse_args():
     ap.add_argument("--max-points-per-node", type=int, default=20000)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--payload", default="", help="comma separated attribute columns (e.g. rgb,intensity): after the "
+                    "timed region also build the node lists and gather the node payload on the device; reported "
+                    "separately under \"payload\", never part of `value`")
     return ap.parse_args()
 
 
@@ -75,6 +80,42 @@ def cpu_baseline(args, spacing):
     return {"value": round(n / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
             "sample": "%d uniform points, %s, d=%g, max_points_per_node=%d, ACCURATE, one batch (%.1f s)" % (
                 n, args.sampler, args.diagonal_fraction, args.max_points_per_node, dt)}
+
+
+def payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n):
+    """node lists + permuted gather of positions and attribute columns into node order
+    (what a lossless persistence writes).  Algorithmic bytes per point: 8 (perm + order) + 4 (composed index) +
+    4 + 2 x 24 (positions) + 4 + 2 x row bytes per attribute."""
+    names = [a for a in args.payload.split(",") if a]
+    ws = ctx.workspace_bytes()
+    ctx.release_workspace()  # the sampling workspace (MIN_DISTANCE: most of the HBM) is not needed any more
+    cols = {}
+    for a in names:
+        idx, dt, width = swz.ATTRIBUTES[a]
+        t = torch.empty((n, width) if width > 1 else (n,), dtype=getattr(torch, np.dtype(dt).name), device=dev)
+        t.random_(0, 200) if not t.is_floating_point() else t.normal_()
+        cols[a] = t
+    order = torch.empty(n, dtype=torch.int32, device=dev)
+    out_xyz = torch.empty_like(xyz)
+    out_cols = {a: torch.empty_like(t) for a, t in cols.items()}
+    res = {}
+    for rep in range(2):  # first pass warms the workspace
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nodes = ctx.build_node_lists_device(keys.data_ptr(), level.data_ptr(), n, order.data_ptr())
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        ctx.gather_payload_device(perm.data_ptr(), order.data_ptr(), n, xyz.data_ptr(), {a: t.data_ptr() for a, t in cols.items()},
+                                  out_xyz.data_ptr(), {a: t.data_ptr() for a, t in out_cols.items()})
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        row = sum(np.dtype(swz.ATTRIBUTES[a][1]).itemsize * swz.ATTRIBUTES[a][2] for a in names)
+        alg = 12 + 52 + sum(4 + 2 * np.dtype(swz.ATTRIBUTES[a][1]).itemsize * swz.ATTRIBUTES[a][2] for a in names)
+        res = {"tile_workspace_GB": round(ws / 1e9, 1), "columns": ["position"] + names, "attribute_bytes_per_point": row, "nodes": int(nodes["level"].shape[0]),
+               "node_lists_ms": round((t1 - t0) * 1e3, 3), "gather_ms": round((t2 - t1) * 1e3, 3),
+               "gather_Mpoints_per_s": round(n / (t2 - t1) / 1e6, 1), "algorithmic_bytes_per_point": alg,
+               "gather_hbm_frac": round(alg * n / (t2 - t1) / (HBM_PEAK_GBS * 1e9), 4)}
+    return res
 
 
 def main():
@@ -180,6 +221,8 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
+        if world == 1 and args.payload:
+            out["payload"] = payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, spacing)
         print(json.dumps(out))

@@ -23,7 +23,7 @@
 namespace swz {
 
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
-constexpr int SP_K = 12;  // recorded neighbours per point; more -> the point re-searches every round
+constexpr int SP_K = 8;  // recorded neighbours per point (32 B); more -> the point re-searches every round
 enum : uint8_t { SP_U = 0, SP_A = 1, SP_R = 2 };
 
 struct SpArgs {
@@ -279,9 +279,10 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
   SWZ_TRY(c->get("sp_table", (size_t)entries, &a.table));
   double4* rec = nullptr;
-  SWZ_TRY(c->get("sp_rec", (size_t)m, &rec));
+  SWZ_TRY(c->get("md_pos", (size_t)m * 4, reinterpret_cast<double**>(&rec)));  // shared with the sweep
   a.rec = rec;
-  SWZ_TRY(c->get("sp_nbr", (size_t)m * SP_K, &a.nbr));
+  static_assert(SP_K * sizeof(uint32_t) == 4 * sizeof(double), "md_acc holds 32 bytes per point");
+  SWZ_TRY(c->get("md_acc", (size_t)m * 4, reinterpret_cast<double**>(&a.nbr)));  // shared with the sweep
   SWZ_TRY(c->get("sp_ncount", (size_t)m, &a.ncount));
   SWZ_TRY(c->get("sp_state", (size_t)m, &a.state));
   uint32_t *u0 = nullptr, *u1 = nullptr, *cnt = nullptr;

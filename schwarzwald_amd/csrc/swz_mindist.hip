@@ -788,9 +788,11 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   }
   if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
     double *ax = nullptr, *ay = nullptr, *az = nullptr;
-    SWZ_TRY(c->get("md_ax", (size_t)m, &ax));
-    SWZ_TRY(c->get("md_ay", (size_t)m, &ay));
-    SWZ_TRY(c->get("md_az", (size_t)m, &az));
+    // the two big per-point buffers are shared with the sparse path (never live at the same time):
+    // "md_pos" = 32 B per point (x[], y[], z[] here, {x,y,z,key} records there), "md_acc" = 32 B per point
+    SWZ_TRY(c->get("md_pos", (size_t)m * 4, &ax));
+    ay = ax + m;
+    az = ay + m;
     hipLaunchKernelGGL(md_gather_active_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.aidx, m, sp.X, sp.Y,
                        sp.Z, ax, ay, az);
     SWZ_LAUNCH_CHECK(c);
@@ -817,7 +819,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_TRY(c->get("md_cell4", (size_t)ncells, &a.cell));
   SWZ_TRY(c->get("md_nbr_id", (size_t)ncells * 27, &a.nbr_id));
   SWZ_TRY(c->get("md_nbr_slot", (size_t)ncells * 32, &a.nbr_slot));
-  SWZ_TRY(c->get("md_acc_xyz", (size_t)m * 3, &a.acc_xyz));
+  SWZ_TRY(c->get("md_acc", (size_t)m * 4, &a.acc_xyz));  // 3 doubles per point used (see md_pos above)
   SWZ_TRY(c->get("md_queue0", (size_t)ncells, &a.queue[0]));
   SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
   const uint64_t grid_entries = (uint64_t)sample_nodes * cells_per_node;

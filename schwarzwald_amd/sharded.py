@@ -86,6 +86,12 @@ class ShardedTiler:
         rank's shard; self.result holds (recv_xyz, keys, perm, level) for the points this rank owns."""
         ctx, dev, world = self.ctx, self.device, self.world
         n = xyz.shape[0]
+        if dev.type == "cuda":
+            # keys + perm + send buffer + receive buffer are about 3 x the positions; when a previous batch left a
+            # workspace that does not leave room for them, give it back first (it is re-grown on demand)
+            free, _ = torch.cuda.mem_get_info(dev)
+            if free < int(3.2 * n * 24) and ctx.workspace_bytes() > 0:
+                ctx.release_workspace()
         # 1. encode locally, group by destination
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         ctx.morton_encode_device(xyz.data_ptr(), n, self.bmin, self.bmax, keys.data_ptr())
