@@ -8,6 +8,7 @@ python bench.py --points 100000000 --sampler GRID_CENTER --steps 5 --warmup 2 --
 for s in RANDOM_GRID GRID_CENTER JITTERED; do
   python bench.py --sampler $s --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_$s.json 2>> $OUT/bench.err
 done
+python bench.py --steps 2 --warmup 1 --cpu-sample 0 --payload rgb,intensity > $OUT/bench_1B_min_distance_payload.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py > $OUT/stats_run.json 2>/dev/null
 find $OUT/stats -name "*kernel_trace*" -delete
