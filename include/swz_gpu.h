@@ -202,6 +202,30 @@ int swz_bin_persist_nodes(swz_ctx* ctx, const char* dir, uint64_t num_nodes, con
 /* "r" + octant digits of a node; name_out must hold 23 bytes */
 int swz_node_name(int8_t node_level, uint64_t node_key, char* name_out);
 
+/* ---- LAS point records -> positions + attribute columns: the step right in
+ * front of the path.  The reference reads points through LASzip into a laszip_point and converts them in
+ * position_from_las_point (core/io/LASFile.cpp:79-94: offset + X * scale per axis, then clamped into the
+ * header's bounding box) and las_read_points_into (:578-632: RGB >> 8, the other attributes copied).  LASzip
+ * itself (github.com/LASzip/LASzip, built from LAStools per the reference's README.md:24-37, version not
+ * pinned there) is not part of the reference tree; for UNCOMPRESSED files its reader only unpacks the fixed
+ * point data record of the LAS 1.2 specification, which is restated here for formats 0-3:
+ *   X,Y,Z i32 | intensity u16 | return number:3, number of returns:3, scan direction:1, edge of flight line:1 |
+ *   classification:5 (+3 flag bits) | scan angle rank i8 | user data u8 | point source id u16  (20 bytes)
+ *   | format 1,3: gps time f64 | format 2,3: R,G,B u16.
+ * d_records: n records of record_bytes each (>= the format's size; trailing extra bytes are skipped), device
+ * memory, 4-byte aligned.  Columns absent from d_out are skipped; attributes the format lacks (gps time in
+ * format 0/2, RGB in 0/1) are written as 0 like an untouched laszip_point. */
+typedef struct {
+  double scale[3];       /* laszip_header::x_scale_factor, y_, z_ */
+  double offset[3];      /* x_offset, ... */
+  double min[3];         /* min_x, ... : positions are clamped into [min, max] */
+  double max[3];
+  uint32_t point_format; /* 0..3 */
+  uint32_t record_bytes; /* point data record length */
+} swz_las_layout;
+int swz_las_decode_device(swz_ctx* ctx, const uint8_t* d_records, uint64_t n, const swz_las_layout* layout,
+                          double* d_xyz_out, const swz_attribute_columns* d_out);
+
 /* ---- multi-GPU sharding: one context per GPU, points owned by their top
  * Morton bits (level-0 octant, MortonIndex::get_octant_at_level(0), MortonIndex.h:133-138), so every
  * node at level >= 0 lives on exactly one GPU.  The reference has no counterpart (it is a single

@@ -915,6 +915,85 @@ int32_t orc_bin_retrieve_points(const char* path, uint32_t* bitmask_out, uint64_
   return ok ? ORC_OK : ORC_ERR_BAD_ARG;
 }
 
+/* ---- LAS records ------------------------------------------------------------------------------------ */
+namespace {
+/* what LASzip's reader leaves in a laszip_point for point data record formats 0-3 (LAS 1.2 specification,
+ * "Point Data Record Format 0..3"; laszip_api.h: return_number:3, number_of_returns:3, scan_direction_flag:1,
+ * edge_of_flight_line:1, classification:5 + 3 flag bits) */
+struct LasPoint {
+  int32_t X, Y, Z;
+  uint16_t intensity;
+  uint8_t return_number, number_of_returns, scan_direction_flag, edge_of_flight_line, classification;
+  int8_t scan_angle_rank;
+  uint8_t user_data;
+  uint16_t point_source_ID;
+  double gps_time;
+  uint16_t rgb[3];
+};
+LasPoint las_read_record(const uint8_t* r, uint32_t format) {
+  LasPoint p{};
+  std::memcpy(&p.X, r, 4);
+  std::memcpy(&p.Y, r + 4, 4);
+  std::memcpy(&p.Z, r + 8, 4);
+  std::memcpy(&p.intensity, r + 12, 2);
+  p.return_number = r[14] & 7;
+  p.number_of_returns = (r[14] >> 3) & 7;
+  p.scan_direction_flag = (r[14] >> 6) & 1;
+  p.edge_of_flight_line = (r[14] >> 7) & 1;
+  p.classification = r[15] & 31;
+  p.scan_angle_rank = (int8_t)r[16];
+  p.user_data = r[17];
+  std::memcpy(&p.point_source_ID, r + 18, 2);
+  size_t at = 20;
+  if (format == 1 || format == 3) {
+    std::memcpy(&p.gps_time, r + at, 8);
+    at += 8;
+  }
+  if (format == 2 || format == 3) std::memcpy(p.rgb, r + at, 6);
+  return p;
+}
+}  // namespace
+
+int32_t orc_las_decode(const uint8_t* records, uint64_t n, const orc_las_layout* L, double* xyz_out,
+                       void* const col[12]) {
+  static const uint32_t min_bytes[4] = {20, 28, 26, 34};
+  if (!L || L->point_format > 3 || L->record_bytes < min_bytes[L->point_format]) return ORC_ERR_BAD_ARG;
+  for (uint64_t i = 0; i < n; ++i) {
+    const LasPoint p = las_read_record(records + i * L->record_bytes, L->point_format);
+    if (xyz_out) {
+      /* position_from_las_point, LASFile.cpp:82-92 */
+      double x = L->offset[0] + p.X * L->scale[0];
+      double y = L->offset[1] + p.Y * L->scale[1];
+      double z = L->offset[2] + p.Z * L->scale[2];
+      x = std::min(L->max[0], std::max(L->min[0], x));
+      y = std::min(L->max[1], std::max(L->min[1], y));
+      z = std::min(L->max[2], std::max(L->min[2], z));
+      xyz_out[3 * i] = x;
+      xyz_out[3 * i + 1] = y;
+      xyz_out[3 * i + 2] = z;
+    }
+    if (!col) continue;
+    /* las_read_points_into, LASFile.cpp:590-628 */
+    if (col[0]) {
+      uint8_t* c = static_cast<uint8_t*>(col[0]) + 3 * i;
+      c[0] = static_cast<uint8_t>(p.rgb[0] >> 8);
+      c[1] = static_cast<uint8_t>(p.rgb[1] >> 8);
+      c[2] = static_cast<uint8_t>(p.rgb[2] >> 8);
+    }
+    if (col[2]) static_cast<uint16_t*>(col[2])[i] = p.intensity;
+    if (col[3]) static_cast<uint8_t*>(col[3])[i] = p.classification;
+    if (col[5]) static_cast<double*>(col[5])[i] = p.gps_time;
+    if (col[4]) static_cast<uint8_t*>(col[4])[i] = p.edge_of_flight_line;
+    if (col[6]) static_cast<uint8_t*>(col[6])[i] = p.number_of_returns;
+    if (col[7]) static_cast<uint8_t*>(col[7])[i] = p.return_number;
+    if (col[8]) static_cast<uint16_t*>(col[8])[i] = p.point_source_ID;
+    if (col[10]) static_cast<int8_t*>(col[10])[i] = p.scan_angle_rank;
+    if (col[9]) static_cast<uint8_t*>(col[9])[i] = p.scan_direction_flag;
+    if (col[11]) static_cast<uint8_t*>(col[11])[i] = p.user_data;
+  }
+  return ORC_OK;
+}
+
 void orc_generate_uniform(uint64_t seed, uint64_t first_point, uint64_t n, double* xyz) {
   /* splitmix64 stream; draw k of the stream is mix(seed + (k+1)*GOLDEN).  Point i uses draws
    * 3i, 3i+1, 3i+2 so any slice can be generated independently. */

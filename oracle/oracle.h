@@ -136,6 +136,18 @@ int32_t orc_bin_persist_points(const char* path, const uint32_t* point_refs, uin
 int32_t orc_bin_retrieve_points(const char* path, uint32_t* bitmask_out, uint64_t* count_out, double* xyz_out,
                                 void* const columns_out[12]);
 
+/* LAS point records -> positions + attributes: position_from_las_point (core/io/LASFile.cpp:79-94) and
+ * las_read_points_into (:578-632) applied to the laszip_point that LASzip's reader fills from an UNCOMPRESSED
+ * point data record (LAS 1.2 formats 0-3; LASzip is not in the reference tree, see include/swz_gpu.h).
+ * columns_out uses the indices of orc_bin_persist_points; NULL entries are skipped.  PARITY UNPINNED: the
+ * reference's LAS tests (test/TestLASFile.cpp) need LASzip and its test files. */
+typedef struct {
+  double scale[3], offset[3], min[3], max[3];
+  uint32_t point_format, record_bytes;
+} orc_las_layout;
+int32_t orc_las_decode(const uint8_t* records, uint64_t n, const orc_las_layout* layout, double* xyz_out,
+                       void* const columns_out[12]);
+
 /* splitmix64 synthetic workload of SURVEY.md section 8(d): point i draws x,y,z consecutively. */
 void orc_generate_uniform(uint64_t seed, uint64_t first_point, uint64_t n, double* xyz);
 

@@ -83,6 +83,11 @@ ATTRIBUTES = {
 }
 
 
+class _LasLayout(C.Structure):
+    _fields_ = [("scale", C.c_double * 3), ("offset", C.c_double * 3), ("min", C.c_double * 3), ("max", C.c_double * 3),
+                ("point_format", C.c_uint32), ("record_bytes", C.c_uint32)]
+
+
 class _AttributeColumns(C.Structure):
     _fields_ = [("column", C.c_void_p * 12)]
 
@@ -198,6 +203,7 @@ def load_library():
     L.swz_bin_read_node.argtypes = [vp, C.c_char_p, C.c_int, _dp, cols]
     L.swz_bin_persist_nodes.argtypes = [vp, C.c_char_p, C.c_uint64, _i8p, _u64p, _u64p, _u64p, _dp, cols, C.c_int]
     L.swz_node_name.argtypes = [C.c_int8, C.c_uint64, C.c_char_p]
+    L.swz_las_decode_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(_LasLayout), vp, cols]
     L.swz_partition_by_octant_device.argtypes = [vp, vp, C.c_uint64, vp, _u64p]
     L.swz_shard_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.POINTER(_ShardInfo),
                                          _u64p]
@@ -212,7 +218,8 @@ def load_library():
                  "swz_profile_enable", "swz_profile_reset", "swz_profile_get", "swz_partition_by_octant_device",
                  "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device",
                  "swz_build_node_lists_device", "swz_gather_payload_device", "swz_bin_write_node",
-                 "swz_bin_read_header", "swz_bin_read_node", "swz_bin_persist_nodes", "swz_node_name"):
+                 "swz_bin_read_header", "swz_bin_read_node", "swz_bin_persist_nodes", "swz_node_name",
+                 "swz_las_decode_device"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -391,6 +398,13 @@ class Context:
         self._check(self._lib.swz_gather_payload_device(self._ctx, C.c_void_p(d_perm), C.c_void_p(d_order), int(n),
                                                         C.c_void_p(d_xyz), C.byref(cin), C.c_void_p(d_xyz_out),
                                                         C.byref(cout)))
+
+    def las_decode_device(self, d_records, n, scale, offset, bmin, bmax, point_format, record_bytes, d_xyz, d_attrs=None):
+        """Raw LAS 1.2 point records (formats 0-3, device memory) -> positions and attribute columns on the device."""
+        lay = _LasLayout(_vec3(scale), _vec3(offset), _vec3(bmin), _vec3(bmax), int(point_format), int(record_bytes))
+        cols = device_columns(d_attrs)
+        self._check(self._lib.swz_las_decode_device(self._ctx, C.c_void_p(d_records), int(n), C.byref(lay),
+                                                    C.c_void_p(d_xyz), C.byref(cols)))
 
     def bin_persist_nodes(self, directory, nodes, xyz, attrs=None, compressed=False):
         """One BinaryPersistence file per node of a node table from the gathered (host) payload."""

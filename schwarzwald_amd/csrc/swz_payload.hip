@@ -333,3 +333,112 @@ int swz_bin_persist_nodes(swz_ctx* c, const char* dir, uint64_t num_nodes, const
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------- LAS point records (F2)
+namespace swz {
+
+struct LasArgs {
+  double scale[3], offset[3], mn[3], mx[3];
+  uint32_t format, record_bytes;
+  double* xyz;
+  void* col[SWZ_ATTR_COUNT];
+};
+
+constexpr int LAS_POINTS_PER_BLOCK = 256;
+constexpr int LAS_MAX_RECORD = 96;  // staged through LDS; longer records (many extra bytes) are read directly
+
+__device__ __forceinline__ uint32_t las_u16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ int32_t las_i32(const uint8_t* p) {
+  return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+}
+
+__device__ __forceinline__ void las_unpack(const LasArgs& a, const uint8_t* r, uint32_t i) {
+  // position_from_las_point (LASFile.cpp:79-94): offset + X * scale, then min(max, max(min, p)) per axis
+  if (a.xyz) {
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      double p = a.offset[ax] + (double)las_i32(r + 4 * ax) * a.scale[ax];
+      p = fmin(a.mx[ax], fmax(a.mn[ax], p));
+      a.xyz[(size_t)i * 3 + ax] = p;
+    }
+  }
+  const uint32_t bits = r[14], cls = r[15];
+  if (a.col[SWZ_ATTR_INTENSITY]) ((uint16_t*)a.col[SWZ_ATTR_INTENSITY])[i] = (uint16_t)las_u16(r + 12);
+  if (a.col[SWZ_ATTR_RETURN_NUMBER]) ((uint8_t*)a.col[SWZ_ATTR_RETURN_NUMBER])[i] = (uint8_t)(bits & 7u);
+  if (a.col[SWZ_ATTR_NUMBER_OF_RETURNS]) ((uint8_t*)a.col[SWZ_ATTR_NUMBER_OF_RETURNS])[i] = (uint8_t)((bits >> 3) & 7u);
+  if (a.col[SWZ_ATTR_SCAN_DIRECTION_FLAG]) ((uint8_t*)a.col[SWZ_ATTR_SCAN_DIRECTION_FLAG])[i] = (uint8_t)((bits >> 6) & 1u);
+  if (a.col[SWZ_ATTR_EDGE_OF_FLIGHT_LINE]) ((uint8_t*)a.col[SWZ_ATTR_EDGE_OF_FLIGHT_LINE])[i] = (uint8_t)((bits >> 7) & 1u);
+  if (a.col[SWZ_ATTR_CLASSIFICATION]) ((uint8_t*)a.col[SWZ_ATTR_CLASSIFICATION])[i] = (uint8_t)(cls & 31u);
+  if (a.col[SWZ_ATTR_SCAN_ANGLE_RANK]) ((int8_t*)a.col[SWZ_ATTR_SCAN_ANGLE_RANK])[i] = (int8_t)r[16];
+  if (a.col[SWZ_ATTR_USER_DATA]) ((uint8_t*)a.col[SWZ_ATTR_USER_DATA])[i] = r[17];
+  if (a.col[SWZ_ATTR_POINT_SOURCE_ID]) ((uint16_t*)a.col[SWZ_ATTR_POINT_SOURCE_ID])[i] = (uint16_t)las_u16(r + 18);
+  const bool has_gps = a.format == 1u || a.format == 3u, has_rgb = a.format == 2u || a.format == 3u;
+  if (a.col[SWZ_ATTR_GPS_TIME]) {
+    uint64_t v = 0;
+    if (has_gps)
+      for (int b = 7; b >= 0; --b) v = (v << 8) | r[20 + b];
+    ((double*)a.col[SWZ_ATTR_GPS_TIME])[i] = __longlong_as_double((long long)v);
+  }
+  if (a.col[SWZ_ATTR_RGB]) {
+    const uint8_t* c = r + (has_gps ? 28 : 20);
+    uint8_t* o = (uint8_t*)a.col[SWZ_ATTR_RGB] + (size_t)i * 3;
+    // las_read_points_into (LASFile.cpp:592-597): static_cast<uint8_t>(rgb[k] >> 8)
+    for (int k = 0; k < 3; ++k) o[k] = has_rgb ? c[2 * k + 1] : (uint8_t)0;
+  }
+}
+
+__global__ __launch_bounds__(LAS_POINTS_PER_BLOCK) void las_decode_kernel(const uint8_t* __restrict__ rec, uint32_t n, LasArgs a) {
+  __shared__ uint32_t stage[LAS_POINTS_PER_BLOCK * LAS_MAX_RECORD / 4];
+  const uint32_t first = blockIdx.x * LAS_POINTS_PER_BLOCK;
+  const uint32_t cnt = min((uint32_t)LAS_POINTS_PER_BLOCK, n - first);
+  const uint32_t i = first + threadIdx.x;
+  if (a.record_bytes <= (uint32_t)LAS_MAX_RECORD && (a.record_bytes & 1u) == 0) {
+    // the block's records are one contiguous, 4-byte aligned run (256 x an even length): coalesced word loads
+    const size_t byte0 = (size_t)first * a.record_bytes;
+    const uint32_t bytes = cnt * a.record_bytes, words = bytes / 4u;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(rec + byte0);
+    for (uint32_t w = threadIdx.x; w < words; w += LAS_POINTS_PER_BLOCK) stage[w] = src[w];
+    if (threadIdx.x < (bytes & 3u))  // the last block may end in a partial word: no read past the buffer
+      reinterpret_cast<uint8_t*>(stage)[words * 4u + threadIdx.x] = rec[byte0 + words * 4u + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < cnt) las_unpack(a, reinterpret_cast<const uint8_t*>(stage) + (size_t)threadIdx.x * a.record_bytes, i);
+  } else if (threadIdx.x < cnt) {
+    las_unpack(a, rec + (size_t)i * a.record_bytes, i);
+  }
+}
+
+}  // namespace swz
+
+extern "C" int swz_las_decode_device(swz_ctx* c, const uint8_t* d_records, uint64_t n, const swz_las_layout* layout,
+                                     double* d_xyz_out, const swz_attribute_columns* d_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  if (!layout) return c->fail(SWZ_ERR_BAD_ARG, "swz_las_decode_device: NULL layout");
+  static const uint32_t kMinBytes[4] = {20, 28, 26, 34};
+  if (layout->point_format > 3) return c->fail(SWZ_ERR_BAD_ARG, "only LAS point data record formats 0-3 are decoded");
+  if (layout->record_bytes < kMinBytes[layout->point_format])
+    return c->fail(SWZ_ERR_BAD_ARG, "record length shorter than the point format");
+  if (n == 0) return SWZ_OK;
+  if (n > 0xFFFFFFFFull) return c->fail(SWZ_ERR_BAD_ARG, "more than 2^32-1 points in one batch");
+  if (!d_records) return c->fail(SWZ_ERR_BAD_ARG, "swz_las_decode_device: NULL records");
+  if (((uintptr_t)d_records & 3u) != 0) return c->fail(SWZ_ERR_BAD_ARG, "records must be 4-byte aligned");
+  swz::LasArgs a{};
+  uint64_t out_bytes = d_xyz_out ? 24 : 0;
+  for (int k = 0; k < 3; ++k) {
+    a.scale[k] = layout->scale[k];
+    a.offset[k] = layout->offset[k];
+    a.mn[k] = layout->min[k];
+    a.mx[k] = layout->max[k];
+  }
+  a.format = layout->point_format;
+  a.record_bytes = layout->record_bytes;
+  a.xyz = d_xyz_out;
+  for (int k = 0; k < SWZ_ATTR_COUNT; ++k) {
+    a.col[k] = (d_out && k != SWZ_ATTR_NORMAL) ? d_out->column[k] : nullptr;  // LAS points carry no normals
+    if (a.col[k]) out_bytes += swz::ATTR_BYTES[k];
+  }
+  swz::ProfScope ps(c, "las_decode", (uint64_t)n * (layout->record_bytes + out_bytes), 1);
+  hipLaunchKernelGGL(swz::las_decode_kernel, dim3(swz::div_up((uint32_t)n, swz::LAS_POINTS_PER_BLOCK)),
+                     dim3(swz::LAS_POINTS_PER_BLOCK), 0, c->stream, d_records, (uint32_t)n, a);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}

@@ -94,6 +94,8 @@ def lib():
         L.orc_bin_persist_points.argtypes = [C.c_char_p, _u32p, C.c_uint64, _dp, C.POINTER(C.c_void_p)]
         L.orc_bin_retrieve_points.restype = C.c_int32
         L.orc_bin_retrieve_points.argtypes = [C.c_char_p, _u32p, _u64p, _dp, C.POINTER(C.c_void_p)]
+        L.orc_las_decode.restype = C.c_int32
+        L.orc_las_decode.argtypes = [_u8p, C.c_uint64, C.POINTER(LasLayout), _dp, C.POINTER(C.c_void_p)]
         L.orc_generate_uniform.restype = None
         L.orc_generate_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _dp]
         _lib = L
@@ -262,6 +264,29 @@ def bin_retrieve_points(path):
     st = lib().orc_bin_retrieve_points(os.fsencode(path), C.byref(mask), C.byref(count), _ptr(xyz, _dp), cols)
     assert st == 0, st
     return int(mask.value), xyz, keep
+
+
+class LasLayout(C.Structure):
+    _fields_ = [("scale", C.c_double * 3), ("offset", C.c_double * 3), ("min", C.c_double * 3), ("max", C.c_double * 3),
+                ("point_format", C.c_uint32), ("record_bytes", C.c_uint32)]
+
+
+LAS_ATTRIBUTES = [a for a in ATTRIBUTES if a != "normal"]
+
+
+def las_decode(records, n, scale, offset, bmin, bmax, point_format, record_bytes, names=LAS_ATTRIBUTES):
+    """position_from_las_point + las_read_points_into on raw LAS 1.2 point records: (xyz, attrs)."""
+    rec = np.ascontiguousarray(records, dtype=np.uint8)
+    lay = LasLayout(_vec3(scale), _vec3(offset), _vec3(bmin), _vec3(bmax), point_format, record_bytes)
+    xyz = np.empty((n, 3), dtype=np.float64)
+    out = {}
+    for name in names:
+        idx, dt, width = ATTRIBUTES[name]
+        out[name] = np.zeros((n, width) if width > 1 else n, dtype=dt)
+    cols, keep = _columns(out)
+    st = lib().orc_las_decode(_ptr(rec, _u8p), n, C.byref(lay), _ptr(xyz, _dp), cols)
+    assert st == 0, st
+    return xyz, keep
 
 
 def generate_uniform(seed, n, first_point=0):
