@@ -292,12 +292,15 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   // lane r < nnb: the r-th earlier adjacent cell, latest (largest Morton code) first -- decisions arrive
   // roughly in Morton order, so the blocker found first tends to be decided last and one sleep covers the
   // others; lane 27: this cell (its committed accepted points join the rejection list)
-  const uint32_t nnb = a.nbr_slot[(size_t)c * 32 + 31];
+  // (the table rows are requested together with the cell record: lane 31 of the slot row holds the count)
+  const uint32_t raw_nb = a.nbr_id[(size_t)c * 27 + (l < 27u ? l : 26u)];
+  const uint32_t raw_slot = a.nbr_slot[(size_t)c * 32 + (l & 31u)];
+  const uint32_t nnb = bcast_u32(raw_slot, 31);
   uint32_t nb = NONE32, n_cnt = 0, n_start = 0, n_pos = 0, n_end = 0, slot_of_rank = 13;
   bool earlier = false;
   if (l < nnb) {
-    nb = a.nbr_id[(size_t)c * 27 + l];
-    slot_of_rank = a.nbr_slot[(size_t)c * 32 + l];
+    nb = raw_nb;
+    slot_of_rank = raw_slot;
     earlier = true;
     const uint4 o = a.cell[nb];
     n_start = o.x;
