@@ -39,6 +39,9 @@ def parse_args():
     ap.add_argument("--max-points-per-node", type=int, default=20000)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--bounds-scale", type=float, default=1.0, help="experiment: tile the unit-cube points inside a "
+                    "cube this many times larger (2 = the points fill one octant of the root, which is what one rank "
+                    "of an 8-GPU run sees at the root level)")
     ap.add_argument("--payload", default="", help="comma separated attribute columns (e.g. rgb,intensity): after the "
                     "timed region also build the node lists and gather the node payload on the device; reported "
                     "separately under \"payload\", never part of `value`")
@@ -137,7 +140,7 @@ def main():
     dev = torch.device("cuda", local_rank if distributed else 0)
 
     n = args.points
-    bmin, bmax = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    bmin, bmax = [0.0, 0.0, 0.0], [args.bounds_scale] * 3
     spacing = swz.spacing_from_diagonal(bmin, bmax, args.diagonal_fraction)
     params = swz.TileParams(sampler=swz.SAMPLERS[args.sampler], max_points_per_node=args.max_points_per_node,
                             spacing_at_root=spacing, max_depth=100, strategy=swz.ACCURATE)
