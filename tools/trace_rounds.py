@@ -11,7 +11,7 @@ level = -1
 cur = None
 levels = []
 for s, e, k in rows:
-    if k == "md_fill_queue_kernel":
+    if k in ("md_fill_queue_kernel", "md_lazy_start_kernel"):
         cur = {"k": collections.defaultdict(lambda: [0, 0]), "gap": 0, "last": None, "rounds": [], "t0": s}
         levels.append(cur)
     if cur is None or k not in ("md_sweep_kernel", "md_commit_kernel", "md_requeue_kernel"):
