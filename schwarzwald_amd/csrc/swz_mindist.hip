@@ -867,8 +867,14 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     ev1 = c->take_event();
     (void)hipEventRecord(ev0, c->stream);
   }
-  const uint32_t sweep_grid = std::min<uint32_t>(2048u, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
-  const uint32_t commit_grid = std::min<uint32_t>(1024u, std::max<uint32_t>(1u, div_up(ncells, 256)));
+  // grid-stride kernels: whole multiples of the resident workgroups (256 CUs x 5 per CU) avoid a ragged tail
+  uint32_t sweep_cap = 2560u, commit_cap = 1280u;
+  if (const char* e = getenv("SWZ_MD_GRID")) {
+    sweep_cap = (uint32_t)atoi(e);
+    commit_cap = std::max(1u, sweep_cap / 2u);
+  }
+  const uint32_t sweep_grid = std::min<uint32_t>(sweep_cap, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
+  const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
   const uint32_t batch = 32;
   const uint64_t max_rounds = 4ull * m + 1024;
