@@ -38,6 +38,9 @@ def parse_args():
     ap.add_argument("--diagonal-fraction", type=float, default=250.0)
     ap.add_argument("--max-points-per-node", type=int, default=20000)
     ap.add_argument("--cpu-sample", type=int, default=4_000_000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--strategy", default="ACCURATE", choices=["ACCURATE", "FAST"],
+                    help="tiling strategy (TilingAlgorithmV1 / V3); the headline is ACCURATE, the canonical top-down semantics")
+    ap.add_argument("--fast-concurrency", type=int, default=8, help="FAST: the thread count its start level depends on")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--bounds-scale", type=float, default=1.0, help="experiment: tile the unit-cube points inside a "
                     "cube this many times larger (2 = the points fill one octant of the root, which is what one rank "
@@ -77,12 +80,13 @@ def cpu_baseline(args, spacing):
     n = args.cpu_sample
     xyz = O.generate_uniform(SEED + 3, n)
     t0 = time.perf_counter()
-    r = O.tile(xyz, [0, 0, 0], [1, 1, 1], getattr(O, args.sampler), args.max_points_per_node, spacing)
+    r = O.tile(xyz, [0, 0, 0], [args.bounds_scale] * 3, getattr(O, args.sampler), args.max_points_per_node, spacing,
+               strategy=getattr(O, args.strategy), fast_concurrency=args.fast_concurrency)
     dt = time.perf_counter() - t0
     assert r["status"] == 0
     return {"value": round(n / dt / 1e6, 4), "unit": "Mpoints/s", "cores": 1, "kind": "port",
-            "sample": "%d uniform points, %s, d=%g, max_points_per_node=%d, ACCURATE, one batch (%.1f s)" % (
-                n, args.sampler, args.diagonal_fraction, args.max_points_per_node, dt)}
+            "sample": "%d uniform points, %s, d=%g, max_points_per_node=%d, %s, one batch (%.1f s)" % (
+                n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy, dt)}
 
 
 def payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n):
@@ -143,7 +147,8 @@ def main():
     bmin, bmax = [0.0, 0.0, 0.0], [args.bounds_scale] * 3
     spacing = swz.spacing_from_diagonal(bmin, bmax, args.diagonal_fraction)
     params = swz.TileParams(sampler=swz.SAMPLERS[args.sampler], max_points_per_node=args.max_points_per_node,
-                            spacing_at_root=spacing, max_depth=100, strategy=swz.ACCURATE)
+                            spacing_at_root=spacing, max_depth=100, strategy=getattr(swz, args.strategy),
+                            fast_concurrency=args.fast_concurrency)
     ctx = swz.Context(dev.index)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
@@ -212,9 +217,9 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 keys / f64 positions", "data": "synthetic",
             "config": {"workload": "%d uniform points per GPU in the unit cube, %s sampling, spacing = diagonal/%g, "
-                                   "max_points_per_node=%d, ACCURATE strategy, one batch" % (
-                                       n, args.sampler, args.diagonal_fraction, args.max_points_per_node),
-                       "points_per_gpu": n, "sampler": args.sampler, "strategy": "ACCURATE",
+                                   "max_points_per_node=%d, %s strategy, one batch" % (
+                                       n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy),
+                       "points_per_gpu": n, "sampler": args.sampler, "strategy": args.strategy,
                        "min_distance_mode": "exact" if args.sampler == "MIN_DISTANCE" else None,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
             "visit_factor": round(visit, 4),
