@@ -250,6 +250,13 @@ typedef struct {
 } swz_shard_info;
 int swz_partition_by_octant_device(swz_ctx* ctx, const uint64_t* d_keys, uint64_t n, uint32_t* d_perm_out,
                                    uint64_t counts_out[8]);
+/* Optional, before swz_shard_begin_device with the same d_xyz_local / n: does the part of it that does not
+ * depend on the ghosts (index + sort + gather of the local points), leaving room for up to ghost_capacity
+ * ghosts.  When the root couples the shards (MIN_DISTANCE) every shard calls this right after the exchange,
+ * all at the same time, and only the root node itself remains in the chain that hands the ghosts from shard
+ * to shard (ghosts sort in front of all local points: they lie in lower octants). */
+int swz_shard_presort_device(swz_ctx* ctx, const double* d_xyz_local, uint64_t n, const double bounds_min[3],
+                             const double bounds_max[3], const swz_tile_params* params, uint64_t ghost_capacity);
 int swz_shard_begin_device(swz_ctx* ctx, const double* d_xyz_local, uint64_t n, const double bounds_min[3],
                            const double bounds_max[3], const swz_tile_params* params,
                            const swz_shard_info* shard, uint64_t* num_root_taken_out);

@@ -207,6 +207,7 @@ def load_library():
     L.swz_partition_by_octant_device.argtypes = [vp, vp, C.c_uint64, vp, _u64p]
     L.swz_shard_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.POINTER(_ShardInfo),
                                          _u64p]
+    L.swz_shard_presort_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.c_uint64]
     L.swz_shard_root_taken_device.argtypes = [vp, vp]
     L.swz_shard_finish_device.argtypes = [vp, vp, vp, vp, C.POINTER(_TileStats)]
     L.swz_profile_enable.argtypes = [vp, C.c_int]
@@ -219,7 +220,7 @@ def load_library():
                  "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device",
                  "swz_build_node_lists_device", "swz_gather_payload_device", "swz_bin_write_node",
                  "swz_bin_read_header", "swz_bin_read_node", "swz_bin_persist_nodes", "swz_node_name",
-                 "swz_las_decode_device"):
+                 "swz_las_decode_device", "swz_shard_presort_device"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -426,6 +427,12 @@ class Context:
         self._check(self._lib.swz_partition_by_octant_device(self._ctx, C.c_void_p(d_keys), int(n),
                                                              C.c_void_p(d_perm), counts))
         return [int(v) for v in counts]
+
+    def shard_presort_device(self, d_xyz_local, n, bmin, bmax, params, ghost_capacity):
+        """The ghost-independent part of shard_begin_device (index + sort + gather), done ahead of time."""
+        p = params._c()
+        self._check(self._lib.swz_shard_presort_device(self._ctx, C.c_void_p(d_xyz_local), int(n), _vec3(bmin), _vec3(bmax),
+                                                       C.byref(p), int(ghost_capacity)))
 
     def shard_begin_device(self, d_xyz_local, n, bmin, bmax, params, global_points, d_ghost_xyz=None, num_ghosts=0):
         """Indexes + sorts the shard and samples the root node.  Returns how many local points the root took."""

@@ -386,6 +386,19 @@ int swz_partition_by_octant_device(swz_ctx* c, const uint64_t* d_keys, uint64_t 
   return sync(c);
 }
 
+int swz_shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint64_t n, const double bmin[3],
+                             const double bmax[3], const swz_tile_params* params, uint64_t ghost_capacity) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n + ghost_capacity));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  SWZ_TRY(check_params(c, params));
+  if (n == 0 || !d_xyz_local) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_presort_device: empty shard");
+  int st = swz::shard_presort_device(c, d_xyz_local, (uint32_t)n, bmin, bmax, *params, (uint32_t)ghost_capacity);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
+}
+
 int swz_shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint64_t n, const double bmin[3],
                            const double bmax[3], const swz_tile_params* params, const swz_shard_info* shard,
                            uint64_t* num_root_taken_out) {

@@ -139,6 +139,8 @@ int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], con
 int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3],
                        const double bmax[3], const swz_tile_params& p, uint64_t global_points,
                        const double* d_ghost_xyz, uint32_t ghosts, uint64_t* num_root_taken);
+int shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
+                         const swz_tile_params& p, uint32_t ghost_capacity);
 int shard_root_taken_device(swz_ctx* c, double* d_xyz_out);
 int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
                         swz_tile_stats* stats);

@@ -626,8 +626,10 @@ struct TileSession {
 };
 
 // K1 + K2 + gather: index, sort, positions into Morton order
+// `front`: entries kept free in FRONT of every per-sorted-position array (sharded batches prepend ghosts).
 static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n, const double bmin[3],
-                           const double bmax[3], const swz_tile_params& p, const TileDeviceOut& out) {
+                           const double bmax[3], const swz_tile_params& p, const TileDeviceOut& out,
+                           uint32_t front = 0) {
   t = TileSession{};
   t.n = n;
   for (int a = 0; a < 3; ++a) {
@@ -652,15 +654,18 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   }
   double *X = nullptr, *Y = nullptr, *Z = nullptr;
   if (p.sampler != SWZ_RANDOM_GRID) {  // RANDOM_GRID decides on the keys alone
-    SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
-    SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));
-    SWZ_TRY(c->get("sorted_z", (size_t)n, &Z));
+    SWZ_TRY(c->get("sorted_x", (size_t)n + front, &X));
+    SWZ_TRY(c->get("sorted_y", (size_t)n + front, &Y));
+    SWZ_TRY(c->get("sorted_z", (size_t)n + front, &Z));
+    X += front;
+    Y += front;
+    Z += front;
     SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
   }
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(out.level, 0x80, (size_t)n, c->stream));  // -128 = not persisted yet
   t.sp = SortedPoints{X, Y, Z};
-  SWZ_TRY(alloc_level_buffers(c, n, &t.lb));
+  SWZ_TRY(alloc_level_buffers(c, n + front, &t.lb));
   // survivors ping-pong between the sort's secondary buffers and one extra pair
   t.key_buf[0] = keys_b;
   t.idx_buf[0] = vals_b;
@@ -849,6 +854,11 @@ struct ShardState {
   TileSession t;
   uint32_t n_local = 0;
   bool open = false;
+  // swz_shard_presort_device ran: the local points are indexed and sorted, `front` entries are free in front
+  bool presorted = false;
+  uint32_t front = 0;
+  const double* xyz_local = nullptr;
+  bool perm_local = false;  // perm of the local points counts from the first LOCAL point
 };
 
 static ShardState* shard_state(swz_ctx* c) {
@@ -881,13 +891,74 @@ __global__ __launch_bounds__(256) void root_taken_gather_kernel(const int8_t* __
 __global__ __launch_bounds__(256) void shard_strip_kernel(const uint64_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ perm,
                                                           const int8_t* __restrict__ level, uint32_t ghosts,
-                                                          uint32_t n_local, uint64_t* __restrict__ okeys,
-                                                          uint32_t* __restrict__ operm, int8_t* __restrict__ olevel) {
+                                                          uint32_t perm_base, uint32_t n_local,
+                                                          uint64_t* __restrict__ okeys, uint32_t* __restrict__ operm,
+                                                          int8_t* __restrict__ olevel) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n_local) return;
   okeys[i] = keys[ghosts + i];
-  operm[i] = perm[ghosts + i] - ghosts;
+  operm[i] = perm[ghosts + i] - perm_base;
   olevel[i] = level[ghosts + i];
+}
+
+// Everything of swz_shard_begin_device that does not depend on the ghosts: index + sort + gather of the local
+// points, with room for up to ghost_capacity ghosts in front of every array.  All shards can do this at the
+// same time, so that only the root node itself is left in the chain that passes the ghosts from shard to shard.
+int shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
+                         const swz_tile_params& p, uint32_t ghost_capacity) {
+  if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  if ((uint64_t)n + ghost_capacity > 0xFFFFFFFEull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "shard + ghosts exceed 2^32-2 points");
+  ShardState* s = shard_state(c);
+  s->open = false;
+  s->presorted = false;
+  TileDeviceOut out{};
+  const size_t cap = (size_t)n + ghost_capacity;
+  SWZ_TRY(c->get("shard_keys", cap, &out.keys));
+  SWZ_TRY(c->get("shard_perm", cap, &out.perm));
+  SWZ_TRY(c->get("shard_level", cap, &out.level));
+  out.keys += ghost_capacity;
+  out.perm += ghost_capacity;
+  out.level += ghost_capacity;
+  SWZ_TRY(session_prepare(c, s->t, const_cast<double*>(d_xyz_local), n, bmin, bmax, p, out, ghost_capacity));
+  s->n_local = n;
+  s->front = ghost_capacity;
+  s->xyz_local = d_xyz_local;
+  s->perm_local = true;
+  s->presorted = true;
+  return SWZ_OK;
+}
+
+// ghosts lie in lower octants, so their keys are smaller than every local key: sorted ghosts ++ sorted locals
+// is the sorted whole.  Writes the g ghosts into the free entries in front of the presorted arrays.
+static int shard_attach_ghosts(swz_ctx* c, ShardState* s, const double* d_ghost_xyz, uint32_t g) {
+  TileSession& t = s->t;
+  if (g) {
+    uint64_t* tmpk = nullptr;
+    uint32_t* tmpv = nullptr;
+    SWZ_TRY(c->get("ghost_keys", (size_t)g, &tmpk));
+    SWZ_TRY(c->get("ghost_vals", (size_t)g, &tmpv));
+    uint64_t* gk = t.keys - g;
+    uint32_t* gp = t.perm - g;
+    double* gx = const_cast<double*>(d_ghost_xyz);  // inside the bounds already: the clamp of the encode is a no-op
+    if (radix_result_in_second()) {
+      SWZ_TRY(encode_device(c, gx, g, t.bmin, t.bmax, tmpk));
+      SWZ_TRY(radix_sort_pairs(c, tmpk, tmpv, gk, gp, g, true));
+    } else {
+      SWZ_TRY(encode_device(c, gx, g, t.bmin, t.bmax, gk));
+      SWZ_TRY(radix_sort_pairs(c, gk, gp, tmpk, tmpv, g, true));
+    }
+    if (t.sp.X) SWZ_TRY(gather_positions(c, d_ghost_xyz, gp, g, const_cast<double*>(t.sp.X) - g, const_cast<double*>(t.sp.Y) - g,
+                                         const_cast<double*>(t.sp.Z) - g));
+    SWZ_HIP(c, hipMemsetAsync(t.level - g, 0x80, (size_t)g, c->stream));
+    t.keys -= g;
+    t.perm -= g;
+    t.level -= g;
+    if (t.sp.X) t.sp = SortedPoints{t.sp.X - g, t.sp.Y - g, t.sp.Z - g};
+    t.n += g;
+    t.as = ActiveSet{t.keys, nullptr, t.n};
+  }
+  t.ghosts = g;
+  return SWZ_OK;
 }
 
 int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3],
@@ -897,6 +968,12 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   ShardState* s = shard_state(c);
   s->open = false;
   const uint32_t total = n + ghosts;
+  const bool fast = s->presorted && s->xyz_local == d_xyz_local && s->n_local == n && ghosts <= s->front;
+  s->presorted = false;
+  if (fast) {
+    SWZ_TRY(shard_attach_ghosts(c, s, d_ghost_xyz, ghosts));
+  } else {
+  s->perm_local = false;
   double* xyz = nullptr;
   if (ghosts == 0) {
     xyz = const_cast<double*>(d_xyz_local);  // already inside the bounds (it was encoded before the exchange)
@@ -915,6 +992,7 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   SWZ_TRY(session_prepare(c, s->t, xyz, total, bmin, bmax, p, out));
   s->t.ghosts = ghosts;
   s->n_local = n;
+  }
   // the root node spans all shards: its take-all / sample decision uses the global point count
   const LevelPlan root_plan =
     make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
@@ -955,7 +1033,7 @@ int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, 
   s->open = false;
   SWZ_TRY(session_run_levels(c, s->t, 20, -1));
   hipLaunchKernelGGL(shard_strip_kernel, dim3(div_up(s->n_local, 256)), dim3(256), 0, c->stream, s->t.keys, s->t.perm,
-                     s->t.level, s->t.ghosts, s->n_local, d_keys_out, d_perm_out, d_level_out);
+                     s->t.level, s->t.ghosts, s->perm_local ? 0u : s->t.ghosts, s->n_local, d_keys_out, d_perm_out, d_level_out);
   SWZ_LAUNCH_CHECK(c);
   session_stats(s->t, stats);
   return SWZ_OK;

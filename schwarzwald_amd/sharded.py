@@ -9,7 +9,8 @@ the root node spans ranks:
     samples its slice of the root locally;
   * MIN_DISTANCE at the root is the greedy sweep in Morton order, which visits the octants in rank order: rank r
     waits for the root samples of the lower ranks ("ghosts", a few MB), sweeps its slice, and passes its own on.
-    Levels >= 0 then run concurrently on all ranks.
+    Index + sort of the local points happen before that on all ranks at once (shard_presort_device), so the
+    chain holds the root sweeps only.  Levels >= 0 then run concurrently on all ranks.
 
 torch is used for device memory, index_select and torch.distributed only.
 """
@@ -117,6 +118,10 @@ class ShardedTiler:
         if not sequential_root:
             ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points)
         else:
+            if m > 0:
+                # everything that does not depend on the ghosts happens on all ranks at once; only the root
+                # node itself is left in the chain below
+                ctx.shard_presort_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, GHOST_HEADROOM)
             ghosts = []
             for r in range(world):
                 cnt = torch.zeros(1, dtype=torch.int64, device=dev)

@@ -317,3 +317,45 @@ def test_min_distance_sweep_scheduling_modes(ctx, monkeypatch, mode):
         g = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=mppn, spacing_at_root=spacing))
         assert np.array_equal(g.keys, o["keys"]) and np.array_equal(g.perm, o["perm"])
         assert np.array_equal(g.level, o["level"])
+
+
+@pytest.mark.parametrize("presort", [False, True])
+def test_shard_api_with_ghosts_matches_oracle(presort):
+    """Two shards (octants 0-3 / 4-7) driven by hand through swz_shard_*: the upper shard receives the lower
+    shard's root samples as ghosts, either through swz_shard_begin_device alone or after swz_shard_presort_device."""
+    import torch
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(808)
+    n = 300_000
+    xyz = rng.random((n, 3))
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    o = O.tile(xyz, *UNIT, O.MIN_DISTANCE, 2000, spacing)
+    keys = O.index_points(xyz, *UNIT)[0]
+    upper = (keys >> np.uint64(62)) & np.uint64(1) == 1           # top octant bit: x >= 0.5
+    dev = torch.device("cuda:0")
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=2000, spacing_at_root=spacing)
+    ghosts = None
+    got_level = np.empty(n, dtype=np.int8)
+    for part in (~upper, upper):
+        ids = np.nonzero(part)[0]
+        ctx = swz.Context(0)
+        loc = torch.from_numpy(xyz[ids]).to(dev)
+        m = len(ids)
+        g = 0 if ghosts is None else ghosts.shape[0]
+        if presort:
+            ctx.shard_presort_device(loc.data_ptr(), m, *UNIT, params, 100_000)
+        taken = ctx.shard_begin_device(loc.data_ptr(), m, *UNIT, params, n, ghosts.data_ptr() if g else None, g)
+        mine = torch.empty((taken, 3), dtype=torch.float64, device=dev)
+        ctx.shard_root_taken_device(mine.data_ptr())
+        k = torch.empty(m, dtype=torch.int64, device=dev)
+        p = torch.empty(m, dtype=torch.int32, device=dev)
+        lv = torch.empty(m, dtype=torch.int8, device=dev)
+        ctx.shard_finish_device(k.data_ptr(), p.data_ptr(), lv.data_ptr())
+        torch.cuda.synchronize()
+        got_level[ids[p.cpu().numpy()]] = lv.cpu().numpy()
+        assert np.array_equal(k.cpu().numpy().view(np.uint64), np.sort(keys[ids]))
+        ghosts = mine
+        ctx.close()
+    want = np.empty(n, dtype=np.int8)
+    want[o["perm"]] = o["level"]
+    assert np.array_equal(got_level, want)
