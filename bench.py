@@ -134,7 +134,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    # SWZ_BENCH_FORCE_SHARDED=1: run the sharded driver (RCCL init, exchange, shard API) even with one rank
+    distributed = world > 1 or os.environ.get("SWZ_BENCH_FORCE_SHARDED") == "1"
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

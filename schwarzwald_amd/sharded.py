@@ -14,6 +14,10 @@ the root node spans ranks:
 
 torch is used for device memory, index_select and torch.distributed only.
 """
+import os
+import sys
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -36,11 +40,45 @@ def rank_send_counts(octant_counts, world):
 GHOST_HEADROOM = 4 << 20  # rows reserved in front of the received points for MIN_DISTANCE root ghosts
 
 
-def exchange_rows(rows, send_counts, group=None, headroom=0):
-    """all_to_all_single of row blocks.  rows: [n, k] tensor already grouped by destination rank;
-    send_counts[r] rows go to rank r.  Returns (buffer, recv_counts): the received rows are buffer[headroom:]
-    (the first `headroom` rows are left free so that a few rows can later be put right in front)."""
+EXCHANGE_CHUNK_BYTES = 64 << 20  # per (source, destination) pair and round of the exchange
+
+
+def exchange_plan(send_counts, recv_counts, rank, chunk_rows, headroom=0):
+    """Rounds of the exchange for one rank: a list of rounds, each a list of (peer, send_slice, recv_slice) with
+    slices as (first_row, rows) into the send rows / the receive buffer; at most chunk_rows rows per pair and
+    round, empty transfers left out.  The rank's own block is not part of any round (it is copied directly):
+    own_copy = (first send row, first buffer row, rows).  All ranks derive the same number of rounds for a pair
+    from the same two counts, so sends and receives match up."""
+    world = len(send_counts)
+    send_off = [sum(send_counts[:r]) for r in range(world)]
+    recv_off = [headroom + sum(recv_counts[:r]) for r in range(world)]
+    own_copy = (send_off[rank], recv_off[rank], send_counts[rank])
+    most = max([max(send_counts[r], recv_counts[r]) for r in range(world) if r != rank] + [0])
+    rounds = []
+    for k in range((most + chunk_rows - 1) // chunk_rows):
+        ops = []
+        for r in range(world):
+            if r == rank:
+                continue
+            s_len = min(chunk_rows, max(0, send_counts[r] - k * chunk_rows))
+            r_len = min(chunk_rows, max(0, recv_counts[r] - k * chunk_rows))
+            if s_len or r_len:
+                ops.append((r, (send_off[r] + k * chunk_rows, s_len), (recv_off[r] + k * chunk_rows, r_len)))
+        rounds.append(ops)
+    return own_copy, rounds
+
+
+def exchange_rows(rows, send_counts, group=None, headroom=0, chunk_bytes=None):
+    """All-to-all of row blocks.  rows: [n, k] tensor already grouped by destination rank; send_counts[r] rows go
+    to rank r.  Returns (buffer, recv_counts): the received rows, ordered by source rank, are buffer[headroom:]
+    (the first `headroom` rows are left free so that a few rows can later be put right in front).
+
+    The rows that stay on this rank are copied directly; the others travel as grouped point-to-point transfers
+    (one RCCL group per round) of at most chunk_bytes per pair and round.  One big all_to_all_single is avoided
+    on purpose: RCCL 2.26 (ROCm 7.0) was measured to drop the second half of a single large block (1.9 GB to
+    self: the rows from n/2 on never arrive; tools/a2a_test.py), and bounded messages bound its staging memory."""
     world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
     backend = dist.get_backend(group)
     dev = rows.device
     comm_dev = dev if backend == "nccl" else torch.device("cpu")
@@ -48,17 +86,43 @@ def exchange_rows(rows, send_counts, group=None, headroom=0):
     rc = torch.empty(world, dtype=torch.int64, device=comm_dev)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(v) for v in rc.tolist()]
+    send_counts = [int(v) for v in send_counts]
     m = sum(recv_counts)
     buf = torch.empty((headroom + m,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=dev)
-    if comm_dev == dev:
-        dist.all_to_all_single(buf[headroom:], rows.contiguous(), recv_counts, [int(v) for v in send_counts],
-                               group=group)
+    rows = rows.contiguous()
+    row_bytes = (rows[0:1].numel() if rows.shape[0] else 1) * rows.element_size()
+    chunk = max(1, int(chunk_bytes or EXCHANGE_CHUNK_BYTES) // max(1, row_bytes))
+    (s0, r0, cnt), rounds = exchange_plan(send_counts, recv_counts, rank, chunk, headroom)
+    buf[r0:r0 + cnt].copy_(rows[s0:s0 + cnt])
+    if comm_dev != dev and rounds:  # gloo with device tensors (tests): the transfers go through host memory
+        src, dst = rows.to(comm_dev), torch.empty((headroom + m,) + tuple(rows.shape[1:]), dtype=rows.dtype)
     else:
-        recv = torch.empty((m,) + tuple(rows.shape[1:]), dtype=rows.dtype, device=comm_dev)
-        dist.all_to_all_single(recv, rows.to(comm_dev).contiguous(), recv_counts, [int(v) for v in send_counts],
-                               group=group)
-        buf[headroom:].copy_(recv)
+        src, dst = rows, buf
+    for ops in rounds:
+        p2p = []
+        for peer, (ss, sl), (rs, rl) in ops:
+            if sl:
+                p2p.append(dist.P2POp(dist.isend, src[ss:ss + sl], peer, group))
+            if rl:
+                p2p.append(dist.P2POp(dist.irecv, dst[rs:rs + rl], peer, group))
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
+    if dst is not buf:
+        for r in range(world):
+            if r != rank and recv_counts[r]:
+                o = headroom + sum(recv_counts[:r])
+                buf[o:o + recv_counts[r]].copy_(dst[o:o + recv_counts[r]])
     return buf, recv_counts
+
+
+def _trace(dev, what, t0):
+    """SWZ_DEBUG=1: stage timings on stderr (synchronises the device, debugging only)."""
+    if os.environ.get("SWZ_DEBUG"):
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        sys.stderr.write("[swz sharded] %-28s %8.1f ms\n" % (what, (time.perf_counter() - t0) * 1e3))
+        sys.stderr.flush()
+    return time.perf_counter()
 
 
 class ShardedTiler:
@@ -71,6 +135,8 @@ class ShardedTiler:
         if self.world not in (1, 2, 4, 8):
             raise ValueError("world size must be 1, 2, 4 or 8 (octants are dealt out in contiguous blocks)")
         self.result = None
+        self._keepalive = None
+        self._batches = 0
 
     def _bcast(self, tensor, src):
         backend = dist.get_backend(self.group)
@@ -87,12 +153,24 @@ class ShardedTiler:
         rank's shard; self.result holds (recv_xyz, keys, perm, level) for the points this rank owns."""
         ctx, dev, world = self.ctx, self.device, self.world
         n = xyz.shape[0]
+        # the previous batch's buffers are the caller's no longer
+        self.result = None
+        self._keepalive = None
         if dev.type == "cuda":
-            # keys + perm + send buffer + receive buffer are about 3 x the positions; when a previous batch left a
-            # workspace that does not leave room for them, give it back first (it is re-grown on demand)
+            # keys + perm + send buffer + receive buffer are about 2.5 x the positions; when a previous batch left
+            # a workspace that does not leave room for them, give it back first.  Re-growing it costs seconds
+            # (about 25 ms per GB), so this is a last resort, not the steady state.
+            need = int(2.6 * n * 24)
+            cached = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)  # torch can reuse these
             free, _ = torch.cuda.mem_get_info(dev)
-            if free < int(3.2 * n * 24) and ctx.workspace_bytes() > 0:
-                ctx.release_workspace()
+            if free + cached < need:
+                torch.cuda.empty_cache()
+                free, _ = torch.cuda.mem_get_info(dev)
+                if free < need and ctx.workspace_bytes() > 0:
+                    ctx.release_workspace()
+                    if os.environ.get("SWZ_DEBUG"):
+                        sys.stderr.write("[swz sharded] workspace released: %.1f GB were free\n" % (free / 1e9))
+        t0 = time.perf_counter()
         # 1. encode locally, group by destination
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         ctx.morton_encode_device(xyz.data_ptr(), n, self.bmin, self.bmax, keys.data_ptr())
@@ -100,8 +178,10 @@ class ShardedTiler:
         octant_counts = ctx.partition_by_octant_device(keys.data_ptr(), n, perm.data_ptr())
         del keys
         send_counts = rank_send_counts(octant_counts, world)
+        t0 = _trace(dev, "encode + partition", t0)
         send = xyz.index_select(0, perm.long())
         del perm
+        t0 = _trace(dev, "group rows by destination", t0)
         # 2. the one exchange step
         total = torch.tensor([n], dtype=torch.int64, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(total, group=self.group)
@@ -110,8 +190,12 @@ class ShardedTiler:
         headroom = GHOST_HEADROOM if (sequential_root and self.rank > 0) else 0
         buf, _ = exchange_rows(send, send_counts, self.group, headroom)
         del send
-        if dev.type == "cuda":
-            torch.cuda.empty_cache()  # hand the freed send buffers back: the context allocates with hipMalloc
+        t0 = _trace(dev, "exchange", t0)
+        if dev.type == "cuda" and self._batches == 0:
+            # first batch: hand the freed send buffers back before the context grows its workspace with hipMalloc
+            # (later batches find the workspace in place and torch's cached blocks are reused instead)
+            torch.cuda.empty_cache()
+        self._batches += 1
         recv = buf[headroom:]
         m = recv.shape[0]
         # 3. root node
@@ -150,11 +234,13 @@ class ShardedTiler:
                     self._bcast(b, r)
                 if self.rank > r:
                     ghosts.append(b)
+        t0 = _trace(dev, "root node", t0)
         # 4. everything below the root is local
         okeys = torch.empty(m, dtype=torch.int64, device=dev)
         operm = torch.empty(m, dtype=torch.int32, device=dev)
         olevel = torch.empty(m, dtype=torch.int8, device=dev)
         stats = ctx.shard_finish_device(okeys.data_ptr(), operm.data_ptr(), olevel.data_ptr())
+        _trace(dev, "levels below the root", t0)
         self.result = (recv, okeys, operm, olevel)
         self._keepalive = buf  # the context reads the points until shard_finish returned
         stats["shard_points"] = m

@@ -37,7 +37,7 @@ def _cloud(n, seed):
 
 
 # ------------------------------------------------------------------ CPU: exchange plumbing
-def _exchange_worker(rank, world, port, n, q):
+def _exchange_worker(rank, world, port, n, q, chunk_bytes=None):
     _init(rank, world, port)
     from schwarzwald_amd import sharded
     xyz = _cloud(n, 100 + rank)
@@ -47,17 +47,20 @@ def _exchange_worker(rank, world, port, n, q):
     counts = np.bincount(octant, minlength=8).tolist()
     send_counts = sharded.rank_send_counts(counts, world)
     rows = torch.from_numpy(xyz[order])
-    buf, recv_counts = sharded.exchange_rows(rows, send_counts, headroom=3)
+    buf, recv_counts = sharded.exchange_rows(rows, send_counts, headroom=3, chunk_bytes=chunk_bytes)
     q.put((rank, buf[3:].numpy(), recv_counts))
     dist.destroy_process_group()
 
 
-def test_exchange_moves_points_to_octant_owner():
-    world, n = 2, 5000
+@pytest.mark.parametrize("world,chunk_bytes", [(2, None), (2, 24 * 257), (4, 24 * 100)])
+def test_exchange_moves_points_to_octant_owner(world, chunk_bytes):
+    """chunk_bytes forces the exchange into many rounds of grouped point-to-point transfers (the code path RCCL
+    runs at full size); the result must not depend on it."""
+    n = 5000
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, n, q, chunk_bytes)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
@@ -85,6 +88,38 @@ def test_exchange_moves_points_to_octant_owner():
             assert np.array_equal(recv[off:off + rc[s]], clouds[s][mine])
             off += rc[s]
     assert sum(len(got[r][0]) for r in range(world)) == world * n
+
+
+def test_exchange_plan_covers_every_row_exactly_once():
+    """The per-rank plans of all ranks, executed together in one process, are an all-to-all."""
+    from schwarzwald_amd import sharded
+    rng = np.random.default_rng(5)
+    for world, chunk in ((1, 7), (2, 3), (4, 5), (8, 1000), (8, 1)):
+        counts = rng.integers(0, 23, (world, world))           # counts[s][d]: rows source s sends to d
+        counts[rng.integers(0, world)][rng.integers(0, world)] = 0
+        send = [np.arange(counts[s].sum()) + 1000 * s for s in range(world)]
+        head = 2
+        bufs = [np.full(head + counts[:, d].sum(), -1) for d in range(world)]
+        plans = [sharded.exchange_plan(counts[r].tolist(), counts[:, r].tolist(), r, chunk, head) for r in range(world)]
+        for r, ((s0, r0, cnt), rounds) in enumerate(plans):
+            bufs[r][r0:r0 + cnt] = send[r][s0:s0 + cnt]
+        nrounds = max(len(p[1]) for p in plans)
+        for k in range(nrounds):
+            # every send of round k must meet a receive of the same length in the peer's round k
+            for r, (_, rounds) in enumerate(plans):
+                if k >= len(rounds):
+                    continue
+                for peer, (ss, sl), (rs, rl) in rounds[k]:
+                    assert sl <= chunk and rl <= chunk
+                    if sl:
+                        match = [op for op in plans[peer][1][k] if op[0] == r]
+                        assert len(match) == 1 and match[0][2][1] == sl
+                        o = match[0][2][0]
+                        assert np.all(bufs[peer][o:o + sl] == -1)
+                        bufs[peer][o:o + sl] = send[r][ss:ss + sl]
+        for d in range(world):
+            want = np.concatenate([send[s][counts[s][:d].sum():counts[s][:d].sum() + counts[s][d]] for s in range(world)])
+            assert np.array_equal(bufs[d][head:], want) and np.all(bufs[d][:head] == -1)
 
 
 def test_owner_map_is_monotone_and_balanced():
