@@ -230,7 +230,7 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
-        if world == 1 and args.payload:
+        if world == 1 and not distributed and args.payload:
             out["payload"] = payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, spacing)
