@@ -160,6 +160,26 @@ _dp, _u64p, _u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_
 _i8p, _u8p = C.POINTER(C.c_int8), C.POINTER(C.c_uint8)
 
 
+def _preload_hip_runtime():
+    """A PyTorch-ROCm wheel ships its own libamdhip64.so and loads it by path, so a process that loads
+    libswz_gpu.so first (resolving the system's libamdhip64.so.7) and imports torch later would run two HIP
+    runtimes, the second of which finds no devices.  Loading torch's copy first (same SONAME) makes both use one.
+    Without torch installed the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """Loads libswz_gpu.so; raises OSError when it has not been built (run __graft_entry__.build())."""
     global _lib
@@ -169,6 +189,7 @@ def load_library():
     if not os.path.exists(path):
         raise OSError("libswz_gpu.so not found at %s -- build it with `make -C schwarzwald_amd/csrc` "
                       "(there is no CPU fallback)" % path)
+    _preload_hip_runtime()
     L = C.CDLL(path)
     vp = C.c_void_p
     L.swz_abi_version.restype = C.c_int

@@ -836,17 +836,20 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(md_nbr_build_kernel, dim3(div_up(ncells, 8)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
-  // With many small cells a round is bound by activation throughput: futile re-activations must be
-  // cheap, and a stalled cell sleeps until the whole blocking cell is finished (fewer, later wake-ups:
-  // measured at 1 B points, level 1: 302 -> 259 ms).  With few large cells a round is bound by the latency
-  // of one activation and the level by the number of rounds: no extra scan, wake up as early as possible.
-  a.early_recheck = (ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0) ? 1u : 0u;
-  a.latest_first = a.early_recheck;
-  a.patient = a.early_recheck;
+  // With many small cells a level is bound by activation throughput: start lazily and let a stalled cell sleep
+  // until the whole blocking cell is finished (fewer, later wake-ups; measured at 1 B points, level 1:
+  // 302 -> 173 ms).  With few large cells it is bound by the latency of a round times the number of rounds:
+  // wake up as early as possible.  The cheap re-check of a stalled candidate and the latest-first scan order
+  // (both from before blocker scans could tell dead points) no longer pay and stay off; they remain
+  // selectable for the scheduling tests.
+  const bool many_small = ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0;
+  a.early_recheck = 0;
+  a.latest_first = 0;
+  a.patient = many_small ? 1u : 0u;
   if (const char* e = getenv("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
   if (const char* e = getenv("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
   if (const char* e = getenv("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
-  bool lazy = a.early_recheck != 0;
+  bool lazy = many_small;
   if (const char* e = getenv("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
   a.lazy_frac = getenv("SWZ_MD_LAZY_FRAC") ? (float)atof(getenv("SWZ_MD_LAZY_FRAC")) : 0.5f;
   if (lazy) {
