@@ -37,6 +37,9 @@ struct SpArgs {
   uint32_t cell_levels;
   uint64_t cells_per_node;
   double sq_spacing;
+  uint32_t sub_levels;      // key levels below the cell level that give a point's slab inside its cell
+  double usq[3];            // squared slab width per axis
+  double cull_sq;           // squared spacing with a 2^-18 margin: adjacent cells farther than this are skipped
   uint2* table;             // [sample node][cell code] -> {first, end} active index of the cell's run
   uint32_t* nbr;            // [point][SP_K]
   uint8_t* ncount;          // recorded neighbours, SP_K + 1 = overflow
@@ -106,26 +109,51 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   const uint32_t dx[3] = {vx ? ((vx - 1u) & mx) : SP_NONE, vx, vx != mx ? (((vx | ~mx) + 1u) & mx) : SP_NONE};
   const uint32_t dy[3] = {vy ? ((vy - 1u) & my) : SP_NONE, vy, vy != my ? (((vy | ~my) + 1u) & my) : SP_NONE};
   const uint32_t dz[3] = {vz ? ((vz - 1u) & mz) : SP_NONE, vz, vz != mz ? (((vz | ~mz) + 1u) & mz) : SP_NONE};
-  // nine cells (one z slab) at a time: their table entries, then the j-th record of every run, are
-  // requested together, so a slab costs 1 + (longest run) memory round trips instead of one per record
+  // Adjacent cells this point cannot reach are skipped (about 40 % of them): squared gap between the point's
+  // slab inside its cell and the neighbour, per axis and direction, from the key bits below the cell level
+  // (conservative: a slab never overstates the gap).
+  uint32_t reach = 0;  // bit k: adjacent cell k (x fastest) can hold a point closer than the spacing
+  {
+    const uint64_t sub = (sp_key(me) >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+    const int smax = (1 << a.sub_levels) - 1;
+    const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1), sz = (int)contract_bits_by_3(sub);
+    const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy), lz = (double)sz,
+                 hz = (double)(smax - sz);
+    const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
+    const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
+    const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+      if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) reach |= 1u << k;
+  }
+  // the cells this point has to look at: inside the node, not later in Morton order, within reach
+  uint32_t need = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const uint32_t X = dx[k % 3], Y = dy[(k / 3) % 3], Z = dz[k / 9];
+    if (X != SP_NONE && Y != SP_NONE && Z != SP_NONE && (X | Y | Z) <= code && ((reach >> k) & 1u)) need |= 1u << k;
+  }
+  // Up to nine of them at a time (usually all: about eight remain): their table entries, then the j-th record
+  // of every run, are requested together, so the search costs 1 + (longest run) memory round trips.
   const uint2* __restrict__ tab = a.table + base;
-  const uint64_t npre0 = pre - code;
-  (void)npre0;
-  for (int zs = 0; zs < 3; ++zs) {
-    const uint32_t Z = zs == 0 ? dz[0] : (zs == 1 ? dz[1] : dz[2]);
-    if (Z == SP_NONE) continue;
+  while (need) {
     uint32_t q[9], qe[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-      const uint32_t X = dx[i % 3], Y = dy[i / 3];
-      const uint32_t ncode = X | Y | Z;
-      // a cell with a larger code holds later points only
-      const bool want = X != SP_NONE && Y != SP_NONE && ncode <= code;
-      uint2 e = make_uint2(0u, 0u);
-      if (want) e = tab[ncode];
-      q[i] = e.x;
-      qe[i] = (want && e.x != SP_NONE) ? min(e.y, p) : 0u;  // own cell: earlier points only; empty: {NONE, NONE}
-      if (qe[i] == 0u) q[i] = 0u;
+      q[i] = 0u;
+      qe[i] = 0u;
+      if (need) {
+        const uint32_t k = (uint32_t)__ffs((int)need) - 1u;
+        need &= need - 1u;
+        const uint32_t kx = k % 3u, ky = (k / 3u) % 3u, kz = k / 9u;
+        const uint32_t ncode = (kx == 0u ? dx[0] : (kx == 1u ? dx[1] : dx[2])) | (ky == 0u ? dy[0] : (ky == 1u ? dy[1] : dy[2])) |
+                               (kz == 0u ? dz[0] : (kz == 1u ? dz[1] : dz[2]));
+        const uint2 e = tab[ncode];
+        if (e.x != SP_NONE) {  // empty cells are {NONE, NONE}
+          q[i] = e.x;
+          qe[i] = min(e.y, p);  // own cell: earlier points only
+        }
+      }
     }
     for (;;) {
       double rx[9], ry[9], rz[9];
@@ -158,7 +186,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
 // phase 1: record the earlier neighbours; points without any are accepted right away
 __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ ulist,
                                                             uint32_t* __restrict__ ucount,
-                                                            uint32_t* __restrict__ overflow, uint32_t xcd) {
+                                                            uint32_t* __restrict__ overflow, uint32_t xcd, int iters) {
   // workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the points, so the
   // neighbourhoods a workgroup reads were mostly fetched into the same L2 by the workgroups just before it
   const uint32_t blk = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
@@ -183,7 +211,7 @@ __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* 
   }
   // A few fixpoint iterations right here: workgroups run roughly in Morton order, so most earlier
   // neighbours are already final (or become final in this wavefront within an iteration or two).
-  for (int it = 0; it < 4; ++it) {
+  for (int it = 0; it < iters; ++it) {
     if (!__ballot(undecided)) break;
     if (undecided && a.ncount[p] <= (uint8_t)SP_K) {
       const uint8_t r = sp_eval(a.state, a.nbr + (size_t)p * SP_K, a.ncount[p]);
@@ -194,14 +222,23 @@ __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* 
       }
     }
   }
+  // append the undecided points to the list: one atomic per workgroup
+  __shared__ uint32_t wave_count[4], wave_base[4];
   const uint64_t bm = __ballot(undecided);
-  if (bm) {
-    const int leader = __ffsll((unsigned long long)bm) - 1;
-    uint32_t off = 0;
-    if ((int)lane_id() == leader) off = atomicAdd(ucount, (uint32_t)__popcll(bm));
-    off = __shfl(off, leader, WAVE);
-    if (undecided) ulist[off + (uint32_t)__popcll(bm & lanemask_lt())] = p;
+  const uint32_t w = threadIdx.x / WAVE;
+  if (lane_id() == 0) wave_count[w] = (uint32_t)__popcll(bm);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t c0 = wave_count[0], c1 = wave_count[1], c2 = wave_count[2], c3 = wave_count[3];
+    const uint32_t total = c0 + c1 + c2 + c3;
+    const uint32_t base = total ? atomicAdd(ucount, total) : 0u;
+    wave_base[0] = base;
+    wave_base[1] = base + c0;
+    wave_base[2] = base + c0 + c1;
+    wave_base[3] = base + c0 + c1 + c2;
   }
+  __syncthreads();
+  if (undecided) ulist[wave_base[w] + (uint32_t)__popcll(bm & lanemask_lt())] = p;
 }
 
 // phase 2: one fixpoint round over the undecided points
@@ -275,6 +312,16 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.cells_per_node = 1ull << (3 * cl);
   a.cell_shift = (plan.node_shift == 63u ? 63u : plan.node_shift) - 3u * (uint32_t)cl;
   a.sq_spacing = plan.sq_spacing;
+  {
+    const int sub = std::max(0, std::min(4, 20 - (plan.level + cl)));
+    a.sub_levels = (uint32_t)sub;
+    const double ext[3] = {plan.root.maxx - plan.root.minx, plan.root.maxy - plan.root.miny, plan.root.maxz - plan.root.minz};
+    for (int ax = 0; ax < 3; ++ax) {
+      const double u = std::ldexp(ext[ax], -(plan.level + 1 + cl + sub));
+      a.usq[ax] = u * u;
+    }
+    a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
+  }
   a.taken = lb.taken;
   const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
   SWZ_TRY(c->get("sp_table", (size_t)entries, &a.table));
@@ -308,7 +355,7 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     (void)hipEventRecord(ev0, c->stream);
   }
   hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nb, 8) * 8 : nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2,
-                     xcd);
+                     xcd, getenv("SWZ_SP_ITERS") ? atoi(getenv("SWZ_SP_ITERS")) : 8);
   SWZ_LAUNCH_CHECK(c);
   if (dbg) (void)hipEventRecord(ev1, c->stream);
   uint32_t* uin = u0;
