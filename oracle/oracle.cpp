@@ -22,6 +22,13 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <functional>
 #include <map>
 #include <unordered_map>
@@ -516,6 +523,60 @@ static void partition_points_into_child_octants(const IP* begin, const IP* end, 
 /* ------------------------------------------------------------------ tiler */
 constexpr uint32_t MAX_OCTREE_LEVELS = 21; /* TilingAlgorithms.cpp:20 */
 
+/* Worker threads for node tasks, standing in for the reference's taskflow executor (Scheduler.cpp:49-61):
+ * children with at least MIN_POINTS_FOR_ASYNC_PROCESSING points become tasks, the others are tiled by the
+ * thread that produced them (TilingAlgorithms.cpp:25, 499-561). */
+constexpr size_t MIN_POINTS_FOR_ASYNC_PROCESSING = 100000;
+struct TaskPool {
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<std::function<void()>> queue;
+  size_t unfinished = 0;
+  bool stop = false;
+  std::vector<std::thread> workers;
+  explicit TaskPool(unsigned threads) {
+    for (unsigned i = 0; i < threads; ++i) workers.emplace_back([this] { run(); });
+  }
+  ~TaskPool() {
+    {
+      std::lock_guard<std::mutex> g(m);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto& w : workers) w.join();
+  }
+  void submit(std::function<void()> f) {
+    {
+      std::lock_guard<std::mutex> g(m);
+      queue.push_back(std::move(f));
+      ++unfinished;
+    }
+    cv.notify_one();
+  }
+  void run() {
+    for (;;) {
+      std::function<void()> f;
+      {
+        std::unique_lock<std::mutex> g(m);
+        cv.wait(g, [this] { return stop || !queue.empty(); });
+        if (queue.empty()) return;
+        f = std::move(queue.front());
+        queue.pop_front();
+      }
+      f();
+      {
+        std::lock_guard<std::mutex> g(m);
+        --unfinished;
+      }
+      cv.notify_all();
+    }
+  }
+  void wait_all() {
+    std::unique_lock<std::mutex> g(m);
+    cv.wait(g, [this] { return unfinished == 0; });
+  }
+};
+
 struct Tiler {
   SampleCtx ctx;
   orc_tile_params params;
@@ -523,11 +584,14 @@ struct Tiler {
   const std::vector<IP>* sorted = nullptr;
   int8_t* level_out = nullptr;
   orc_tile_stats stats{};
-  int32_t error = ORC_OK;
+  std::atomic<int32_t> error{ORC_OK};
   std::vector<uint32_t> pos_of_idx; /* original index -> sorted position */
+  TaskPool* pool = nullptr;         /* NULL: everything on the calling thread */
+  std::mutex stats_mutex;
 
   void persist(const IP* b, const IP* e, int32_t level) {
     for (const IP* p = b; p != e; ++p) level_out[pos_of_idx[p->idx]] = (int8_t)level;
+    std::lock_guard<std::mutex> g(stats_mutex);
     stats.num_nodes += 1;
     if (e != b) stats.max_level = std::max(stats.max_level, level);
   }
@@ -539,7 +603,10 @@ struct Tiler {
   void do_tiling_for_node(std::vector<IP>&& node_data, const NodeStructure& node,
                           const NodeStructure& root) {
     if (error) return;
-    stats.points_visited += node_data.size();
+    {
+      std::lock_guard<std::mutex> g(stats_mutex);
+      stats.points_visited += node_data.size();
+    }
     const int32_t req = required_morton_index_depth(ctx.sampler, node.level, root);
     const bool requires_deeper = req > node.level;
     const int32_t max_level = (int32_t)std::min(MAX_OCTREE_LEVELS - 1, node.max_depth);
@@ -581,7 +648,13 @@ struct Tiler {
       child.bounds = get_octant_bounds(octant, node.bounds);
       child.level = child_level;
       child.max_spacing /= 2;
-      do_tiling_for_node(std::vector<IP>(ranges[octant], ranges[octant + 1]), child, root);
+      std::vector<IP> data(ranges[octant], ranges[octant + 1]);
+      if (pool && data.size() >= MIN_POINTS_FOR_ASYNC_PROCESSING) {
+        auto shared = std::make_shared<std::vector<IP>>(std::move(data));
+        pool->submit([this, shared, child, root] { do_tiling_for_node(std::move(*shared), child, root); });
+      } else {
+        do_tiling_for_node(std::move(data), child, root);
+      }
     }
   }
 };
@@ -724,11 +797,27 @@ void orc_sparse_grid_greedy(const double* xyz, const uint32_t* idx, uint64_t n, 
 int32_t orc_tile(double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
                  const orc_tile_params* params, uint64_t* keys_out, uint32_t* perm_out,
                  int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out) {
+  return orc_tile_mt(xyz, n, bmin, bmax, params, 1, keys_out, perm_out, level_out, dup_mask_out, stats_out);
+}
+
+int32_t orc_tile_mt(double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                    const orc_tile_params* params, uint32_t threads, uint64_t* keys_out, uint32_t* perm_out,
+                    int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out) {
   if (!params || n > 0xFFFFFFFFull) return ORC_ERR_BAD_ARG;
+  if (threads == 0) threads = 1;
   const AABB bounds = make_aabb(bmin, bmax);
-  /* index (V1 :588-598 / V3 :1262-1285) */
+  /* index (V1 :588-598 / V3 :1262-1285): chunks of the batch on the indexing threads (Parallel.h:172-213) */
   std::vector<uint64_t> keys(n);
-  orc_index_points(xyz, n, bmin, bmax, MAX_OCTREE_LEVELS, keys.data());
+  if (threads == 1 || n < 2 * MIN_POINTS_FOR_ASYNC_PROCESSING) {
+    orc_index_points(xyz, n, bmin, bmax, MAX_OCTREE_LEVELS, keys.data());
+  } else {
+    std::vector<std::thread> ts;
+    for (uint32_t t = 0; t < threads; ++t) {
+      const uint64_t b = n * t / threads, e = n * (t + 1) / threads;
+      ts.emplace_back([=, &keys] { orc_index_points(xyz + 3 * b, e - b, bmin, bmax, MAX_OCTREE_LEVELS, keys.data() + b); });
+    }
+    for (auto& th : ts) th.join();
+  }
   /* sort (V1 :600-604 / V3 :1292), canonical tie order */
   std::vector<uint32_t> perm(n);
   orc_sort_by_key(keys.data(), n, perm.data());
@@ -763,8 +852,16 @@ int32_t orc_tile(double* xyz, uint64_t n, const double bmin[3], const double bma
     return ORC_OK;
   }
 
+  std::unique_ptr<TaskPool> pool;
+  if (threads > 1) {
+    pool.reset(new TaskPool(threads));
+    t.pool = pool.get();
+  }
   if (params->strategy == ORC_ACCURATE) {
+    /* one task for the root; the whole-batch sort above and the root node run on one thread like
+     * TilingAlgorithmV1's graph (:600-626) */
     t.do_tiling_for_node(std::vector<IP>(sorted), root, root);
+    if (pool) pool->wait_all();
   } else {
     /* V3 first iteration :1287-1353 */
     const size_t S = estimate_start_node_level(sorted, params->fast_concurrency);
@@ -782,9 +879,17 @@ int32_t orc_tile(double* xyz, uint64_t n, const double bmin[3], const double bma
       node.max_spacing = (float)(root.max_spacing / std::pow(2, (double)S));
       node.morton_index = prefix << shift; /* to_static_morton_index, OctreeNodeIndex.h:347-351 */
       node.bounds = get_bounds_from_morton_index(node.morton_index, MAX_OCTREE_LEVELS, bounds, (uint32_t)S);
-      t.do_tiling_for_node(std::vector<IP>(sorted.begin() + i, sorted.begin() + j), node, root);
+      if (pool) { /* the start nodes are independent tasks of V3's graph (:1345-1353) */
+        auto data = std::make_shared<std::vector<IP>>(sorted.begin() + i, sorted.begin() + j);
+        Tiler* tp = &t;
+        pool->submit([tp, data, node, root] { tp->do_tiling_for_node(std::move(*data), node, root); });
+      } else {
+        t.do_tiling_for_node(std::vector<IP>(sorted.begin() + i, sorted.begin() + j), node, root);
+      }
       i = j;
     }
+    if (pool) pool->wait_all();
+    t.pool = nullptr; /* the reconstruction below is sequential (finalize, :1717-1784) */
     /* finalize -> reconstruct_left_out_nodes :1717-1784, reconstruct_single_node :1661-1715.
      * stored[levels][index] = sorted positions persisted under that node, Morton order. */
     if (!t.error) {

@@ -115,6 +115,14 @@ int32_t orc_tile(double* xyz, uint64_t n, const double bmin[3], const double bma
                  const orc_tile_params* params, uint64_t* keys_out, uint32_t* perm_out,
                  int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats);
 
+/* Same with `threads` worker threads used the way the reference uses its indexing executor: the encode runs in
+ * chunks on all threads (util/Parallel.h:172-213), the whole-batch sort and (ACCURATE) the root node on one
+ * thread (TilingAlgorithms.cpp:600-626), child nodes with >= 100 000 points as tasks, smaller ones inline
+ * (:25, 499-561); FAST start nodes are independent tasks (:1345-1353).  Results do not depend on threads. */
+int32_t orc_tile_mt(double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                    const orc_tile_params* params, uint32_t threads, uint64_t* keys_out, uint32_t* perm_out,
+                    int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out);
+
 /* util/algorithms/Algorithm.h restatements on int ranges, for the reference's TestAlgorithm vectors */
 int64_t orc_stable_partition_take_multiples(int32_t* values, int64_t n, int32_t modulus);
 void orc_merge_ranges_i32(const int32_t* const* ranges, const int64_t* sizes, int64_t num_ranges,

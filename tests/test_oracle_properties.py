@@ -124,3 +124,18 @@ def test_jittered_errors_match_reference_throws():
     # a deep node: grid level >= 21 (Sampling.h:642-653)
     t, _, _ = O.sample_points(O.JITTERED, 10, keys[order], order, xyz, 0, 15, *UNIT, 0.001, O.ALWAYS_ADHERE)
     assert t == O.ERR_JITTER_NODE_TOO_DEEP
+
+
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.MIN_DISTANCE])
+@pytest.mark.parametrize("strategy", [O.ACCURATE, O.FAST])
+def test_threaded_oracle_gives_the_same_tiles(sampler, strategy):
+    """orc_tile_mt spreads node tasks over worker threads like the reference's executor; nodes are independent,
+    so the result must not depend on the thread count (this is the CPU baseline bench.py times)."""
+    xyz = O.generate_uniform(77, 1_200_000)
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250)
+    a = O.tile(xyz, [0, 0, 0], [1, 1, 1], sampler, 5000, spacing, strategy=strategy, threads=1)
+    b = O.tile(xyz, [0, 0, 0], [1, 1, 1], sampler, 5000, spacing, strategy=strategy, threads=6)
+    assert a["status"] == 0 and b["status"] == 0
+    for k in ("keys", "perm", "level", "dup"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["stats"] == b["stats"]
