@@ -37,7 +37,7 @@ def parse_args():
     ap.add_argument("--sampler", default="MIN_DISTANCE", choices=["RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED"])
     ap.add_argument("--diagonal-fraction", type=float, default=250.0)
     ap.add_argument("--max-points-per-node", type=int, default=20000)
-    ap.add_argument("--cpu-sample", type=int, default=8_000_000, help="points of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=24_000_000, help="points of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all host cores available)")
     ap.add_argument("--strategy", default="ACCURATE", choices=["ACCURATE", "FAST"],
                     help="tiling strategy (TilingAlgorithmV1 / V3); the headline is ACCURATE, the canonical top-down semantics")
