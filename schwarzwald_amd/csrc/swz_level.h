@@ -75,9 +75,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
                        uint32_t sample_points, uint32_t* rounds_out);
 
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
-// qualify.  snode_of: node -> index among the sampled nodes.
+// qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                               const LevelBuffers& lb, const uint32_t* snode_of, uint32_t sample_nodes,
-                              uint32_t sample_points, uint32_t* rounds_out, bool* used);
+                              uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used);
 
 }  // namespace swz

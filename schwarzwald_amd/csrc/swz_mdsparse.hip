@@ -290,14 +290,14 @@ __global__ void sp_zero_kernel(uint32_t* p) { *p = 0; }
 // to false when the level does not qualify (the caller then runs the frontier sweep).
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                               const LevelBuffers& lb, const uint32_t* snode_of, uint32_t sample_nodes,
-                              uint32_t sample_points, uint32_t* rounds_out, bool* used) {
+                              uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used) {
   *used = false;
-  const double avg = (double)sample_points / (double)sample_nodes;
   int cl = plan.cell_levels_geo;
   // the table must stay addressable and affordable: at most 2^31 entries
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
-  const double per_cell = avg / std::pow(8.0, cl);
-  double limit = 1.5;
+  // points per OCCUPIED cell: clustered data fills a small part of a node's volume
+  const double per_cell = (double)sample_points / (double)std::max(1u, occupied[cl]);
+  double limit = 2.0;  // per occupied cell; a uniform level with 1.5 points per cell of volume has 1.93
   if (const char* e = getenv("SWZ_MD_SPARSE_LIMIT")) limit = atof(e);
   if (!(per_cell < limit)) return SWZ_OK;
   const uint32_t m = as.m;

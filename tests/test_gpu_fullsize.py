@@ -26,14 +26,24 @@ MAX_POINTS = 20000
 SEED = 0x5C4A72A1D + 3
 
 
-@pytest.fixture(scope="module")
-def tiled():
+@pytest.fixture(scope="module", params=["uniform", "clustered"])
+def tiled(request):
     import torch
     import schwarzwald_amd as swz
     dev = torch.device("cuda:0")
     ctx = swz.Context(0)
     xyz = torch.empty((N, 3), dtype=torch.float64, device=dev)
     ctx.generate_uniform_device(SEED, 0, N, xyz.data_ptr())
+    if request.param == "clustered":
+        # surface-like data (what LAS files look like): a thin wavy sheet, a dense blob and a sparse background,
+        # so that sparse and dense MIN_DISTANCE levels, the sparse path's give-up and deep nodes all occur
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234)
+        k = N // 3
+        xyz[:k, 2] = 0.3 + 0.05 * torch.sin(6.0 * xyz[:k, 0]) * torch.cos(4.0 * xyz[:k, 1]) \
+            + 0.0005 * torch.randn(k, dtype=torch.float64, device=dev, generator=g)
+        xyz[k:2 * k] = 0.6 + 0.03 * torch.randn((k, 3), dtype=torch.float64, device=dev, generator=g)
+        xyz.clamp_(0.0, 1.0)
     spacing = O.spacing_from_diagonal(*UNIT, 250)
     out = {}
     for sampler in (swz.MIN_DISTANCE, swz.RANDOM_GRID):
@@ -94,19 +104,29 @@ def _check_level(tiled, L, rng, target_points=1_500_000):
     # a box holding about target_points of them
     frac = min(1.0, target_points / max(1, int(in_sampling.sum())))
     h = 0.5 * frac ** (1.0 / 3.0)
-    c = rng.random(3) * (1.0 - 2.0 * h) + h
     idx_all = torch.nonzero(in_sampling).squeeze(1)
     pos = tiled["xyz"][perm[idx_all].long()]
-    lo = torch.tensor(c - h - float(s) * 1.01, device=pos.device)
-    hi = torch.tensor(c + h + float(s) * 1.01, device=pos.device)
-    near = ((pos >= lo) & (pos <= hi)).all(dim=1)
+    # centred on a random point of the level (so that dense parts are visited in proportion to their points) and
+    # shrunk until it holds about target_points
+    c = pos[int(rng.integers(0, pos.shape[0]))].cpu().numpy()
+    c = np.clip(c, h, 1.0 - h)
+    while True:
+        lo = torch.tensor(c - h - float(s) * 1.01, device=pos.device)
+        hi = torch.tensor(c + h + float(s) * 1.01, device=pos.device)
+        near = ((pos >= lo) & (pos <= hi)).all(dim=1)
+        if int(near.sum()) <= 2 * target_points or h < 4.0 * float(s):
+            break
+        h *= 0.75
     idx = idx_all[near]
     P = pos[near].cpu().numpy()
     sorted_index = idx.cpu().numpy()
     node_h = node[idx].cpu().numpy()
     taken = (level[idx] == L).cpu().numpy()
     del pos, near, idx_all, in_sampling, active, node
-    inner = np.all((P >= c - h) & (P <= c + h), axis=1)              # the points to verify
+    inner = np.all((P >= c - h) & (P <= c + h), axis=1)              # the points to verify ...
+    if int(inner.sum()) > target_points:                              # ... a random subset of them in dense parts
+        drop = rng.choice(np.nonzero(inner)[0], size=int(inner.sum()) - target_points, replace=False)
+        inner[drop] = False
     Q, Qi = P[inner], np.nonzero(inner)[0]
     T, Ti = P[taken], np.nonzero(taken)[0]
     pairs = cKDTree(Q).sparse_distance_matrix(cKDTree(T), float(s) * (1.0 + 1e-9), output_type="ndarray")
