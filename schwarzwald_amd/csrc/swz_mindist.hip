@@ -81,6 +81,7 @@ struct MdArgs {
   uint32_t latest_first;     // blocker scans visit the latest adjacent cell first (else the earliest)
   uint32_t patient;          // 1 = a stalled cell sleeps until the blocking CELL is finished, not just the blocking point
   float lazy_frac;           // lazy start: sleep until this fraction of the latest earlier neighbour is decided
+  uint32_t ff_min;           // cells with more remaining points than this try the fast-forward first
   uint32_t xcd_chunks;       // 1 = each XCD sweeps a contiguous eighth of the queue
   uint32_t ablate;           // debugging only (SWZ_MD_ABLATE): 1 = never blocked, 2 = no rejection tests
   double usq[3];
@@ -456,6 +457,31 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   uint32_t out_pos = e, out_status = ST_FINISHED;
   uint32_t b_slot = 0, b_q = 0, b_cell = 0;
   bool stop = false;
+
+  // Very large cells (dense blobs: thousands of points per cell): skip stretches in which every point is already
+  // rejected by the committed accepted points, four chunks per memory round trip.
+  if (live_wn && e - cur > a.ff_min && !(a.ablate & 16u)) {
+    while (e - cur > 4u * WAVE) {
+      double x[4], y[4], z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = cur + (uint32_t)u * WAVE + l;
+        x[u] = a.X[q];
+        y[u] = a.Y[q];
+        z[u] = a.Z[q];
+      }
+      bool alive_l = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        bool rej_u = false;
+        for (uint32_t ti = 0; ti < live_wn; ++ti)
+          if (sq_dist(x[u], y[u], z[u], lds.ex[ti], lds.ey[ti], lds.ez[ti]) < t) rej_u = true;
+        alive_l |= !rej_u;
+      }
+      if (__ballot(alive_l)) break;
+      cur += 4u * WAVE;
+    }
+  }
 
   while (cur < e && !stop) {
     const uint32_t p = cur + l;
@@ -878,6 +904,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       a.usq[ax] = u * u;
     }
     a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
+    a.ff_min = getenv("SWZ_MD_FF_MIN") ? (uint32_t)atoi(getenv("SWZ_MD_FF_MIN")) : 1024u;
     a.xcd_chunks = getenv("SWZ_MD_XCD") ? (uint32_t)atoi(getenv("SWZ_MD_XCD")) & 1u : 0u;
     a.ablate = getenv("SWZ_MD_ABLATE") ? (uint32_t)atoi(getenv("SWZ_MD_ABLATE")) : 0u;
     // expected points per spacing-sized cell; far below one almost every candidate is accepted
