@@ -55,7 +55,12 @@ int swz_create(swz_ctx** ctx_out, int device);
 int swz_destroy(swz_ctx* ctx);
 const char* swz_last_error(const swz_ctx* ctx); /* ctx may be NULL: returns the create() error */
 int swz_abi_version(void);
-/* Run on an existing hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+/* A context launches on its OWN non-blocking stream: device buffers handed to the *_device entry points must be
+ * complete before the call (synchronise, or wait on an event), and the entry points return after their own work
+ * finished (they synchronise that stream).  swz_set_stream makes the context run on an existing hipStream_t
+ * instead (e.g. torch's current stream), which orders it with the caller's kernels on that stream.  NULL is the
+ * device's default stream (a real stream: PyTorch's default); SWZ_OWN_STREAM restores the own stream. */
+#define SWZ_OWN_STREAM ((void*)(intptr_t)-1)
 int swz_set_stream(swz_ctx* ctx, void* hip_stream);
 /* Frees all device workspace held by the context (it regrows on demand). */
 int swz_release_workspace(swz_ctx* ctx);

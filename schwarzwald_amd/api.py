@@ -290,7 +290,10 @@ class Context:
 
     # ------------------------------------------------------------------ plumbing
     def set_stream(self, hip_stream):
-        self._check(self._lib.swz_set_stream(self._ctx, C.c_void_p(hip_stream)))
+        """Run on an existing HIP stream (an integer handle such as torch.cuda.current_stream().cuda_stream; 0 is the
+        device's default stream, which is PyTorch's default).  None restores the context's own non-blocking stream."""
+        handle = C.c_void_p(-1) if hip_stream is None else C.c_void_p(int(hip_stream))
+        self._check(self._lib.swz_set_stream(self._ctx, handle))
 
     def release_workspace(self):
         self._check(self._lib.swz_release_workspace(self._ctx))

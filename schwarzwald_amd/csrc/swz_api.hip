@@ -26,6 +26,11 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
                                  " bytes): " + hipGetErrorString(e));
     }
     b.cap = want;
+    // SWZ_POISON=<byte>: fill new workspace memory (hipMalloc does not): shakes out reads of never-written memory
+    if (const char* e = getenv("SWZ_POISON")) {
+      const char* only = getenv("SWZ_POISON_ONLY");
+      if (!only || strstr(name, only)) SWZ_HIP(this, hipMemsetAsync(b.ptr, atoi(e), want, stream));
+    }
   }
   *out = b.ptr;
   return SWZ_OK;
@@ -172,7 +177,8 @@ const char* swz_last_error(const swz_ctx* c) { return c ? c->err.c_str() : g_cre
 int swz_set_stream(swz_ctx* c, void* hip_stream) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
-  c->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : c->own_stream;
+  // hipStream_t 0 is a real stream (the device's default stream, which is what torch uses unless told otherwise)
+  c->stream = hip_stream == SWZ_OWN_STREAM ? c->own_stream : reinterpret_cast<hipStream_t>(hip_stream);
   return SWZ_OK;
 }
 
@@ -317,6 +323,7 @@ int swz_tile_device(swz_ctx* c, double* d_xyz, uint64_t n, const double bmin[3],
                     uint32_t* d_dup_mask_out, swz_tile_stats* stats) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
+  if (getenv("SWZ_SYNC_ENTRY")) SWZ_HIP(c, hipDeviceSynchronize());
   SWZ_TRY(check_n(c, n));
   SWZ_TRY(check_bounds(c, bmin, bmax));
   SWZ_TRY(check_params(c, params));

@@ -5,6 +5,8 @@
 #include <stdint.h>
 
 #include <map>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -103,6 +105,16 @@ struct ProfScope {
   }
   ~ProfScope() { c->prof_end(name, launches, bytes); }
 };
+
+// SWZ_TRACE=1: synchronise and report after a stage (debugging hangs; never on in production)
+#define SWZ_STAGE(ctx, what)                                                              \
+  do {                                                                                    \
+    if (getenv("SWZ_TRACE")) {                                                            \
+      const hipError_t _e = hipStreamSynchronize((ctx)->stream);                          \
+      fprintf(stderr, "[swz trace] %s:%d %s -> %s\n", __FILE__, __LINE__, what, hipGetErrorString(_e)); \
+      fflush(stderr);                                                                     \
+    }                                                                                     \
+  } while (0)
 
 // ---- stage entry points (each in its own .hip file) -------------------------------------------
 int encode_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],

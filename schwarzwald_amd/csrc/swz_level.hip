@@ -647,6 +647,7 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vals_b));
   if (radix_result_in_second()) {  // place the input so that the sorted result lands in the output buffers
     SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, keys_b));
+    SWZ_STAGE(c, "encode");
     SWZ_TRY(radix_sort_pairs(c, keys_b, vals_b, out.keys, out.perm, n, true));
   } else {
     SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, out.keys));
@@ -660,7 +661,9 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
     X += front;
     Y += front;
     Z += front;
+    SWZ_STAGE(c, "sort");
     SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
+    SWZ_STAGE(c, "gather");
   }
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(out.level, 0x80, (size_t)n, c->stream));  // -128 = not persisted yet

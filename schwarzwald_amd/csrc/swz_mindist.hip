@@ -829,6 +829,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
                        lb.nid, lb.nmode, m, nsh,
                        (uint32_t)plan.cell_levels_geo, d_hist);
     SWZ_LAUNCH_CHECK(c);
+    SWZ_STAGE(c, "md cell hist");
     uint32_t h[16];
     SWZ_HIP(c, hipMemcpyAsync(h, d_hist, 64, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -859,6 +860,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     hipLaunchKernelGGL(md_cell_pop_kernel, dim3(MD_POP_SAMPLES / 256), dim3(256), 0, c->stream, as.akey, lb.nid, lb.nmode, m, nsh,
                        (uint32_t)plan.cell_levels_geo, d_pop);
     SWZ_LAUNCH_CHECK(c);
+    SWZ_STAGE(c, "md cell pop");
     unsigned long long h[4];
     SWZ_HIP(c, hipMemcpyAsync(h, d_pop, 32, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -969,8 +971,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(md_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
+  SWZ_STAGE(c, "md cells");
   hipLaunchKernelGGL(md_nbr_build_kernel, dim3(div_up(ncells, 8)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
+  SWZ_STAGE(c, "md neighbour tables");
   // With many small cells a level is bound by activation throughput: start lazily and let a stalled cell sleep
   // until the whole blocking cell is finished (fewer, later wake-ups; measured at 1 B points, level 1:
   // 302 -> 173 ms).  With few large cells it is bound by the latency of a round times the number of rounds:
@@ -999,6 +1003,11 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
 
   // rounds; the host only looks at the done counter every `batch` rounds
   const bool dbg = getenv("SWZ_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d starts: %u pts in %u nodes, cell levels %d of %d, %u cells (occupied at the finest: %u), "
+                    "mean population after coarsening %.0f / %.0f / %.0f, lazy %d patient %u\n",
+            plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells, occupied[plan.cell_levels_geo], pop[0], pop[1],
+            pop[2], (int)lazy, a.patient);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg) {
     ev0 = c->take_event();
@@ -1015,7 +1024,8 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
   const uint32_t batch = 32;
-  const uint64_t max_rounds = 4ull * m + 1024;
+  uint64_t max_rounds = 4ull * m + 1024;
+  if (const char* e = getenv("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
   while (done < ncells) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
       hipLaunchKernelGGL(md_sweep_kernel, dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
@@ -1032,9 +1042,16 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       (void)hipEventSynchronize(e);
       (void)hipEventElapsedTime(&t, ev0, e);
       c->event_pool.push_back(e);
-      fprintf(stderr, " r%u:%.1fms:%.3f%%", round, t, 100.0 * done / ncells);
+      uint32_t qn[3] = {0, 0, 0};
+      (void)hipMemcpy(qn, lb.counters + CTR_Q0, 12, hipMemcpyDeviceToHost);
+      fprintf(stderr, " r%u:%.1fms:%.3f%%:q%u", round, t, 100.0 * done / ncells, qn[round % 3]);
     }
-    if (round > max_rounds) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE frontier sweep did not terminate");
+    if (round > max_rounds) {
+      char msg[160];
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE frontier sweep did not terminate: level %d, %u of %u cells done after %u rounds",
+               plan.level, done, ncells, round);
+      return c->fail(SWZ_ERR_INTERNAL, msg);
+    }
   }
   if (rounds_out) *rounds_out += round;
   if (dbg) {

@@ -232,6 +232,7 @@ int swz_gather_payload_device(swz_ctx* c, const uint32_t* d_perm, const uint32_t
     SWZ_LAUNCH_CHECK(c);
     ps.bytes = bytes;
   }
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
   return SWZ_OK;
 }
 
@@ -440,5 +441,6 @@ extern "C" int swz_las_decode_device(swz_ctx* c, const uint8_t* d_records, uint6
   hipLaunchKernelGGL(swz::las_decode_kernel, dim3(swz::div_up((uint32_t)n, swz::LAS_POINTS_PER_BLOCK)),
                      dim3(swz::LAS_POINTS_PER_BLOCK), 0, c->stream, d_records, (uint32_t)n, a);
   SWZ_LAUNCH_CHECK(c);
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
   return SWZ_OK;
 }

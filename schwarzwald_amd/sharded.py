@@ -137,6 +137,10 @@ class ShardedTiler:
         self.result = None
         self._keepalive = None
         self._batches = 0
+        if device.type == "cuda":
+            # the context otherwise runs on its own non-blocking stream: torch's kernels (grouping, exchange) and the
+            # library's must be ordered, so both use torch's current stream
+            ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
 
     def _bcast(self, tensor, src):
         backend = dist.get_backend(self.group)

@@ -152,6 +152,7 @@ def test_gpu_node_files_match_the_oracle_pipeline(tmp_path, sampler, names):
 
     dev = torch.device("cuda:0")
     ctx = swz.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)  # ordered with the torch kernels that fill the buffers
     d_xyz = torch.from_numpy(xyz).to(dev)
     d_attr = {k: torch.from_numpy(v).to(dev) for k, v in attrs.items()}
     keys = torch.empty(n, dtype=torch.int64, device=dev)

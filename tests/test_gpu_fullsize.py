@@ -32,6 +32,9 @@ def tiled(request):
     import schwarzwald_amd as swz
     dev = torch.device("cuda:0")
     ctx = swz.Context(0)
+    # the context has its own non-blocking stream: run it on torch's, or the tile could start while the torch
+    # kernels below are still writing the points (that race once made this fixture look like a hang)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
     xyz = torch.empty((N, 3), dtype=torch.float64, device=dev)
     ctx.generate_uniform_device(SEED, 0, N, xyz.data_ptr())
     if request.param == "clustered":

@@ -339,6 +339,7 @@ def test_shard_api_with_ghosts_matches_oracle(presort):
     for part in (~upper, upper):
         ids = np.nonzero(part)[0]
         ctx = swz.Context(0)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         loc = torch.from_numpy(xyz[ids]).to(dev)
         m = len(ids)
         g = 0 if ghosts is None else ghosts.shape[0]

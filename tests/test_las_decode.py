@@ -81,6 +81,7 @@ def test_gpu_las_decode_matches_oracle(fmt, extra, n):
                                   r.dtype.itemsize)
     dev = torch.device("cuda:0")
     ctx = swz.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)  # ordered with the torch kernels that fill the buffers
     d_rec = torch.from_numpy(r.view(np.uint8).copy()).to(dev)
     d_xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
     d_attr = {}
@@ -131,6 +132,7 @@ def test_gpu_las_records_to_node_files(tmp_path):
 
     dev = torch.device("cuda:0")
     ctx = swz.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)  # ordered with the torch kernels that fill the buffers
     d_rec = torch.from_numpy(r.view(np.uint8).copy()).to(dev)
     d_xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
     d_attr = {"rgb": torch.empty((n, 3), dtype=torch.uint8, device=dev), "intensity": torch.empty(n, dtype=torch.uint16, device=dev)}

@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
-"""Times one tile of surface-like clustered data (same generator as tests/test_gpu_fullsize.py) with the library's
-per-level debug output.  usage: clustered_probe.py N SAMPLER"""
+"""Tiles clustered points in a process whose free device memory was filled with a byte pattern first: catches reads
+of workspace memory that was never written (hipMalloc does not zero).  usage: dirty_probe.py N [pattern]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import schwarzwald_amd as swz
-N = int(sys.argv[1]); sampler = sys.argv[2]
+N = int(sys.argv[1]); pat = int(sys.argv[2]) if len(sys.argv) > 2 else 0xAB
 dev = torch.device("cuda:0")
+free, _ = torch.cuda.mem_get_info(dev)
+junk = torch.full((int(free * 0.9),), pat, dtype=torch.uint8, device=dev)
+torch.cuda.synchronize(); del junk; torch.cuda.empty_cache()
 ctx = swz.Context(0)
 ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)  # same stream as the torch kernels that make the input
 xyz = torch.empty((N, 3), dtype=torch.float64, device=dev)
@@ -17,8 +20,9 @@ xyz[:k, 2] = 0.3 + 0.05 * torch.sin(6.0 * xyz[:k, 0]) * torch.cos(4.0 * xyz[:k, 
 xyz[k:2 * k] = 0.6 + 0.03 * torch.randn((k, 3), dtype=torch.float64, device=dev, generator=g)
 xyz.clamp_(0.0, 1.0)
 keys = torch.empty(N, dtype=torch.int64, device=dev); perm = torch.empty(N, dtype=torch.int32, device=dev); level = torch.empty(N, dtype=torch.int8, device=dev)
-p = swz.TileParams(sampler=getattr(swz, sampler), max_points_per_node=20000, spacing_at_root=swz.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250))
-torch.cuda.synchronize(); t0 = time.perf_counter()
-st = ctx.tile_device(xyz.data_ptr(), N, [0, 0, 0], [1, 1, 1], p, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
-torch.cuda.synchronize()
-print("N=%d %s: %.1f ms" % (N, sampler, (time.perf_counter() - t0) * 1e3), st, flush=True)
+for sampler in sys.argv[3:] or ["MIN_DISTANCE"]:
+    p = swz.TileParams(sampler=getattr(swz, sampler), max_points_per_node=20000, spacing_at_root=swz.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250))
+    t0 = time.perf_counter()
+    st = ctx.tile_device(xyz.data_ptr(), N, [0, 0, 0], [1, 1, 1], p, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+    torch.cuda.synchronize()
+    print("N=%d %s: %.1f ms" % (N, sampler, (time.perf_counter() - t0) * 1e3), st, flush=True)
