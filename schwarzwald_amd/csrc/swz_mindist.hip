@@ -21,6 +21,7 @@
 // hence the accepted set is bit-identical; the number of rounds is the true dependency depth of the
 // greedy sweep instead of the length of the cell adjacency chains.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -1024,6 +1025,11 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
   const uint32_t batch = 32;
+  // a level that does not finish is reported, not waited for: points that change while they are being tiled
+  // (keys and positions no longer agree) can make single cells arbitrarily expensive
+  const auto wall0 = std::chrono::steady_clock::now();
+  double wall_limit = 900.0;
+  if (const char* e = getenv("SWZ_MD_TIME_LIMIT")) wall_limit = atof(e);
   uint64_t max_rounds = 4ull * m + 1024;
   if (const char* e = getenv("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
   while (done < ncells) {
@@ -1045,6 +1051,12 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       uint32_t qn[3] = {0, 0, 0};
       (void)hipMemcpy(qn, lb.counters + CTR_Q0, 12, hipMemcpyDeviceToHost);
       fprintf(stderr, " r%u:%.1fms:%.3f%%:q%u", round, t, 100.0 * done / ncells, qn[round % 3]);
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > wall_limit) {
+      char msg[200];
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE frontier sweep exceeded %.0f s: level %d, %u of %u cells done after %u rounds "
+               "(were the points modified while they were being tiled?)", wall_limit, plan.level, done, ncells, round);
+      return c->fail(SWZ_ERR_INTERNAL, msg);
     }
     if (round > max_rounds) {
       char msg[160];
