@@ -154,7 +154,8 @@ def main():
                             spacing_at_root=spacing, max_depth=100, strategy=getattr(swz, args.strategy),
                             fast_concurrency=args.fast_concurrency)
     ctx = swz.Context(dev.index)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    if os.environ.get("SWZ_BENCH_OWN_STREAM") != "1":  # default: share torch's current stream (ordered with its kernels)
+        ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
 
     # synthetic input, resident in HBM before the timed region
     xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
