@@ -207,6 +207,20 @@ int swz_bin_persist_nodes(swz_ctx* ctx, const char* dir, uint64_t num_nodes, con
 /* "r" + octant digits of a node; name_out must hold 23 bytes */
 int swz_node_name(int8_t node_level, uint64_t node_key, char* name_out);
 
+/* ---- hierarchy metadata of the node table; host functions.
+ *   swz_node_name_entwine / swz_node_from_entwine_name: "D-X-Y-Z" (depth = number of octants, then the node's
+ *     grid coordinates at that depth; OctreeNodeIndex::to_string_entwine / from_string, core/datastructures/
+ *     OctreeNodeIndex.h:556-573, 480-540).  name_out must hold 72 bytes.
+ *   swz_node_bounds: the node's box by descending from the root box octant by octant (get_octant_bounds,
+ *     core/tiling/OctreeAlgorithms.cpp:3-18, the way Cesium3DTilesPersistence::on_write_node walks down,
+ *     core/io/Cesium3DTilesPersistence.cpp:100-112).
+ *   swz_node_geometric_error: spacing_at_root / 2^depth (Cesium3DTilesPersistence.cpp:91-92). */
+int swz_node_name_entwine(int8_t node_level, uint64_t node_key, char* name_out);
+int swz_node_from_entwine_name(const char* name, int8_t* node_level_out, uint64_t* node_key_out);
+int swz_node_bounds(int8_t node_level, uint64_t node_key, const double root_min[3], const double root_max[3],
+                    double min_out[3], double max_out[3]);
+double swz_node_geometric_error(int8_t node_level, float spacing_at_root);
+
 /* ---- LAS point records -> positions + attribute columns: the step right in
  * front of the path.  The reference reads points through LASzip into a laszip_point and converts them in
  * position_from_las_point (core/io/LASFile.cpp:79-94: offset + X * scale per axis, then clamped into the

@@ -121,6 +121,35 @@ def node_name(level, key):
     return buf.value.decode()
 
 
+def node_name_entwine(level, key):
+    """Entwine's "D-X-Y-Z" name of a node (OctreeNodeIndex.h:556-573)."""
+    buf = C.create_string_buffer(72)
+    if load_library().swz_node_name_entwine(int(level), int(key), buf) != 0:
+        raise ValueError("bad node level %d" % level)
+    return buf.value.decode()
+
+
+def node_from_entwine_name(name):
+    """(level, key) of an Entwine node name; ValueError for a malformed name or more than 21 levels."""
+    lv, key = C.c_int8(), C.c_uint64()
+    if load_library().swz_node_from_entwine_name(name.encode(), C.byref(lv), C.byref(key)) != 0:
+        raise ValueError("not an Entwine node name: %r" % name)
+    return int(lv.value), int(key.value)
+
+
+def node_bounds(level, key, root_min, root_max):
+    """Box of a node, descending octant by octant from the root box like get_octant_bounds."""
+    mn, mx = (C.c_double * 3)(), (C.c_double * 3)()
+    if load_library().swz_node_bounds(int(level), int(key), _vec3(root_min), _vec3(root_max), mn, mx) != 0:
+        raise ValueError("bad node level %d" % level)
+    return list(mn), list(mx)
+
+
+def node_geometric_error(level, spacing_at_root):
+    """Cesium tileset geometricError of a node: spacing_at_root / 2^depth."""
+    return float(load_library().swz_node_geometric_error(int(level), C.c_float(spacing_at_root)))
+
+
 def bin_write_node(path, xyz, attrs=None, compressed=False):
     """BinaryPersistence::persist_points for one node (host only, no GPU needed)."""
     x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
@@ -224,6 +253,11 @@ def load_library():
     L.swz_bin_read_node.argtypes = [vp, C.c_char_p, C.c_int, _dp, cols]
     L.swz_bin_persist_nodes.argtypes = [vp, C.c_char_p, C.c_uint64, _i8p, _u64p, _u64p, _u64p, _dp, cols, C.c_int]
     L.swz_node_name.argtypes = [C.c_int8, C.c_uint64, C.c_char_p]
+    L.swz_node_name_entwine.argtypes = [C.c_int8, C.c_uint64, C.c_char_p]
+    L.swz_node_from_entwine_name.argtypes = [C.c_char_p, _i8p, _u64p]
+    L.swz_node_bounds.argtypes = [C.c_int8, C.c_uint64, _dp, _dp, _dp, _dp]
+    L.swz_node_geometric_error.argtypes = [C.c_int8, C.c_float]
+    L.swz_node_geometric_error.restype = C.c_double
     L.swz_las_decode_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(_LasLayout), vp, cols]
     L.swz_partition_by_octant_device.argtypes = [vp, vp, C.c_uint64, vp, _u64p]
     L.swz_shard_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.POINTER(_ShardInfo),
@@ -241,7 +275,8 @@ def load_library():
                  "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device",
                  "swz_build_node_lists_device", "swz_gather_payload_device", "swz_bin_write_node",
                  "swz_bin_read_header", "swz_bin_read_node", "swz_bin_persist_nodes", "swz_node_name",
-                 "swz_las_decode_device", "swz_shard_presort_device"):
+                 "swz_las_decode_device", "swz_shard_presort_device", "swz_node_name_entwine",
+                 "swz_node_from_entwine_name", "swz_node_bounds"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -3,6 +3,7 @@
 // core/tiling/TilingAlgorithms.cpp:139, 232-236).
 #include <zlib.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -243,6 +244,62 @@ int swz_node_name(int8_t node_level, uint64_t node_key, char* name_out) {
   for (int l = 0; l <= node_level; ++l) name_out[k++] = (char)('0' + ((node_key >> level_shift(l)) & 7u));
   name_out[k] = 0;
   return SWZ_OK;
+}
+
+int swz_node_name_entwine(int8_t node_level, uint64_t node_key, char* name_out) {
+  if (!name_out || node_level < -1 || node_level > 20) return SWZ_ERR_BAD_ARG;
+  uint64_t x = 0, y = 0, z = 0;
+  for (int l = 0; l <= node_level; ++l) {
+    const uint32_t o = (uint32_t)(node_key >> level_shift(l)) & 7u;
+    x = (x << 1) | ((o >> 2) & 1u);
+    y = (y << 1) | ((o >> 1) & 1u);
+    z = (z << 1) | (o & 1u);
+  }
+  snprintf(name_out, 72, "%d-%llu-%llu-%llu", node_level + 1, (unsigned long long)x, (unsigned long long)y,
+           (unsigned long long)z);
+  return SWZ_OK;
+}
+
+int swz_node_from_entwine_name(const char* name, int8_t* node_level_out, uint64_t* node_key_out) {
+  if (!name || !node_level_out || !node_key_out) return SWZ_ERR_BAD_ARG;
+  unsigned long long d = 0, x = 0, y = 0, z = 0;
+  char tail = 0;
+  if (sscanf(name, "%llu-%llu-%llu-%llu%c", &d, &x, &y, &z, &tail) != 4) return SWZ_ERR_BAD_ARG;
+  if (d > 21) return SWZ_ERR_BAD_ARG;  // more levels than a 64-bit index holds (OctreeNodeIndex64)
+  if (d < 64 && ((x >> d) || (y >> d) || (z >> d))) return SWZ_ERR_BAD_ARG;
+  uint64_t key = 0;
+  for (unsigned l = 0; l < d; ++l) {
+    const unsigned b = (unsigned)d - 1u - l;
+    const uint64_t o = (((x >> b) & 1ull) << 2) | (((y >> b) & 1ull) << 1) | ((z >> b) & 1ull);
+    key |= o << level_shift((int)l);
+  }
+  *node_level_out = (int8_t)((int)d - 1);
+  *node_key_out = key;
+  return SWZ_OK;
+}
+
+int swz_node_bounds(int8_t node_level, uint64_t node_key, const double root_min[3], const double root_max[3],
+                    double min_out[3], double max_out[3]) {
+  if (!root_min || !root_max || !min_out || !max_out || node_level < -1 || node_level > 20) return SWZ_ERR_BAD_ARG;
+  double mn[3] = {root_min[0], root_min[1], root_min[2]}, mx[3] = {root_max[0], root_max[1], root_max[2]};
+  for (int l = 0; l <= node_level; ++l) {
+    const uint32_t o = (uint32_t)(node_key >> level_shift(l)) & 7u;
+    const uint32_t bit[3] = {(o >> 2) & 1u, (o >> 1) & 1u, o & 1u};
+    for (int ax = 0; ax < 3; ++ax) {  // get_octant_bounds: min (+ extent / 2), max = min + extent / 2
+      const double e = mx[ax] - mn[ax];
+      if (bit[ax]) mn[ax] = mn[ax] + e / 2;
+      mx[ax] = mn[ax] + e / 2;
+    }
+  }
+  for (int ax = 0; ax < 3; ++ax) {
+    min_out[ax] = mn[ax];
+    max_out[ax] = mx[ax];
+  }
+  return SWZ_OK;
+}
+
+double swz_node_geometric_error(int8_t node_level, float spacing_at_root) {
+  return spacing_at_root / std::pow(2.0, (double)(node_level + 1));
 }
 
 int swz_bin_write_node(swz_ctx* c, const char* path, uint64_t count, const double* xyz, const swz_attribute_columns* columns,
