@@ -105,6 +105,8 @@ def exchange_rows(rows, send_counts, group=None, headroom=0, chunk_bytes=None):
                 p2p.append(dist.P2POp(dist.isend, src[ss:ss + sl], peer, group))
             if rl:
                 p2p.append(dist.P2POp(dist.irecv, dst[rs:rs + rl], peer, group))
+        if not p2p:
+            continue  # this rank's pairs are done; others may still have rounds
         for req in dist.batch_isend_irecv(p2p):
             req.wait()
     if dst is not buf:
