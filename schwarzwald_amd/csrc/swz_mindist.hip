@@ -872,7 +872,8 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < per_cell &&
          pop[plan.cell_levels_geo - cl] <= max_pop)
     --cl;
-  while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > std::max(268435456.0, 2.0 * (double)sample_points)) --cl;
+  // the dense [node][cell] map: at most 2^31 entries (8.6 GB; it is memset once per level, a few ms)
+  while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
   if (const char* e = getenv("SWZ_MD_COARSEN")) {
     const double thr = getenv("SWZ_MD_COARSEN_MIN") ? atof(getenv("SWZ_MD_COARSEN_MIN")) : 32.0;
     if (avg / std::pow(8.0, cl) >= thr) cl = std::max(0, cl - atoi(e));
