@@ -194,13 +194,17 @@ class ShardedTiler:
         global_points = int(total.item())
         sequential_root = self.params.sampler == api.MIN_DISTANCE and global_points > self.params.max_points_per_node
         headroom = GHOST_HEADROOM if (sequential_root and self.rank > 0) else 0
-        buf, _ = exchange_rows(send, send_counts, self.group, headroom)
+        buf, recv_counts = exchange_rows(send, send_counts, self.group, headroom)
+        recv_counts_total = sum(recv_counts)
         del send
         t0 = _trace(dev, "exchange", t0)
         if dev.type == "cuda" and self._batches == 0:
-            # first batch: hand the freed send buffers back before the context grows its workspace with hipMalloc
-            # (later batches find the workspace in place and torch's cached blocks are reused instead)
-            torch.cuda.empty_cache()
+            # first batch: the context is about to grow its workspace with hipMalloc (up to ~160 B per point for
+            # MIN_DISTANCE); hand torch's cached send buffers back only when that would not fit otherwise --
+            # giving them back costs the next batch ~0.7 s of re-allocation
+            free, _ = torch.cuda.mem_get_info(dev)
+            if free < int(7.0 * max(n, recv_counts_total) * 24):
+                torch.cuda.empty_cache()
         self._batches += 1
         recv = buf[headroom:]
         m = recv.shape[0]
