@@ -127,8 +127,14 @@ __global__ __launch_bounds__(256) void take_all_kernel(uint32_t m, const uint32_
 // ----------------------------------------------------------------------------- GRID_CENTER / JITTERED (K4b, K4d)
 // Both pick, per run of equal grid-cell prefix, the first point with the smallest squared distance
 // to a per-cell target (std::min_element, Sampling.h:392-403 / :741-750): a segmented arg-min.
-constexpr int GA_THREADS = 256;
-constexpr int GA_IPT = 1;
+#ifndef SWZ_GA_THREADS
+#define SWZ_GA_THREADS 256
+#endif
+#ifndef SWZ_GA_IPT
+#define SWZ_GA_IPT 2
+#endif
+constexpr int GA_THREADS = SWZ_GA_THREADS;
+constexpr int GA_IPT = SWZ_GA_IPT;
 constexpr int GA_TILE = GA_THREADS * GA_IPT;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
