@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void md_cell_hist_kernel(const uint64_t* __res
   if (threadIdx.x < 16 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
-// Points-weighted mean cell population at the cell levels cl_geo-1, -2, -3 (out[0..2] = sums over the samples,
-// out[3] = samples): the population of the cell of every MD_POP_SAMPLES-th point, found by binary search for the
+// Points-weighted mean cell population at the cell levels cl_geo, cl_geo-1, -2, -3 (out[0..3] = sums over the
+// samples, out[4] = samples): the population of the cell of every MD_POP_SAMPLES-th point, found by binary search for the
 // cell's run in the sorted keys.  Tells whether the TYPICAL point would sit in an oversized cell after coarsening,
 // which the plain average over cells does not (a dense blob in a sparse background).
 constexpr uint32_t MD_POP_SAMPLES = 1u << 16;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void md_cell_pop_kernel(const uint64_t* __rest
   const uint32_t i = (uint32_t)(((uint64_t)t * m) / MD_POP_SAMPLES);
   if (i >= m || nmode[nid[i]] != MODE_SAMPLE) return;
   const uint64_t key = akey[i];
-  for (uint32_t k = 1; k <= 3u && k <= cl_geo; ++k) {
+  for (uint32_t k = 0; k <= 3u && k <= cl_geo; ++k) {
     const uint32_t sh = node_shift - 3u * (cl_geo - k);
     const uint64_t pre = key >> sh;
     uint32_t lo = 0, hi = i;  // first index with prefix >= pre
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(256) void md_cell_pop_kernel(const uint64_t* __rest
       const uint32_t mid = lo + (hi - lo) / 2u;
       if ((akey[mid] >> sh) <= pre) lo = mid + 1u; else hi = mid;
     }
-    atomicAdd(&out[k - 1], (unsigned long long)(lo - first));
+    atomicAdd(&out[k], (unsigned long long)(lo - first));
   }
-  atomicAdd(&out[3], 1ull);
+  atomicAdd(&out[4], 1ull);
 }
 
 __global__ __launch_bounds__(256) void md_cell_head_kernel(MdArgs a, uint32_t* __restrict__ flags) {
@@ -852,25 +852,25 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   // says little, and cells that are too large for the dense part cost far more (long serial activations) than
   // cells that are too small for the sparse part (more, cheap activations).  Measured on 100 M clustered points:
   // 11.4 s with the volume average, 0.66 s with this rule; uniform data choose the same cells as before.
-  double pop[3] = {0, 0, 0};
-  if (cl > 0 && (double)sample_points / (double)std::max(1u, occupied[cl]) < per_cell) {
+  double pop[4] = {0, 0, 0, 0};  // at cell level cl_geo, cl_geo - 1, - 2, - 3
+  {
     unsigned long long* d_pop = nullptr;
-    SWZ_TRY(c->get("md_pop", (size_t)4, &d_pop));
-    SWZ_HIP(c, hipMemsetAsync(d_pop, 0, 32, c->stream));
+    SWZ_TRY(c->get("md_pop", (size_t)8, &d_pop));
+    SWZ_HIP(c, hipMemsetAsync(d_pop, 0, 64, c->stream));
     const uint32_t nsh = plan.node_shift == 63u ? 63u : plan.node_shift;
     hipLaunchKernelGGL(md_cell_pop_kernel, dim3(MD_POP_SAMPLES / 256), dim3(256), 0, c->stream, as.akey, lb.nid, lb.nmode, m, nsh,
                        (uint32_t)plan.cell_levels_geo, d_pop);
     SWZ_LAUNCH_CHECK(c);
     SWZ_STAGE(c, "md cell pop");
-    unsigned long long h[4];
-    SWZ_HIP(c, hipMemcpyAsync(h, d_pop, 32, hipMemcpyDeviceToHost, c->stream));
+    unsigned long long h[5];
+    SWZ_HIP(c, hipMemcpyAsync(h, d_pop, 40, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    for (int k = 0; k < 3; ++k) pop[k] = h[3] ? (double)h[k] / (double)h[3] : 1e30;
+    for (int k = 0; k < 4; ++k) pop[k] = h[4] ? (double)h[k] / (double)h[4] : 1e30;
   }
   double max_pop = 160.0;
   if (const char* e = getenv("SWZ_MD_MAX_POP")) max_pop = atof(e);
   while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < per_cell &&
-         pop[plan.cell_levels_geo - cl] <= max_pop)
+         pop[plan.cell_levels_geo - cl + 1] <= max_pop)
     --cl;
   // the dense [node][cell] map: at most 2^31 entries (8.6 GB; it is memset once per level, a few ms)
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
@@ -990,9 +990,15 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   if (const char* e = getenv("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
   if (const char* e = getenv("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
   if (const char* e = getenv("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
-  bool lazy = many_small;
+  // every level starts lazily (no first round in which all cells scan their neighbourhood only to learn that
+  // they must wait); levels bound by the number of rounds wake a cell as soon as its latest earlier neighbour has
+  // decided its first point (1 B points, root: 147 -> 117 ms), throughput-bound ones once half of it is decided
+  // -- unless the typical point sits in a very large cell (dense blobs, N x denser roots of sharded batches),
+  // where an early wake-up only adds expensive activations
+  const double typical = pop[std::min(3, plan.cell_levels_geo - cl)];
+  bool lazy = many_small || typical <= 2048.0;
   if (const char* e = getenv("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
-  a.lazy_frac = getenv("SWZ_MD_LAZY_FRAC") ? (float)atof(getenv("SWZ_MD_LAZY_FRAC")) : 0.5f;
+  a.lazy_frac = getenv("SWZ_MD_LAZY_FRAC") ? (float)atof(getenv("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
   if (lazy) {
     SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_Q0, 0, 4, c->stream));
     hipLaunchKernelGGL(md_lazy_start_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, a.queue[0],
@@ -1007,9 +1013,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const bool dbg = getenv("SWZ_DEBUG") != nullptr;
   if (dbg)
     fprintf(stderr, "[swz] MIN_DISTANCE level %d starts: %u pts in %u nodes, cell levels %d of %d, %u cells (occupied at the finest: %u), "
-                    "mean population after coarsening %.0f / %.0f / %.0f, lazy %d patient %u\n",
+                    "points-weighted mean cell population at the finest level and coarser %.0f / %.0f / %.0f / %.0f, lazy %d patient %u\n",
             plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells, occupied[plan.cell_levels_geo], pop[0], pop[1],
-            pop[2], (int)lazy, a.patient);
+            pop[2], pop[3], (int)lazy, a.patient);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg) {
     ev0 = c->take_event();
