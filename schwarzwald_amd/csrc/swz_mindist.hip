@@ -996,7 +996,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   // -- unless the typical point sits in a very large cell (dense blobs, N x denser roots of sharded batches),
   // where an early wake-up only adds expensive activations
   const double typical = pop[std::min(3, plan.cell_levels_geo - cl)];
-  bool lazy = many_small || typical <= 2048.0;
+  bool lazy = many_small || typical <= 1024.0;
   if (const char* e = getenv("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
   a.lazy_frac = getenv("SWZ_MD_LAZY_FRAC") ? (float)atof(getenv("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
   if (lazy) {
