@@ -116,6 +116,17 @@ struct ProfScope {
     }                                                                                     \
   } while (0)
 
+// hipMemsetAsync in pieces of 1 GiB: a single call of exactly 4 GiB (512 nodes x 2^21 cells x 4 bytes) was
+// observed not to fill the buffer on ROCm 7.0 / gfx950 (tools/debug_fullsize.py: neighbour cells went missing)
+inline hipError_t memset_large(void* p, int value, size_t bytes, hipStream_t stream) {
+  const size_t piece = size_t(1) << 30;
+  for (size_t at = 0; at < bytes; at += piece) {
+    const hipError_t e = hipMemsetAsync(static_cast<char*>(p) + at, value, bytes - at < piece ? bytes - at : piece, stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // ---- stage entry points (each in its own .hip file) -------------------------------------------
 int encode_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
                   uint64_t* d_keys);

@@ -337,9 +337,9 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_TRY(c->get("sp_ulist1", (size_t)m, &u1));
   SWZ_TRY(c->get("sp_counts", (size_t)4, &cnt));
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
-  SWZ_HIP(c, hipMemsetAsync(a.table, 0xFF, (size_t)entries * sizeof(uint2), c->stream));
+  SWZ_HIP(c, memset_large(a.table, 0xFF, (size_t)entries * sizeof(uint2), c->stream));
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
-  SWZ_HIP(c, hipMemsetAsync(a.state, SP_U, (size_t)m, c->stream));
+  SWZ_HIP(c, memset_large(a.state, SP_U, (size_t)m, c->stream));
   const uint32_t nb = div_up(m, 256);
   hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, rec);
   SWZ_LAUNCH_CHECK(c);

@@ -196,8 +196,11 @@ __global__ __launch_bounds__(256) void md_cell_end_kernel(MdArgs a, uint32_t nce
 // earlier adjacent cells of every cell, sorted latest first (a cell's blocker scans and accepted-point
 // pulls walk this list; it never changes during the sweep).  Half a wavefront per cell: lane k looks up
 // adjacent cell k, its rank is the number of found cells with a larger code.
+// (Grid-stride over the cells: 32 lanes per cell would exceed the 2^32 work-items one dispatch can have from
+// 134 M cells on -- the excess workgroups silently never run; found at 213 M cells, tools/debug_fullsize.py.)
 __global__ __launch_bounds__(256) void md_nbr_build_kernel(MdArgs a, uint32_t ncells) {
-  const uint32_t c = blockIdx.x * 8u + threadIdx.x / 32u;
+ for (uint64_t cbase = (uint64_t)blockIdx.x * 8u; cbase < ncells; cbase += (uint64_t)gridDim.x * 8u) {
+  const uint32_t c = (uint32_t)cbase + threadIdx.x / 32u;
   const uint32_t k = threadIdx.x & 31u;
   uint32_t nrel = 0, nb = NONE32;
   bool have = false;
@@ -239,6 +242,7 @@ __global__ __launch_bounds__(256) void md_nbr_build_kernel(MdArgs a, uint32_t nc
     a.nbr_slot[(size_t)c * 32 + rank] = (uint8_t)k;
   }
   if (k == 31u && c < ncells) a.nbr_slot[(size_t)c * 32 + 31] = (uint8_t)__popc(found);
+ }
 }
 
 // next cell (rank) of a blocker scan: latest first when the level is throughput bound, earliest first when
@@ -966,7 +970,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
   const uint64_t grid_entries = (uint64_t)sample_nodes * cells_per_node;
   SWZ_TRY(c->get("md_gridmap", (size_t)grid_entries, &a.gridmap));
-  SWZ_HIP(c, hipMemsetAsync(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
+  SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
 
   hipLaunchKernelGGL(md_cell_build_kernel, dim3(nb), dim3(256), 0, c->stream, a, lb.flags);
   SWZ_LAUNCH_CHECK(c);
@@ -974,7 +978,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   hipLaunchKernelGGL(md_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "md cells");
-  hipLaunchKernelGGL(md_nbr_build_kernel, dim3(div_up(ncells, 8)), dim3(256), 0, c->stream, a, ncells);
+  hipLaunchKernelGGL(md_nbr_build_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "md neighbour tables");
   // With many small cells a level is bound by activation throughput: start lazily and let a stalled cell sleep

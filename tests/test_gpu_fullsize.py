@@ -31,6 +31,7 @@ def tiled(request):
     import torch
     import schwarzwald_amd as swz
     dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()  # the library allocates with hipMalloc: hand back what earlier tests left in torch's cache
     ctx = swz.Context(0)
     # the context has its own non-blocking stream: run it on torch's, or the tile could start while the torch
     # kernels below are still writing the points (that race once made this fixture look like a hang)
