@@ -36,7 +36,7 @@ enum {
   SWZ_ERR_JITTER_GRID_TOO_SMALL = 3, /* JitteredSampling throws: Sampling.h:632-635 */
   SWZ_ERR_JITTER_NODE_TOO_DEEP = 4,  /* JitteredSampling throws: Sampling.h:642-653 */
   SWZ_ERR_REROOT_UNSUPPORTED = 5,    /* node needs Morton re-rooting, TilingAlgorithms.cpp:444-483 */
-  SWZ_ERR_TOO_MANY_POINTS = 6,       /* more than 2^32-2 points in one batch */
+  SWZ_ERR_TOO_MANY_POINTS = 6,       /* more than 2^32-65536 points in one batch */
   SWZ_ERR_INTERNAL = 7
 };
 

@@ -111,7 +111,9 @@ int sync(swz_ctx* c) {
   return SWZ_OK;
 }
 int check_n(swz_ctx* c, uint64_t n) {
-  if (n > 0xFFFFFFFEull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-2 points in one batch");
+  // 32-bit point indices, and one-thread-per-point launches rounded up to whole workgroups must stay below the
+  // 2^32 work-items of a dispatch
+  if (n > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points in one batch");
   return SWZ_OK;
 }
 int check_bounds(swz_ctx* c, const double mn[3], const double mx[3]) {
