@@ -978,7 +978,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   hipLaunchKernelGGL(md_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "md cells");
-  hipLaunchKernelGGL(md_nbr_build_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
+  hipLaunchKernelGGL(md_nbr_build_kernel,
+                     dim3(std::min<uint32_t>(div_up(ncells, 8), getenv("SWZ_MD_NBR_GRID") ? (uint32_t)atoi(getenv("SWZ_MD_NBR_GRID")) : 1u << 20)),
+                     dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "md neighbour tables");
   // With many small cells a level is bound by activation throughput: start lazily and let a stalled cell sleep

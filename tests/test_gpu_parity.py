@@ -299,6 +299,7 @@ def test_min_distance_sparse_path_and_its_fallback(ctx, monkeypatch):
     {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "0", "SWZ_MD_LATEST_FIRST": "0"},
     {"SWZ_MD_EARLY": "0", "SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "1"},
     {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "1", "SWZ_MD_ABLATE": "8"},  # 8: no dead-point test
+    {"SWZ_MD_NBR_GRID": "3", "SWZ_MD_GRID": "40"},  # tiny launch grids: the grid-stride loops must cover every cell
 ], ids=lambda m: "-".join("%s%s" % (k[7:10], v) for k, v in m.items()))
 def test_min_distance_sweep_scheduling_modes(ctx, monkeypatch, mode):
     """The frontier sweep picks its scheduling per level from the cell statistics (early re-check, patient stalls,
