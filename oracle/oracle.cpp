@@ -966,6 +966,321 @@ void orc_merge_ranges_i32(const int32_t* const* ranges, const int64_t* sizes, in
   }
 }
 
+/* ==================================================================================================
+ * Multi-batch tiler: what Tiler does when the input is larger than
+ * internal_cache_size (executable/main.cpp:233-236, default 10 M points): build_execution_graph is called
+ * once per batch on the SAME TilingAlgorithm object and every node re-reads what earlier batches persisted
+ * under its name.  The persistence restated here is BinaryPersistence (core/io/BinaryPersistence.h:45-57:
+ * one file per node name, opened with std::ios::out, i.e. REPLACED by every persist_points call; a call with
+ * zero points returns before opening the file; is_lossless() == true).  (MemoryPersistence.h:23-32 appends
+ * instead and would duplicate the cached points; it is "mostly for unit testing".)
+ * PARITY UNPINNED: the reference's only multi-batch tests (test/TestTiler.cpp:85-190) are commented out.
+ * ================================================================================================== */
+namespace {
+
+struct MBTiler {
+  AABB bounds;
+  orc_tile_params params;
+  std::vector<double> xyz;                                           /* clamped positions by global id */
+  std::map<std::pair<int32_t, uint64_t>, std::vector<uint32_t>> files; /* (node level, node morton index) -> ids */
+  int32_t level_of_start_nodes = -1;                                  /* V3::_level_of_start_nodes */
+  uint64_t batches = 0;
+  bool finalized = false;
+  int32_t error = ORC_OK;
+  orc_tile_stats stats{};
+  uint64_t unsorted_cached_nodes = 0;
+
+  SampleCtx ctx() const { return SampleCtx{params.sampler, params.max_points_per_node, Positions{xyz.data()}, MAX_OCTREE_LEVELS}; }
+  V3 pos(uint32_t id) const { return {xyz[3 * (size_t)id], xyz[3 * (size_t)id + 1], xyz[3 * (size_t)id + 2]}; }
+
+  /* PointsPersistence::persist_points, BinaryPersistence.h:46-57 */
+  void persist(const IP* b, const IP* e, const NodeStructure& node) {
+    if (b == e) return;
+    std::vector<uint32_t>& f = files[{node.level, node.morton_index}];
+    f.clear();
+    for (const IP* p = b; p != e; ++p) f.push_back(p->idx);
+    stats.num_nodes += 1;
+    stats.max_level = std::max(stats.max_level, node.level);
+  }
+
+  /* read_pnts_from_disk -- TilingAlgorithms.cpp:50-109: the cached points keep the node's own Morton index
+   * and get the levels below it from an index computed relative to the NODE's bounds (no clamp); a lossless
+   * persistence is not sorted again (:103-106). */
+  std::vector<IP> read_pnts_from_disk(const NodeStructure& node) {
+    std::vector<IP> out;
+    auto it = files.find({node.level, node.morton_index});
+    if (it == files.end() || it->second.empty()) return out;
+    out.reserve(it->second.size());
+    const uint32_t start_level = static_cast<uint32_t>(node.level + 1);
+    for (uint32_t id : it->second) {
+      uint64_t idx = node.morton_index;
+      const uint64_t rel = calculate_morton_index(pos(id), node.bounds, MAX_OCTREE_LEVELS);
+      for (uint32_t level = start_level; level < MAX_OCTREE_LEVELS; ++level)
+        idx = set_octant_at_level(idx, level, get_octant_at_level(rel, level - start_level, MAX_OCTREE_LEVELS),
+                                  MAX_OCTREE_LEVELS);
+      out.push_back({id, idx});
+    }
+    for (size_t i = 1; i < out.size(); ++i)
+      if (out[i].key < out[i - 1].key) {
+        ++unsorted_cached_nodes; /* bookkeeping for the tests only: the reference does not look */
+        break;
+      }
+    return out;
+  }
+
+  /* octree::merge_node_data_sorted / _unsorted -- core/tiling/Node.cpp:4-35 */
+  static std::vector<IP> merge_sorted(std::vector<IP>&& first, std::vector<IP>&& second) {
+    if (first.empty()) return std::move(second);
+    if (second.empty()) return std::move(first);
+    std::vector<IP> merged;
+    merged.reserve(first.size() + second.size());
+    std::merge(first.begin(), first.end(), second.begin(), second.end(), std::back_inserter(merged),
+               [](const IP& l, const IP& r) { return l.key < r.key; });
+    return merged;
+  }
+  static std::vector<IP> merge_unsorted(std::vector<IP>&& first, std::vector<IP>&& second) {
+    if (first.empty()) return std::move(second);
+    if (second.empty()) return std::move(first);
+    first.insert(first.end(), second.begin(), second.end());
+    return std::move(first);
+  }
+
+  /* tile_internal_node -- TilingAlgorithms.cpp:247-349, then split_range_into_child_nodes :116-162 and the
+   * recursion of do_tiling_for_node :499-561 (sequential here; the order of sibling tasks does not matter,
+   * every node name is touched by exactly one task per batch) */
+  void tile_internal_node(std::vector<IP>& all, const NodeStructure& node, const NodeStructure& root,
+                          size_t previously_taken) {
+    const int behaviour = previously_taken > 0 ? ORC_ALWAYS_ADHERE : ORC_TAKE_ALL_WHEN_BELOW_MAX; /* :272-275 */
+    const int32_t rel_level = node.level - (root.level + 1);                                       /* :277 */
+    IP* b = all.data();
+    IP* e = b + all.size();
+    const SampleCtx c = ctx();
+    const int64_t taken = sample_points(c, b, e, node.morton_index, rel_level, root.bounds, root.max_spacing, behaviour);
+    if (taken < 0) {
+      error = (int32_t)taken;
+      return;
+    }
+    persist(b, b + taken, node);
+    const int32_t child_level = node.level + 1;
+    const IP* ranges[9];
+    partition_points_into_child_octants(b + taken, e, (uint32_t)child_level, MAX_OCTREE_LEVELS, ranges);
+    for (uint8_t octant = 0; octant < 8; ++octant) {
+      if (ranges[octant + 1] == ranges[octant]) continue;
+      NodeStructure child = node;
+      child.morton_index = set_octant_at_level(child.morton_index, (uint32_t)child_level, octant, MAX_OCTREE_LEVELS);
+      child.bounds = get_octant_bounds(octant, node.bounds);
+      child.level = child_level;
+      child.max_spacing /= 2;
+      do_tiling_for_node(std::vector<IP>(ranges[octant], ranges[octant + 1]), child, root);
+      if (error) return;
+    }
+  }
+
+  /* tile_node -- TilingAlgorithms.cpp:351-492 */
+  void do_tiling_for_node(std::vector<IP>&& node_data, const NodeStructure& node, const NodeStructure& root) {
+    if (error) return;
+    std::vector<IP> cached = read_pnts_from_disk(node);
+    const size_t cached_count = cached.size();
+    stats.points_visited += node_data.size() + cached_count;
+    const int32_t req = required_morton_index_depth(params.sampler, node.level, root);
+    const bool requires_deeper = req > node.level;
+    const int32_t max_level = (int32_t)std::min(MAX_OCTREE_LEVELS - 1, node.max_depth);
+    if (!requires_deeper) {
+      if (req >= max_level) { /* :421-427 */
+        const std::vector<IP> all = merge_unsorted(std::move(node_data), std::move(cached));
+        persist(all.data(), all.data() + all.size(), node); /* tile_terminal_node :206-241 */
+        return;
+      }
+      std::vector<IP> all = merge_sorted(std::move(node_data), std::move(cached));
+      tile_internal_node(all, node, root, cached_count);
+      return;
+    }
+    if (node.level >= max_level) { /* :436-442 */
+      const std::vector<IP> all = merge_unsorted(std::move(node_data), std::move(cached));
+      persist(all.data(), all.data() + all.size(), node);
+      return;
+    }
+    if (req >= (int32_t)MAX_OCTREE_LEVELS) {
+      /* :444-483: the node becomes the root of a new 21-level index.  Literal restatement, including that
+       * (a) calculate_morton_index does not clamp, so a point outside new_root.bounds feeds a negative double
+       * to static_cast<uint64_t> (the value x86-64 gcc produces is kept: this file is built by it), and
+       * (b) the children are still split at the ABSOLUTE level node.level + 1 of the re-rooted keys (:124-125
+       * via :479-482).  The reference's own test of this path (test/TestTiler.cpp:164-190) is disabled. */
+      std::vector<IP> all = merge_unsorted(std::move(node_data), std::move(cached));
+      NodeStructure new_root = node;
+      new_root.max_depth = node.max_depth - (uint32_t)node.level;
+      for (IP& p : all) p.key = calculate_morton_index(pos(p.idx), new_root.bounds, MAX_OCTREE_LEVELS);
+      std::stable_sort(all.begin(), all.end(), [](const IP& l, const IP& r) { return l.key < r.key; }); /* :476 */
+      tile_internal_node(all, node, new_root, cached_count);
+      return;
+    }
+    std::vector<IP> all = merge_sorted(std::move(node_data), std::move(cached));
+    tile_internal_node(all, node, root, cached_count);
+  }
+
+  NodeStructure root_node() const { /* V1 :606-612, V3 :1327-1333 */
+    NodeStructure root;
+    root.bounds = bounds;
+    root.level = -1;
+    root.max_depth = params.max_depth;
+    root.max_spacing = params.spacing_at_root;
+    root.morton_index = 0;
+    return root;
+  }
+
+  int32_t add_batch(double* batch_xyz, uint64_t n) {
+    if (finalized) return ORC_ERR_BAD_ARG;
+    if (xyz.size() / 3 + n > 0xFFFFFFFFull) return ORC_ERR_BAD_ARG;
+    const double bmin[3] = {bounds.min.x, bounds.min.y, bounds.min.z}, bmax[3] = {bounds.max.x, bounds.max.y, bounds.max.z};
+    /* parallel::scatter throws when the batch has fewer points than indexing threads (Parallel.h:181-186) */
+    if (params.strategy == ORC_FAST && n < params.fast_concurrency) return ORC_ERR_BAD_ARG;
+    const uint32_t base = (uint32_t)(xyz.size() / 3);
+    std::vector<uint64_t> keys(n);
+    orc_index_points(batch_xyz, n, bmin, bmax, MAX_OCTREE_LEVELS, keys.data()); /* clamps in place */
+    xyz.insert(xyz.end(), batch_xyz, batch_xyz + 3 * n);
+    /* V1 :600-604: one sort; V3 first batch :1292: one sort; V3 later batches :1380-1395 + :1599-1606: per-thread
+     * chunks sorted, split at the start level and k-way merged per start node, earlier chunk first on ties
+     * (merge_ranges, Algorithm.h:111-150) -- with the canonical tie order (key, original index) and chunks
+     * that are consecutive index ranges, all three are the same sequence: the stable sort by key. */
+    std::vector<uint32_t> perm(n);
+    orc_sort_by_key(keys.data(), n, perm.data());
+    std::vector<IP> sorted(n);
+    for (uint64_t i = 0; i < n; ++i) sorted[i] = {base + perm[i], keys[perm[i]]};
+    ++batches;
+    if (n == 0) return ORC_OK;
+    const NodeStructure root = root_node();
+    if (params.strategy == ORC_ACCURATE) {
+      do_tiling_for_node(std::move(sorted), root, root);
+      return error;
+    }
+    if (level_of_start_nodes < 0) /* first iteration :1294-1295 */
+      level_of_start_nodes = (int32_t)estimate_start_node_level(sorted, params.fast_concurrency);
+    stats.fast_start_levels = level_of_start_nodes;
+    const uint32_t S = (uint32_t)level_of_start_nodes;
+    const uint32_t shift = (MAX_OCTREE_LEVELS - S) * 3;
+    uint64_t i = 0;
+    while (i < n && !error) { /* split_indexed_points_into_subranges :1537-1578 / prepare_range_for_tiling :1620-1659 */
+      const uint64_t prefix = sorted[i].key >> shift;
+      uint64_t j = i;
+      while (j < n && (sorted[j].key >> shift) == prefix) ++j;
+      NodeStructure node;
+      node.level = (int32_t)S - 1;
+      node.max_depth = root.max_depth;
+      node.max_spacing = (float)(root.max_spacing / std::pow(2, (double)S));
+      node.morton_index = prefix << shift;
+      node.bounds = get_bounds_from_morton_index(node.morton_index, MAX_OCTREE_LEVELS, bounds, S);
+      do_tiling_for_node(std::vector<IP>(sorted.begin() + (ptrdiff_t)i, sorted.begin() + (ptrdiff_t)j), node, root);
+      i = j;
+    }
+    return error;
+  }
+
+  /* TilingAlgorithmV3::finalize -> reconstruct_left_out_nodes :1717-1784, reconstruct_single_node :1661-1715 */
+  int32_t finalize() {
+    if (finalized) return error;
+    finalized = true;
+    if (params.strategy != ORC_FAST || level_of_start_nodes <= 0) return error;
+    const uint32_t S = (uint32_t)level_of_start_nodes;
+    /* ancestors of the existing nodes with S octants, deepest first */
+    std::vector<std::map<uint64_t, int>> todo(S); /* todo[lv]: node indices (lv octants) to reconstruct */
+    for (const auto& kv : files) {
+      if (kv.first.first != (int32_t)S - 1 || kv.second.empty()) continue;
+      uint64_t index = kv.first.second >> ((MAX_OCTREE_LEVELS - S) * 3);
+      for (uint32_t lv = S; lv-- > 0;) {
+        index >>= 3;
+        todo[lv][index] = 1;
+      }
+    }
+    const SampleCtx c = ctx();
+    for (uint32_t lv = S; lv-- > 0 && !error;) {
+      for (const auto& nk : todo[lv]) {
+        const uint64_t index = nk.first;
+        const uint64_t node_key = (lv == 0) ? 0 : (index << ((MAX_OCTREE_LEVELS - lv) * 3));
+        std::vector<IP> data;
+        for (uint8_t octant = 0; octant < 8; ++octant) { /* :1665-1679 */
+          const uint64_t child_key = node_key | ((uint64_t)octant << ((MAX_OCTREE_LEVELS - lv - 1) * 3));
+          auto it = files.find({(int32_t)lv, child_key});
+          if (it == files.end()) continue;
+          /* index_points<21>(..., root_bounds, ClampToBounds) :1682-1688 on a copy of the positions */
+          for (uint32_t id : it->second) {
+            V3 p = pos(id);
+            if (!bounds.isInside(p)) {
+              p.x = std::min(bounds.max.x, std::max(bounds.min.x, p.x));
+              p.y = std::min(bounds.max.y, std::max(bounds.min.y, p.y));
+              p.z = std::min(bounds.max.z, std::max(bounds.min.z, p.z));
+            }
+            data.push_back({id, calculate_morton_index(p, bounds, MAX_OCTREE_LEVELS)});
+          }
+        }
+        if (data.empty()) continue;
+        for (size_t q = 1; q < data.size(); ++q)
+          if (data[q].key < data[q - 1].key) {
+            ++unsorted_cached_nodes;
+            break;
+          }
+        const int64_t taken = sample_points(c, data.data(), data.data() + data.size(), node_key, (int32_t)lv - 1, bounds,
+                                            params.spacing_at_root, ORC_ALWAYS_ADHERE);
+        if (taken < 0) {
+          error = (int32_t)taken;
+          break;
+        }
+        NodeStructure node;
+        node.level = (int32_t)lv - 1;
+        node.morton_index = node_key;
+        persist(data.data(), data.data() + taken, node);
+      }
+    }
+    return error;
+  }
+};
+
+}  // namespace
+
+struct orc_tiler {
+  MBTiler t;
+};
+
+orc_tiler* orc_tiler_create(const double bmin[3], const double bmax[3], const orc_tile_params* params) {
+  if (!params) return nullptr;
+  orc_tiler* h = new orc_tiler();
+  h->t.bounds = make_aabb(bmin, bmax);
+  h->t.params = *params;
+  h->t.stats.max_level = -1;
+  h->t.stats.fast_start_levels = -1;
+  return h;
+}
+void orc_tiler_destroy(orc_tiler* h) { delete h; }
+int32_t orc_tiler_add_batch(orc_tiler* h, double* xyz, uint64_t n) { return h ? h->t.add_batch(xyz, n) : ORC_ERR_BAD_ARG; }
+int32_t orc_tiler_finalize(orc_tiler* h) { return h ? h->t.finalize() : ORC_ERR_BAD_ARG; }
+void orc_tiler_counts(const orc_tiler* h, uint64_t* num_nodes, uint64_t* num_stored, uint64_t* num_points,
+                      uint64_t* unsorted_cached_nodes) {
+  uint64_t nn = 0, ns = 0;
+  for (const auto& kv : h->t.files) {
+    if (kv.second.empty()) continue;
+    ++nn;
+    ns += kv.second.size();
+  }
+  if (num_nodes) *num_nodes = nn;
+  if (num_stored) *num_stored = ns;
+  if (num_points) *num_points = h->t.xyz.size() / 3;
+  if (unsorted_cached_nodes) *unsorted_cached_nodes = h->t.unsorted_cached_nodes;
+}
+void orc_tiler_stats(const orc_tiler* h, orc_tile_stats* out) { *out = h->t.stats; }
+void orc_tiler_export(const orc_tiler* h, int8_t* node_level, uint64_t* node_key, uint64_t* node_offset,
+                      uint64_t* node_count, uint32_t* ids, double* xyz_out) {
+  uint64_t k = 0, off = 0;
+  for (const auto& kv : h->t.files) { /* std::map order = (level, key) ascending */
+    if (kv.second.empty()) continue;
+    node_level[k] = (int8_t)kv.first.first;
+    node_key[k] = kv.first.second;
+    node_offset[k] = off;
+    node_count[k] = kv.second.size();
+    for (uint32_t id : kv.second) ids[off++] = id;
+    ++k;
+  }
+  if (xyz_out) std::memcpy(xyz_out, h->t.xyz.data(), h->t.xyz.size() * sizeof(double));
+}
+
 /* ---- BinaryPersistence, uncompressed --------------------------------------------------------------- */
 namespace {
 const size_t kAttrBytes[12] = {3, 12, 2, 1, 1, 8, 1, 1, 2, 1, 1, 1};

@@ -123,6 +123,30 @@ int32_t orc_tile_mt(double* xyz, uint64_t n, const double bmin[3], const double 
                     const orc_tile_params* params, uint32_t threads, uint64_t* keys_out, uint32_t* perm_out,
                     int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out);
 
+/* ---- multi-batch tiler: one TilingAlgorithm object fed batch after batch the way
+ * Tiler::index does when the input exceeds internal_cache_size (core/process/Tiler.cpp:509-510), over a
+ * BinaryPersistence-like store (a node's file is replaced by every persist_points).  Restates
+ * read_pnts_from_disk (TilingAlgorithms.cpp:50-109), merge_node_data_sorted/_unsorted (Node.cpp:4-35), the
+ * behaviour switch on the cached count (:272-275), re-rooting (:444-483), V3's later iterations
+ * (:1362-1453, 1620-1659) and finalize (:1661-1784).  Point ids count the points of all batches in input
+ * order.  PARITY UNPINNED (the reference's multi-batch tests, test/TestTiler.cpp:85-190, are commented out). */
+typedef struct orc_tiler orc_tiler;
+orc_tiler* orc_tiler_create(const double bmin[3], const double bmax[3], const orc_tile_params* params);
+void orc_tiler_destroy(orc_tiler* t);
+/* one build_execution_graph + run; xyz (n x 3) is clamped in place like index_point does */
+int32_t orc_tiler_add_batch(orc_tiler* t, double* xyz, uint64_t n);
+/* TilingAlgorithmBase::finalize (FAST: reconstruct_left_out_nodes); no-op for ACCURATE */
+int32_t orc_tiler_finalize(orc_tiler* t);
+/* node files present / points stored in them (FAST stores copies in reconstructed nodes) / points added /
+ * nodes whose re-keyed cached points were not in ascending order (the reference does not check, :103-106) */
+void orc_tiler_counts(const orc_tiler* t, uint64_t* num_nodes, uint64_t* num_stored, uint64_t* num_points,
+                      uint64_t* unsorted_cached_nodes);
+void orc_tiler_stats(const orc_tiler* t, orc_tile_stats* out);
+/* nodes ordered by (level, Morton index); ids[node_offset[k] .. +node_count[k]) = the node's points in file
+ * order; xyz_out (may be NULL) receives the clamped positions of all points by id */
+void orc_tiler_export(const orc_tiler* t, int8_t* node_level, uint64_t* node_key, uint64_t* node_offset,
+                      uint64_t* node_count, uint32_t* ids, double* xyz_out);
+
 /* util/algorithms/Algorithm.h restatements on int ranges, for the reference's TestAlgorithm vectors */
 int64_t orc_stable_partition_take_multiples(int32_t* values, int64_t n, int32_t modulus);
 void orc_merge_ranges_i32(const int32_t* const* ranges, const int64_t* sizes, int64_t num_ranges,

@@ -101,6 +101,20 @@ def lib():
         L.orc_las_decode.argtypes = [_u8p, C.c_uint64, C.POINTER(LasLayout), _dp, C.POINTER(C.c_void_p)]
         L.orc_generate_uniform.restype = None
         L.orc_generate_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, _dp]
+        L.orc_tiler_create.restype = C.c_void_p
+        L.orc_tiler_create.argtypes = [_dp, _dp, C.POINTER(TileParams)]
+        L.orc_tiler_destroy.restype = None
+        L.orc_tiler_destroy.argtypes = [C.c_void_p]
+        L.orc_tiler_add_batch.restype = C.c_int32
+        L.orc_tiler_add_batch.argtypes = [C.c_void_p, _dp, C.c_uint64]
+        L.orc_tiler_finalize.restype = C.c_int32
+        L.orc_tiler_finalize.argtypes = [C.c_void_p]
+        L.orc_tiler_counts.restype = None
+        L.orc_tiler_counts.argtypes = [C.c_void_p, _u64p, _u64p, _u64p, _u64p]
+        L.orc_tiler_stats.restype = None
+        L.orc_tiler_stats.argtypes = [C.c_void_p, C.POINTER(TileStats)]
+        L.orc_tiler_export.restype = None
+        L.orc_tiler_export.argtypes = [C.c_void_p, _i8p, _u64p, _u64p, _u64p, _u32p, _dp]
         _lib = L
     return _lib
 
@@ -221,6 +235,58 @@ def tile(xyz, bmin, bmax, sampler, max_points_per_node, spacing_at_root, max_dep
     return dict(status=int(st), keys=keys, perm=perm, level=level, dup=dup, xyz_clamped=x,
                 stats=dict(num_nodes=int(stats.num_nodes), points_visited=int(stats.points_visited),
                            max_level=int(stats.max_level), fast_start_levels=int(stats.fast_start_levels)))
+
+
+class Tiler:
+    """Multi-batch oracle tiler (orc_tiler_*): one TilingAlgorithm object fed batch after batch."""
+
+    def __init__(self, bmin, bmax, sampler, max_points_per_node, spacing_at_root, max_depth=100, strategy=ACCURATE,
+                 fast_concurrency=8):
+        params = TileParams(sampler, max_points_per_node, spacing_at_root, max_depth, strategy, fast_concurrency)
+        self._h = lib().orc_tiler_create(_vec3(bmin), _vec3(bmax), C.byref(params))
+        assert self._h
+
+    def close(self):
+        if self._h:
+            lib().orc_tiler_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def add_batch(self, xyz):
+        """Returns the status (0 = OK, negative = ORC_ERR_*)."""
+        x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3).copy()
+        return int(lib().orc_tiler_add_batch(self._h, _ptr(x, _dp), x.shape[0]))
+
+    def finalize(self):
+        return int(lib().orc_tiler_finalize(self._h))
+
+    def counts(self):
+        v = [C.c_uint64() for _ in range(4)]
+        lib().orc_tiler_counts(self._h, *[C.byref(x) for x in v])
+        return dict(num_nodes=int(v[0].value), num_stored=int(v[1].value), num_points=int(v[2].value),
+                    unsorted_cached_nodes=int(v[3].value))
+
+    def stats(self):
+        s = TileStats()
+        lib().orc_tiler_stats(self._h, C.byref(s))
+        return dict(num_nodes=int(s.num_nodes), points_visited=int(s.points_visited), max_level=int(s.max_level),
+                    fast_start_levels=int(s.fast_start_levels))
+
+    def export(self):
+        """dict(level, key, offset, count, ids, xyz): node table ordered by (level, key) and the ids per node."""
+        c = self.counts()
+        nn, ns, npts = c["num_nodes"], c["num_stored"], c["num_points"]
+        lv = np.empty(max(nn, 1), dtype=np.int8)
+        key = np.empty(max(nn, 1), dtype=np.uint64)
+        off = np.empty(max(nn, 1), dtype=np.uint64)
+        cnt = np.empty(max(nn, 1), dtype=np.uint64)
+        ids = np.empty(max(ns, 1), dtype=np.uint32)
+        xyz = np.empty((max(npts, 1), 3), dtype=np.float64)
+        lib().orc_tiler_export(self._h, _ptr(lv, _i8p), _ptr(key, _u64p), _ptr(off, _u64p), _ptr(cnt, _u64p),
+                               _ptr(ids, _u32p), _ptr(xyz, _dp))
+        return dict(level=lv[:nn], key=key[:nn], offset=off[:nn], count=cnt[:nn], ids=ids[:ns], xyz=xyz[:npts])
 
 
 # attribute columns: name -> (bit of BinaryPersistence's bitmask, dtype, row width)
