@@ -283,6 +283,63 @@ int swz_shard_root_taken_device(swz_ctx* ctx, double* d_xyz_out);
 int swz_shard_finish_device(swz_ctx* ctx, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
                             swz_tile_stats* stats);
 
+/* ---- multi-batch tiling (BASELINE config 5's single-GPU shape).
+ * The reference calls TilingAlgorithmBase::build_execution_graph once per batch of at most internal_cache_size
+ * points (core/process/Tiler.cpp:509-510; executable/main.cpp:233-236, default 10 M) on one algorithm object;
+ * every node a batch reaches re-reads its file, re-keys those points relative to the node
+ * (read_pnts_from_disk, core/tiling/TilingAlgorithms.cpp:50-109), merges them with the new ones
+ * (merge_node_data_sorted, core/tiling/Node.cpp:4-22), samples with AlwaysAdhereToMinSpacing (:272-275) and
+ * REPLACES the file (BinaryPersistence.h:46-57).  FAST: later iterations (:1362-1453, 1620-1659) + finalize
+ * (:1661-1784).  swz_tiler keeps the node files in device memory: one context, one tiler per data set.
+ *   Point ids count the points of all batches in input order (batch 0's points are 0..n0-1, ...).
+ *   swz_tiler_add_batch_device: d_xyz (n x 3, device) is clamped in place like index_point does and copied
+ *     into the tiler's position pool.
+ *   swz_tiler_stage_batch / swz_tiler_tile_staged: the same from HOST memory (pinned: swz_host_alloc_pinned, or
+ *     hipHostRegister'ed by the caller), copied with hipMemcpyAsync on a copy stream straight into the pools; up
+ *     to two batches may be staged, so the copy of batch k+1 runs while batch k is tiled:
+ *         stage(0); for k: { if (k+1 < K) stage(k+1); tile_staged(); }
+ *     attrs_host (may be NULL) are the batch's attribute columns (host pointers); every batch must carry the same
+ *     set.  The host copy of the positions is NOT clamped; the pools (swz_tiler_pools_device) hold the clamped ones.
+ *   swz_tiler_finalize: TilingAlgorithmBase::finalize (FAST: reconstruct_left_out_nodes); no more batches after.
+ *   swz_tiler_export_device / swz_tiler_node_table: the node files: nodes ordered by (level, Morton index);
+ *     entries [node_offset[k], +node_count[k]) of keys/ids/level are node k's points in file order (FAST stores
+ *     copies of a point in reconstructed ancestors, so num_stored >= num_points).  ids index the pools: rows of
+ *     the files are swz_gather_payload_device(ctx, d_ids, NULL, num_stored, pool_xyz, pool_attrs, ...).
+ *   rekey_inversions: re-keyed file contents whose order was not ascending any more (a point within an ulp of a
+ *     cell boundary); the reference merges them unsorted for a lossless persistence (:103-106), this library sorts
+ *     them like the reference does for a lossy one -- results may differ from the reference only when > 0.
+ *   A node that needs Morton re-rooting (:444-483) fails the batch with SWZ_ERR_REROOT_UNSUPPORTED. */
+typedef struct swz_tiler swz_tiler;
+typedef struct {
+  uint64_t num_points;       /* points added so far */
+  uint64_t num_stored;       /* entries in node files */
+  uint64_t num_nodes;        /* node files */
+  uint64_t num_batches;
+  uint64_t rekey_inversions;
+  int32_t fast_start_levels; /* FAST: _level_of_start_nodes once known, else -1 */
+  uint64_t staged_bytes;     /* bytes copied by swz_tiler_stage_batch */
+  double staged_wait_ms;     /* time swz_tiler_tile_staged waited for its copy (0 = fully hidden behind tiling) */
+} swz_tiler_info;
+int swz_tiler_create(swz_ctx* ctx, const double bounds_min[3], const double bounds_max[3],
+                     const swz_tile_params* params, uint64_t capacity_hint_points, swz_tiler** tiler_out);
+int swz_tiler_destroy(swz_tiler* tiler); /* before swz_destroy of its context */
+int swz_tiler_add_batch_device(swz_tiler* tiler, double* d_xyz, uint64_t n, swz_tile_stats* stats);
+int swz_tiler_stage_batch(swz_tiler* tiler, const double* xyz_host, uint64_t n, const swz_attribute_columns* attrs_host);
+int swz_tiler_tile_staged(swz_tiler* tiler, swz_tile_stats* stats);
+/* stage + tile of one host batch, no overlap */
+int swz_tiler_add_batch(swz_tiler* tiler, const double* xyz_host, uint64_t n, const swz_attribute_columns* attrs_host,
+                        swz_tile_stats* stats);
+int swz_tiler_finalize(swz_tiler* tiler, swz_tile_stats* stats);
+int swz_tiler_get_info(swz_tiler* tiler, swz_tiler_info* info);
+int swz_tiler_export_device(swz_tiler* tiler, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out);
+int swz_tiler_node_table(swz_tiler* tiler, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
+                         uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out);
+/* the pools by point id: positions (num_points x 3, clamped) and the attribute columns staged so far */
+int swz_tiler_pools_device(swz_tiler* tiler, const double** d_xyz_out, swz_attribute_columns* d_attrs_out);
+/* page-locked host memory for the staging entry points (hipHostMalloc / hipHostFree) */
+int swz_host_alloc_pinned(uint64_t bytes, void** out);
+int swz_host_free_pinned(void* p);
+
 /* ---- synthetic workload of BASELINE.json / SURVEY.md section 8(d): uniform points in the unit
  * cube from a counter-based splitmix64 stream (point i draws x,y,z = draws 3i..3i+2). */
 int swz_generate_uniform_device(swz_ctx* ctx, uint64_t seed, uint64_t first_point, uint64_t n,

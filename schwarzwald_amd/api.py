@@ -39,6 +39,12 @@ class _ShardInfo(C.Structure):
     _fields_ = [("global_points", C.c_uint64), ("d_ghost_xyz", C.c_void_p), ("num_ghosts", C.c_uint64)]
 
 
+class _TilerInfo(C.Structure):
+    _fields_ = [("num_points", C.c_uint64), ("num_stored", C.c_uint64), ("num_nodes", C.c_uint64),
+                ("num_batches", C.c_uint64), ("rekey_inversions", C.c_uint64), ("fast_start_levels", C.c_int32),
+                ("staged_bytes", C.c_uint64), ("staged_wait_ms", C.c_double)]
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algorithmic_bytes", C.c_uint64)]
@@ -265,6 +271,19 @@ def load_library():
     L.swz_shard_presort_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.c_uint64]
     L.swz_shard_root_taken_device.argtypes = [vp, vp]
     L.swz_shard_finish_device.argtypes = [vp, vp, vp, vp, C.POINTER(_TileStats)]
+    L.swz_tiler_create.argtypes = [vp, _dp, _dp, C.POINTER(_TileParams), C.c_uint64, C.POINTER(vp)]
+    L.swz_tiler_destroy.argtypes = [vp]
+    L.swz_tiler_add_batch_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(_TileStats)]
+    L.swz_tiler_stage_batch.argtypes = [vp, vp, C.c_uint64, cols]
+    L.swz_tiler_tile_staged.argtypes = [vp, C.POINTER(_TileStats)]
+    L.swz_tiler_add_batch.argtypes = [vp, vp, C.c_uint64, cols, C.POINTER(_TileStats)]
+    L.swz_tiler_finalize.argtypes = [vp, C.POINTER(_TileStats)]
+    L.swz_tiler_get_info.argtypes = [vp, C.POINTER(_TilerInfo)]
+    L.swz_tiler_export_device.argtypes = [vp, vp, vp, vp]
+    L.swz_tiler_node_table.argtypes = [vp, C.c_uint64, _i8p, _u64p, _u64p, _u64p, _u64p]
+    L.swz_tiler_pools_device.argtypes = [vp, C.POINTER(vp), cols]
+    L.swz_host_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(vp)]
+    L.swz_host_free_pinned.argtypes = [vp]
     L.swz_profile_enable.argtypes = [vp, C.c_int]
     L.swz_profile_reset.argtypes = [vp]
     L.swz_profile_get.argtypes = [vp, C.POINTER(_KernelStat), C.c_uint32, _u32p]
@@ -276,7 +295,10 @@ def load_library():
                  "swz_build_node_lists_device", "swz_gather_payload_device", "swz_bin_write_node",
                  "swz_bin_read_header", "swz_bin_read_node", "swz_bin_persist_nodes", "swz_node_name",
                  "swz_las_decode_device", "swz_shard_presort_device", "swz_node_name_entwine",
-                 "swz_node_from_entwine_name", "swz_node_bounds"):
+                 "swz_node_from_entwine_name", "swz_node_bounds", "swz_tiler_create", "swz_tiler_destroy",
+                 "swz_tiler_add_batch_device", "swz_tiler_stage_batch", "swz_tiler_tile_staged", "swz_tiler_add_batch",
+                 "swz_tiler_finalize", "swz_tiler_get_info", "swz_tiler_export_device", "swz_tiler_node_table",
+                 "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -510,3 +532,109 @@ class Context:
         self._check(self._lib.swz_shard_finish_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_perm),
                                                       C.c_void_p(d_level), C.byref(stats)))
         return _stats_dict(stats)
+
+
+def pinned_empty(shape, dtype):
+    """numpy array over page-locked host memory (swz_host_alloc_pinned).  The memory is released when the array
+    and all its views are gone; keep it alive while asynchronous copies from it are in flight."""
+    import weakref
+    L = load_library()
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dt.itemsize, 1)
+    ptr = C.c_void_p()
+    st = L.swz_host_alloc_pinned(nbytes, C.byref(ptr))
+    if st != 0:
+        raise SwzError(st, "swz_host_alloc_pinned(%d bytes) failed" % nbytes)
+    buf = (C.c_char * nbytes).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=count).reshape(shape)
+    weakref.finalize(arr, L.swz_host_free_pinned, C.c_void_p(ptr.value))
+    return arr
+
+
+class Tiler:
+    """swz_tiler: one data set tiled batch after batch on one context (multi-batch semantics of the reference's
+    TilingAlgorithm objects, TilingAlgorithms.cpp:50-109, 272-275, 1362-1453, 1661-1784)."""
+
+    def __init__(self, ctx, bmin, bmax, params, capacity_hint=0):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self._t = C.c_void_p()
+        p = params._c()
+        ctx._check(self._lib.swz_tiler_create(ctx._ctx, _vec3(bmin), _vec3(bmax), C.byref(p), int(capacity_hint),
+                                              C.byref(self._t)))
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "_t", None):
+            self._lib.swz_tiler_destroy(self._t)
+            self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add_batch_device(self, d_xyz, n):
+        stats = _TileStats()
+        self._ctx._check(self._lib.swz_tiler_add_batch_device(self._t, C.c_void_p(d_xyz), int(n), C.byref(stats)))
+        return _stats_dict(stats)
+
+    def stage_batch(self, xyz, attrs=None):
+        """Asynchronous copy of a host batch (use pinned_empty arrays for real overlap) into the device pools."""
+        x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        cols, keep = _host_columns(attrs, x.shape[0])
+        self._keep.append((x, keep))
+        self._ctx._check(self._lib.swz_tiler_stage_batch(self._t, C.c_void_p(x.ctypes.data), x.shape[0], C.byref(cols)))
+
+    def tile_staged(self):
+        stats = _TileStats()
+        self._ctx._check(self._lib.swz_tiler_tile_staged(self._t, C.byref(stats)))
+        if self._keep:
+            self._keep.pop(0)
+        return _stats_dict(stats)
+
+    def add_batch(self, xyz, attrs=None):
+        self.stage_batch(xyz, attrs)
+        return self.tile_staged()
+
+    def finalize(self):
+        stats = _TileStats()
+        self._ctx._check(self._lib.swz_tiler_finalize(self._t, C.byref(stats)))
+        return _stats_dict(stats)
+
+    def info(self):
+        i = _TilerInfo()
+        self._ctx._check(self._lib.swz_tiler_get_info(self._t, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in _TilerInfo._fields_}
+
+    def node_table(self):
+        cap = max(int(self.info()["num_nodes"]), 1)
+        nl = np.empty(cap, dtype=np.int8)
+        nk = np.empty(cap, dtype=np.uint64)
+        no = np.empty(cap, dtype=np.uint64)
+        nc = np.empty(cap, dtype=np.uint64)
+        num = C.c_uint64()
+        self._ctx._check(self._lib.swz_tiler_node_table(self._t, cap, nl.ctypes.data_as(_i8p), nk.ctypes.data_as(_u64p),
+                                                        no.ctypes.data_as(_u64p), nc.ctypes.data_as(_u64p), C.byref(num)))
+        m = int(num.value)
+        return dict(level=nl[:m].copy(), key=nk[:m].copy(), offset=no[:m].copy(), count=nc[:m].copy())
+
+    def export_device(self, d_keys, d_ids, d_level):
+        self._ctx._check(self._lib.swz_tiler_export_device(self._t, C.c_void_p(d_keys), C.c_void_p(d_ids),
+                                                           C.c_void_p(d_level)))
+
+    def pools_device(self):
+        """(device pointer of the clamped positions by point id, dict name -> device pointer of the attribute pools)"""
+        xyz = C.c_void_p()
+        cols = _AttributeColumns()
+        self._ctx._check(self._lib.swz_tiler_pools_device(self._t, C.byref(xyz), C.byref(cols)))
+        attrs = {name: int(cols.column[idx]) for name, (idx, _, _) in ATTRIBUTES.items() if cols.column[idx]}
+        return int(xyz.value or 0), attrs

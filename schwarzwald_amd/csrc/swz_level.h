@@ -30,6 +30,11 @@ struct ActiveSet {
   const uint64_t* akey = nullptr;  // key of every active point
   const uint32_t* aidx = nullptr;  // its position in the fully sorted arrays (X/Y/Z/level)
   uint32_t m = 0;
+  // multi-batch tiling (swz_tiler.hip): the keys of the points earlier batches persisted in the nodes of this level
+  // that the active set touches, ascending by node prefix.  A node that has some is sampled with
+  // SamplingBehaviour::AlwaysAdhereToMinSpacing (tile_internal_node, TilingAlgorithms.cpp:272-275).
+  const uint64_t* ckey = nullptr;
+  uint32_t nc = 0;
 };
 
 struct SortedPoints {
@@ -67,6 +72,24 @@ struct LevelBuffers {
   uint8_t* taken = nullptr;    // m
   uint32_t* counters = nullptr; // CTR_COUNT (device)
 };
+
+struct LevelResult {
+  uint32_t remaining = 0;
+  uint32_t num_nodes = 0;
+  uint32_t md_rounds = 0;
+};
+
+// What the host decides for the nodes of one level (tiler_rules: the terminal / re-root tests of tile_node,
+// TilingAlgorithms.cpp:408-444; off for a bare sample_points call).
+LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_at_root, uint32_t max_depth,
+                    const double bmin[3], const double bmax[3], bool force_sample, bool tiler_rules);
+int alloc_level_buffers(swz_ctx* c, uint32_t m, LevelBuffers* lb);
+// Samples every node of the level.  When okey/oidx are given the survivors are compacted into them and level_out
+// receives plan.level for the taken points; otherwise only lb.taken is produced.
+int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+               int8_t* level_out, uint64_t* okey, uint32_t* oidx, LevelResult* res);
+// estimate_start_node_level_in_octree (TilingAlgorithms.cpp:1473-1535) of a sorted batch
+int fast_start_level(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint32_t concurrency, int* start_level);
 
 // MIN_DISTANCE for one level; fills lb.taken for the points of MODE_SAMPLE nodes (take-all points
 // are flagged by the caller).  rounds_out accumulates the dependency rounds executed.

@@ -89,11 +89,22 @@ __global__ __launch_bounds__(256) void node_finish_kernel(const uint32_t* __rest
 __global__ __launch_bounds__(256) void node_mode_kernel(const uint32_t* __restrict__ nstart,
                                                         uint8_t* __restrict__ nmode, uint32_t* __restrict__ counters,
                                                         uint64_t max_points, int force_sample, int terminal,
-                                                        int reroot) {
+                                                        int reroot, const uint64_t* __restrict__ akey, uint32_t nsh,
+                                                        const uint64_t* __restrict__ ckey, uint32_t nc) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= counters[CTR_NUM_NODES]) return;
   const uint32_t cnt = nstart[j + 1] - nstart[j];
-  const bool sample = !terminal && (force_sample || (uint64_t)cnt > max_points);
+  bool cached = false;  // previously_taken_points_count > 0 (TilingAlgorithms.cpp:272-275)
+  if (nc) {
+    const uint64_t prefix = akey[nstart[j]] >> nsh;
+    uint32_t lo = 0, hi = nc;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if ((ckey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
+    }
+    cached = lo < nc && (ckey[lo] >> nsh) == prefix;
+  }
+  const bool sample = !terminal && (force_sample || cached || (uint64_t)cnt > max_points);
   nmode[j] = sample ? MODE_SAMPLE : MODE_TAKE_ALL;
   if (sample) {
     if (reroot) atomicMax(&counters[CTR_ERROR], (uint32_t)SWZ_ERR_REROOT_UNSUPPORTED);
@@ -464,7 +475,7 @@ static int required_depth_host(int sampler, int node_level, double root_extent_x
   }
 }
 
-static LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_at_root, uint32_t max_depth,
+LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_at_root, uint32_t max_depth,
                            const double bmin[3], const double bmax[3], bool force_sample, bool tiler_rules) {
   LevelPlan p;
   p.level = level;
@@ -507,15 +518,9 @@ static LevelPlan make_plan(int level, int sampler, uint64_t max_points, float sp
 }
 
 // ----------------------------------------------------------------------------- one level
-struct LevelResult {
-  uint32_t remaining = 0;
-  uint32_t num_nodes = 0;
-  uint32_t md_rounds = 0;
-};
-
 // Samples every node of the level.  When okey/oidx are given the survivors are compacted into them
 // and level_out receives plan.level for the taken points; otherwise only lb.taken is produced.
-static int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                       const LevelBuffers& lb, int8_t* level_out, uint64_t* okey, uint32_t* oidx,
                       LevelResult* res) {
   const uint32_t m = as.m;
@@ -526,7 +531,8 @@ static int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, co
     SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
                        lb.counters + CTR_NUM_NODES, "lvl"));
     hipLaunchKernelGGL(node_mode_kernel, dim3(nb), dim3(256), 0, c->stream, lb.nstart, lb.nmode, lb.counters,
-                       plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0);
+                       plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0, as.akey,
+                       plan.node_shift, as.ckey, as.nc);
     SWZ_LAUNCH_CHECK(c);
   }
 
@@ -596,7 +602,7 @@ static int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, co
   return SWZ_OK;
 }
 
-static int alloc_level_buffers(swz_ctx* c, uint32_t m, LevelBuffers* lb) {
+int alloc_level_buffers(swz_ctx* c, uint32_t m, LevelBuffers* lb) {
   SWZ_TRY(c->get("lvl_flags", (size_t)m, &lb->flags));
   SWZ_TRY(c->get("lvl_nid", (size_t)m, &lb->nid));
   SWZ_TRY(c->get("lvl_nstart", (size_t)m + 1, &lb->nstart));
@@ -796,6 +802,20 @@ __global__ __launch_bounds__(256) void recon_mark_kernel(const uint32_t* __restr
   if (i < m && taken[i]) dup[aidx[i]] |= bit;
 }
 
+int fast_start_level(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint32_t concurrency, int* start_level) {
+  const uint32_t nbins = 1u << 18;
+  uint32_t* d_starts = nullptr;
+  SWZ_TRY(c->get("fast_starts", (size_t)nbins + 1, &d_starts));
+  hipLaunchKernelGGL(prefix_bounds_kernel, dim3(div_up(nbins + 1, 256)), dim3(256), 0, c->stream, d_keys_sorted, n,
+                     d_starts, nbins);
+  SWZ_LAUNCH_CHECK(c);
+  std::vector<uint32_t> starts(nbins + 1);
+  SWZ_HIP(c, hipMemcpyAsync(starts.data(), d_starts, (nbins + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  *start_level = (int)estimate_start_level_host(starts, concurrency);
+  return SWZ_OK;
+}
+
 int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
                 const swz_tile_params& p, const TileDeviceOut& out_in, swz_tile_stats* stats) {
   TileDeviceOut out = out_in;
@@ -808,16 +828,8 @@ int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], con
     return SWZ_OK;
   }
   // ---- FAST: TilingAlgorithmV3 first iteration (:1250-1360) + finalize (:1717-1784)
-  const uint32_t nbins = 1u << 18;
-  uint32_t* d_starts = nullptr;
-  SWZ_TRY(c->get("fast_starts", (size_t)nbins + 1, &d_starts));
-  hipLaunchKernelGGL(prefix_bounds_kernel, dim3(div_up(nbins + 1, 256)), dim3(256), 0, c->stream, t.keys, n, d_starts,
-                     nbins);
-  SWZ_LAUNCH_CHECK(c);
-  std::vector<uint32_t> starts(nbins + 1);
-  SWZ_HIP(c, hipMemcpyAsync(starts.data(), d_starts, (nbins + 1) * 4, hipMemcpyDeviceToHost, c->stream));
-  SWZ_HIP(c, hipStreamSynchronize(c->stream));
-  const int S = (int)estimate_start_level_host(starts, p.fast_concurrency);
+  int S = 0;
+  SWZ_TRY(fast_start_level(c, t.keys, n, p.fast_concurrency, &S));
   t.fast_start = S;
   // every point starts in the node made of its first S octants (split_indexed_points_into_subranges)
   t.next_level = S - 1;

@@ -1,0 +1,911 @@
+// swz_tiler.hip -- the multi-batch tiler (BASELINE config 5's single-GPU shape).
+//
+// The reference tiles a data set larger than internal_cache_size (executable/main.cpp:233-236, default 10 M points)
+// batch by batch on ONE TilingAlgorithm object: every node a batch reaches re-reads the points earlier batches
+// persisted under its name, re-keys them relative to the node (read_pnts_from_disk, core/tiling/TilingAlgorithms.cpp:
+// 50-109), merges them with the new points (merge_node_data_sorted, core/tiling/Node.cpp:4-22: std::merge, new
+// points first on equal keys), samples the union with AlwaysAdhereToMinSpacing (:272-275), REPLACES the node's file
+// with the taken points (BinaryPersistence.h:46-57) and hands the rest -- new and displaced old points alike -- to
+// the children.  Nodes no point of the batch reaches are not touched.
+//
+// Here the "files" are a device-resident node store: per octree level one array of (key, point id) ordered by node
+// prefix and, inside a node, in file order; positions (and attribute columns) of all points ever added live in pools
+// indexed by point id (= running index over all batches).  A batch runs the same level-synchronous loop as a single
+// batch (swz_level.hip); per level the store entries of the nodes the active set touches are pulled out, re-keyed,
+// merged in, and the level's taken points are merged back into the store.  FAST (TilingAlgorithmV3) later iterations
+// (:1362-1453, 1620-1659: per-thread chunks sorted, split at the start level, k-way merged, earlier chunk first on
+// ties) are the stable sort of the batch; finalize (:1661-1784) rebuilds the skipped levels from the store.
+//
+// Staging (BASELINE config 5): swz_tiler_stage_batch copies the NEXT batch from pinned host memory straight into
+// its final place in the pools with hipMemcpyAsync on a copy stream while the current batch is tiled.
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <vector>
+
+#include "swz_level.h"
+#include "swz_scan.h"
+
+namespace swz {
+
+static const uint32_t TILER_ATTR_BYTES[SWZ_ATTR_COUNT] = {3, 12, 2, 1, 1, 8, 1, 1, 2, 1, 1, 1};
+
+struct StoreLevel {
+  uint64_t* key[2] = {nullptr, nullptr};
+  uint32_t* gid[2] = {nullptr, nullptr};
+  size_t cap[2] = {0, 0};
+  int cur = 0;
+  uint32_t cnt = 0;
+};
+
+}  // namespace swz
+
+struct swz_tiler {
+  swz_ctx* c = nullptr;
+  double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+  swz_tile_params p{};
+  // pools by point id
+  double* pool_xyz = nullptr;
+  void* pool_attr[SWZ_ATTR_COUNT] = {nullptr};
+  uint32_t attr_mask = 0;   // attribute columns the pools hold (fixed by the first staged batch)
+  size_t pool_cap = 0;      // points
+  uint32_t total = 0;       // points tiled so far
+  uint32_t staged_total = 0;  // points copied (or being copied) into the pools
+  std::vector<uint32_t> staged_sizes;  // batches staged and not yet tiled (at most 2)
+  std::vector<hipEvent_t> staged_events;
+  hipStream_t copy_stream = nullptr;
+  swz::StoreLevel lv[22];  // index = node level + 1
+  int fast_start = -1;
+  bool finalized = false;
+  uint64_t batches = 0;
+  uint64_t rekey_inversions = 0;
+  uint64_t staged_bytes = 0;
+  double staged_wait_ms = 0.0;  // time swz_tiler_tile_staged had to WAIT for its copy (0 when fully overlapped)
+};
+
+namespace swz {
+
+// ---------------------------------------------------------------------------------------------- kernels
+__global__ __launch_bounds__(256) void tl_wgid_kernel(const uint32_t* __restrict__ perm, uint32_t n, uint32_t base,
+                                                      uint32_t* __restrict__ wgid) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) wgid[i] = base + perm[i];
+}
+
+// store entry j lies in a node the active set reaches <=> some active key has the same node prefix
+__global__ __launch_bounds__(256) void tl_touch_kernel(const uint64_t* __restrict__ skey, uint32_t cnt,
+                                                       const uint64_t* __restrict__ akey, uint32_t m, uint32_t nsh,
+                                                       uint8_t* __restrict__ touch) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= cnt) return;
+  const uint64_t prefix = skey[j] >> nsh;
+  uint32_t lo = 0, hi = m;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if ((akey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
+  }
+  touch[j] = (lo < m && (akey[lo] >> nsh) == prefix) ? 1 : 0;
+}
+struct TouchF {
+  const uint8_t* touch;
+  __device__ uint32_t operator()(uint32_t i) const { return touch[i]; }
+};
+struct SplitG {  // touched entries -> cached set, the others stay
+  const uint64_t* skey;
+  const uint32_t* sgid;
+  uint64_t* ckey;
+  uint32_t* cgid;
+  uint64_t* rkey;
+  uint32_t* rgid;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t t) const {
+    if (t) {
+      ckey[excl] = skey[i];
+      cgid[excl] = sgid[i];
+    } else {
+      rkey[i - excl] = skey[i];
+      rgid[i - excl] = sgid[i];
+    }
+  }
+};
+
+// static_cast<uint64_t>(double) the way x86-64 gcc compiles it for the reference (cvttsd2si): values in (-1, 0)
+// give 0, values <= -1 wrap to huge numbers (which std::min then turns into 2^21 - 1); formally undefined, but it is
+// what calculate_morton_index (OctreeAlgorithms.h:76-79) does for a point outside the box it is indexed against.
+__device__ __forceinline__ uint64_t cvt_u64_like_x86(double v) {
+  return v < 0.0 ? (uint64_t)(int64_t)v : (uint64_t)v;
+}
+// calculate_morton_index<21>(p, box) without clamping the position -- OctreeAlgorithms.h:64-87
+__device__ __forceinline__ uint64_t morton_in_box(double x, double y, double z, const Box& b) {
+  const double two21 = 2097152.0;
+  const double sx = two21 / (b.maxx - b.minx), sy = two21 / (b.maxy - b.miny), sz = two21 / (b.maxz - b.minz);
+  const double nx = (x - b.minx) * sx, ny = (y - b.miny) * sy, nz = (z - b.minz) * sz;
+  const uint64_t lim = (1ull << 21) - 1ull;
+  uint64_t bx = cvt_u64_like_x86(nx), by = cvt_u64_like_x86(ny), bz = cvt_u64_like_x86(nz);
+  bx = bx < lim ? bx : lim;
+  by = by < lim ? by : lim;
+  bz = bz < lim ? bz : lim;
+  return expand_bits_by_3(bz) | (expand_bits_by_3(by) << 1) | (expand_bits_by_3(bx) << 2);
+}
+
+// read_pnts_from_disk, TilingAlgorithms.cpp:80-99: idx = node.morton_index; levels node.level+1 .. 20 are levels
+// 0 .. of the index of the position inside node.bounds (bounds by descending octant by octant from the root).
+__global__ __launch_bounds__(256) void tl_rekey_kernel(uint64_t* __restrict__ ckey, const uint32_t* __restrict__ cgid,
+                                                       uint32_t nc, const double* __restrict__ pool, Box root,
+                                                       int level) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nc) return;
+  const uint64_t old = ckey[j];
+  const Box nb = bounds_from_key(old, root, level + 1);
+  const size_t g = cgid[j];
+  const uint64_t rel = morton_in_box(pool[3 * g], pool[3 * g + 1], pool[3 * g + 2], nb);
+  const uint32_t start_level = (uint32_t)(level + 1);
+  const uint64_t prefix = start_level == 0 ? 0ull : ((old >> level_shift(level)) << level_shift(level));
+  ckey[j] = prefix | (rel >> (3u * start_level));
+}
+
+// index_points<21>(root bounds, ClampToBounds) on a COPY of the positions (reconstruct_single_node :1682-1688)
+__global__ __launch_bounds__(256) void tl_reencode_kernel(const uint32_t* __restrict__ gid, uint32_t n,
+                                                          const double* __restrict__ pool, Box b,
+                                                          uint64_t* __restrict__ keys) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const size_t g = gid[j];
+  double x = pool[3 * g], y = pool[3 * g + 1], z = pool[3 * g + 2];
+  const bool inside = (x >= b.minx && x <= b.maxx && y >= b.miny && y <= b.maxy && z >= b.minz && z <= b.maxz);
+  if (!inside) {
+    x = (b.minx < x) ? x : b.minx;
+    x = (x < b.maxx) ? x : b.maxx;
+    y = (b.miny < y) ? y : b.miny;
+    y = (y < b.maxy) ? y : b.maxy;
+    z = (b.minz < z) ? z : b.minz;
+    z = (z < b.maxz) ? z : b.maxz;
+  }
+  keys[j] = morton_in_box(x, y, z, b);
+}
+
+// pairs of neighbours inside one node (same prefix >> nsh) whose keys descend
+__global__ __launch_bounds__(256) void tl_inversion_kernel(const uint64_t* __restrict__ key, uint32_t n, uint32_t nsh,
+                                                           uint32_t* __restrict__ count) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  const bool bad = j > 0 && j < n && (key[j] >> nsh) == (key[j - 1] >> nsh) && key[j] < key[j - 1];
+  const uint64_t b = __ballot(bad);
+  if (lane_id() == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+}
+
+// positions of the pulled points into the working pool (SoA), behind the batch's own points
+__global__ __launch_bounds__(256) void tl_fill_kernel(const uint32_t* __restrict__ cgid, uint32_t nc,
+                                                      const double* __restrict__ pool, double* __restrict__ X,
+                                                      double* __restrict__ Y, double* __restrict__ Z,
+                                                      uint32_t* __restrict__ wgid) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nc) return;
+  const size_t g = cgid[j];
+  X[j] = pool[3 * g];
+  Y[j] = pool[3 * g + 1];
+  Z[j] = pool[3 * g + 2];
+  wgid[j] = (uint32_t)g;
+}
+
+// std::merge(first, second, comp = key <): elements of `first` precede equal elements of `second`.
+// Keys are compared after >> sh (sh = node shift merges by node only: merge_node_data_unsorted's "new ++ cached").
+__global__ __launch_bounds__(256) void tl_merge_first_kernel(const uint64_t* __restrict__ k1,
+                                                             const uint32_t* __restrict__ v1, uint32_t n1,
+                                                             const uint64_t* __restrict__ k2, uint32_t n2, uint32_t sh,
+                                                             uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n1) return;
+  const uint64_t k = k1[i];
+  const uint64_t ks = k >> sh;
+  uint32_t lo = 0, hi = n2;  // number of second elements strictly below
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if ((k2[mid] >> sh) < ks) lo = mid + 1; else hi = mid;
+  }
+  ok[i + lo] = k;
+  ov[i + lo] = v1 ? v1[i] : i;
+}
+__global__ __launch_bounds__(256) void tl_merge_second_kernel(const uint64_t* __restrict__ k2,
+                                                              const uint32_t* __restrict__ v2, uint32_t n2,
+                                                              const uint64_t* __restrict__ k1, uint32_t n1, uint32_t sh,
+                                                              uint32_t base, uint64_t* __restrict__ ok,
+                                                              uint32_t* __restrict__ ov) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n2) return;
+  const uint64_t k = k2[j];
+  const uint64_t ks = k >> sh;
+  uint32_t lo = 0, hi = n1;  // number of first elements below or equal
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if ((k1[mid] >> sh) <= ks) lo = mid + 1; else hi = mid;
+  }
+  ok[j + lo] = k;
+  ov[j + lo] = v2 ? v2[j] : base + j;
+}
+
+struct TakenF {
+  const uint8_t* taken;
+  __device__ uint32_t operator()(uint32_t i) const { return taken[i] ? 1u : 0u; }
+};
+struct TakeG {  // the node's new file content: taken points in the order of the merged range
+  const uint64_t* mkey;
+  const uint32_t* midx;
+  const uint32_t* wgid;
+  uint64_t* tkey;
+  uint32_t* tgid;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t t) const {
+    if (!t) return;
+    tkey[excl] = mkey[i];
+    tgid[excl] = wgid[midx ? midx[i] : i];
+  }
+};
+
+struct HeadF {
+  const uint64_t* key;
+  uint32_t nsh;
+  __device__ uint32_t operator()(uint32_t i) const { return (i == 0 || (key[i] >> nsh) != (key[i - 1] >> nsh)) ? 1u : 0u; }
+};
+struct HeadG {
+  const uint64_t* key;
+  uint32_t nsh;
+  uint32_t* head_pos;
+  uint64_t* head_key;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t h) const {
+    if (!h) return;
+    head_pos[excl] = i;
+    head_key[excl] = nsh >= 63 ? 0ull : ((key[i] >> nsh) << nsh);
+  }
+};
+
+__global__ __launch_bounds__(256) void tl_fill_level_kernel(int8_t* __restrict__ out, uint32_t n, int8_t v) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------- host helpers
+static Box root_box(const swz_tiler* t) { return Box{t->bmin[0], t->bmin[1], t->bmin[2], t->bmax[0], t->bmax[1], t->bmax[2]}; }
+
+static int store_reserve(swz_ctx* c, StoreLevel& s, int which, size_t count) {
+  if (s.cap[which] >= count) return SWZ_OK;
+  if (s.key[which]) {
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    SWZ_HIP(c, hipFree(s.key[which]));
+    SWZ_HIP(c, hipFree(s.gid[which]));
+    s.key[which] = nullptr;
+    s.gid[which] = nullptr;
+    s.cap[which] = 0;
+  }
+  const size_t want = count + count / 4 + 1024;
+  hipError_t e = hipMalloc((void**)&s.key[which], want * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&s.gid[which], want * sizeof(uint32_t));
+  if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(node store): ") + hipGetErrorString(e));
+  s.cap[which] = want;
+  return SWZ_OK;
+}
+
+static void store_free(StoreLevel& s) {
+  for (int w = 0; w < 2; ++w) {
+    if (s.key[w]) (void)hipFree(s.key[w]);
+    if (s.gid[w]) (void)hipFree(s.gid[w]);
+    s.key[w] = nullptr;
+    s.gid[w] = nullptr;
+    s.cap[w] = 0;
+  }
+  s.cnt = 0;
+}
+
+// makes room for `points` points in the pools (positions and the attribute columns in use); keeps the content
+static int pool_reserve(swz_tiler* t, size_t points) {
+  swz_ctx* c = t->c;
+  if (points <= t->pool_cap) return SWZ_OK;
+  // nothing may still be writing into or reading from the old pools
+  if (t->copy_stream) SWZ_HIP(c, hipStreamSynchronize(t->copy_stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  const size_t want = std::max(points, t->pool_cap + t->pool_cap / 2);
+  const size_t used = t->staged_total;
+  double* nx = nullptr;
+  hipError_t e = hipMalloc((void**)&nx, want * 24);
+  if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(position pool): ") + hipGetErrorString(e));
+  if (used) SWZ_HIP(c, hipMemcpy(nx, t->pool_xyz, used * 24, hipMemcpyDeviceToDevice));
+  if (t->pool_xyz) SWZ_HIP(c, hipFree(t->pool_xyz));
+  t->pool_xyz = nx;
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a) {
+    if (!(t->attr_mask & (1u << a))) continue;
+    void* na = nullptr;
+    e = hipMalloc(&na, want * TILER_ATTR_BYTES[a]);
+    if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(attribute pool): ") + hipGetErrorString(e));
+    if (used && t->pool_attr[a]) SWZ_HIP(c, hipMemcpy(na, t->pool_attr[a], used * TILER_ATTR_BYTES[a], hipMemcpyDeviceToDevice));
+    if (t->pool_attr[a]) SWZ_HIP(c, hipFree(t->pool_attr[a]));
+    t->pool_attr[a] = na;
+  }
+  t->pool_cap = want;
+  return SWZ_OK;
+}
+
+static int merge_pairs(swz_ctx* c, const uint64_t* k1, const uint32_t* v1, uint32_t n1, const uint64_t* k2,
+                       const uint32_t* v2, uint32_t n2, uint32_t sh, uint32_t base2, uint64_t* ok, uint32_t* ov) {
+  if (n1) {
+    hipLaunchKernelGGL(tl_merge_first_kernel, dim3(div_up(n1, 256)), dim3(256), 0, c->stream, k1, v1, n1, k2, n2, sh, ok, ov);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  if (n2) {
+    hipLaunchKernelGGL(tl_merge_second_kernel, dim3(div_up(n2, 256)), dim3(256), 0, c->stream, k2, v2, n2, k1, n1, sh,
+                       base2, ok, ov);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  return SWZ_OK;
+}
+
+static int read_u32(swz_ctx* c, const uint32_t* d, uint32_t* h) {
+  SWZ_HIP(c, hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  return SWZ_OK;
+}
+
+// (key, gid) ascending by key when the re-keyed order is not (the reference only sorts for a lossy persistence,
+// :103-106 / :1690-1692; counted in rekey_inversions)
+static int sort_pairs_by_key(swz_ctx* c, uint64_t* key, uint32_t* gid, uint32_t n) {
+  uint64_t* kb = nullptr;
+  uint32_t* vb = nullptr;
+  SWZ_TRY(c->get("tl_sort_k", (size_t)n, &kb));
+  SWZ_TRY(c->get("tl_sort_v", (size_t)n, &vb));
+  if (radix_result_in_second()) {
+    SWZ_HIP(c, hipMemcpyAsync(kb, key, (size_t)n * 8, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_HIP(c, hipMemcpyAsync(vb, gid, (size_t)n * 4, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_TRY(radix_sort_pairs(c, kb, vb, key, gid, n, false));
+  } else {
+    SWZ_TRY(radix_sort_pairs(c, key, gid, kb, vb, n, false));
+  }
+  return SWZ_OK;
+}
+
+// One level of one batch.  `as` is the active set handed down (new points and displaced old ones), Morton sorted;
+// on return *next is the active set of the next level.
+struct BatchWork {
+  uint32_t n = 0;          // points of the batch
+  uint32_t wused = 0;      // working-pool entries in use
+  uint32_t wcap = 0;
+  double *wx = nullptr, *wy = nullptr, *wz = nullptr;
+  int8_t* wlevel = nullptr;
+  uint32_t* wgid = nullptr;
+  uint64_t* surv_key[2] = {nullptr, nullptr};
+  uint32_t* surv_idx[2] = {nullptr, nullptr};
+  int which = 0;
+};
+
+static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, ActiveSet& as, LevelResult* res,
+                       uint32_t* merged_out) {
+  swz_ctx* c = t->c;
+  StoreLevel& st = t->lv[plan.level + 1];
+  const uint32_t nsh = plan.node_shift;
+  uint32_t* counters = nullptr;
+  SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+
+  // ---- pull the files of the nodes this level's active set reaches
+  uint64_t *ckey = nullptr, *rkey = nullptr;
+  uint32_t *cgid = nullptr, *rgid = nullptr;
+  uint32_t nc = 0, nr = 0;
+  if (st.cnt) {
+    uint8_t* touch = nullptr;
+    SWZ_TRY(c->get("tl_touch", (size_t)st.cnt, &touch));
+    SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
+    SWZ_TRY(c->get("tl_cgid", (size_t)st.cnt, &cgid));
+    SWZ_TRY(c->get("tl_rkey", (size_t)st.cnt, &rkey));
+    SWZ_TRY(c->get("tl_rgid", (size_t)st.cnt, &rgid));
+    hipLaunchKernelGGL(tl_touch_kernel, dim3(div_up(st.cnt, 256)), dim3(256), 0, c->stream, st.key[st.cur], st.cnt,
+                       as.akey, as.m, nsh, touch);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(fused_scan(c, TouchF{touch}, SplitG{st.key[st.cur], st.gid[st.cur], ckey, cgid, rkey, rgid}, st.cnt,
+                       counters, "tl"));
+    SWZ_TRY(read_u32(c, counters, &nc));
+    nr = st.cnt - nc;
+  }
+  ActiveSet ms = as;
+  if (nc) {
+    hipLaunchKernelGGL(tl_rekey_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, cgid, nc, t->pool_xyz,
+                       root_box(t), plan.level);
+    SWZ_LAUNCH_CHECK(c);
+    if (!plan.terminal) {
+      SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
+      hipLaunchKernelGGL(tl_inversion_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, nc, nsh, counters + 1);
+      SWZ_LAUNCH_CHECK(c);
+      uint32_t inv = 0;
+      SWZ_TRY(read_u32(c, counters + 1, &inv));
+      if (inv) {
+        t->rekey_inversions += inv;
+        SWZ_TRY(sort_pairs_by_key(c, ckey, cgid, nc));
+      }
+    }
+    if (w.wused + nc > w.wcap) return c->fail(SWZ_ERR_INTERNAL, "working pool overflow");
+    hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, cgid, nc, t->pool_xyz,
+                       w.wx + w.wused, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
+    SWZ_LAUNCH_CHECK(c);
+    uint64_t* mkey = nullptr;
+    uint32_t* midx = nullptr;
+    SWZ_TRY(c->get("tl_mkey", (size_t)as.m + nc, &mkey));
+    SWZ_TRY(c->get("tl_midx", (size_t)as.m + nc, &midx));
+    // tile_node :421-442: terminal nodes append (new ++ cached), the others std::merge by key
+    SWZ_TRY(merge_pairs(c, as.akey, as.aidx, as.m, ckey, nullptr, nc, plan.terminal ? nsh : 0u, w.wused, mkey, midx));
+    w.wused += nc;
+    ms.akey = mkey;
+    ms.aidx = midx;
+    ms.m = as.m + nc;
+    ms.ckey = ckey;
+    ms.nc = nc;
+  }
+  *merged_out = ms.m;
+
+  // ---- sample / take all, compact the survivors
+  SWZ_TRY(c->get(w.which ? "tl_surv_key_1" : "tl_surv_key_0", (size_t)ms.m, &w.surv_key[w.which]));
+  SWZ_TRY(c->get(w.which ? "tl_surv_idx_1" : "tl_surv_idx_0", (size_t)ms.m, &w.surv_idx[w.which]));
+  LevelBuffers lb;
+  SWZ_TRY(alloc_level_buffers(c, ms.m, &lb));
+  const SortedPoints sp{w.wx, w.wy, w.wz};
+  SWZ_TRY(level_step(c, plan, ms, sp, lb, w.wlevel, w.surv_key[w.which], w.surv_idx[w.which], res));
+
+  // ---- the nodes' new files, merged back between the files of the untouched nodes
+  const uint32_t nt = ms.m - res->remaining;
+  uint64_t* tkey = nullptr;
+  uint32_t* tgid = nullptr;
+  SWZ_TRY(c->get("tl_tkey", (size_t)nt, &tkey));
+  SWZ_TRY(c->get("tl_tgid", (size_t)nt, &tgid));
+  SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{ms.akey, ms.aidx, w.wgid, tkey, tgid}, ms.m, counters + 2, "tl"));
+  const int dst = st.cur ^ 1;
+  SWZ_TRY(store_reserve(c, st, dst, (size_t)nr + nt));
+  SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey, tgid, nt, nsh, 0u, st.key[dst], st.gid[dst]));
+  st.cur = dst;
+  st.cnt = nr + nt;
+
+  as = ActiveSet{w.surv_key[w.which], w.surv_idx[w.which], res->remaining};
+  w.which ^= 1;
+  return SWZ_OK;
+}
+
+static void zero_stats(swz_tile_stats* s) {
+  if (!s) return;
+  std::memset(s, 0, sizeof(*s));
+  s->max_level = -1;
+  s->fast_start_levels = -1;
+}
+
+static uint64_t stored_total(const swz_tiler* t) {
+  uint64_t s = 0;
+  for (int l = 0; l < 22; ++l) s += t->lv[l].cnt;
+  return s;
+}
+
+// d_xyz: the batch inside the position pool (already there) or anywhere else on the device (copied in)
+static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_stats* stats) {
+  swz_ctx* c = t->c;
+  zero_stats(stats);
+  if (t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
+  if (n == 0) {
+    ++t->batches;
+    return SWZ_OK;
+  }
+  // parallel::scatter throws for a batch with fewer points than indexing threads (util/threading/Parallel.h:181-186)
+  if (t->p.strategy == SWZ_FAST && n < t->p.fast_concurrency)
+    return c->fail(SWZ_ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points");
+  const uint32_t base = t->total;
+  double* slot = t->pool_xyz + (size_t)base * 3;
+  const bool in_pool = d_xyz == slot;
+
+  // ---- index + sort + positions into Morton order (K1, K2, gather), exactly like a single batch
+  uint64_t *keys = nullptr, *keys_b = nullptr;
+  uint32_t *perm = nullptr, *vals_b = nullptr;
+  SWZ_TRY(c->get("tl_keys", (size_t)n, &keys));
+  SWZ_TRY(c->get("tl_perm", (size_t)n, &perm));
+  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
+  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vals_b));
+  if (radix_result_in_second()) {
+    SWZ_TRY(encode_device(c, d_xyz, n, t->bmin, t->bmax, keys_b));
+    SWZ_TRY(radix_sort_pairs(c, keys_b, vals_b, keys, perm, n, true));
+  } else {
+    SWZ_TRY(encode_device(c, d_xyz, n, t->bmin, t->bmax, keys));
+    SWZ_TRY(radix_sort_pairs(c, keys, perm, keys_b, vals_b, n, true));
+  }
+  if (!in_pool)  // clamped positions (index_point clamps in place, OctreeAlgorithms.h:167-169) into the pool
+    SWZ_HIP(c, hipMemcpyAsync(slot, d_xyz, (size_t)n * 24, hipMemcpyDeviceToDevice, c->stream));
+
+  BatchWork w;
+  w.n = n;
+  const uint64_t wcap64 = (uint64_t)n + stored_total(t);
+  if (wcap64 > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "batch + stored points exceed 2^32-65536");
+  w.wcap = (uint32_t)wcap64;
+  SWZ_TRY(c->get("tl_wx", (size_t)w.wcap, &w.wx));
+  SWZ_TRY(c->get("tl_wy", (size_t)w.wcap, &w.wy));
+  SWZ_TRY(c->get("tl_wz", (size_t)w.wcap, &w.wz));
+  SWZ_TRY(c->get("tl_wlevel", (size_t)w.wcap, &w.wlevel));
+  SWZ_TRY(c->get("tl_wgid", (size_t)w.wcap, &w.wgid));
+  SWZ_TRY(gather_positions(c, d_xyz, perm, n, w.wx, w.wy, w.wz));
+  hipLaunchKernelGGL(tl_wgid_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, perm, n, base, w.wgid);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_HIP(c, hipMemsetAsync(w.wlevel, 0x80, (size_t)w.wcap, c->stream));
+  w.wused = n;
+
+  int first_level = -1;
+  if (t->p.strategy == SWZ_FAST) {
+    if (t->fast_start < 0) SWZ_TRY(fast_start_level(c, keys, n, t->p.fast_concurrency, &t->fast_start));
+    first_level = t->fast_start - 1;
+  }
+  ActiveSet as{keys, nullptr, n};
+  uint64_t visited = 0, nodes = 0;
+  uint32_t rounds = 0, nlevels = 0;
+  int max_level = -1;
+  for (int level = first_level; as.m > 0; ++level) {
+    if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
+    const LevelPlan plan = make_plan(level, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
+                                     t->bmin, t->bmax, false, true);
+    LevelResult r;
+    uint32_t merged = 0;
+    SWZ_TRY(tiler_level(t, w, plan, as, &r, &merged));
+    visited += merged;
+    nodes += r.num_nodes;
+    rounds += r.md_rounds;
+    max_level = level;
+    ++nlevels;
+  }
+  t->total += n;
+  if (t->staged_total < t->total) t->staged_total = t->total;
+  ++t->batches;
+  if (stats) {
+    stats->num_nodes = nodes;
+    stats->points_visited = visited;
+    stats->max_level = max_level;
+    stats->fast_start_levels = t->fast_start;
+    stats->num_levels = nlevels;
+    stats->min_distance_rounds = rounds;
+  }
+  return SWZ_OK;
+}
+
+// TilingAlgorithmV3::finalize -> reconstruct_left_out_nodes (:1717-1784): every ancestor of a start node samples the
+// points its children hold (children in octant order = the store order of the level below), re-indexed against the
+// root bounds, with AlwaysAdhereToMinSpacing (reconstruct_single_node :1661-1715).
+static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats) {
+  swz_ctx* c = t->c;
+  zero_stats(stats);
+  if (t->finalized) return SWZ_OK;
+  if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_finalize: staged batches have not been tiled");
+  t->finalized = true;
+  if (t->p.strategy != SWZ_FAST || t->fast_start <= 0) return SWZ_OK;
+  const int S = t->fast_start;
+  uint64_t nodes = 0;
+  uint32_t rounds = 0;
+  uint32_t* counters = nullptr;
+  SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+  for (int lv = S - 1; lv >= 0; --lv) {  // children at node level lv, parents at lv - 1
+    StoreLevel& src = t->lv[lv + 1];
+    StoreLevel& dst = t->lv[lv];
+    const uint32_t m = src.cnt;
+    if (m == 0) continue;
+    uint64_t* keys = nullptr;
+    uint32_t *gid = nullptr, *wgid = nullptr;
+    double *wx = nullptr, *wy = nullptr, *wz = nullptr;
+    SWZ_TRY(c->get("tl_keys", (size_t)m, &keys));
+    SWZ_TRY(c->get("tl_perm", (size_t)m, &gid));
+    SWZ_TRY(c->get("tl_wx", (size_t)m, &wx));
+    SWZ_TRY(c->get("tl_wy", (size_t)m, &wy));
+    SWZ_TRY(c->get("tl_wz", (size_t)m, &wz));
+    SWZ_TRY(c->get("tl_wgid", (size_t)m, &wgid));
+    SWZ_HIP(c, hipMemcpyAsync(gid, src.gid[src.cur], (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(tl_reencode_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, gid, m, t->pool_xyz, root_box(t), keys);
+    SWZ_LAUNCH_CHECK(c);
+    // inside one PARENT the appended children must ascend (reconstruct_single_node does not sort a lossless store)
+    const uint32_t psh = lv == 0 ? 63u : level_shift(lv - 1);
+    SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
+    hipLaunchKernelGGL(tl_inversion_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, keys, m, psh, counters + 1);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t inv = 0;
+    SWZ_TRY(read_u32(c, counters + 1, &inv));
+    if (inv) {
+      t->rekey_inversions += inv;
+      SWZ_TRY(sort_pairs_by_key(c, keys, gid, m));
+    }
+    hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, gid, m, t->pool_xyz, wx, wy, wz, wgid);
+    SWZ_LAUNCH_CHECK(c);
+    const LevelPlan plan = make_plan(lv - 1, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
+                                     t->bmin, t->bmax, true, false);
+    LevelBuffers lb;
+    SWZ_TRY(alloc_level_buffers(c, m, &lb));
+    ActiveSet as{keys, nullptr, m};
+    LevelResult r;
+    SWZ_TRY(level_step(c, plan, as, SortedPoints{wx, wy, wz}, lb, nullptr, nullptr, nullptr, &r));
+    // count the taken points, then write them as the parents' files
+    uint64_t* tkey = nullptr;
+    uint32_t* tgid = nullptr;
+    SWZ_TRY(c->get("tl_tkey", (size_t)m, &tkey));
+    SWZ_TRY(c->get("tl_tgid", (size_t)m, &tgid));
+    SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{keys, nullptr, wgid, tkey, tgid}, m, counters + 2, "tl"));
+    uint32_t nt = 0;
+    SWZ_TRY(read_u32(c, counters + 2, &nt));
+    const int w = dst.cur ^ 1;
+    SWZ_TRY(store_reserve(c, dst, w, nt));
+    SWZ_HIP(c, hipMemcpyAsync(dst.key[w], tkey, (size_t)nt * 8, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_HIP(c, hipMemcpyAsync(dst.gid[w], tgid, (size_t)nt * 4, hipMemcpyDeviceToDevice, c->stream));
+    dst.cur = w;
+    dst.cnt = nt;
+    nodes += r.num_nodes;
+    rounds += r.md_rounds;
+  }
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  if (stats) {
+    stats->num_nodes = nodes;
+    stats->fast_start_levels = S;
+    stats->min_distance_rounds = rounds;
+  }
+  return SWZ_OK;
+}
+
+// node table of the store: per level the runs of equal node prefix
+static int tiler_node_table(swz_tiler* t, std::vector<int8_t>* nl, std::vector<uint64_t>* nk, std::vector<uint64_t>* no,
+                            std::vector<uint64_t>* nc, uint64_t* num_nodes) {
+  swz_ctx* c = t->c;
+  uint64_t offset = 0, nn = 0;
+  uint32_t* counters = nullptr;
+  SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+  for (int l = 0; l < 22; ++l) {
+    const StoreLevel& s = t->lv[l];
+    if (!s.cnt) continue;
+    const int level = l - 1;
+    const uint32_t nsh = level < 0 ? 63u : level_shift(level);
+    uint32_t* hp = nullptr;
+    uint64_t* hk = nullptr;
+    SWZ_TRY(c->get("tl_head_pos", (size_t)s.cnt, &hp));
+    SWZ_TRY(c->get("tl_head_key", (size_t)s.cnt, &hk));
+    SWZ_TRY(fused_scan(c, HeadF{s.key[s.cur], nsh}, HeadG{s.key[s.cur], nsh, hp, hk}, s.cnt, counters + 3, "tl"));
+    uint32_t heads = 0;
+    SWZ_TRY(read_u32(c, counters + 3, &heads));
+    if (nl) {
+      std::vector<uint32_t> pos(heads);
+      std::vector<uint64_t> key(heads);
+      SWZ_HIP(c, hipMemcpyAsync(pos.data(), hp, (size_t)heads * 4, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipMemcpyAsync(key.data(), hk, (size_t)heads * 8, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      for (uint32_t k = 0; k < heads; ++k) {
+        nl->push_back((int8_t)level);
+        nk->push_back(key[k]);
+        no->push_back(offset + pos[k]);
+        nc->push_back((k + 1 < heads ? pos[k + 1] : s.cnt) - pos[k]);
+      }
+    }
+    nn += heads;
+    offset += s.cnt;
+  }
+  *num_nodes = nn;
+  return SWZ_OK;
+}
+
+}  // namespace swz
+
+using namespace swz;
+
+// ================================================================================================== C ABI
+extern "C" {
+
+int swz_tiler_create(swz_ctx* c, const double bmin[3], const double bmax[3], const swz_tile_params* params,
+                     uint64_t capacity_hint, swz_tiler** out) {
+  if (!c || !out) return SWZ_ERR_BAD_ARG;
+  *out = nullptr;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (!bmin || !bmax || !params) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_create: NULL argument");
+  for (int a = 0; a < 3; ++a)
+    if (!(bmax[a] > bmin[a])) return c->fail(SWZ_ERR_BAD_ARG, "bounds must have positive extent on every axis");
+  if (params->sampler < SWZ_RANDOM_GRID || params->sampler > SWZ_JITTERED) return c->fail(SWZ_ERR_BAD_ARG, "unknown sampler");
+  if (params->strategy != SWZ_ACCURATE && params->strategy != SWZ_FAST) return c->fail(SWZ_ERR_BAD_ARG, "unknown strategy");
+  if (!(params->spacing_at_root > 0.f)) return c->fail(SWZ_ERR_BAD_ARG, "spacing_at_root must be > 0");
+  if (params->strategy == SWZ_FAST && params->fast_concurrency == 0)
+    return c->fail(SWZ_ERR_BAD_ARG, "FAST needs fast_concurrency >= 1");
+  if (capacity_hint > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
+  swz_tiler* t = new swz_tiler();
+  t->c = c;
+  for (int a = 0; a < 3; ++a) {
+    t->bmin[a] = bmin[a];
+    t->bmax[a] = bmax[a];
+  }
+  t->p = *params;
+  hipError_t e = hipStreamCreateWithFlags(&t->copy_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete t;
+    return c->fail(SWZ_ERR_HIP, std::string("hipStreamCreate(copy stream): ") + hipGetErrorString(e));
+  }
+  if (capacity_hint) {
+    const int st = pool_reserve(t, (size_t)capacity_hint);
+    if (st != SWZ_OK) {
+      (void)hipStreamDestroy(t->copy_stream);
+      delete t;
+      return st;
+    }
+  }
+  *out = t;
+  return SWZ_OK;
+}
+
+int swz_tiler_destroy(swz_tiler* t) {
+  if (!t) return SWZ_OK;
+  (void)hipSetDevice(t->c->device);
+  if (t->copy_stream) (void)hipStreamSynchronize(t->copy_stream);
+  (void)hipStreamSynchronize(t->c->stream);
+  for (hipEvent_t e : t->staged_events) (void)hipEventDestroy(e);
+  for (int l = 0; l < 22; ++l) store_free(t->lv[l]);
+  if (t->pool_xyz) (void)hipFree(t->pool_xyz);
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (t->pool_attr[a]) (void)hipFree(t->pool_attr[a]);
+  if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
+  delete t;
+  return SWZ_OK;
+}
+
+int swz_tiler_add_batch_device(swz_tiler* t, double* d_xyz, uint64_t n, swz_tile_stats* stats) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_add_batch_device: staged batches are pending");
+  if (n && !d_xyz) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_add_batch_device: NULL buffer");
+  if ((uint64_t)t->total + n > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
+  if (t->attr_mask) return c->fail(SWZ_ERR_BAD_ARG, "this tiler carries attribute columns: use swz_tiler_stage_batch");
+  SWZ_TRY(pool_reserve(t, (size_t)t->total + n));
+  const int st = tiler_add_batch(t, d_xyz, (uint32_t)n, stats);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  c->prof_collect();
+  if (st != SWZ_OK) return st;
+  SWZ_HIP(c, e);
+  return SWZ_OK;
+}
+
+int swz_tiler_stage_batch(swz_tiler* t, const double* xyz_host, uint64_t n, const swz_attribute_columns* attrs_host) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
+  if (t->staged_sizes.size() >= 2) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_stage_batch: two batches are already staged");
+  if (n && !xyz_host) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_stage_batch: NULL buffer");
+  if ((uint64_t)t->staged_total + n > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
+  uint32_t mask = 0;
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (attrs_host && attrs_host->column[a]) mask |= 1u << a;
+  if (t->staged_total == 0 && t->batches == 0) {
+    t->attr_mask = mask;
+    if (mask && t->pool_cap) {  // the pools were presized before the columns were known
+      const size_t cap = t->pool_cap;
+      t->pool_cap = 0;
+      if (t->pool_xyz) SWZ_HIP(c, hipFree(t->pool_xyz));
+      t->pool_xyz = nullptr;
+      SWZ_TRY(pool_reserve(t, cap));
+    }
+  } else if (mask != t->attr_mask) {
+    return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_stage_batch: every batch must carry the same attribute columns");
+  }
+  SWZ_TRY(pool_reserve(t, (size_t)t->staged_total + n));
+  const size_t at = t->staged_total;
+  if (n) {
+    SWZ_HIP(c, hipMemcpyAsync(t->pool_xyz + at * 3, xyz_host, (size_t)n * 24, hipMemcpyHostToDevice, t->copy_stream));
+    t->staged_bytes += n * 24;
+    for (int a = 0; a < SWZ_ATTR_COUNT; ++a) {
+      if (!(mask & (1u << a))) continue;
+      const size_t rb = TILER_ATTR_BYTES[a];
+      SWZ_HIP(c, hipMemcpyAsync((char*)t->pool_attr[a] + at * rb, attrs_host->column[a], (size_t)n * rb,
+                                hipMemcpyHostToDevice, t->copy_stream));
+      t->staged_bytes += n * rb;
+    }
+  }
+  hipEvent_t ev = nullptr;
+  SWZ_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  SWZ_HIP(c, hipEventRecord(ev, t->copy_stream));
+  t->staged_events.push_back(ev);
+  t->staged_sizes.push_back((uint32_t)n);
+  t->staged_total += (uint32_t)n;
+  return SWZ_OK;
+}
+
+int swz_tiler_tile_staged(swz_tiler* t, swz_tile_stats* stats) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_tile_staged: nothing is staged");
+  const uint32_t n = t->staged_sizes.front();
+  hipEvent_t ev = t->staged_events.front();
+  t->staged_sizes.erase(t->staged_sizes.begin());
+  t->staged_events.erase(t->staged_events.begin());
+  // this batch needs its copy complete; the copy of the NEXT staged batch keeps running beside the kernels
+  const auto t0 = std::chrono::steady_clock::now();
+  SWZ_HIP(c, hipEventSynchronize(ev));
+  t->staged_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  const int st = tiler_add_batch(t, t->pool_xyz + (size_t)t->total * 3, n, stats);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  (void)hipEventDestroy(ev);
+  c->prof_collect();
+  if (st != SWZ_OK) return st;
+  SWZ_HIP(c, e);
+  return SWZ_OK;
+}
+
+int swz_tiler_add_batch(swz_tiler* t, const double* xyz_host, uint64_t n, const swz_attribute_columns* attrs_host,
+                        swz_tile_stats* stats) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  if (!t->staged_sizes.empty()) return t->c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_add_batch: staged batches are pending");
+  SWZ_TRY(swz_tiler_stage_batch(t, xyz_host, n, attrs_host));
+  return swz_tiler_tile_staged(t, stats);
+}
+
+int swz_tiler_finalize(swz_tiler* t, swz_tile_stats* stats) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(t->c, hipSetDevice(t->c->device));
+  const int st = tiler_finalize(t, stats);
+  t->c->prof_collect();
+  return st;
+}
+
+int swz_tiler_get_info(swz_tiler* t, swz_tiler_info* info) {
+  if (!t || !info) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(t->c, hipSetDevice(t->c->device));
+  std::memset(info, 0, sizeof(*info));
+  info->num_points = t->total;
+  info->num_stored = stored_total(t);
+  info->num_batches = t->batches;
+  info->rekey_inversions = t->rekey_inversions;
+  info->fast_start_levels = t->fast_start;
+  info->staged_bytes = t->staged_bytes;
+  info->staged_wait_ms = t->staged_wait_ms;
+  uint64_t nn = 0;
+  SWZ_TRY(tiler_node_table(t, nullptr, nullptr, nullptr, nullptr, &nn));
+  info->num_nodes = nn;
+  return SWZ_OK;
+}
+
+int swz_tiler_node_table(swz_tiler* t, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
+                         uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out) {
+  if (!t || !num_nodes_out) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  std::vector<int8_t> nl;
+  std::vector<uint64_t> nk, no, nc;
+  uint64_t nn = 0;
+  SWZ_TRY(tiler_node_table(t, &nl, &nk, &no, &nc, &nn));
+  *num_nodes_out = nn;
+  if (nn > max_nodes) return c->fail(SWZ_ERR_BAD_ARG, "max_nodes too small");
+  if (!node_level_out || !node_key_out || !node_offset_out || !node_count_out)
+    return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_node_table: NULL buffer");
+  std::memcpy(node_level_out, nl.data(), nn);
+  std::memcpy(node_key_out, nk.data(), nn * 8);
+  std::memcpy(node_offset_out, no.data(), nn * 8);
+  std::memcpy(node_count_out, nc.data(), nn * 8);
+  return SWZ_OK;
+}
+
+int swz_tiler_export_device(swz_tiler* t, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  size_t off = 0;
+  for (int l = 0; l < 22; ++l) {
+    const StoreLevel& s = t->lv[l];
+    if (!s.cnt) continue;
+    if (d_keys_out) SWZ_HIP(c, hipMemcpyAsync(d_keys_out + off, s.key[s.cur], (size_t)s.cnt * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (d_ids_out) SWZ_HIP(c, hipMemcpyAsync(d_ids_out + off, s.gid[s.cur], (size_t)s.cnt * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (d_level_out) {
+      hipLaunchKernelGGL(tl_fill_level_kernel, dim3(div_up(s.cnt, 256)), dim3(256), 0, c->stream, d_level_out + off, s.cnt,
+                         (int8_t)(l - 1));
+      SWZ_LAUNCH_CHECK(c);
+    }
+    off += s.cnt;
+  }
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  return SWZ_OK;
+}
+
+int swz_tiler_pools_device(swz_tiler* t, const double** d_xyz_out, swz_attribute_columns* d_attrs_out) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  if (d_xyz_out) *d_xyz_out = t->pool_xyz;
+  if (d_attrs_out)
+    for (int a = 0; a < SWZ_ATTR_COUNT; ++a) d_attrs_out->column[a] = (t->attr_mask & (1u << a)) ? t->pool_attr[a] : nullptr;
+  return SWZ_OK;
+}
+
+int swz_host_alloc_pinned(uint64_t bytes, void** out) {
+  if (!out) return SWZ_ERR_BAD_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? SWZ_OK : SWZ_ERR_HIP;
+}
+int swz_host_free_pinned(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? SWZ_OK : SWZ_ERR_HIP; }
+
+}  // extern "C"

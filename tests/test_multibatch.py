@@ -1,0 +1,185 @@
+"""Multi-batch tiling: swz_tiler fed k batches must produce the node files the
+multi-batch oracle (oracle/oracle.cpp MBTiler: read_pnts_from_disk, merge_node_data_sorted, the behaviour switch on
+the cached count, FAST later iterations + finalize) produces: same nodes, same point ids, same order in every file."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+ODD = ([-512.25, 1000.5, -3.125], [-512.25 + 777.7, 1000.5 + 777.7, -3.125 + 777.7])
+SAMPLERS = [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED]
+
+
+def _oracle_files(bounds, xyz, k, sampler, max_points, spacing, strategy, concurrency, max_depth=100):
+    t = O.Tiler(bounds[0], bounds[1], sampler, max_points, spacing, max_depth=max_depth, strategy=strategy,
+                fast_concurrency=concurrency)
+    for part in np.array_split(xyz, k):
+        st = t.add_batch(part)
+        assert st == 0, st
+    assert t.finalize() == 0
+    ex = t.export()
+    c = t.counts()
+    t.close()
+    return ex, c
+
+
+def _points(rng, n, bounds, clustered):
+    lo, hi = np.array(bounds[0]), np.array(bounds[1])
+    if not clustered:
+        return lo + rng.random((n, 3)) * (hi - lo)
+    k = n // 3
+    a = np.column_stack([rng.random(k), rng.random(k), 0.3 + 0.002 * rng.standard_normal(k)])
+    b = 0.6 + 0.03 * rng.standard_normal((k, 3))
+    base = rng.random((max((n - 2 * k) // 6, 1), 3))
+    d = base[rng.integers(0, base.shape[0], n - 2 * k)]  # exact duplicates: equal keys across batches
+    u = np.clip(np.vstack([a, b, d]), 0.0, 1.0)
+    u = u[rng.permutation(n)]
+    return lo + u * (hi - lo)
+
+
+# --------------------------------------------------------------------------------------------------- CPU
+@pytest.mark.parametrize("sampler", SAMPLERS)
+@pytest.mark.parametrize("strategy", [O.ACCURATE, O.FAST])
+def test_oracle_one_batch_equals_single_batch_tiler(sampler, strategy):
+    """k = 1 must reproduce orc_tile (the single-batch restatement pinned in round 1)."""
+    rng = np.random.default_rng(5)
+    n = 40000
+    xyz = _points(rng, n, ODD, False)
+    sp = O.spacing_from_diagonal(*ODD, 32)
+    one = O.tile(xyz, *ODD, sampler, 64, sp, strategy=strategy, fast_concurrency=2)
+    assert one["status"] == 0
+    ex, c = _oracle_files(ODD, xyz, 1, sampler, 64, sp, strategy, 2)
+    expect = {}
+    for i in range(n):
+        lv = int(one["level"][i])
+        masks = [lv] + [b - 1 for b in range(22) if (int(one["dup"][i]) >> b) & 1]
+        for l in masks:
+            sh = (20 - l) * 3 if l >= 0 else 63
+            key = ((int(one["keys"][i]) >> sh) << sh) if l >= 0 else 0
+            expect.setdefault((l, key), []).append(int(one["perm"][i]))
+    got = {(int(ex["level"][j]), int(ex["key"][j])): list(ex["ids"][int(ex["offset"][j]):int(ex["offset"][j] + ex["count"][j])])
+           for j in range(len(ex["level"]))}
+    assert got == expect
+
+
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_oracle_multibatch_invariants(sampler):
+    """The invariants of the reference's (disabled) integration test, test/TestTiler.cpp:113-161: every point stored
+    exactly once (ACCURATE), inside its node; a node that was sampled before never takes all."""
+    rng = np.random.default_rng(11)
+    n = 30000
+    xyz = _points(rng, n, UNIT, True)
+    sp = O.spacing_from_diagonal(*UNIT, 32)
+    ex, c = _oracle_files(UNIT, xyz, 4, sampler, 200, sp, O.ACCURATE, 2)
+    assert c["num_stored"] == n and np.array_equal(np.sort(ex["ids"]), np.arange(n, dtype=np.uint32))
+    keys, clamped = O.index_points(xyz, *UNIT)
+    for j in range(len(ex["level"])):
+        lv = int(ex["level"][j])
+        if lv < 0:
+            continue
+        ids = ex["ids"][int(ex["offset"][j]):int(ex["offset"][j] + ex["count"][j])]
+        sh = (20 - lv) * 3
+        assert np.all((keys[ids] >> np.uint64(sh)) == (ex["key"][j] >> np.uint64(sh)))
+
+
+# --------------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def ctx():
+    import schwarzwald_amd as swz
+    c = swz.Context(0)
+    yield c
+    c.close()
+
+
+def _gpu_files(ctx, bounds, xyz, k, sampler, max_points, spacing, strategy, concurrency, staged, max_depth=100):
+    import schwarzwald_amd as swz
+    import torch
+    params = swz.TileParams(sampler=sampler, max_points_per_node=max_points, spacing_at_root=spacing, max_depth=max_depth,
+                            strategy=strategy, fast_concurrency=concurrency)
+    visited = 0
+    with swz.Tiler(ctx, bounds[0], bounds[1], params) as t:
+        parts = np.array_split(xyz, k)
+        if staged:
+            pinned = []
+            for p in parts:
+                a = swz.pinned_empty(p.shape, np.float64)
+                a[...] = p
+                pinned.append(a)
+            t.stage_batch(pinned[0])
+            for i in range(k):
+                if i + 1 < k:
+                    t.stage_batch(pinned[i + 1])
+                visited += t.tile_staged()["points_visited"]
+        else:
+            for p in parts:
+                d = torch.from_numpy(np.ascontiguousarray(p)).cuda()
+                torch.cuda.synchronize()
+                visited += t.add_batch_device(d.data_ptr(), p.shape[0])["points_visited"]
+        t.finalize()
+        info = t.info()
+        table = t.node_table()
+        ns = int(info["num_stored"])
+        d_keys = torch.empty(max(ns, 1), dtype=torch.int64, device="cuda")
+        d_ids = torch.empty(max(ns, 1), dtype=torch.int32, device="cuda")
+        d_lvl = torch.empty(max(ns, 1), dtype=torch.int8, device="cuda")
+        t.export_device(d_keys.data_ptr(), d_ids.data_ptr(), d_lvl.data_ptr())
+        ids = d_ids.cpu().numpy().view(np.uint32)[:ns]
+        lvl = d_lvl.cpu().numpy()[:ns]
+    return dict(table=table, ids=ids, level=lvl, info=info, visited=visited)
+
+
+def _compare(g, ex, c):
+    tb = g["table"]
+    assert len(tb["level"]) == len(ex["level"]) == c["num_nodes"]
+    assert np.array_equal(tb["level"], ex["level"])
+    assert np.array_equal(tb["key"], ex["key"])
+    assert np.array_equal(tb["offset"], ex["offset"])
+    assert np.array_equal(tb["count"], ex["count"])
+    assert np.array_equal(g["ids"], ex["ids"])
+    # the exported per-entry level agrees with the table
+    assert np.array_equal(g["level"], np.repeat(ex["level"], ex["count"].astype(np.int64)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", SAMPLERS)
+@pytest.mark.parametrize("strategy", [O.ACCURATE, O.FAST])
+@pytest.mark.parametrize("k", [1, 2, 5])
+def test_gpu_multibatch_matches_oracle(ctx, sampler, strategy, k):
+    rng = np.random.default_rng(100 * sampler + 10 * strategy + k)
+    n = 120000
+    bounds = ODD if (sampler + k) % 2 else UNIT
+    xyz = _points(rng, n, bounds, clustered=(k == 5))
+    sp = O.spacing_from_diagonal(*bounds, 32)
+    ex, c = _oracle_files(bounds, xyz, k, sampler, 300, sp, strategy, 2)
+    g = _gpu_files(ctx, bounds, xyz, k, sampler, 300, sp, strategy, 2, staged=(k == 2))
+    assert g["info"]["rekey_inversions"] == 0 and c["unsorted_cached_nodes"] == 0
+    _compare(g, ex, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_gpu_multibatch_d250_large_nodes(ctx, sampler):
+    """BASELINE's spacing (diagonal / 250) and real node sizes: 5 batches of 200 k points, max 20 000 per node."""
+    rng = np.random.default_rng(7 + sampler)
+    n = 1000000
+    xyz = _points(rng, n, UNIT, clustered=False)
+    sp = O.spacing_from_diagonal(*UNIT, 250)
+    ex, c = _oracle_files(UNIT, xyz, 5, sampler, 20000, sp, O.ACCURATE, 8)
+    g = _gpu_files(ctx, UNIT, xyz, 5, sampler, 20000, sp, O.ACCURATE, 8, staged=True)
+    _compare(g, ex, c)
+    assert g["info"]["num_points"] == n and g["info"]["num_batches"] == 5
+
+
+@pytest.mark.gpu
+def test_gpu_multibatch_terminal_nodes(ctx):
+    """max_depth = 2 makes level 2 terminal: its nodes append new ++ cached without sampling
+    (tile_node :421-442, merge_node_data_unsorted)."""
+    rng = np.random.default_rng(3)
+    xyz = _points(rng, 60000, UNIT, clustered=True)
+    sp = O.spacing_from_diagonal(*UNIT, 32)
+    for sampler in (O.RANDOM_GRID, O.MIN_DISTANCE):
+        ex, c = _oracle_files(UNIT, xyz, 3, sampler, 100, sp, O.ACCURATE, 2, max_depth=2)
+        g = _gpu_files(ctx, UNIT, xyz, 3, sampler, 100, sp, O.ACCURATE, 2, staged=False, max_depth=2)
+        _compare(g, ex, c)
+        assert int(ex["level"].max()) == 2
