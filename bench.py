@@ -49,7 +49,33 @@ def parse_args():
     ap.add_argument("--payload", default="", help="comma separated attribute columns (e.g. rgb,intensity): after the "
                     "timed region also build the node lists and gather the node payload on the device; reported "
                     "separately under \"payload\", never part of `value`")
+    ap.add_argument("--batches", type=int, default=1, help="tile the points in this many batches through the multi-batch "
+                    "tiler (swz_tiler_*: cached-point re-read + merge like the reference with internal_cache_size < N); "
+                    "a step is then the whole data set, batch after batch, into a fresh tiler")
+    ap.add_argument("--staged", action="store_true", help="with --batches: additionally time the batches coming from "
+                    "PINNED HOST memory through swz_tiler_stage_batch / swz_tiler_tile_staged (hipMemcpyAsync of batch "
+                    "k+1 under the kernels of batch k; attribute columns of --payload travel along); reported under "
+                    "\"staged\" (PCIe-inclusive, never `value`)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as CHILD processes (one per GPU, RCCL) before this
+    process touches a GPU, relay their output, exit with their code."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()  # does not initialise the GPU
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
 
 
 def algorithmic_bytes_per_point(sampler, visit_factor):
@@ -128,8 +154,59 @@ def payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n):
     return res
 
 
+def multibatch_leg(args, ctx, swz, torch, dev, xyz, n, bmin, bmax, params):
+    """--batches k: the same points through the multi-batch tiler, device resident (the timed `value`) and, with
+    --staged, from pinned host memory with the copy of batch i+1 under the kernels of batch i."""
+    k = args.batches
+    bounds = [(i * n) // k for i in range(k + 1)]
+    names = [a for a in args.payload.split(",") if a]
+
+    def run_device():
+        stats = []
+        with swz.Tiler(ctx, bmin, bmax, params, capacity_hint=n) as t:
+            for i in range(k):
+                lo, hi = bounds[i], bounds[i + 1]
+                stats.append(t.add_batch_device(xyz[lo:hi].data_ptr(), hi - lo))
+            t.finalize()
+            info = t.info()
+        return stats, info
+
+    out = {"run_device": run_device}
+    if args.staged:
+        host = swz.pinned_empty((n, 3), np.float64)
+        torch.from_numpy(host).copy_(xyz)  # D2H once, outside every timed region
+        cols = {}
+        rng = np.random.default_rng(1)
+        for a in names:
+            idx, dt, width = swz.ATTRIBUTES[a]
+            arr = swz.pinned_empty((n, width) if width > 1 else (n,), dt)
+            arr[...] = rng.integers(0, 200, arr.shape).astype(dt)
+            cols[a] = arr
+
+        def run_staged():
+            with swz.Tiler(ctx, bmin, bmax, params, capacity_hint=n) as t:
+                def stage(i):
+                    lo, hi = bounds[i], bounds[i + 1]
+                    t.stage_batch(host[lo:hi], {a: c[lo:hi] for a, c in cols.items()})
+                stage(0)
+                for i in range(k):
+                    if i + 1 < k:
+                        stage(i + 1)
+                    t.tile_staged()
+                t.finalize()
+                return t.info()
+        out["run_staged"] = run_staged
+        out["staged_bytes_per_point"] = 24 + sum(np.dtype(swz.ATTRIBUTES[a][1]).itemsize * swz.ATTRIBUTES[a][2] for a in names)
+    return out
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("SWZ_BENCH_FORCE_SHARDED") != "1":
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE=%s\n" % (args.gpus, os.environ.get("WORLD_SIZE")))
+        sys.exit(2)
     import torch
 
     import schwarzwald_amd as swz
@@ -161,12 +238,24 @@ def main():
     xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
     ctx.generate_uniform_device(SEED + 3, rank * n, n, xyz.data_ptr())
 
+    mb = None
     if distributed:
         from schwarzwald_amd import sharded
         runner = sharded.ShardedTiler(ctx, dev, bmin, bmax, params)
 
         def step():
             return runner.tile(xyz)
+    elif args.batches > 1:
+        mb = multibatch_leg(args, ctx, swz, torch, dev, xyz, n, bmin, bmax, params)
+        mb_info = {}
+
+        def step():
+            per_batch, info = mb["run_device"]()
+            mb_info.update(info)
+            return dict(num_nodes=int(info["num_nodes"]), points_visited=sum(b["points_visited"] for b in per_batch),
+                        max_level=max(b["max_level"] for b in per_batch), fast_start_levels=int(info["fast_start_levels"]),
+                        num_levels=sum(b["num_levels"] for b in per_batch),
+                        min_distance_rounds=sum(b["min_distance_rounds"] for b in per_batch))
     else:
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         perm = torch.empty(n, dtype=torch.int32, device=dev)
@@ -222,11 +311,14 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64 keys / f64 positions", "data": "synthetic",
             "config": {"workload": "%d uniform points per GPU in the unit cube, %s sampling, spacing = diagonal/%g, "
-                                   "max_points_per_node=%d, %s strategy, one batch" % (
-                                       n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy),
+                                   "max_points_per_node=%d, %s strategy, %s" % (
+                                       n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy,
+                                       "one batch" if args.batches <= 1 else "%d batches through the multi-batch tiler" % args.batches),
                        "points_per_gpu": n, "sampler": args.sampler, "strategy": args.strategy,
                        "min_distance_mode": "exact" if args.sampler == "MIN_DISTANCE" else None,
+                       "batches": args.batches,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
+            "ranks_in_process_group": dist.get_world_size() if distributed else 1,
             "visit_factor": round(visit, 4),
             "hbm_frac_end_to_end": round(alg * total_points / world / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "algorithmic_bytes_per_point": round(alg, 1),
@@ -234,7 +326,22 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
-        if world == 1 and not distributed and args.payload:
+        if mb is not None and "run_staged" in mb:
+            mb["run_staged"]()  # warm-up: pools and workspace sized
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            info = mb["run_staged"]()
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            copied = int(info["staged_bytes"])
+            out["staged"] = {"ms": round(dt * 1e3, 3), "Mpoints_per_s_pcie_inclusive": round(n / dt / 1e6, 3),
+                             "h2d_bytes": copied, "h2d_bytes_per_point": mb["staged_bytes_per_point"],
+                             "h2d_GBs_if_serial": round(copied / dt / 1e9, 2),
+                             "copy_wait_ms": round(float(info["staged_wait_ms"]), 3),
+                             "device_resident_ms": round(ms_per_step, 3),
+                             "note": "batch i+1 is copied from pinned host memory (hipMemcpyAsync, copy stream) while "
+                                     "batch i is tiled; copy_wait_ms is the time tiling had to wait for a copy"}
+        if world == 1 and not distributed and args.payload and mb is None:
             out["payload"] = payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, spacing)

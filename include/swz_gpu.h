@@ -89,7 +89,9 @@ int swz_sort_by_key_device(swz_ctx* ctx, const uint64_t* d_keys, uint64_t n, uin
  * behaviour): core/tiling/Sampling.h:799-821.  keys/idx describe a Morton-sorted range of n
  * IndexedPoint64 (idx[i] = row of xyz).  taken_out[i] = 1 when element i belongs to the
  * [begin, partition_point) half of the reference's stable partition, else 0 (both halves keep
- * their order, so the partition itself is a stable compaction by this flag). */
+ * their order, so the partition itself is a stable compaction by this flag).
+ * Precondition (checked on the device, SWZ_ERR_BAD_ARG otherwise): for node_level >= 0 every key of the range
+ * has node_key's first node_level + 1 octants -- the range is what tile_node hands to sample_points. */
 int swz_sample_points(swz_ctx* ctx, int sampler, uint64_t max_points_per_node, const uint64_t* keys,
                       const uint32_t* idx, uint64_t n, const double* xyz, uint64_t num_points,
                       uint64_t node_key, int32_t node_level, const double root_min[3],
@@ -260,7 +262,9 @@ int swz_las_decode_device(swz_ctx* ctx, const uint8_t* d_records, uint64_t n, co
  *   swz_shard_root_taken_device: positions (N x 3) of the LOCAL points the root took, Morton order:
  *     the ghosts to hand to the shards owning higher octants.
  *   swz_shard_finish_device: tiles levels >= 0 and writes the outputs of swz_tile_device for the n
- *     local points (keys ascending, perm = index into the local xyz, level). */
+ *     local points (keys ascending, perm = index into the local xyz, level).
+ *   A shard without points (n == 0: its octants are empty) is valid everywhere: presort is a no-op, begin takes
+ *   nothing of the root, finish reports zero points. */
 typedef struct {
   uint64_t global_points;      /* points of the whole batch over all shards */
   const double* d_ghost_xyz;   /* device, num_ghosts x 3; all ghosts must lie in lower octants.  When the
@@ -339,6 +343,12 @@ int swz_tiler_pools_device(swz_tiler* tiler, const double** d_xyz_out, swz_attri
 /* page-locked host memory for the staging entry points (hipHostMalloc / hipHostFree) */
 int swz_host_alloc_pinned(uint64_t bytes, void** out);
 int swz_host_free_pinned(void* p);
+/* device memory and copies for host code that does not include HIP headers itself (hipMalloc / hipFree on the
+ * current device; the copies run on the context's stream and return when done) */
+int swz_device_alloc(uint64_t bytes, void** d_out);
+int swz_device_free(void* d_ptr);
+int swz_copy_to_host(swz_ctx* ctx, void* dst_host, const void* d_src, uint64_t bytes);
+int swz_copy_to_device(swz_ctx* ctx, void* d_dst, const void* src_host, uint64_t bytes);
 
 /* ---- synthetic workload of BASELINE.json / SURVEY.md section 8(d): uniform points in the unit
  * cube from a counter-based splitmix64 stream (point i draws x,y,z = draws 3i..3i+2). */

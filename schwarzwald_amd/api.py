@@ -15,6 +15,7 @@ SAMPLERS = {"RANDOM_GRID": RANDOM_GRID, "GRID_CENTER": GRID_CENTER, "MIN_DISTANC
             "JITTERED": JITTERED}
 TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS, ALWAYS_ADHERE_TO_MIN_SPACING = 0, 1
 ACCURATE, FAST = 0, 1
+ERR_PEER_FAILED = 100  # raised by the multi-GPU driver on the ranks that did not fail themselves
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 

@@ -187,6 +187,7 @@ int swz_set_stream(swz_ctx* c, void* hip_stream) {
 int swz_release_workspace(swz_ctx* c) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
+  swz::shard_free(c);  // an open or presorted sharded batch points into the workspace that goes away
   c->release_all();
   return SWZ_OK;
 }
@@ -402,7 +403,8 @@ int swz_shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint64_t n, 
   SWZ_TRY(check_n(c, n + ghost_capacity));
   SWZ_TRY(check_bounds(c, bmin, bmax));
   SWZ_TRY(check_params(c, params));
-  if (n == 0 || !d_xyz_local) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_presort_device: empty shard");
+  if (n && !d_xyz_local) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_presort_device: NULL buffer");
+  if (n == 0) return SWZ_OK;  // a shard without points (its octants are empty) has nothing to prepare
   int st = swz::shard_presort_device(c, d_xyz_local, (uint32_t)n, bmin, bmax, *params, (uint32_t)ghost_capacity);
   int st2 = sync(c);
   return st != SWZ_OK ? st : st2;
@@ -419,7 +421,13 @@ int swz_shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint64_t n, co
   SWZ_TRY(check_params(c, params));
   if ((n && !d_xyz_local) || (shard->num_ghosts && !shard->d_ghost_xyz))
     return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_begin_device: NULL buffer");
-  if (n + shard->num_ghosts == 0) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_begin_device: empty shard");
+  if (num_root_taken_out) *num_root_taken_out = 0;
+  if (n == 0) {
+    // the octants this shard owns are empty (flat terrain in a cubic root box leaves the upper octants without
+    // points): nothing of the root is decided here whatever the ghosts are; the batch stays "open" so that
+    // swz_shard_finish_device pairs up and reports zero points
+    return swz::shard_begin_empty(c);
+  }
   int st = swz::shard_begin_device(c, d_xyz_local, (uint32_t)n, bmin, bmax, *params, shard->global_points,
                                    shard->d_ghost_xyz, (uint32_t)shard->num_ghosts, num_root_taken_out);
   int st2 = sync(c);

@@ -167,6 +167,7 @@ int shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, cons
 int shard_root_taken_device(swz_ctx* c, double* d_xyz_out);
 int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
                         swz_tile_stats* stats);
+int shard_begin_empty(swz_ctx* c);
 void shard_free(swz_ctx* c);
 // One radix pass on the top key digit: perm groups the points by octant (stable); octants (host)
 // receives the eight counts.

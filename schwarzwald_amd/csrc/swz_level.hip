@@ -880,11 +880,21 @@ struct ShardState {
   uint32_t front = 0;
   const double* xyz_local = nullptr;
   bool perm_local = false;  // perm of the local points counts from the first LOCAL point
+  bool empty = false;       // the open batch has no local points
 };
 
 static ShardState* shard_state(swz_ctx* c) {
   if (!c->shard) c->shard = new ShardState();
   return static_cast<ShardState*>(c->shard);
+}
+int shard_begin_empty(swz_ctx* c) {
+  ShardState* s = shard_state(c);
+  s->presorted = false;
+  s->t = TileSession{};
+  s->n_local = 0;
+  s->empty = true;
+  s->open = true;
+  return SWZ_OK;
 }
 void shard_free(swz_ctx* c) {
   delete static_cast<ShardState*>(c->shard);
@@ -988,6 +998,7 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
   ShardState* s = shard_state(c);
   s->open = false;
+  s->empty = false;
   const uint32_t total = n + ghosts;
   const bool fast = s->presorted && s->xyz_local == d_xyz_local && s->n_local == n && ghosts <= s->front;
   s->presorted = false;
@@ -1039,6 +1050,7 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
 int shard_root_taken_device(swz_ctx* c, double* d_xyz_out) {
   ShardState* s = shard_state(c);
   if (!s->open) return c->fail(SWZ_ERR_BAD_ARG, "no sharded batch is open");
+  if (s->empty) return SWZ_OK;
   const uint32_t total = s->t.n;
   // lb.flags still holds the exclusive scan of the root-taken flags of swz_shard_begin
   hipLaunchKernelGGL(root_taken_gather_kernel, dim3(div_up(total, 256)), dim3(256), 0, c->stream, s->t.level,
@@ -1052,6 +1064,11 @@ int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, 
   ShardState* s = shard_state(c);
   if (!s->open) return c->fail(SWZ_ERR_BAD_ARG, "no sharded batch is open");
   s->open = false;
+  if (s->empty) {
+    s->empty = false;
+    session_stats(s->t, stats);
+    return SWZ_OK;
+  }
   SWZ_TRY(session_run_levels(c, s->t, 20, -1));
   hipLaunchKernelGGL(shard_strip_kernel, dim3(div_up(s->n_local, 256)), dim3(256), 0, c->stream, s->t.keys, s->t.perm,
                      s->t.level, s->t.ghosts, s->perm_local ? 0u : s->t.ghosts, s->n_local, d_keys_out, d_perm_out, d_level_out);
@@ -1068,10 +1085,33 @@ __global__ __launch_bounds__(256) void count_taken_kernel(const uint8_t* __restr
   if (lane_id() == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
 }
 
+// every key of the range must lie in the node: the reference takes the node's bounds from node_key
+// (Sampling.h:441, 622), this implementation from the keys' own prefix -- the two agree exactly then
+__global__ __launch_bounds__(256) void node_key_check_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t nsh,
+                                                             uint64_t prefix, uint32_t* __restrict__ bad) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool b = i < n && (keys[i] >> nsh) != prefix;
+  const uint64_t m = __ballot(b);
+  if (lane_id() == 0 && m) atomicAdd(bad, (uint32_t)__popcll(m));
+}
+
 int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uint64_t* d_keys, const uint32_t* d_idx,
-                         uint32_t n, const double* d_xyz, uint64_t /*node_key*/, int32_t node_level,
+                         uint32_t n, const double* d_xyz, uint64_t node_key, int32_t node_level,
                          const double rmin[3], const double rmax[3], float spacing, int behaviour, uint8_t* d_taken,
                          uint64_t* num_taken) {
+  if (node_level >= 0) {
+    uint32_t* d_bad = nullptr;
+    SWZ_TRY(c->get("lvl_counters", (size_t)CTR_COUNT, &d_bad));
+    SWZ_HIP(c, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), c->stream));
+    const uint32_t nsh = level_shift(node_level);
+    hipLaunchKernelGGL(node_key_check_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, d_keys, n, nsh,
+                       node_key >> nsh, d_bad);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t bad = 0;
+    SWZ_HIP(c, hipMemcpyAsync(&bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (bad) return c->fail(SWZ_ERR_BAD_ARG, "swz_sample_points: " + std::to_string(bad) + " keys of the range do not lie in node_key's node");
+  }
   double *X = nullptr, *Y = nullptr, *Z = nullptr;
   SWZ_TRY(c->get("sorted_x", (size_t)n, &X));
   SWZ_TRY(c->get("sorted_y", (size_t)n, &Y));

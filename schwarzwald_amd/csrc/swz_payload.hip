@@ -155,6 +155,7 @@ int swz_build_node_lists_device(swz_ctx* c, const uint64_t* d_keys_sorted, const
                                 uint32_t* d_order_out, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
                                 uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out) {
   if (!c || !num_nodes_out) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
   *num_nodes_out = 0;
   if (n == 0) return SWZ_OK;
   if (n > 0xFFFFFFFFull) return c->fail(SWZ_ERR_BAD_ARG, "more than 2^32-1 points in one batch");
@@ -201,6 +202,7 @@ int swz_build_node_lists_device(swz_ctx* c, const uint64_t* d_keys_sorted, const
 int swz_gather_payload_device(swz_ctx* c, const uint32_t* d_perm, const uint32_t* d_order, uint64_t n, const double* d_xyz,
                               const swz_attribute_columns* d_in, double* d_xyz_out, const swz_attribute_columns* d_out) {
   if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
   if (n == 0) return SWZ_OK;
   if (n > 0xFFFFFFFFull) return c->fail(SWZ_ERR_BAD_ARG, "more than 2^32-1 points in one batch");
   if (!d_perm) return c->fail(SWZ_ERR_BAD_ARG, "swz_gather_payload_device: NULL perm");
@@ -470,6 +472,7 @@ __global__ __launch_bounds__(LAS_POINTS_PER_BLOCK) void las_decode_kernel(const 
 extern "C" int swz_las_decode_device(swz_ctx* c, const uint8_t* d_records, uint64_t n, const swz_las_layout* layout,
                                      double* d_xyz_out, const swz_attribute_columns* d_out) {
   if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
   if (!layout) return c->fail(SWZ_ERR_BAD_ARG, "swz_las_decode_device: NULL layout");
   static const uint32_t kMinBytes[4] = {20, 28, 26, 34};
   if (layout->point_format > 3) return c->fail(SWZ_ERR_BAD_ARG, "only LAS point data record formats 0-3 are decoded");

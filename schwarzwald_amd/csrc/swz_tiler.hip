@@ -908,4 +908,25 @@ int swz_host_alloc_pinned(uint64_t bytes, void** out) {
 }
 int swz_host_free_pinned(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? SWZ_OK : SWZ_ERR_HIP; }
 
+int swz_device_alloc(uint64_t bytes, void** d_out) {
+  if (!d_out) return SWZ_ERR_BAD_ARG;
+  *d_out = nullptr;
+  return hipMalloc(d_out, bytes ? bytes : 1) == hipSuccess ? SWZ_OK : SWZ_ERR_HIP;
+}
+int swz_device_free(void* d_ptr) { return (!d_ptr || hipFree(d_ptr) == hipSuccess) ? SWZ_OK : SWZ_ERR_HIP; }
+int swz_copy_to_host(swz_ctx* c, void* dst_host, const void* d_src, uint64_t bytes) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (bytes) SWZ_HIP(c, hipMemcpyAsync(dst_host, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  return SWZ_OK;
+}
+int swz_copy_to_device(swz_ctx* c, void* d_dst, const void* src_host, uint64_t bytes) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (bytes) SWZ_HIP(c, hipMemcpyAsync(d_dst, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  return SWZ_OK;
+}
+
 }  // extern "C"

@@ -160,99 +160,114 @@ inline IndexedPoint64* sample_points(Context& ctx, const SamplingStrategy& strat
 // What the adapter needs from PointsPersistence (core/io/PointsPersistence.h:23-53).
 struct PointsSink {
   virtual ~PointsSink() = default;
-  // points of one node, in Morton order; indices are rows of the batch's position array
-  virtual void persist_points(const uint32_t* indices_begin, const uint32_t* indices_end, const AABB& node_bounds,
-                              const std::string& node_name) = 0;
+  // The complete content of one node file, in file (Morton) order.  ids are point ids: the running index of the
+  // point over ALL batches in input order (batch 0 holds ids 0..n0-1, batch 1 the next n1, ...); positions are
+  // the node's count x 3 clamped positions, gathered on the device (what persist_points reads through the
+  // PointReferences, core/tiling/TilingAlgorithms.cpp:232-236, 316-322).
+  virtual void persist_points(const uint32_t* ids_begin, const uint32_t* ids_end, const double* positions,
+                              const AABB& node_bounds, const std::string& node_name) = 0;
 };
 
-// The shape of TilingAlgorithmBase (core/tiling/TilingAlgorithms.h:70-116): one object per Tiler, fed one
-// batch at a time.  tile_batch() is what the single task emitted by build_execution_graph() runs:
-// upload -> kernels -> download -> one persist_points() call per node.
+// The shape of TilingAlgorithmBase (core/tiling/TilingAlgorithms.h:70-116): one object per Tiler, fed one batch at
+// a time (Tiler.cpp:509-510), finalize() once at the end.  tile_batch() is what the single task emitted by
+// build_execution_graph() runs.  Unlike the reference, which rewrites the files of every node a batch reaches
+// (and re-reads them for the next batch, TilingAlgorithms.cpp:50-109), the node files live in device memory
+// between the batches (swz_tiler) and each is handed to the persistence ONCE, by finalize(): same final files,
+// no intermediate ones.
 class TilingAlgorithmGPU {
 public:
   TilingAlgorithmGPU(SamplingStrategy sampling_strategy, PointsSink& persistence, TilerMetaParameters meta,
                      int device = 0)
     : _ctx(device), _sampling_strategy(sampling_strategy), _persistence(persistence), _meta(meta) {}
+  ~TilingAlgorithmGPU() { swz_tiler_destroy(_tiler); }
+  TilingAlgorithmGPU(const TilingAlgorithmGPU&) = delete;
+  TilingAlgorithmGPU& operator=(const TilingAlgorithmGPU&) = delete;
 
-  struct BatchResult {
-    swz_tile_stats stats;
-    size_t nodes_persisted;
-  };
-
-  // positions: n x 3 doubles of this batch (clamped in place); bounds: the octree's (cubic) root bounds
-  BatchResult tile_batch(double* positions, size_t n, const AABB& bounds) {
-    swz_tile_params p{};
-    p.sampler = _sampling_strategy.kind;
-    p.max_points_per_node = _sampling_strategy.max_points_per_node;
-    p.spacing_at_root = _meta.spacing_at_root;
-    p.max_depth = _meta.max_depth;
-    p.strategy = _meta.tiling_strategy == TilingStrategy::Fast ? SWZ_FAST : SWZ_ACCURATE;
-    p.fast_concurrency = _meta.num_indexing_threads;
-    std::vector<uint64_t> keys(n);
-    std::vector<uint32_t> perm(n), dup(n), order(n);
-    std::vector<int8_t> level(n);
+  // positions: n x 3 doubles of this batch (host memory; pinned memory makes the copy asynchronous);
+  // bounds: the octree's (cubic) root bounds, the same for every batch
+  swz_tile_stats tile_batch(const double* positions, size_t n, const AABB& bounds) {
+    if (_finalized) throw std::runtime_error{"TilingAlgorithmGPU: tile_batch after finalize"};
+    if (!_tiler) {
+      swz_tile_params p{};
+      p.sampler = _sampling_strategy.kind;
+      p.max_points_per_node = _sampling_strategy.max_points_per_node;
+      p.spacing_at_root = _meta.spacing_at_root;
+      p.max_depth = _meta.max_depth;
+      p.strategy = _meta.tiling_strategy == TilingStrategy::Fast ? SWZ_FAST : SWZ_ACCURATE;
+      p.fast_concurrency = _meta.num_indexing_threads;
+      const double mn[3] = {bounds.min.x, bounds.min.y, bounds.min.z}, mx[3] = {bounds.max.x, bounds.max.y, bounds.max.z};
+      _ctx.check(swz_tiler_create(_ctx.get(), mn, mx, &p, 0, &_tiler));
+      _bounds = bounds;
+    }
     swz_tile_stats stats{};
-    const double mn[3] = {bounds.min.x, bounds.min.y, bounds.min.z}, mx[3] = {bounds.max.x, bounds.max.y, bounds.max.z};
-    _ctx.check(swz_tile(_ctx.get(), positions, n, mn, mx, &p, keys.data(), perm.data(), level.data(), dup.data(),
-                        &stats));
-    // group the points by node and hand every node to the persistence
-    const uint64_t cap = n ? n : 1;
-    std::vector<int8_t> nl(cap);
-    std::vector<uint64_t> nk(cap), no(cap), nc(cap);
-    uint64_t nn = 0;
-    _ctx.check(swz_build_node_lists(_ctx.get(), keys.data(), level.data(), n, order.data(), cap, nl.data(), nk.data(),
-                                    no.data(), nc.data(), &nn));
-    size_t persisted = 0;
-    std::vector<uint32_t> indices;
-    for (uint64_t j = 0; j < nn; ++j) {
-      indices.resize(nc[j]);
-      for (uint64_t q = 0; q < nc[j]; ++q) indices[q] = perm[order[no[j] + q]];
-      persist_node(nl[j], nk[j], indices, bounds);
-      ++persisted;
-    }
-    // FAST: the reconstructed ancestors hold copies of some of their descendants' points
-    if (p.strategy == SWZ_FAST) {
-      for (int lv = stats.fast_start_levels - 1; lv >= 0; --lv) {
-        const uint32_t bit = 1u << lv;
-        const uint32_t sh = lv == 0 ? 63u : (MortonIndex64Levels - static_cast<uint32_t>(lv)) * 3u;
-        size_t i = 0;
-        while (i < n) {
-          if (!(dup[i] & bit)) {
-            ++i;
-            continue;
-          }
-          const uint64_t prefix = keys[i] >> sh;
-          indices.clear();
-          size_t j = i;
-          for (; j < n && (keys[j] >> sh) == prefix; ++j)
-            if (dup[j] & bit) indices.push_back(perm[j]);
-          persist_node(static_cast<int8_t>(lv - 1), lv == 0 ? 0 : (prefix << sh), indices, bounds);
-          ++persisted;
-          i = j;
-        }
-      }
-    }
-    return {stats, persisted};
+    _ctx.check(swz_tiler_add_batch(_tiler, positions, n, nullptr, &stats));
+    return stats;
   }
 
-  void finalize(const AABB&) {}  // FAST's reconstruction already happened inside tile_batch (single batch)
+  // TilingAlgorithmBase::finalize (FAST: reconstruct_left_out_nodes), then every node file goes to the persistence.
+  // Returns the number of nodes persisted.
+  size_t finalize(const AABB&) {
+    if (!_tiler || _finalized) return 0;
+    _finalized = true;
+    swz_tile_stats stats{};
+    _ctx.check(swz_tiler_finalize(_tiler, &stats));
+    swz_tiler_info info{};
+    _ctx.check(swz_tiler_get_info(_tiler, &info));
+    const uint64_t ns = info.num_stored, nn = info.num_nodes;
+    if (ns == 0) return 0;
+    // node order on the device: ids, then the positions gathered by id
+    void *d_ids = nullptr, *d_xyz = nullptr;
+    DeviceBuffer ids_buf(ns * 4), xyz_buf(ns * 24);
+    d_ids = ids_buf.ptr;
+    d_xyz = xyz_buf.ptr;
+    _ctx.check(swz_tiler_export_device(_tiler, nullptr, static_cast<uint32_t*>(d_ids), nullptr));
+    const double* pool = nullptr;
+    _ctx.check(swz_tiler_pools_device(_tiler, &pool, nullptr));
+    _ctx.check(swz_gather_payload_device(_ctx.get(), static_cast<const uint32_t*>(d_ids), nullptr, ns, pool, nullptr,
+                                         static_cast<double*>(d_xyz), nullptr));
+    std::vector<uint32_t> ids(ns);
+    std::vector<double> xyz(ns * 3);
+    _ctx.check(swz_copy_to_host(_ctx.get(), ids.data(), d_ids, ns * 4));
+    _ctx.check(swz_copy_to_host(_ctx.get(), xyz.data(), d_xyz, ns * 24));
+    std::vector<int8_t> nl(nn);
+    std::vector<uint64_t> nk(nn), no(nn), nc(nn);
+    uint64_t got = 0;
+    _ctx.check(swz_tiler_node_table(_tiler, nn, nl.data(), nk.data(), no.data(), nc.data(), &got));
+    for (uint64_t j = 0; j < got; ++j) {
+      std::string name = "r";  // node names: "r" + octant digits, TilingAlgorithms.cpp:139
+      AABB b = _bounds;
+      for (int l = 0; l <= nl[j]; ++l) {
+        const uint8_t o = get_octant_at_level(nk[j], static_cast<uint32_t>(l));
+        name.push_back(static_cast<char>('0' + o));
+        b = get_octant_bounds(o, b);
+      }
+      _persistence.persist_points(ids.data() + no[j], ids.data() + no[j] + nc[j], xyz.data() + 3 * no[j], b, name);
+    }
+    return static_cast<size_t>(got);
+  }
+
+  swz_tiler_info info() {
+    swz_tiler_info i{};
+    if (_tiler) _ctx.check(swz_tiler_get_info(_tiler, &i));
+    return i;
+  }
 
 private:
-  void persist_node(int8_t level, uint64_t key, const std::vector<uint32_t>& indices, const AABB& root) {
-    std::string name = "r";  // node names: "r" + octant digits, TilingAlgorithms.cpp:139
-    AABB b = root;
-    for (int l = 0; l <= level; ++l) {
-      const uint8_t o = get_octant_at_level(key, static_cast<uint32_t>(l));
-      name.push_back(static_cast<char>('0' + o));
-      b = get_octant_bounds(o, b);
+  struct DeviceBuffer {  // device scratch through the ABI (no HIP headers needed by the host code)
+    void* ptr = nullptr;
+    explicit DeviceBuffer(uint64_t bytes) {
+      if (swz_device_alloc(bytes, &ptr) != SWZ_OK) throw std::runtime_error{"swz_device_alloc failed"};
     }
-    _persistence.persist_points(indices.data(), indices.data() + indices.size(), b, name);
-  }
+    ~DeviceBuffer() { swz_device_free(ptr); }
+  };
 
   Context _ctx;
   SamplingStrategy _sampling_strategy;
   PointsSink& _persistence;
   TilerMetaParameters _meta;
+  swz_tiler* _tiler = nullptr;
+  AABB _bounds;
+  bool _finalized = false;
 };
 
 }  // namespace swz_host

@@ -76,7 +76,7 @@ def exchange_rows(rows, send_counts, group=None, headroom=0, chunk_bytes=None):
     The rows that stay on this rank are copied directly; the others travel as grouped point-to-point transfers
     (one RCCL group per round) of at most chunk_bytes per pair and round.  One big all_to_all_single is avoided
     on purpose: RCCL 2.26 (ROCm 7.0) was measured to drop the second half of a single large block (1.9 GB to
-    self: the rows from n/2 on never arrive; tools/a2a_test.py), and bounded messages bound its staging memory."""
+    self: the rows from n/2 on never arrive; tools/a2a_probe.py), and bounded messages bound its staging memory."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     backend = dist.get_backend(group)
@@ -208,33 +208,48 @@ class ShardedTiler:
         self._batches += 1
         recv = buf[headroom:]
         m = recv.shape[0]
-        # 3. root node
+        # A failing library call on ONE rank must not strand the others in the collectives below: the rank keeps
+        # taking part (with nothing to contribute) and the failure is raised on all ranks together at the end.
+        failure = []
+
+        def guarded(fn, default):
+            if failure:
+                return default
+            try:
+                return fn()
+            except api.SwzError as e:
+                failure.append(e)
+                return default
+
+        # 3. root node.  m == 0 (this rank's octants are empty, e.g. the upper half of a cubic box around flat
+        # terrain) is an ordinary shard: the library takes nothing of the root and reports zero points.
         if not sequential_root:
-            ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points)
+            guarded(lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points), 0)
         else:
             if m > 0:
                 # everything that does not depend on the ghosts happens on all ranks at once; only the root
                 # node itself is left in the chain below
-                ctx.shard_presort_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, GHOST_HEADROOM)
+                guarded(lambda: ctx.shard_presort_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params,
+                                                         GHOST_HEADROOM), None)
             ghosts = []
             for r in range(world):
                 cnt = torch.zeros(1, dtype=torch.int64, device=dev)
                 mine = None
                 if r == self.rank:
                     g = sum(t.shape[0] for t in ghosts)
-                    if g == 0:
-                        gptr = None
+                    if g == 0 or m == 0:
+                        gptr, g = None, 0
                     elif g <= headroom:  # ghosts go right in front of the received points: no staging copy
                         torch.cat(ghosts, out=buf[headroom - g:headroom])
                         gptr = buf[headroom - g:].data_ptr()
                     else:
                         gbuf = torch.cat(ghosts)
                         gptr = gbuf.data_ptr()
-                    taken = ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points,
-                                                   gptr, g)
+                    taken = guarded(lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params,
+                                                                   global_points, gptr, g), 0)
                     mine = torch.empty((taken, 3), dtype=torch.float64, device=dev)
                     if taken:
-                        ctx.shard_root_taken_device(mine.data_ptr())
+                        guarded(lambda: ctx.shard_root_taken_device(mine.data_ptr()), None)
                     cnt[0] = taken
                 if r == world - 1:
                     break  # nobody owns higher octants
@@ -249,8 +264,16 @@ class ShardedTiler:
         okeys = torch.empty(m, dtype=torch.int64, device=dev)
         operm = torch.empty(m, dtype=torch.int32, device=dev)
         olevel = torch.empty(m, dtype=torch.int8, device=dev)
-        stats = ctx.shard_finish_device(okeys.data_ptr(), operm.data_ptr(), olevel.data_ptr())
+        zero = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
+        stats = guarded(lambda: ctx.shard_finish_device(okeys.data_ptr(), operm.data_ptr(), olevel.data_ptr()), zero)
         _trace(dev, "levels below the root", t0)
+        flag = torch.tensor([1 if failure else 0], dtype=torch.int64,
+                            device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if int(flag.item()):
+            if failure:
+                raise failure[0]
+            raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
         self.result = (recv, okeys, operm, olevel)
         self._keepalive = buf  # the context reads the points until shard_finish returned
         stats["shard_points"] = m

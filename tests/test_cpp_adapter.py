@@ -29,4 +29,4 @@ def test_adapter_tiles_like_the_oracle(tmp_path):
     exe = _build(str(tmp_path))
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(" ok: ") == 4
+    assert r.stdout.count(" ok: ") == 8

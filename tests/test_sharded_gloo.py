@@ -131,7 +131,17 @@ def test_owner_map_is_monotone_and_balanced():
 
 
 # ------------------------------------------------------------------ GPU: full sharded tiler, 2 ranks on one GPU
-def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q):
+def _corner_cloud(n, seed, world):
+    """Points in the octants of rank 0 only: every other rank's shard is empty (flat terrain in a cubic
+    root box leaves whole octants, i.e. whole ranks, without points)."""
+    xyz = _cloud(n, seed)
+    xyz[:, 0] *= 0.5            # x < 0.5: octants 0..3
+    if world > 2:
+        xyz[:, 1] *= 0.5        # and y < 0.5: octants 0, 1
+    return xyz
+
+
+def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False):
     _init(rank, world, port)
     import schwarzwald_amd as swz
     from schwarzwald_amd import sharded
@@ -139,7 +149,7 @@ def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q):
     torch.cuda.set_device(dev)
     ctx = swz.Context(0)
     params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
-    xyz = torch.from_numpy(_cloud(n, 300 + rank)).to(dev)
+    xyz = torch.from_numpy(_corner_cloud(n, 300 + rank, world) if corner else _cloud(n, 300 + rank)).to(dev)
     tiler = sharded.ShardedTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
     stats = tiler.tile(xyz)
     recv, keys, perm, level = tiler.result
@@ -187,3 +197,37 @@ def test_sharded_tile_matches_oracle(sampler):
     a, b = canon(keys, level, pos), canon(ref["keys"], ref["level"], ref_xyz)
     assert np.array_equal(a, b)
     assert sum(got[r][4]["num_nodes"] for r in range(world)) - (world - 1) == ref["stats"]["num_nodes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+def test_sharded_tile_with_empty_shards(sampler, world):
+    """Ranks whose octants hold no point must neither fail nor hang the others (all ranks share cuda:0 here)."""
+    n, max_pts = 30000, 500
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q, True))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert got[r][0].shape[0] == 0 and got[r][4]["points_visited"] == 0
+    union = np.vstack([_corner_cloud(n, 300 + r, world) for r in range(world)])
+    ref = O.tile(union, [0, 0, 0], [1, 1, 1], sampler, max_pts, spacing)
+    assert ref["status"] == 0
+    assert np.array_equal(got[0][1], ref["keys"])
+    ref_xyz = ref["xyz_clamped"][ref["perm"]]
+    pos = got[0][0][got[0][2]]
+    rec = lambda k, lv, p: np.sort(np.rec.fromarrays([k, lv, p[:, 0], p[:, 1], p[:, 2]], names="k,l,x,y,z"),
+                                   order=["k", "x", "y", "z", "l"])
+    assert np.array_equal(rec(got[0][1], got[0][3], pos), rec(ref["keys"], ref["level"], ref_xyz))
