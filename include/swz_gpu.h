@@ -90,8 +90,9 @@ int swz_sort_by_key_device(swz_ctx* ctx, const uint64_t* d_keys, uint64_t n, uin
  * IndexedPoint64 (idx[i] = row of xyz).  taken_out[i] = 1 when element i belongs to the
  * [begin, partition_point) half of the reference's stable partition, else 0 (both halves keep
  * their order, so the partition itself is a stable compaction by this flag).
- * Precondition (checked on the device, SWZ_ERR_BAD_ARG otherwise): for node_level >= 0 every key of the range
- * has node_key's first node_level + 1 octants -- the range is what tile_node hands to sample_points. */
+ * RANDOM_GRID and GRID_CENTER ignore node_key like the reference does (the range is the node).  For MIN_DISTANCE
+ * and JITTERED, which take the node's box from node_key (Sampling.h:441, 622), every key of the range must have
+ * node_key's first node_level + 1 octants (checked on the device, SWZ_ERR_BAD_ARG otherwise). */
 int swz_sample_points(swz_ctx* ctx, int sampler, uint64_t max_points_per_node, const uint64_t* keys,
                       const uint32_t* idx, uint64_t n, const double* xyz, uint64_t num_points,
                       uint64_t node_key, int32_t node_level, const double root_min[3],

@@ -1099,7 +1099,11 @@ int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uin
                          uint32_t n, const double* d_xyz, uint64_t node_key, int32_t node_level,
                          const double rmin[3], const double rmax[3], float spacing, int behaviour, uint8_t* d_taken,
                          uint64_t* num_taken) {
-  if (node_level >= 0) {
+  // RANDOM_GRID and GRID_CENTER never look at node_key: the whole range is "the node" (count, candidate level from
+  // node_level; the reference's own test samples a range spanning all octants at node level 0,
+  // test/TestOctreeIndexing.cpp:169-252).  MIN_DISTANCE and JITTERED take the node's box from node_key.
+  const bool uses_node_key = sampler == SWZ_MIN_DISTANCE || sampler == SWZ_JITTERED;
+  if (node_level >= 0 && uses_node_key) {
     uint32_t* d_bad = nullptr;
     SWZ_TRY(c->get("lvl_counters", (size_t)CTR_COUNT, &d_bad));
     SWZ_HIP(c, hipMemsetAsync(d_bad, 0, sizeof(uint32_t), c->stream));
@@ -1119,8 +1123,9 @@ int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uin
   SWZ_TRY(gather_positions(c, d_xyz, d_idx, n, X, Y, Z));
   LevelBuffers lb;
   SWZ_TRY(alloc_level_buffers(c, n, &lb));
-  const LevelPlan plan = make_plan(node_level, sampler, max_points, spacing, 100, rmin, rmax,
-                                   behaviour == SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, false);
+  LevelPlan plan = make_plan(node_level, sampler, max_points, spacing, 100, rmin, rmax,
+                             behaviour == SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, false);
+  if (!uses_node_key) plan.node_shift = 63;  // one node: the range
   ActiveSet as{d_keys, nullptr, n};
   SortedPoints sp{X, Y, Z};
   LevelResult r;

@@ -361,3 +361,26 @@ def test_shard_api_with_ghosts_matches_oracle(presort):
     want = np.empty(n, dtype=np.int8)
     want[o["perm"]] = o["level"]
     assert np.array_equal(got_level, want)
+
+
+def test_sample_points_checks_node_key(ctx):
+    """MIN_DISTANCE / JITTERED take the node's box from node_key: a range outside that node is refused instead of
+    silently sampled as several pseudo-nodes; RANDOM_GRID / GRID_CENTER ignore node_key like the
+    reference (its own test hands them a range spanning all octants, test/TestOctreeIndexing.cpp:169-252)."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(2)
+    xyz = rng.random((5000, 3))
+    ks, order, _ = _sorted_cloud(xyz, *UNIT)
+    with pytest.raises(swz.SwzError) as e:
+        ctx.sample_points(swz.MIN_DISTANCE, 10, ks, order, xyz, 0, 0, *UNIT, 0.05)
+    assert e.value.code == 2 and "node_key" in str(e.value)
+    inside = (ks >> np.uint64(60)) == 3
+    node_key = 3 << 60
+    got = ctx.sample_points(swz.MIN_DISTANCE, 10, ks[inside], order[inside], xyz, node_key, 0, *UNIT, 0.05)
+    cnt, k2, i2 = O.sample_points(O.MIN_DISTANCE, 10, ks[inside], order[inside], xyz, node_key, 0, *UNIT, 0.05)
+    assert int(got.sum()) == cnt and np.array_equal(order[inside][got == 1], i2[:cnt])
+    # the whole cloud as ONE node at level 0 for the grid samplers: count and candidate level only
+    for sampler in (swz.RANDOM_GRID, swz.GRID_CENTER):
+        got = ctx.sample_points(sampler, 10, ks, order, xyz, 0, 0, *UNIT, 0.05)
+        cnt, k2, i2 = O.sample_points(sampler, 10, ks, order, xyz, 0, 0, *UNIT, 0.05)
+        assert int(got.sum()) == cnt and np.array_equal(order[got == 1], i2[:cnt])
