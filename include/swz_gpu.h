@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SWZ_ABI_VERSION 1
+#define SWZ_ABI_VERSION 2
 
 /* status codes */
 enum {
@@ -110,7 +110,17 @@ typedef struct {
   int32_t strategy;             /* SWZ_ACCURATE | SWZ_FAST */
   uint32_t fast_concurrency;    /* FAST: num_indexing_threads, decides the start level
                                    (TilingAlgorithms.cpp:1473-1535) */
+  uint32_t flags;               /* SWZ_FLAG_*; 0 = the reference's semantics everywhere */
 } swz_tile_params;
+/* MIN_DISTANCE "property" mode (not the reference's result): the taken set of every sampled
+ * node is still a maximal set of points pairwise >= the node's spacing apart under the reference's compare
+ * (squared double distance against the float-squared spacing, GridCell.cpp:52) and deterministic, but the greedy
+ * priority is (cell colour, Morton order) instead of Morton order alone: the node is cut into octree cells >= one
+ * spacing wide, cells of equal colour (parity of the cell coordinates) are never adjacent and are decided together,
+ * eight phases per level instead of thousands of dependent rounds.  Take-all, terminal and all other rules are
+ * unchanged.  What the reference's author tests for this sampler (test/TestTiler.cpp:361-421: min distance on
+ * sampled nodes) holds; point-for-point equality with the reference does not. */
+#define SWZ_FLAG_MIN_DISTANCE_PROPERTY 1u
 
 typedef struct {
   uint64_t num_nodes;         /* nodes that persisted points (incl. FAST reconstructed ones) */

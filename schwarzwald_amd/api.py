@@ -28,7 +28,11 @@ class SwzError(RuntimeError):
 
 class _TileParams(C.Structure):
     _fields_ = [("sampler", C.c_int32), ("max_points_per_node", C.c_uint64), ("spacing_at_root", C.c_float),
-                ("max_depth", C.c_uint32), ("strategy", C.c_int32), ("fast_concurrency", C.c_uint32)]
+                ("max_depth", C.c_uint32), ("strategy", C.c_int32), ("fast_concurrency", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
+FLAG_MIN_DISTANCE_PROPERTY = 1
 
 
 class _TileStats(C.Structure):
@@ -59,10 +63,11 @@ class TileParams:
     max_depth: int = 100                  # TilerProcess.cpp:624-629
     strategy: int = ACCURATE
     fast_concurrency: int = 8
+    flags: int = 0                        # FLAG_MIN_DISTANCE_PROPERTY: see include/swz_gpu.h
 
     def _c(self):
         return _TileParams(self.sampler, self.max_points_per_node, self.spacing_at_root, self.max_depth,
-                           self.strategy, self.fast_concurrency)
+                           self.strategy, self.fast_concurrency, self.flags)
 
 
 @dataclass

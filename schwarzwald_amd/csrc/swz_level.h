@@ -53,6 +53,7 @@ struct LevelPlan {
   bool force_sample = false; // SamplingBehaviour::AlwaysAdhereToMinSpacing
   bool terminal = false;     // tile_terminal_node: every node of this level keeps all its points
   bool reroot = false;       // sampling this level would need Morton re-rooting
+  bool md_property = false;  // MIN_DISTANCE: SWZ_FLAG_MIN_DISTANCE_PROPERTY (swz_mdprop.hip)
   Box root;
   // RANDOM_GRID / GRID_CENTER: candidate_level_in_octree (Sampling.h:223-229); -1 = first point only
   int cand = -1;
@@ -96,6 +97,11 @@ int fast_start_level(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint
 int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                        const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes,
                        uint32_t sample_points, uint32_t* rounds_out);
+
+// SWZ_FLAG_MIN_DISTANCE_PROPERTY: coloured cell phases instead of the exact Morton-order greedy (swz_mdprop.hip)
+int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+                                const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes,
+                                uint32_t sample_points, uint32_t* phases_out);
 
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
 // qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.

@@ -575,9 +575,14 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     SWZ_HIP(c, hipMemcpyAsync(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
     if (h[CTR_ERROR]) return c->fail((int)h[CTR_ERROR], "node needs Morton re-rooting (unsupported)");
-    if (h[CTR_SAMPLE_NODES] > 0)
-      SWZ_TRY(min_distance_level(c, plan, as, sp, lb, h[CTR_NUM_NODES], h[CTR_SAMPLE_NODES], h[CTR_SAMPLE_POINTS],
-                                 &res->md_rounds));
+    if (h[CTR_SAMPLE_NODES] > 0) {
+      if (plan.md_property)
+        SWZ_TRY(min_distance_property_level(c, plan, as, sp, lb, h[CTR_NUM_NODES], h[CTR_SAMPLE_NODES],
+                                            h[CTR_SAMPLE_POINTS], &res->md_rounds));
+      else
+        SWZ_TRY(min_distance_level(c, plan, as, sp, lb, h[CTR_NUM_NODES], h[CTR_SAMPLE_NODES], h[CTR_SAMPLE_POINTS],
+                                   &res->md_rounds));
+    }
   }
 
   if (okey) {
@@ -700,6 +705,7 @@ static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int fi
     }
     LevelPlan plan = make_plan(level, t.params.sampler, t.params.max_points_per_node, t.params.spacing_at_root,
                                t.params.max_depth, t.bmin, t.bmax, false, true);
+    plan.md_property = (t.params.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
     if (first_mode >= 0 && level == t.next_level && !plan.terminal) {
       if (first_mode == 1) {
         plan.force_sample = true;
@@ -855,8 +861,9 @@ int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], con
     SWZ_HIP(c, hipMemcpyAsync(&m, t.lb.counters + CTR_REMAINING, 4, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
     if (m == 0) continue;
-    const LevelPlan plan = make_plan(lv - 1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin,
-                                     bmax, true, false);
+    LevelPlan plan = make_plan(lv - 1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin,
+                               bmax, true, false);
+    plan.md_property = (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
     ActiveSet as{rkey, ridx, m};
     LevelResult r;
     SWZ_TRY(level_step(c, plan, as, t.sp, t.lb, nullptr, nullptr, nullptr, &r));
@@ -938,6 +945,7 @@ __global__ __launch_bounds__(256) void shard_strip_kernel(const uint64_t* __rest
 int shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
                          const swz_tile_params& p, uint32_t ghost_capacity) {
   if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  if (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
   if ((uint64_t)n + ghost_capacity > 0xFFFFFFFEull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "shard + ghosts exceed 2^32-2 points");
   ShardState* s = shard_state(c);
   s->open = false;
@@ -996,6 +1004,7 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
                        const double bmax[3], const swz_tile_params& p, uint64_t global_points,
                        const double* d_ghost_xyz, uint32_t ghosts, uint64_t* num_root_taken) {
   if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  if (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
   ShardState* s = shard_state(c);
   s->open = false;
   s->empty = false;

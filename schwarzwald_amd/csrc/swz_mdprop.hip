@@ -1,0 +1,402 @@
+// swz_mdprop.hip -- MIN_DISTANCE in "property" mode (SWZ_FLAG_MIN_DISTANCE_PROPERTY).
+//
+// The reference's PoissonDiskSampling (core/tiling/Sampling.h:421-471 + SparseGrid.cpp:116-146) is the greedy
+// maximal independent set in Morton order; computing exactly that set needs thousands of dependent rounds per level
+// (swz_mindist.hip).  What the sampler is FOR -- and what the reference's author checks, test/TestTiler.cpp:361-421 --
+// is the property: inside a sampled node no two taken points are closer than the node's spacing, and (greedy sets
+// being maximal) every point left out is closer than the spacing to a taken one.  This file computes a set with
+// exactly that property, with the reference's arithmetic for the compare (squared double distance < float-squared
+// spacing widened to double, GridCell.cpp:43-58), deterministically, in EIGHT phases per level:
+//
+//   * every sampled node is cut into octree cells at least one spacing wide (runs of the sorted keys), so only
+//     points of the same or of adjacent cells can conflict;
+//   * the colour of a cell is the parity of its coordinates = its last octant digit; cells of one colour are never
+//     adjacent, so they decide independently: phase k lets every cell of colour k run the greedy rule over its own
+//     points in Morton order against the points taken so far in its 26 neighbours (colours < k) and in itself.
+//
+// The result is the greedy set for the priority (colour, Morton order) instead of Morton order alone.
+#include <algorithm>
+#include <cmath>
+
+#include "swz_level.h"
+#include "swz_scan.h"
+
+namespace swz {
+
+constexpr uint32_t PM_NONE = 0xFFFFFFFFu;
+constexpr int PM_THREADS = 256;
+constexpr int PM_WAVES = PM_THREADS / WAVE;
+constexpr int PM_WIN = 128;    // taken points of the neighbourhood held in LDS at a time
+constexpr int PM_FRESH = 192;  // taken points of the cell itself held in LDS (more spill to memory reads)
+
+struct PmArgs {
+  const uint64_t* akey;
+  uint32_t m;
+  const uint32_t* nid;
+  const uint8_t* nmode;
+  const uint32_t* nstart;
+  const double* X;  // positions in ACTIVE order
+  const double* Y;
+  const double* Z;
+  uint8_t* taken;
+  uint2* cell;        // {first point, end}
+  uint32_t* ccnt;     // taken points of the cell so far
+  uint32_t* crel;     // cell code inside its node
+  uint32_t* csnode;   // index of its node among the sampled nodes
+  uint32_t* nbr;      // [cell][27]: adjacent cell per direction slot (13 = itself), PM_NONE when absent
+  uint32_t* gridmap;  // [sampled node][cell code] -> cell
+  double* acc;        // taken positions of cell c at slots [cell.x, cell.x + ccnt), 3 doubles each
+  const uint32_t* snode_of;
+  uint32_t* ticket;   // work distribution of the running phase
+  uint32_t cell_shift;
+  uint64_t cells_per_node;
+  double sq_spacing;
+};
+
+__device__ __forceinline__ bool pm_is_head(const PmArgs& a, uint32_t i) {
+  if (a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
+  return i == 0 || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
+}
+struct PmHeadF {
+  PmArgs a;
+  __device__ uint32_t operator()(uint32_t i) const { return pm_is_head(a, i) ? 1u : 0u; }
+};
+struct PmCellG {
+  PmArgs a;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t head) const {
+    if (!head) return;
+    a.cell[excl].x = i;
+    a.ccnt[excl] = 0;
+    a.crel[excl] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
+    a.csnode[excl] = a.snode_of[a.nid[i]];
+  }
+};
+
+__global__ __launch_bounds__(256) void pm_cell_end_kernel(PmArgs a, uint32_t ncells) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const uint32_t s = a.cell[c].x;
+  const uint32_t node_end = a.nstart[a.nid[s] + 1];
+  const uint32_t next = (c + 1 < ncells) ? a.cell[c + 1].x : a.m;
+  a.cell[c].y = next < node_end ? next : node_end;
+  a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + a.crel[c]] = c;
+}
+
+// all 26 adjacent cells of every cell (codes by arithmetic on the dilated coordinates), 32 lanes per cell
+__global__ __launch_bounds__(256) void pm_nbr_kernel(PmArgs a, uint32_t ncells) {
+  for (uint64_t cbase = (uint64_t)blockIdx.x * 8u; cbase < ncells; cbase += (uint64_t)gridDim.x * 8u) {
+    const uint32_t c = (uint32_t)cbase + threadIdx.x / 32u;
+    const uint32_t k = threadIdx.x & 31u;
+    if (c >= ncells || k >= 27u) continue;
+    uint32_t out = PM_NONE;
+    if (k == 13u) {
+      out = c;
+    } else {
+      const uint32_t rel = a.crel[c];
+      const uint32_t all = (uint32_t)(a.cells_per_node - 1ull);
+      const uint32_t mz = all & 0x09249249u, my = mz << 1, mx = mz << 2;
+      const uint32_t v[3] = {rel & mx, rel & my, rel & mz};
+      const uint32_t mk[3] = {mx, my, mz};
+      const uint32_t d[3] = {k % 3u, (k / 3u) % 3u, k / 9u};  // 0: minus one, 1: same, 2: plus one
+      bool inside = true;
+      uint32_t nrel = 0;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        uint32_t w = v[ax];
+        if (d[ax] == 0u) {
+          inside &= w != 0u;
+          w = (w - 1u) & mk[ax];
+        } else if (d[ax] == 2u) {
+          inside &= w != mk[ax];
+          w = ((w | ~mk[ax]) + 1u) & mk[ax];
+        }
+        nrel |= w;
+      }
+      if (inside) out = a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + nrel];
+    }
+    a.nbr[(size_t)c * 27 + k] = out;
+  }
+}
+
+struct PmLds {
+  double wx[PM_WIN], wy[PM_WIN], wz[PM_WIN];
+  double fx[PM_FRESH], fy[PM_FRESH], fz[PM_FRESH];
+  uint8_t owner[PM_WIN];
+};
+
+// window [base, base + PM_WIN) of the flattened list of the neighbourhood's taken points into LDS: lane k < 27 owns
+// the n_cnt entries of adjacent cell k, which start at list offset off
+__device__ __forceinline__ uint32_t pm_fill_window(const PmArgs& a, PmLds& lds, uint32_t base, uint32_t T, uint32_t maxcnt,
+                                                   uint32_t n_cnt, uint32_t n_start, uint32_t off) {
+  const uint32_t l = lane_id();
+  const uint32_t wn = (T - base) < (uint32_t)PM_WIN ? (T - base) : (uint32_t)PM_WIN;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = 0; j < maxcnt; ++j) {
+    if (j < n_cnt) {
+      const uint32_t ti = off + j;
+      if (ti >= base && ti < base + PM_WIN) lds.owner[ti - base] = (uint8_t)l;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t ti = l; ti < ((wn + WAVE - 1) / WAVE) * WAVE; ti += WAVE) {
+    const uint32_t k = ti < wn ? lds.owner[ti] : 0u;
+    const uint32_t ks = __shfl(n_start, (int)k, WAVE), ko = __shfl(off, (int)k, WAVE);
+    if (ti < wn) {
+      const double* src = a.acc + (size_t)(ks + (base + ti - ko)) * 3;
+      lds.wx[ti] = src[0];
+      lds.wy[ti] = src[1];
+      lds.wz[ti] = src[2];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  return wn;
+}
+
+// one wavefront decides all points of one cell
+__device__ void pm_cell(const PmArgs& a, uint32_t c, PmLds& lds) {
+  const uint32_t l = lane_id();
+  const uint2 me = a.cell[c];
+  const uint32_t s0 = me.x, e = me.y;
+  const double t = a.sq_spacing;
+  // lane k < 27, k != 13: adjacent cell in direction slot k
+  uint32_t n_cnt = 0, n_start = 0;
+  if (l < 27u && l != 13u) {
+    const uint32_t nb = a.nbr[(size_t)c * 27 + l];
+    if (nb != PM_NONE) {
+      n_cnt = a.ccnt[nb];
+      n_start = a.cell[nb].x;
+    }
+  }
+  const uint32_t incl = wave_incl_sum(n_cnt);
+  const uint32_t off = incl - n_cnt;
+  const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+  uint32_t maxcnt = n_cnt;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(maxcnt, d, WAVE);
+    maxcnt = o > maxcnt ? o : maxcnt;
+  }
+  uint32_t wn0 = 0;
+  if (T > 0) wn0 = pm_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
+  uint32_t fresh = 0;
+  for (uint32_t cur = s0; cur < e; cur += WAVE) {
+    const uint32_t p = cur + l;
+    const bool valid = p < e;
+    double px = 0, py = 0, pz = 0;
+    if (valid) {
+      px = a.X[p];
+      py = a.Y[p];
+      pz = a.Z[p];
+    }
+    bool rej = !valid;
+    // against the taken points of the adjacent cells, window by window
+    for (uint32_t base = 0; base < T; base += PM_WIN) {
+      const uint32_t wn = (T <= (uint32_t)PM_WIN) ? wn0 : pm_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off);
+      for (uint32_t ti = 0; ti < wn; ++ti)
+        if (sq_dist(px, py, pz, lds.wx[ti], lds.wy[ti], lds.wz[ti]) < t) rej = true;
+      if (!__ballot(!rej)) break;
+    }
+    // against the points this cell has taken already
+    const uint32_t in_lds = fresh < (uint32_t)PM_FRESH ? fresh : (uint32_t)PM_FRESH;
+    for (uint32_t ti = 0; ti < in_lds; ++ti)
+      if (sq_dist(px, py, pz, lds.fx[ti], lds.fy[ti], lds.fz[ti]) < t) rej = true;
+    for (uint32_t ti = PM_FRESH; ti < fresh; ++ti) {  // rare: more than PM_FRESH taken in one cell
+      const double* q = a.acc + (size_t)(s0 + ti) * 3;  // stored by this wavefront: read past the L1
+      const double qx = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double qy = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double qz = __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sq_dist(px, py, pz, qx, qy, qz) < t) rej = true;
+    }
+    // the survivors of the chunk in Morton order
+    uint64_t alive = __ballot(!rej);
+    while (alive) {
+      const int j = __ffsll((unsigned long long)alive) - 1;
+      const int lo = __double2loint(px), hi = __double2hiint(px);
+      const double bx = __hiloint2double(__builtin_amdgcn_readlane(hi, j), __builtin_amdgcn_readlane(lo, j));
+      const int lo2 = __double2loint(py), hi2 = __double2hiint(py);
+      const double by = __hiloint2double(__builtin_amdgcn_readlane(hi2, j), __builtin_amdgcn_readlane(lo2, j));
+      const int lo3 = __double2loint(pz), hi3 = __double2hiint(pz);
+      const double bz = __hiloint2double(__builtin_amdgcn_readlane(hi3, j), __builtin_amdgcn_readlane(lo3, j));
+      if ((int)l == j) {
+        a.taken[cur + (uint32_t)j] = 1;
+        double* dst = a.acc + (size_t)(s0 + fresh) * 3;
+        dst[0] = px;
+        dst[1] = py;
+        dst[2] = pz;
+        if (fresh < (uint32_t)PM_FRESH) {
+          lds.fx[fresh] = px;
+          lds.fy[fresh] = py;
+          lds.fz[fresh] = pz;
+        }
+      }
+      ++fresh;
+      if ((int)l > j && !rej && sq_dist(px, py, pz, bx, by, bz) < t) rej = true;
+      alive = __ballot(!rej && (int)l > j);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (l == 0) a.ccnt[c] = fresh;
+}
+
+// phase `colour`: wavefronts pull cells (eight at a time) and decide those of this colour
+__global__ __launch_bounds__(PM_THREADS) void pm_phase_kernel(PmArgs a, uint32_t ncells, uint32_t colour) {
+  __shared__ PmLds lds[PM_WAVES];
+  const uint32_t w = threadIdx.x / WAVE;
+  for (;;) {
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(a.ticket, 8u);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (base >= ncells) return;
+    const uint32_t end = base + 8u < ncells ? base + 8u : ncells;
+    for (uint32_t c = base; c < end; ++c)
+      if ((a.crel[c] & 7u) == colour) pm_cell(a, c, lds[w]);
+  }
+}
+
+__global__ __launch_bounds__(256) void pm_snode_flag_kernel(const uint8_t* __restrict__ nmode, uint32_t nnodes,
+                                                            uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < nnodes) out[j] = nmode[j] == MODE_SAMPLE ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void pm_gather_active_kernel(const uint32_t* __restrict__ aidx, uint32_t m,
+                                                               const double* __restrict__ X, const double* __restrict__ Y,
+                                                               const double* __restrict__ Z, double* __restrict__ ax,
+                                                               double* __restrict__ ay, double* __restrict__ az) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t s = aidx[i];
+  ax[i] = X[s];
+  ay[i] = Y[s];
+  az[i] = Z[s];
+}
+// occupied cells per candidate cell level (same counting as the exact path's md_cell_hist_kernel)
+__global__ __launch_bounds__(256) void pm_cell_hist_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ nid,
+                                                           const uint8_t* __restrict__ nmode, uint32_t m, uint32_t node_shift,
+                                                           uint32_t cl_geo, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t lh[16];
+  if (threadIdx.x < 16) lh[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t mine = 0;
+  for (uint32_t i0 = blockIdx.x * 256; i0 < m; i0 += gridDim.x * 256) {
+    const uint32_t i = i0 + threadIdx.x;
+    uint32_t bin = 0xFFu;
+    if (i < m && nmode[nid[i]] == MODE_SAMPLE) {
+      if (i == 0 || nid[i - 1] != nid[i]) {
+        bin = 0;
+      } else if (cl_geo) {
+        const uint64_t diff = ((akey[i] ^ akey[i - 1]) >> (node_shift - 3u * cl_geo)) & ((1ull << (3u * cl_geo)) - 1ull);
+        if (diff) bin = cl_geo - (uint32_t)(63 - __clzll((unsigned long long)diff)) / 3u;
+      }
+    }
+    for (uint32_t b = 0; b <= cl_geo; ++b) {
+      const uint32_t cnt = (uint32_t)__popcll(__ballot(bin == b));
+      if (lane_id() == b) mine += cnt;
+    }
+  }
+  if (lane_id() <= cl_geo && mine) atomicAdd(&lh[lane_id()], mine);
+  __syncthreads();
+  if (threadIdx.x < 16 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
+}
+
+int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+                                const LevelBuffers& lb, uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points,
+                                uint32_t* phases_out) {
+  const uint32_t m = as.m;
+  const uint32_t nsh = plan.node_shift;
+  // cells as fine as the spacing allows, coarsened (at most three levels) while an occupied cell would hold fewer
+  // than 24 points on average: one wavefront works on one cell
+  uint32_t occupied[12] = {0};
+  {
+    uint32_t* d_hist = nullptr;
+    SWZ_TRY(c->get("md_hist", (size_t)16, &d_hist));
+    SWZ_HIP(c, hipMemsetAsync(d_hist, 0, 64, c->stream));
+    hipLaunchKernelGGL(pm_cell_hist_kernel, dim3(std::min<uint32_t>(div_up(m, 256), 4096u)), dim3(256), 0, c->stream,
+                       as.akey, lb.nid, lb.nmode, m, nsh, (uint32_t)plan.cell_levels_geo, d_hist);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t h[16];
+    SWZ_HIP(c, hipMemcpyAsync(h, d_hist, 64, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    uint32_t run = 0;
+    for (int b = 0; b < 12; ++b) {
+      run += h[b];
+      occupied[b] = run;
+    }
+  }
+  int cl = plan.cell_levels_geo;
+  while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0) --cl;
+  while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
+  const uint64_t cells_per_node = 1ull << (3 * cl);
+
+  PmArgs a{};
+  a.akey = as.akey;
+  a.m = m;
+  a.nid = lb.nid;
+  a.nmode = lb.nmode;
+  a.nstart = lb.nstart;
+  a.X = sp.X;
+  a.Y = sp.Y;
+  a.Z = sp.Z;
+  a.taken = lb.taken;
+  a.cell_shift = nsh - 3u * (uint32_t)cl;
+  a.cells_per_node = cells_per_node;
+  a.sq_spacing = plan.sq_spacing;
+
+  uint32_t* snode = nullptr;
+  SWZ_TRY(c->get("md_snode", (size_t)nnodes, &snode));
+  a.snode_of = snode;
+  hipLaunchKernelGGL(pm_snode_flag_kernel, dim3(div_up(nnodes, 256)), dim3(256), 0, c->stream, lb.nmode, nnodes, snode);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(scan_exclusive_u32(c, snode, snode, nnodes, nullptr, "mdn"));
+  if (as.aidx) {  // below the root the survivors are a subsequence: positions into active order
+    double* ax = nullptr;
+    SWZ_TRY(c->get("md_pos", (size_t)m * 4, &ax));
+    hipLaunchKernelGGL(pm_gather_active_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.aidx, m, sp.X, sp.Y,
+                       sp.Z, ax, ax + m, ax + 2 * (size_t)m);
+    SWZ_LAUNCH_CHECK(c);
+    a.X = ax;
+    a.Y = ax + m;
+    a.Z = ax + 2 * (size_t)m;
+  }
+  ProfScope ps(c, "sample_min_distance_property", (uint64_t)sample_points * 33ull, 1);
+
+  // cells = runs of the cell prefix inside sampled nodes; the scan that numbers them writes their records
+  const uint32_t max_cells = std::max(1u, std::min(sample_points, occupied[cl] ? occupied[cl] : sample_points));
+  uint32_t* cellbuf = nullptr;
+  SWZ_TRY(c->get("md_cells", (size_t)max_cells * 11, &cellbuf));
+  a.ccnt = cellbuf;
+  a.crel = cellbuf + (size_t)max_cells;
+  a.csnode = cellbuf + 2 * (size_t)max_cells;
+  a.ticket = lb.counters + CTR_Q0;
+  uint4* cell4 = nullptr;
+  SWZ_TRY(c->get("md_cell4", (size_t)max_cells, &cell4));
+  a.cell = reinterpret_cast<uint2*>(cell4);
+  SWZ_TRY(c->get("md_nbr_id", (size_t)max_cells * 27, &a.nbr));
+  SWZ_TRY(c->get("md_acc", (size_t)m * 4, &a.acc));
+  const uint64_t grid_entries = (uint64_t)sample_nodes * cells_per_node;
+  SWZ_TRY(c->get("md_gridmap", (size_t)grid_entries, &a.gridmap));
+  SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
+  SWZ_TRY(fused_scan(c, PmHeadF{a}, PmCellG{a}, m, lb.counters + CTR_NUM_CELLS, "mdc"));
+  uint32_t ncells = 0;
+  SWZ_HIP(c, hipMemcpyAsync(&ncells, lb.counters + CTR_NUM_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  if (ncells == 0) return SWZ_OK;
+  if (ncells > max_cells) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE property mode: more cells than counted");
+  const uint32_t cb = div_up(ncells, 256);
+  hipLaunchKernelGGL(pm_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
+  SWZ_LAUNCH_CHECK(c);
+  hipLaunchKernelGGL(pm_nbr_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
+  SWZ_LAUNCH_CHECK(c);
+  const uint32_t grid = std::min<uint32_t>(256u * 4u, std::max(1u, div_up(ncells, 8u * PM_WAVES)));
+  for (uint32_t colour = 0; colour < 8; ++colour) {
+    SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
+    hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, ncells, colour);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  if (phases_out) *phases_out += 8;
+  if (getenv("SWZ_DEBUG"))
+    fprintf(stderr, "[swz] MIN_DISTANCE property level %d: %u pts in %u nodes, cell levels %d of %d, %u cells\n", plan.level,
+            sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells);
+  return SWZ_OK;
+}
+
+}  // namespace swz

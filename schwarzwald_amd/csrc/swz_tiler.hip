@@ -533,8 +533,9 @@ static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_sta
   int max_level = -1;
   for (int level = first_level; as.m > 0; ++level) {
     if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
-    const LevelPlan plan = make_plan(level, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
-                                     t->bmin, t->bmax, false, true);
+    LevelPlan plan = make_plan(level, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
+                               t->bmin, t->bmax, false, true);
+    plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
     LevelResult r;
     uint32_t merged = 0;
     SWZ_TRY(tiler_level(t, w, plan, as, &r, &merged));
@@ -603,8 +604,9 @@ static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats) {
     }
     hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, gid, m, t->pool_xyz, wx, wy, wz, wgid);
     SWZ_LAUNCH_CHECK(c);
-    const LevelPlan plan = make_plan(lv - 1, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
-                                     t->bmin, t->bmax, true, false);
+    LevelPlan plan = make_plan(lv - 1, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
+                               t->bmin, t->bmax, true, false);
+    plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
     LevelBuffers lb;
     SWZ_TRY(alloc_level_buffers(c, m, &lb));
     ActiveSet as{keys, nullptr, m};

@@ -1,0 +1,254 @@
+"""MIN_DISTANCE in property mode (SWZ_FLAG_MIN_DISTANCE_PROPERTY, swz_mdprop.hip).  There is no reference result to
+compare with point for point; what must hold is what the sampler is for and what the reference's author tests
+(test/TestTiler.cpp:361-421), with the reference's compare (GridCell.cpp:43-58: (dx*dx + dy*dy) + dz*dz < the
+float-squared spacing, widened to double):
+
+  (a) spacing:    inside a sampled node no two taken points are closer than the node's spacing;
+  (b) maximality: every point a sampled node hands down is closer than the spacing to one of its taken points;
+  (c) everything else (keys, order, take-all of nodes with <= max_points points, one node per point) as in exact mode.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+N_FULL = int(os.environ.get("SWZ_FULLSIZE_POINTS", "100000000"))
+
+
+def _check_property(keys, level, pos, spacing_at_root, max_points, max_level, rng=None, box_points=None):
+    """keys/level/pos in Morton order (numpy).  Verifies (a) and (b) on every sampled node (or, with box_points, on
+    the points of a random box).  Returns (pairs checked, points checked for maximality)."""
+    from scipy.spatial import cKDTree
+    checked_a = checked_b = 0
+    for L in range(-1, max_level + 1):
+        s = np.float32(spacing_at_root) / np.float32(2.0 ** (L + 1))
+        sq = float(np.float32(s) * np.float32(s))
+        active = level >= L
+        if not active.any():
+            continue
+        shift = 63 - 3 * (L + 1)
+        node = (keys >> np.uint64(shift)) if shift < 63 else np.zeros_like(keys)
+        uniq, inv, counts = np.unique(node[active], return_inverse=True, return_counts=True)
+        sampled = np.zeros(keys.shape[0], dtype=bool)
+        sampled[np.nonzero(active)[0]] = (counts > max_points)[inv]
+        if not sampled.any():
+            continue
+        idx = np.nonzero(sampled)[0]
+        if box_points is not None and idx.size > box_points:
+            c = pos[idx[int(rng.integers(0, idx.size))]]
+            h = 0.5 * (box_points / idx.size) ** (1.0 / 3.0)
+            c = np.clip(c, h, 1.0 - h)
+            near = np.all((pos[idx] >= c - h - 1.01 * float(s)) & (pos[idx] <= c + h + 1.01 * float(s)), axis=1)
+            inner_box = (c - h, c + h)
+            idx = idx[near]
+        else:
+            inner_box = None
+        P, nd = pos[idx], node[idx]
+        taken = level[idx] == L
+        T, Tn = P[taken], nd[taken]
+        assert T.shape[0] > 0
+        tree = cKDTree(T)
+        # (a) no two taken points of one node closer than the spacing
+        pairs = tree.query_pairs(float(s) * (1.0 + 1e-9), output_type="ndarray")
+        if pairs.size:
+            d = T[pairs[:, 0]] - T[pairs[:, 1]]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            bad = (d2 < sq) & (Tn[pairs[:, 0]] == Tn[pairs[:, 1]])
+            assert not bad.any(), "level %d: %d taken pairs closer than the spacing" % (L, int(bad.sum()))
+        checked_a += int(T.shape[0])
+        # (b) every point handed down has a taken point of its node within the spacing
+        rest = ~taken
+        if inner_box is not None:
+            rest &= np.all((P >= inner_box[0]) & (P <= inner_box[1]), axis=1)
+        Q, Qn = P[rest], nd[rest]
+        if Q.shape[0]:
+            m = cKDTree(Q).sparse_distance_matrix(tree, float(s) * (1.0 + 1e-9), output_type="ndarray")
+            d = Q[m["i"]] - T[m["j"]]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            ok = (d2 < sq) & (Qn[m["i"]] == Tn[m["j"]])
+            covered = np.zeros(Q.shape[0], dtype=bool)
+            covered[m["i"][ok]] = True
+            assert covered.all(), "level %d: %d points left out although no taken point is within the spacing" % (
+                L, int((~covered).sum()))
+            checked_b += int(Q.shape[0])
+    return checked_a, checked_b
+
+
+def _clustered(rng, n):
+    k = n // 3
+    a = np.column_stack([rng.random(k), rng.random(k), 0.3 + 0.002 * rng.standard_normal(k)])
+    b = 0.6 + 0.03 * rng.standard_normal((k, 3))
+    c = rng.random((n - 2 * k, 3))
+    return np.clip(np.vstack([a, b, c]), 0.0, 1.0)[rng.permutation(n)]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import schwarzwald_amd as swz
+    c = swz.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("kind,d,max_points", [("uniform", 250, 2000), ("uniform", 40, 300), ("clustered", 250, 1000),
+                                               ("clustered", 60, 200)])
+def test_property_mode_small(ctx, kind, d, max_points):
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(d)
+    n = 400000
+    xyz = rng.random((n, 3)) if kind == "uniform" else _clustered(rng, n)
+    sp = O.spacing_from_diagonal(*UNIT, d)
+    exact = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=max_points, spacing_at_root=sp))
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=max_points, spacing_at_root=sp,
+                            flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+    r = ctx.tile(xyz, *UNIT, params)
+    r2 = ctx.tile(xyz, *UNIT, params)
+    assert np.array_equal(r.level, r2.level)                                    # deterministic
+    assert np.array_equal(r.keys, exact.keys) and np.array_equal(r.perm, exact.perm)
+    assert r.level.min() >= -1 and r.stats["max_level"] == int(r.level.max())
+    pos = r.xyz_clamped[r.perm]
+    a, b = _check_property(r.keys, r.level, pos, sp, max_points, r.stats["max_level"])
+    assert a > 0 and b > 0
+    # same kind of sample as the exact greedy: the root takes a similar number of points
+    te, tp = int((exact.level == -1).sum()), int((r.level == -1).sum())
+    assert 0.85 < tp / te < 1.15, (te, tp)
+    assert r.stats["min_distance_rounds"] % 8 == 0 and r.stats["min_distance_rounds"] < exact.stats["min_distance_rounds"]
+
+
+def test_property_mode_fast_strategy_and_multibatch(ctx):
+    """The flag travels through FAST's reconstruction and the multi-batch tiler (AlwaysAdhereToMinSpacing nodes)."""
+    import schwarzwald_amd as swz
+    import torch
+    rng = np.random.default_rng(8)
+    n = 300000
+    xyz = rng.random((n, 3))
+    sp = O.spacing_from_diagonal(*UNIT, 100)
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=500, spacing_at_root=sp, strategy=swz.FAST,
+                            fast_concurrency=2, flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+    r = ctx.tile(xyz, *UNIT, params)
+    assert r.stats["fast_start_levels"] >= 3 and int(r.level.min()) >= r.stats["fast_start_levels"] - 1
+    p2 = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=500, spacing_at_root=sp,
+                        flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+    with swz.Tiler(ctx, *UNIT, p2) as t:
+        for part in np.array_split(xyz, 3):
+            d = torch.from_numpy(np.ascontiguousarray(part)).cuda()
+            torch.cuda.synchronize()
+            t.add_batch_device(d.data_ptr(), part.shape[0])
+        t.finalize()
+        info = t.info()
+        table = t.node_table()
+        ids = torch.empty(int(info["num_stored"]), dtype=torch.int32, device="cuda")
+        t.export_device(0, ids.data_ptr(), 0)
+        ids = ids.cpu().numpy().view(np.uint32)
+    assert info["num_stored"] == n and np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))
+    # spacing inside every node that has children (it was sampled in some batch)
+    from scipy.spatial import cKDTree
+    keyset = {(int(l), int(k)) for l, k in zip(table["level"], table["key"])}
+    checked = 0
+    for j in range(len(table["level"])):
+        L, key = int(table["level"][j]), int(table["key"][j])
+        has_child = any((L + 1, key | (o << (3 * (19 - L)))) in keyset for o in range(8)) if L < 20 else False
+        if not has_child:
+            continue
+        pts = xyz[ids[int(table["offset"][j]):int(table["offset"][j] + table["count"][j])]]
+        s = np.float32(sp) / np.float32(2.0 ** (L + 1))
+        sq = float(np.float32(s) * np.float32(s))
+        pairs = cKDTree(pts).query_pairs(float(s) * (1.0 + 1e-9), output_type="ndarray")
+        if pairs.size:
+            dd = pts[pairs[:, 0]] - pts[pairs[:, 1]]
+            d2 = (dd[:, 0] * dd[:, 0] + dd[:, 1] * dd[:, 1]) + dd[:, 2] * dd[:, 2]
+            assert not (d2 < sq).any(), (L, key)
+        checked += 1
+    assert checked > 0
+
+
+def test_property_mode_full_size():
+    """BASELINE's MIN_DISTANCE workload at SWZ_FULLSIZE_POINTS (default 100 M) in property mode: (a) and (b) on the
+    points of random boxes on every level."""
+    import torch
+    import schwarzwald_amd as swz
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    ctx = swz.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    n = N_FULL
+    xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    ctx.generate_uniform_device(0x5C4A72A1D + 3, 0, n, xyz.data_ptr())
+    sp = O.spacing_from_diagonal(*UNIT, 250)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    level = torch.empty(n, dtype=torch.int8, device=dev)
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=20000, spacing_at_root=sp,
+                            flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+    stats = ctx.tile_device(xyz.data_ptr(), n, *UNIT, params, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+    torch.cuda.synchronize()
+    ctx.release_workspace()
+    assert int(level.min()) >= -1 and int(level.max()) == stats["max_level"]
+    rng = np.random.default_rng(3)
+    # a slab of the Morton order (contiguous, so whole nodes of the deeper levels) plus the coarse levels' points
+    total_a = total_b = 0
+    for rep in range(3):
+        # random box: select on the device, verify on the host
+        c = rng.random(3) * 0.8 + 0.1
+        h = 0.5 * (3_000_000 / n) ** (1.0 / 3.0)
+        pos_all = xyz[perm.long()]
+        lo = torch.tensor(c - 3 * h, device=dev)
+        hi = torch.tensor(c + 3 * h, device=dev)
+        sel = ((pos_all >= lo) & (pos_all <= hi)).all(dim=1)
+        del pos_all
+        idx = torch.nonzero(sel).squeeze(1)
+        k = keys[idx].cpu().numpy().view(np.uint64)
+        lv = level[idx].cpu().numpy()
+        P = xyz[perm[idx].long()].cpu().numpy()
+        # nodes cut by the selection box would look under-populated: restrict every level's check to the nodes that
+        # lie inside the selection completely, i.e. verify levels whose nodes are smaller than the margin
+        for L in range(-1, stats["max_level"] + 1):
+            node_size = 0.5 ** (L + 1)
+            if node_size > 2 * h:
+                continue
+            s = np.float32(sp) / np.float32(2.0 ** (L + 1))
+            sq = float(np.float32(s) * np.float32(s))
+            shift = 63 - 3 * (L + 1)
+            node = k >> np.uint64(shift)
+            active = lv >= L
+            # nodes whose box lies inside [c - 3h + eps, c + 3h - eps]
+            from scipy.spatial import cKDTree
+            nmin = np.floor(P / node_size) * node_size
+            inside = np.all((nmin >= c - 3 * h) & (nmin + node_size <= c + 3 * h), axis=1) & active
+            if not inside.any():
+                continue
+            uniq, inv, counts = np.unique(node[inside], return_inverse=True, return_counts=True)
+            sampled = np.zeros(P.shape[0], dtype=bool)
+            sampled[np.nonzero(inside)[0]] = (counts > 20000)[inv]
+            if not sampled.any():
+                continue
+            Pi, ni = P[sampled], node[sampled]
+            tk = lv[sampled] == L
+            T, Tn = Pi[tk], ni[tk]
+            tree = cKDTree(T)
+            pairs = tree.query_pairs(float(s) * (1.0 + 1e-9), output_type="ndarray")
+            if pairs.size:
+                d = T[pairs[:, 0]] - T[pairs[:, 1]]
+                d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+                assert not ((d2 < sq) & (Tn[pairs[:, 0]] == Tn[pairs[:, 1]])).any(), "level %d" % L
+            Q, Qn = Pi[~tk], ni[~tk]
+            if Q.shape[0] > 400000:
+                pick = rng.choice(Q.shape[0], 400000, replace=False)
+                Q, Qn = Q[pick], Qn[pick]
+            m = cKDTree(Q).sparse_distance_matrix(tree, float(s) * (1.0 + 1e-9), output_type="ndarray")
+            d = Q[m["i"]] - T[m["j"]]
+            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            ok = (d2 < sq) & (Qn[m["i"]] == Tn[m["j"]])
+            covered = np.zeros(Q.shape[0], dtype=bool)
+            covered[m["i"][ok]] = True
+            assert covered.all(), "level %d: %d uncovered" % (L, int((~covered).sum()))
+            total_a += int(T.shape[0])
+            total_b += int(Q.shape[0])
+    print("property mode, %d points: %d taken points and %d left-out points verified" % (n, total_a, total_b))
+    assert total_a > 1000 and total_b > 100000
+    ctx.close()
