@@ -49,6 +49,11 @@ def parse_args():
     ap.add_argument("--payload", default="", help="comma separated attribute columns (e.g. rgb,intensity): after the "
                     "timed region also build the node lists and gather the node payload on the device; reported "
                     "separately under \"payload\", never part of `value`")
+    ap.add_argument("--md-mode", default="exact", choices=["exact", "property", "both"], help="MIN_DISTANCE: exact = the "
+                    "reference's Morton-order greedy set, bit-identical (the headline `value`); property = "
+                    "SWZ_FLAG_MIN_DISTANCE_PROPERTY (same spacing + maximality guarantees, different priority order); "
+                    "both = `value` is exact and the property-mode timing of the same workload is reported beside it "
+                    "under \"min_distance_property\"")
     ap.add_argument("--batches", type=int, default=1, help="tile the points in this many batches through the multi-batch "
                     "tiler (swz_tiler_*: cached-point re-read + merge like the reference with internal_cache_size < N); "
                     "a step is then the whole data set, batch after batch, into a fresh tiler")
@@ -229,7 +234,8 @@ def main():
     spacing = swz.spacing_from_diagonal(bmin, bmax, args.diagonal_fraction)
     params = swz.TileParams(sampler=swz.SAMPLERS[args.sampler], max_points_per_node=args.max_points_per_node,
                             spacing_at_root=spacing, max_depth=100, strategy=getattr(swz, args.strategy),
-                            fast_concurrency=args.fast_concurrency)
+                            fast_concurrency=args.fast_concurrency,
+                            flags=swz.FLAG_MIN_DISTANCE_PROPERTY if args.md_mode == "property" else 0)
     ctx = swz.Context(dev.index)
     if os.environ.get("SWZ_BENCH_OWN_STREAM") != "1":  # default: share torch's current stream (ordered with its kernels)
         ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
@@ -315,7 +321,7 @@ def main():
                                        n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy,
                                        "one batch" if args.batches <= 1 else "%d batches through the multi-batch tiler" % args.batches),
                        "points_per_gpu": n, "sampler": args.sampler, "strategy": args.strategy,
-                       "min_distance_mode": "exact" if args.sampler == "MIN_DISTANCE" else None,
+                       "min_distance_mode": ("property" if args.md_mode == "property" else "exact") if args.sampler == "MIN_DISTANCE" else None,
                        "batches": args.batches,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
             "ranks_in_process_group": dist.get_world_size() if distributed else 1,
@@ -326,6 +332,29 @@ def main():
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
         }
+        if args.md_mode == "both" and args.sampler == "MIN_DISTANCE" and not distributed and mb is None:
+            import dataclasses
+            pp = dataclasses.replace(params, flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+
+            def pstep():
+                return ctx.tile_device(xyz.data_ptr(), n, bmin, bmax, pp, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+            pstep()
+            ctx.profile_reset()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                pstats = pstep()
+            torch.cuda.synchronize(dev)
+            pdt = (time.perf_counter() - t0) / args.steps
+            pprof = ctx.profile_get()
+            pvisit = pstats["points_visited"] / float(n)
+            palg = algorithmic_bytes_per_point(args.sampler, pvisit)
+            out["min_distance_property"] = {
+                "ms_per_step": round(pdt * 1e3, 3), "Mpoints_per_s": round(n / pdt / 1e6, 3), "visit_factor": round(pvisit, 4),
+                "hbm_frac_end_to_end": round(palg * n / pdt / (HBM_PEAK_GBS * 1e9), 5), "tile_stats": pstats,
+                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(pprof.items())},
+                "note": "same workload with SWZ_FLAG_MIN_DISTANCE_PROPERTY: spacing and maximality guaranteed "
+                        "(tests/test_min_distance_property.py), taken set differs from the reference's"}
         if mb is not None and "run_staged" in mb:
             mb["run_staged"]()  # warm-up: pools and workspace sized
             torch.cuda.synchronize(dev)
