@@ -16,7 +16,9 @@
 //
 // The result is the greedy set for the priority (colour, Morton order) instead of Morton order alone.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 
 #include "swz_level.h"
 #include "swz_scan.h"
@@ -253,6 +255,68 @@ __global__ __launch_bounds__(PM_THREADS) void pm_phase_kernel(PmArgs a, uint32_t
   }
 }
 
+
+// cells by colour (any order inside a colour: its cells are independent of each other)
+__global__ __launch_bounds__(256) void pm_colour_lists_kernel(PmArgs a, uint32_t ncells, uint32_t* __restrict__ lists,
+                                                              uint32_t* __restrict__ counts) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t colour = c < ncells ? (a.crel[c] & 7u) : 8u;
+  for (uint32_t k = 0; k < 8u; ++k) {
+    const uint64_t mk = __ballot(colour == k);
+    if (!mk) continue;
+    const int leader = __ffsll((unsigned long long)mk) - 1;
+    uint32_t base = 0;
+    if ((int)lane_id() == leader) base = atomicAdd(&counts[k], (uint32_t)__popcll(mk));
+    base = __shfl(base, leader, WAVE);
+    if (colour == k) lists[(size_t)k * ncells + base + (uint32_t)__popcll(mk & lanemask_lt())] = c;
+  }
+}
+
+// Few points per cell (sparse levels): one LANE decides one cell.  First the taken points of the adjacent cells
+// strike out the cell's points (64 at a time, a bit mask), then the survivors run the greedy rule among themselves.
+__global__ __launch_bounds__(256) void pm_lane_kernel(PmArgs a, const uint32_t* __restrict__ list, uint32_t count) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t c = list[i];
+  const uint2 me = a.cell[c];
+  const double t = a.sq_spacing;
+  uint32_t fresh = 0;
+  for (uint32_t base = me.x; base < me.y; base += 64u) {
+    const uint32_t np = (me.y - base) < 64u ? (me.y - base) : 64u;
+    uint64_t rej = 0;
+    for (uint32_t k = 0; k < 27u; ++k) {
+      if (k == 13u) continue;
+      const uint32_t nb = a.nbr[(size_t)c * 27 + k];
+      if (nb == PM_NONE) continue;
+      const uint32_t cnt = a.ccnt[nb];
+      if (!cnt) continue;
+      const double* q = a.acc + (size_t)a.cell[nb].x * 3;
+      for (uint32_t j = 0; j < cnt; ++j) {
+        const double qx = q[3 * j], qy = q[3 * j + 1], qz = q[3 * j + 2];
+        for (uint32_t u = 0; u < np; ++u)
+          if (!((rej >> u) & 1ull) && sq_dist(a.X[base + u], a.Y[base + u], a.Z[base + u], qx, qy, qz) < t) rej |= 1ull << u;
+      }
+    }
+    for (uint32_t u = 0; u < np; ++u) {
+      if ((rej >> u) & 1ull) continue;
+      const double px = a.X[base + u], py = a.Y[base + u], pz = a.Z[base + u];
+      bool r = false;
+      for (uint32_t j = 0; j < fresh && !r; ++j) {  // own stores of this thread
+        const double* q = a.acc + (size_t)(me.x + j) * 3;
+        r = sq_dist(px, py, pz, q[0], q[1], q[2]) < t;
+      }
+      if (r) continue;
+      a.taken[base + u] = 1;
+      double* dst = a.acc + (size_t)(me.x + fresh) * 3;
+      dst[0] = px;
+      dst[1] = py;
+      dst[2] = pz;
+      ++fresh;
+    }
+  }
+  a.ccnt[c] = fresh;
+}
+
 __global__ __launch_bounds__(256) void pm_snode_flag_kernel(const uint8_t* __restrict__ nmode, uint32_t nnodes,
                                                             uint32_t* __restrict__ out) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -303,8 +367,7 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
                                 uint32_t* phases_out) {
   const uint32_t m = as.m;
   const uint32_t nsh = plan.node_shift;
-  // cells as fine as the spacing allows, coarsened (at most three levels) while an occupied cell would hold fewer
-  // than 24 points on average: one wavefront works on one cell
+  const auto wall0 = std::chrono::steady_clock::now();
   uint32_t occupied[12] = {0};
   {
     uint32_t* d_hist = nullptr;
@@ -322,9 +385,21 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
       occupied[b] = run;
     }
   }
+  // Cell size: coarser cells mean fewer, better filled cells, but every point is tested against the taken points of
+  // 27 cells: keep the expected number of taken points per cell small (<= 8).  A cell of side r spacings holds at
+  // most about 0.75 r^3 points that are pairwise a spacing apart (and never more than it has points).
+  const double node_ext = (plan.root.maxx - plan.root.minx) / std::pow(2.0, plan.level + 1);
+  const double r0 = node_ext / std::pow(2.0, plan.cell_levels_geo) / plan.spacing_node;  // finest cells, in spacings
   int cl = plan.cell_levels_geo;
-  while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0) --cl;
+  auto taken_estimate = [&](int lv) {
+    const double r = r0 * std::pow(2.0, plan.cell_levels_geo - lv);
+    const double pts = (double)sample_points / (double)std::max(1u, occupied[lv]);
+    return std::min(pts, 0.75 * r * r * r);
+  };
+  while (cl > 0 && plan.cell_levels_geo - cl < 3 && taken_estimate(cl - 1) <= 8.0) --cl;
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
+  const double pts_per_cell = (double)sample_points / (double)std::max(1u, occupied[cl]);
+  const bool lane_per_cell = pts_per_cell < 24.0;
   const uint64_t cells_per_node = 1ull << (3 * cl);
 
   PmArgs a{};
@@ -386,16 +461,38 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(pm_nbr_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
-  const uint32_t grid = std::min<uint32_t>(256u * 4u, std::max(1u, div_up(ncells, 8u * PM_WAVES)));
-  for (uint32_t colour = 0; colour < 8; ++colour) {
-    SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
-    hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, ncells, colour);
+  if (lane_per_cell) {
+    uint32_t *lists = nullptr, *counts = nullptr;
+    SWZ_TRY(c->get("pm_lists", (size_t)ncells * 8, &lists));
+    SWZ_TRY(c->get("pm_counts", (size_t)8, &counts));
+    SWZ_HIP(c, hipMemsetAsync(counts, 0, 32, c->stream));
+    hipLaunchKernelGGL(pm_colour_lists_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, lists, counts);
     SWZ_LAUNCH_CHECK(c);
+    uint32_t h[8];
+    SWZ_HIP(c, hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t colour = 0; colour < 8; ++colour) {
+      if (!h[colour]) continue;
+      hipLaunchKernelGGL(pm_lane_kernel, dim3(div_up(h[colour], 256)), dim3(256), 0, c->stream, a,
+                         lists + (size_t)colour * ncells, h[colour]);
+      SWZ_LAUNCH_CHECK(c);
+    }
+  } else {
+    const uint32_t grid = std::min<uint32_t>(256u * 5u, std::max(1u, div_up(ncells, 8u * PM_WAVES)));
+    for (uint32_t colour = 0; colour < 8; ++colour) {
+      SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
+      hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, ncells, colour);
+      SWZ_LAUNCH_CHECK(c);
+    }
   }
   if (phases_out) *phases_out += 8;
-  if (getenv("SWZ_DEBUG"))
-    fprintf(stderr, "[swz] MIN_DISTANCE property level %d: %u pts in %u nodes, cell levels %d of %d, %u cells\n", plan.level,
-            sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells);
+  if (getenv("SWZ_DEBUG")) {
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    fprintf(stderr, "[swz] MIN_DISTANCE property level %d: %u pts in %u nodes, cell levels %d of %d, %u cells (%.1f pts each), %s "
+            "per cell, %.1f ms\n", plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells, pts_per_cell,
+            lane_per_cell ? "lane" : "wavefront",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+  }
   return SWZ_OK;
 }
 
