@@ -240,21 +240,20 @@ __device__ void pm_cell(const PmArgs& a, uint32_t c, PmLds& lds) {
   if (l == 0) a.ccnt[c] = fresh;
 }
 
-// phase `colour`: wavefronts pull cells (eight at a time) and decide those of this colour
-__global__ __launch_bounds__(PM_THREADS) void pm_phase_kernel(PmArgs a, uint32_t ncells, uint32_t colour) {
+// phase `colour`: wavefronts pull cells of this colour from its list, sixteen per ticket (one atomic word serves
+// only ~90 tickets per microsecond)
+__global__ __launch_bounds__(PM_THREADS) void pm_phase_kernel(PmArgs a, const uint32_t* __restrict__ list, uint32_t count) {
   __shared__ PmLds lds[PM_WAVES];
   const uint32_t w = threadIdx.x / WAVE;
   for (;;) {
     uint32_t base = 0;
-    if (lane_id() == 0) base = atomicAdd(a.ticket, 8u);
+    if (lane_id() == 0) base = atomicAdd(a.ticket, 16u);
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (base >= ncells) return;
-    const uint32_t end = base + 8u < ncells ? base + 8u : ncells;
-    for (uint32_t c = base; c < end; ++c)
-      if ((a.crel[c] & 7u) == colour) pm_cell(a, c, lds[w]);
+    if (base >= count) return;
+    const uint32_t end = base + 16u < count ? base + 16u : count;
+    for (uint32_t i = base; i < end; ++i) pm_cell(a, list[i], lds[w]);
   }
 }
-
 
 // cells by colour (any order inside a colour: its cells are independent of each other)
 __global__ __launch_bounds__(256) void pm_colour_lists_kernel(PmArgs a, uint32_t ncells, uint32_t* __restrict__ lists,
@@ -272,51 +271,11 @@ __global__ __launch_bounds__(256) void pm_colour_lists_kernel(PmArgs a, uint32_t
   }
 }
 
-// Few points per cell (sparse levels): one LANE decides one cell.  First the taken points of the adjacent cells
-// strike out the cell's points (64 at a time, a bit mask), then the survivors run the greedy rule among themselves.
-__global__ __launch_bounds__(256) void pm_lane_kernel(PmArgs a, const uint32_t* __restrict__ list, uint32_t count) {
+__global__ __launch_bounds__(256) void pm_clear_taken_kernel(const uint32_t* __restrict__ nid, const uint8_t* __restrict__ nmode,
+                                                             uint32_t m, uint8_t* __restrict__ taken) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  const uint32_t c = list[i];
-  const uint2 me = a.cell[c];
-  const double t = a.sq_spacing;
-  uint32_t fresh = 0;
-  for (uint32_t base = me.x; base < me.y; base += 64u) {
-    const uint32_t np = (me.y - base) < 64u ? (me.y - base) : 64u;
-    uint64_t rej = 0;
-    for (uint32_t k = 0; k < 27u; ++k) {
-      if (k == 13u) continue;
-      const uint32_t nb = a.nbr[(size_t)c * 27 + k];
-      if (nb == PM_NONE) continue;
-      const uint32_t cnt = a.ccnt[nb];
-      if (!cnt) continue;
-      const double* q = a.acc + (size_t)a.cell[nb].x * 3;
-      for (uint32_t j = 0; j < cnt; ++j) {
-        const double qx = q[3 * j], qy = q[3 * j + 1], qz = q[3 * j + 2];
-        for (uint32_t u = 0; u < np; ++u)
-          if (!((rej >> u) & 1ull) && sq_dist(a.X[base + u], a.Y[base + u], a.Z[base + u], qx, qy, qz) < t) rej |= 1ull << u;
-      }
-    }
-    for (uint32_t u = 0; u < np; ++u) {
-      if ((rej >> u) & 1ull) continue;
-      const double px = a.X[base + u], py = a.Y[base + u], pz = a.Z[base + u];
-      bool r = false;
-      for (uint32_t j = 0; j < fresh && !r; ++j) {  // own stores of this thread
-        const double* q = a.acc + (size_t)(me.x + j) * 3;
-        r = sq_dist(px, py, pz, q[0], q[1], q[2]) < t;
-      }
-      if (r) continue;
-      a.taken[base + u] = 1;
-      double* dst = a.acc + (size_t)(me.x + fresh) * 3;
-      dst[0] = px;
-      dst[1] = py;
-      dst[2] = pz;
-      ++fresh;
-    }
-  }
-  a.ccnt[c] = fresh;
+  if (i < m && nmode[nid[i]] == MODE_SAMPLE) taken[i] = 0;
 }
-
 __global__ __launch_bounds__(256) void pm_snode_flag_kernel(const uint8_t* __restrict__ nmode, uint32_t nnodes,
                                                             uint32_t* __restrict__ out) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -396,10 +355,12 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
     const double pts = (double)sample_points / (double)std::max(1u, occupied[lv]);
     return std::min(pts, 0.75 * r * r * r);
   };
-  while (cl > 0 && plan.cell_levels_geo - cl < 3 && taken_estimate(cl - 1) <= 8.0) --cl;
+  // one wavefront per cell: coarsen while a cell holds fewer than 24 points, as long as the taken points stay few
+  while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0 &&
+         taken_estimate(cl - 1) <= 64.0)
+    --cl;
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
   const double pts_per_cell = (double)sample_points / (double)std::max(1u, occupied[cl]);
-  const bool lane_per_cell = pts_per_cell < 24.0;
   const uint64_t cells_per_node = 1ull << (3 * cl);
 
   PmArgs a{};
@@ -422,6 +383,17 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   hipLaunchKernelGGL(pm_snode_flag_kernel, dim3(div_up(nnodes, 256)), dim3(256), 0, c->stream, lb.nmode, nnodes, snode);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, snode, snode, nnodes, nullptr, "mdn"));
+  {
+    // Sparse levels (about one point per spacing-sized cell or fewer): the exact Morton-order greedy needs only a few
+    // dependent rounds there and one thread per point beats one wavefront per (nearly empty) cell -- the exact set
+    // has the property a fortiori (swz_mdsparse.hip).
+    bool used = false;
+    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes, sample_points, occupied, phases_out, &used));
+    if (used) return SWZ_OK;
+    // it may have given up half way (locally dense data): its decisions are those of ANOTHER priority order
+    hipLaunchKernelGGL(pm_clear_taken_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, lb.nid, lb.nmode, m, lb.taken);
+    SWZ_LAUNCH_CHECK(c);
+  }
   if (as.aidx) {  // below the root the survivors are a subsequence: positions into active order
     double* ax = nullptr;
     SWZ_TRY(c->get("md_pos", (size_t)m * 4, &ax));
@@ -461,36 +433,27 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(pm_nbr_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
-  if (lane_per_cell) {
-    uint32_t *lists = nullptr, *counts = nullptr;
-    SWZ_TRY(c->get("pm_lists", (size_t)ncells * 8, &lists));
-    SWZ_TRY(c->get("pm_counts", (size_t)8, &counts));
-    SWZ_HIP(c, hipMemsetAsync(counts, 0, 32, c->stream));
-    hipLaunchKernelGGL(pm_colour_lists_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, lists, counts);
+  uint32_t *lists = nullptr, *counts = nullptr;
+  SWZ_TRY(c->get("pm_lists", (size_t)ncells * 8, &lists));
+  SWZ_TRY(c->get("pm_counts", (size_t)8, &counts));
+  SWZ_HIP(c, hipMemsetAsync(counts, 0, 32, c->stream));
+  hipLaunchKernelGGL(pm_colour_lists_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, lists, counts);
+  SWZ_LAUNCH_CHECK(c);
+  uint32_t h[8];
+  SWZ_HIP(c, hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  for (uint32_t colour = 0; colour < 8; ++colour) {
+    if (!h[colour]) continue;
+    const uint32_t grid = std::min<uint32_t>(256u * 5u, std::max(1u, div_up(h[colour], 16u * PM_WAVES)));
+    SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
+    hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, lists + (size_t)colour * ncells, h[colour]);
     SWZ_LAUNCH_CHECK(c);
-    uint32_t h[8];
-    SWZ_HIP(c, hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, c->stream));
-    SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    for (uint32_t colour = 0; colour < 8; ++colour) {
-      if (!h[colour]) continue;
-      hipLaunchKernelGGL(pm_lane_kernel, dim3(div_up(h[colour], 256)), dim3(256), 0, c->stream, a,
-                         lists + (size_t)colour * ncells, h[colour]);
-      SWZ_LAUNCH_CHECK(c);
-    }
-  } else {
-    const uint32_t grid = std::min<uint32_t>(256u * 5u, std::max(1u, div_up(ncells, 8u * PM_WAVES)));
-    for (uint32_t colour = 0; colour < 8; ++colour) {
-      SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
-      hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, ncells, colour);
-      SWZ_LAUNCH_CHECK(c);
-    }
   }
   if (phases_out) *phases_out += 8;
   if (getenv("SWZ_DEBUG")) {
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    fprintf(stderr, "[swz] MIN_DISTANCE property level %d: %u pts in %u nodes, cell levels %d of %d, %u cells (%.1f pts each), %s "
-            "per cell, %.1f ms\n", plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells, pts_per_cell,
-            lane_per_cell ? "lane" : "wavefront",
+    fprintf(stderr, "[swz] MIN_DISTANCE property level %d: %u pts in %u nodes, cell levels %d of %d, %u cells (%.1f pts each), "
+            "%.1f ms\n", plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells, pts_per_cell,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
   }
   return SWZ_OK;
