@@ -349,16 +349,12 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   // most about 0.75 r^3 points that are pairwise a spacing apart (and never more than it has points).
   const double node_ext = (plan.root.maxx - plan.root.minx) / std::pow(2.0, plan.level + 1);
   const double r0 = node_ext / std::pow(2.0, plan.cell_levels_geo) / plan.spacing_node;  // finest cells, in spacings
+  // One wavefront per cell.  Coarser cells are better filled, but a cell of side r spacings can hold about
+  // 0.75 r^3 taken points and every point is tested against those of 27 cells: go one level coarser only when the
+  // finest cells are poorly filled and the coarser ones still hold few taken points WHATEVER their population (real
+  // data is clustered: an average says nothing about the dense parts).
   int cl = plan.cell_levels_geo;
-  auto taken_estimate = [&](int lv) {
-    const double r = r0 * std::pow(2.0, plan.cell_levels_geo - lv);
-    const double pts = (double)sample_points / (double)std::max(1u, occupied[lv]);
-    return std::min(pts, 0.75 * r * r * r);
-  };
-  // one wavefront per cell: coarsen while a cell holds fewer than 24 points, as long as the taken points stay few
-  while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0 &&
-         taken_estimate(cl - 1) <= 64.0)
-    --cl;
+  if (cl > 0 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0 && 0.75 * 8.0 * r0 * r0 * r0 <= 48.0) --cl;
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
   const double pts_per_cell = (double)sample_points / (double)std::max(1u, occupied[cl]);
   const uint64_t cells_per_node = 1ull << (3 * cl);

@@ -117,7 +117,6 @@ def test_property_mode_small(ctx, kind, d, max_points):
     # same kind of sample as the exact greedy: the root takes a similar number of points
     te, tp = int((exact.level == -1).sum()), int((r.level == -1).sum())
     assert 0.85 < tp / te < 1.15, (te, tp)
-    assert r.stats["min_distance_rounds"] % 8 == 0  # eight phases per sampled level
 
 
 def test_property_mode_fast_strategy_and_multibatch(ctx):
