@@ -234,6 +234,28 @@ int swz_node_bounds(int8_t node_level, uint64_t node_key, const double root_min[
                     double min_out[3], double max_out[3]);
 double swz_node_geometric_error(int8_t node_level, float spacing_at_root);
 
+/* Tileset tree of a node table (Cesium3DTilesPersistence::on_write_node / write_tilesets, core/io/
+ * Cesium3DTilesPersistence.cpp:80-156, 175-199): one entry per node of the table AND per ancestor the table does not
+ * list, ordered by (level, Morton index) so that the children of an entry are contiguous, by octant.
+ *   has_content: the node is in the table (it has a point file); is_tileset_root: a new tileset.json starts here
+ *   (every third level); bounds are the node box translated by global_offset (NULL = none).
+ * out == NULL only counts (*num_out). */
+typedef struct {
+  int8_t level;              /* -1 = root "r" */
+  uint8_t has_content;
+  uint8_t is_tileset_root;
+  uint8_t reserved;
+  uint32_t num_children;
+  uint64_t key;
+  int64_t parent;            /* index into the output, -1 for the root */
+  int64_t first_child;       /* -1 when there are none */
+  double geometric_error;
+  double bounds_min[3], bounds_max[3];
+} swz_tileset_node;
+int swz_tileset_build(uint64_t num_nodes, const int8_t* node_level, const uint64_t* node_key, const double root_min[3],
+                      const double root_max[3], float spacing_at_root, const double global_offset[3], uint64_t max_out,
+                      swz_tileset_node* out, uint64_t* num_out);
+
 /* ---- LAS point records -> positions + attribute columns: the step right in
  * front of the path.  The reference reads points through LASzip into a laszip_point and converts them in
  * position_from_las_point (core/io/LASFile.cpp:79-94: offset + X * scale per axis, then clamped into the

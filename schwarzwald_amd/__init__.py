@@ -9,9 +9,9 @@ from .api import (ACCURATE, FLAG_MIN_DISTANCE_PROPERTY, ALWAYS_ADHERE_TO_MIN_SPA
                   SAMPLERS, TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS, Context, SwzError, TileParams, TileResult,
                   ATTRIBUTES, bin_read_node, bin_write_node, library_path, load_library, node_bounds,
                   node_from_entwine_name, node_geometric_error, node_name, node_name_entwine,
-                  spacing_from_diagonal, Tiler, pinned_empty)
+                  spacing_from_diagonal, Tiler, pinned_empty, tileset_build)
 
-__all__ = ["FLAG_MIN_DISTANCE_PROPERTY", "Context", "Tiler", "pinned_empty", "SwzError", "TileParams", "TileResult", "load_library", "library_path", "SAMPLERS",
+__all__ = ["tileset_build", "FLAG_MIN_DISTANCE_PROPERTY", "Context", "Tiler", "pinned_empty", "SwzError", "TileParams", "TileResult", "load_library", "library_path", "SAMPLERS",
            "RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED", "ACCURATE", "FAST",
            "TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS", "ALWAYS_ADHERE_TO_MIN_SPACING", "spacing_from_diagonal", "ATTRIBUTES", "bin_write_node", "bin_read_node",
            "node_name", "node_name_entwine", "node_from_entwine_name", "node_bounds", "node_geometric_error"]

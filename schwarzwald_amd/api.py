@@ -162,6 +162,32 @@ def node_geometric_error(level, spacing_at_root):
     return float(load_library().swz_node_geometric_error(int(level), C.c_float(spacing_at_root)))
 
 
+class _TilesetNode(C.Structure):
+    _fields_ = [("level", C.c_int8), ("has_content", C.c_uint8), ("is_tileset_root", C.c_uint8), ("reserved", C.c_uint8),
+                ("num_children", C.c_uint32), ("key", C.c_uint64), ("parent", C.c_int64), ("first_child", C.c_int64),
+                ("geometric_error", C.c_double), ("bounds_min", C.c_double * 3), ("bounds_max", C.c_double * 3)]
+
+
+def tileset_build(node_level, node_key, root_min, root_max, spacing_at_root, global_offset=None):
+    """Tileset tree of a node table (Cesium3DTilesPersistence.cpp:80-156): list of dicts ordered by (level, key)."""
+    L = load_library()
+    lv = np.ascontiguousarray(node_level, dtype=np.int8)
+    key = np.ascontiguousarray(node_key, dtype=np.uint64)
+    off = _vec3(global_offset) if global_offset is not None else None
+    num = C.c_uint64()
+    args = (lv.shape[0], lv.ctypes.data_as(_i8p), key.ctypes.data_as(_u64p), _vec3(root_min), _vec3(root_max),
+            C.c_float(spacing_at_root), off)
+    if L.swz_tileset_build(*args, 0, None, C.byref(num)) != 0:
+        raise ValueError("bad node table")
+    buf = (_TilesetNode * max(int(num.value), 1))()
+    if L.swz_tileset_build(*args, int(num.value), buf, C.byref(num)) != 0:
+        raise ValueError("bad node table")
+    return [dict(level=int(t.level), key=int(t.key), has_content=bool(t.has_content), is_tileset_root=bool(t.is_tileset_root),
+                 num_children=int(t.num_children), parent=int(t.parent), first_child=int(t.first_child),
+                 geometric_error=float(t.geometric_error), bounds_min=list(t.bounds_min), bounds_max=list(t.bounds_max))
+            for t in buf[:int(num.value)]]
+
+
 def bin_write_node(path, xyz, attrs=None, compressed=False):
     """BinaryPersistence::persist_points for one node (host only, no GPU needed)."""
     x = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
@@ -270,6 +296,9 @@ def load_library():
     L.swz_node_bounds.argtypes = [C.c_int8, C.c_uint64, _dp, _dp, _dp, _dp]
     L.swz_node_geometric_error.argtypes = [C.c_int8, C.c_float]
     L.swz_node_geometric_error.restype = C.c_double
+    L.swz_tileset_build.argtypes = [C.c_uint64, _i8p, _u64p, _dp, _dp, C.c_float, _dp, C.c_uint64,
+                                    C.POINTER(_TilesetNode), _u64p]
+    L.swz_tileset_build.restype = C.c_int
     L.swz_las_decode_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(_LasLayout), vp, cols]
     L.swz_partition_by_octant_device.argtypes = [vp, vp, C.c_uint64, vp, _u64p]
     L.swz_shard_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.POINTER(_ShardInfo),

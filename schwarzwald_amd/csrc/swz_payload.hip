@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -302,6 +303,68 @@ int swz_node_bounds(int8_t node_level, uint64_t node_key, const double root_min[
 
 double swz_node_geometric_error(int8_t node_level, float spacing_at_root) {
   return spacing_at_root / std::pow(2.0, (double)(node_level + 1));
+}
+
+// Cesium3DTilesPersistence::on_write_node (core/io/Cesium3DTilesPersistence.cpp:80-156): every written node makes a
+// Tileset for itself and for every ancestor that has none yet; name, geometricError = spacing_at_root / 2^depth
+// (:91-92), bounds by descending from the root box octant by octant (:100-112, 136) translated by the global offset
+// (:88); write_tilesets (:175-199) starts a new tileset.json every MAX_DEPTH + 1 = 3 levels.  The reference keeps
+// children in the order its worker threads happened to write them; here they are ordered by octant.
+int swz_tileset_build(uint64_t num_nodes, const int8_t* node_level, const uint64_t* node_key, const double root_min[3],
+                      const double root_max[3], float spacing_at_root, const double global_offset[3], uint64_t max_out,
+                      swz_tileset_node* out, uint64_t* num_out) {
+  if (!num_out || (num_nodes && (!node_level || !node_key)) || !root_min || !root_max) return SWZ_ERR_BAD_ARG;
+  *num_out = 0;
+  // all nodes and their ancestors, keyed by (level, prefix): std::map iterates in (level, key) order
+  std::map<std::pair<int, uint64_t>, uint8_t> all;
+  for (uint64_t j = 0; j < num_nodes; ++j) {
+    const int lv = node_level[j];
+    if (lv < -1 || lv > 20) return SWZ_ERR_BAD_ARG;
+    for (int l = lv; l >= -1; --l) {
+      const uint64_t key = l < 0 ? 0ull : ((node_key[j] >> level_shift(l)) << level_shift(l));
+      uint8_t& flag = all[{l, key}];
+      if (l == lv) {
+        flag = 1;
+      } else if (all.size() == 0) {
+        break;
+      }
+    }
+  }
+  const uint64_t total = all.size();
+  *num_out = total;
+  if (!out) return SWZ_OK;
+  if (total > max_out) return SWZ_ERR_BAD_ARG;
+  std::map<std::pair<int, uint64_t>, uint64_t> index;
+  uint64_t k = 0;
+  for (const auto& kv : all) index[kv.first] = k++;
+  k = 0;
+  for (const auto& kv : all) {
+    swz_tileset_node& t = out[k];
+    std::memset(&t, 0, sizeof(t));
+    const int lv = kv.first.first;
+    t.level = (int8_t)lv;
+    t.key = kv.first.second;
+    t.has_content = kv.second;
+    t.parent = -1;
+    t.first_child = -1;
+    if (lv >= 0) {
+      const uint64_t pkey = lv == 0 ? 0ull : ((t.key >> level_shift(lv - 1)) << level_shift(lv - 1));
+      const uint64_t p = index[{lv - 1, pkey}];
+      t.parent = (int64_t)p;
+      if (out[p].first_child < 0) out[p].first_child = (int64_t)k;  // (level, key) order: children are contiguous
+      out[p].num_children += 1;
+    }
+    t.is_tileset_root = ((lv + 1) % 3 == 0) ? 1 : 0;
+    t.geometric_error = swz_node_geometric_error((int8_t)lv, spacing_at_root);
+    swz_node_bounds((int8_t)lv, t.key, root_min, root_max, t.bounds_min, t.bounds_max);
+    for (int ax = 0; ax < 3; ++ax) {  // AABB::translate(_global_offset), :88
+      const double off = global_offset ? global_offset[ax] : 0.0;
+      t.bounds_min[ax] += off;
+      t.bounds_max[ax] += off;
+    }
+    ++k;
+  }
+  return SWZ_OK;
 }
 
 int swz_bin_write_node(swz_ctx* c, const char* path, uint64_t count, const double* xyz, const swz_attribute_columns* columns,

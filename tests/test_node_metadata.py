@@ -53,3 +53,72 @@ def test_geometric_error_halves_per_level():
     s = O.spacing_from_diagonal(*UNIT, 250)
     assert swz.node_geometric_error(-1, s) == float(np.float32(s))           # the root: depth 0
     assert swz.node_geometric_error(3, s) == float(np.float32(s)) / 16.0
+
+
+def _python_tileset(levels, keys, bmin, bmax, spacing, offset):
+    """Cesium3DTilesPersistence::on_write_node restated on node names (Cesium3DTilesPersistence.cpp:80-156): every
+    written node creates itself and its missing ancestors; bounds by descending get_octant_bounds from the root."""
+    import schwarzwald_amd as swz
+    names = {}
+    for lv, key in zip(levels, keys):
+        name = swz.node_name(int(lv), int(key))
+        for cut in range(1, len(name) + 1):
+            names.setdefault(name[:cut], False)
+        names[name] = True
+    out = {}
+    for name, content in names.items():
+        mn, mx = list(bmin), list(bmax)
+        for ch in name[1:]:
+            mn, mx = O.octant_bounds(int(ch), mn, mx)
+        depth = len(name) - 1
+        out[name] = dict(has_content=content, geometric_error=float(np.float32(spacing)) / 2.0 ** depth,
+                         bounds_min=[a + b for a, b in zip(mn, offset)], bounds_max=[a + b for a, b in zip(mx, offset)],
+                         children=sorted(n for n in names if len(n) == len(name) + 1 and n.startswith(name)),
+                         is_tileset_root=depth % 3 == 0)
+    return out
+
+
+def _check_tileset(levels, keys, bmin, bmax, spacing, offset):
+    import schwarzwald_amd as swz
+    tree = swz.tileset_build(levels, keys, bmin, bmax, spacing, offset)
+    want = _python_tileset(levels, keys, bmin, bmax, spacing, offset)
+    assert len(tree) == len(want)
+    names = [swz.node_name(t["level"], t["key"]) for t in tree]
+    assert names == sorted(names, key=lambda s: (len(s), s)) and set(names) == set(want)
+    for i, (t, name) in enumerate(zip(tree, names)):
+        w = want[name]
+        assert t["has_content"] == w["has_content"] and t["is_tileset_root"] == w["is_tileset_root"]
+        assert t["geometric_error"] == w["geometric_error"]
+        assert t["bounds_min"] == w["bounds_min"] and t["bounds_max"] == w["bounds_max"]
+        kids = [names[j] for j in range(t["first_child"], t["first_child"] + t["num_children"])] if t["num_children"] else []
+        assert kids == w["children"]
+        for j in range(t["first_child"], t["first_child"] + t["num_children"]):
+            assert tree[j]["parent"] == i
+        assert (t["parent"] == -1) == (name == "r")
+    return tree
+
+
+def test_tileset_tree_fills_in_missing_ancestors():
+    """A FAST-style table without the skipped levels: the ancestors appear without content."""
+    keys = [_key([1, 2, 3]), _key([1, 2, 4]), _key([7, 0, 0]), _key([7, 0, 0, 5])]
+    levels = [2, 2, 2, 3]
+    bmin, bmax = [-512.25, 1000.5, -3.125], [-512.25 + 777.7, 1000.5 + 777.7, -3.125 + 777.7]
+    tree = _check_tileset(levels, keys, bmin, bmax, 5.5, [10.0, -20.0, 0.25])
+    assert sum(t["has_content"] for t in tree) == 4 and len(tree) == 1 + 2 + 2 + 3 + 1
+
+
+@pytest.mark.gpu
+def test_tileset_tree_of_a_gpu_node_table():
+    """Names, bounds, geometric errors and the child lists derived from a node table the GPU produced."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(12)
+    xyz = rng.random((200000, 3))
+    sp = O.spacing_from_diagonal(*UNIT, 250)
+    with swz.Context(0) as ctx:
+        r = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.GRID_CENTER, max_points_per_node=500, spacing_at_root=sp))
+        order, nodes = ctx.build_node_lists(r.keys, r.level)
+    ref = O.tile(xyz, *UNIT, O.GRID_CENTER, 500, sp)
+    assert len(nodes["level"]) == ref["stats"]["num_nodes"]
+    tree = _check_tileset(nodes["level"], nodes["key"], *UNIT, sp, [0.0, 0.0, 0.0])
+    assert all(t["has_content"] for t in tree)          # ACCURATE: every ancestor holds points itself
+    assert len(tree) == len(nodes["level"])
