@@ -99,6 +99,13 @@ int swz_sample_points(swz_ctx* ctx, int sampler, uint64_t max_points_per_node, c
                       const double root_max[3], float spacing_at_root, int behaviour,
                       uint8_t* taken_out, uint64_t* num_taken_out);
 
+/* required_morton_index_depth (core/tiling/Sampling.cpp:29-62 with get_node_level_to_sample_from /
+ * first_node_level_obeying_spacing, core/tiling/Node.cpp:37-57): the depth of key bits a sampler needs at a node of
+ * level node_level -- what tile_node's terminal / re-root tests use (TilingAlgorithms.cpp:408-444).  Host function,
+ * evaluated with the host's libm exactly like the reference (std::log2f of the ratio narrowed to float). */
+int32_t swz_required_morton_index_depth(int sampler, int32_t node_level, const double root_min[3],
+                                        const double root_max[3], float spacing_at_root);
+
 /* ---- one batch through the tiling algorithm: TilingAlgorithmBase::build_execution_graph
  * (core/tiling/TilingAlgorithms.h:81-85), V1 = ACCURATE (TilingAlgorithms.cpp:577-626),
  * V3 = FAST first iteration + finalize (:1250-1360, :1661-1784). */

@@ -162,6 +162,15 @@ def node_geometric_error(level, spacing_at_root):
     return float(load_library().swz_node_geometric_error(int(level), C.c_float(spacing_at_root)))
 
 
+def required_morton_index_depth(sampler, node_level, root_min, root_max, spacing_at_root):
+    """required_morton_index_depth of the reference (Sampling.cpp:29-62) as the library evaluates it."""
+    L = load_library()
+    L.swz_required_morton_index_depth.restype = C.c_int32
+    L.swz_required_morton_index_depth.argtypes = [C.c_int, C.c_int32, _dp, _dp, C.c_float]
+    return int(L.swz_required_morton_index_depth(int(sampler), int(node_level), _vec3(root_min), _vec3(root_max),
+                                                 C.c_float(spacing_at_root)))
+
+
 class _TilesetNode(C.Structure):
     _fields_ = [("level", C.c_int8), ("has_content", C.c_uint8), ("is_tileset_root", C.c_uint8), ("reserved", C.c_uint8),
                 ("num_children", C.c_uint32), ("key", C.c_uint64), ("parent", C.c_int64), ("first_child", C.c_int64),

@@ -475,6 +475,14 @@ static int required_depth_host(int sampler, int node_level, double root_extent_x
   }
 }
 
+}  // namespace swz
+extern "C" int32_t swz_required_morton_index_depth(int sampler, int32_t node_level, const double root_min[3],
+                                                   const double root_max[3], float spacing_at_root) {
+  if (!root_min || !root_max) return INT32_MIN;
+  return swz::required_depth_host(sampler, node_level, root_max[0] - root_min[0], spacing_at_root);
+}
+namespace swz {
+
 LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_at_root, uint32_t max_depth,
                            const double bmin[3], const double bmax[3], bool force_sample, bool tiler_rules) {
   LevelPlan p;

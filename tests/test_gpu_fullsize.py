@@ -180,3 +180,115 @@ def test_random_grid_takes_the_first_point_of_every_cell(tiled):
         head[1:] = cell[1:] != cell[:-1]
         want_taken = torch.where(sampling, head, torch.ones_like(head))
         assert bool(((lv == L) == want_taken).all()), "level %d" % L
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GRID_CENTER and JITTERED at full size (BASELINE config 2: 100 M uniform points, GRID_CENTER, one GPU), checked against
+# an independent characterisation evaluated with torch on the whole output: in a sampling node at level L every run of
+# equal key prefix at the grid level (L + 7 for d = 250 on a cube) takes exactly one point, the FIRST one (Morton
+# order) with the smallest (dx*dx + dy*dy) + dz*dz to the cell's target -- the centre of the cell's box
+# (GridCenterSampling, Sampling.h:387-403) or the jittered target node_min + (g * cell + (P - 1) * cell / cells)
+# (JitteredSampling, Sampling.h:655-750).  In the unit cube every box edge is a dyadic rational, so targets are exact
+# in any evaluation order and the check does not depend on the oracle.
+def _contract3(v, torch):
+    """every third bit of v (torch int64) -> compact integer: contract_bits_by_3 (stuff.h:223-234)"""
+    v = v & 0x1249249249249249
+    v = (v | (v >> 2)) & 0x30C30C30C30C30C3
+    v = (v | (v >> 4)) & 0xF00F00F00F00F00F
+    v = (v | (v >> 8)) & 0x00FF0000FF0000FF
+    v = (v | (v >> 16)) & 0x00FF00000000FFFF
+    v = (v | (v >> 32)) & 0x00000000FFFFFFFF
+    return v
+
+
+def _jitter_tables():
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "jitter_tables.inc")).read()
+    out = {}
+    for w in (16, 32, 64):
+        body = text.split("SWZ_JITTER_TABLE(%d)" % w)[1].split("};")[0]
+        nums = [int(x) for x in re.findall(r"\b\d+\b", body)]
+        out[w] = np.array(nums[-16 * w:], dtype=np.int64).reshape(16, w)
+    return out
+
+
+@pytest.mark.parametrize("sampler_name", ["GRID_CENTER", "JITTERED"])
+def test_grid_samplers_take_the_first_argmin_of_every_cell(sampler_name):
+    import torch
+    import schwarzwald_amd as swz
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    ctx = swz.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    n = min(N, 100_000_000)
+    xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    ctx.generate_uniform_device(SEED, 0, n, xyz.data_ptr())
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    keys = torch.empty(n, dtype=torch.int64, device=dev)
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    level = torch.empty(n, dtype=torch.int8, device=dev)
+    params = swz.TileParams(sampler=getattr(swz, sampler_name), max_points_per_node=MAX_POINTS, spacing_at_root=spacing)
+    stats = ctx.tile_device(xyz.data_ptr(), n, *UNIT, params, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+    torch.cuda.synchronize()
+    ctx.release_workspace()
+    ctx.close()
+    assert int(level.min()) >= -1 and int(level.max()) == stats["max_level"]
+    tables = _jitter_tables()
+    levels_grid = 7  # prev_pow2((uint32)(extent / spacing)) = 128 cells per axis and node at d = 250
+    checked = 0
+    for L in range(-1, stats["max_level"] + 1):
+        active = torch.nonzero(level >= L).squeeze(1)
+        if active.numel() == 0:
+            continue
+        k = keys[active]
+        shift = 63 - 3 * (L + 1)
+        node = (k >> shift) if shift < 63 else torch.zeros_like(k)
+        _, inv, counts = torch.unique_consecutive(node, return_inverse=True, return_counts=True)
+        sampling = (counts > MAX_POINTS)[inv]
+        taken = level[active] == L
+        assert bool(taken[~sampling].all()), "level %d: a node with <= max points did not take everything" % L
+        if not bool(sampling.any()):
+            continue
+        grid_level = L + levels_grid
+        assert grid_level <= 20
+        csh = 3 * (20 - grid_level)
+        cell = k >> csh                                    # prefix with grid_level + 1 octants
+        depth = grid_level + 1
+        gx, gy, gz = _contract3(cell >> 2, torch), _contract3(cell >> 1, torch), _contract3(cell, torch)
+        pos = xyz[perm[active].long()]
+        size = 0.5 ** depth
+        if sampler_name == "GRID_CENTER":
+            tx = (gx.double() + 0.5) * size
+            ty = (gy.double() + 0.5) * size
+            tz = (gz.double() + 0.5) * size
+        else:
+            cells = 1 << levels_grid
+            m = cells - 1
+            lx, ly, lz = gx & m, gy & m, gz & m           # cell inside the node
+            start = (3 * (L + 1)) % 16
+            tab = torch.from_numpy(tables[64]).to(dev)
+            plen = 64
+            px = tab[start][((ly + lz) % plen)] - 1
+            py = tab[(start + 1) % 16][((lx + lz) % plen)] - 1
+            pz = tab[(start + 2) % 16][((lx + ly) % plen)] - 1
+            perm_size = size / cells
+            tx = gx.double() * size + px.double() * perm_size   # node_min + (g_local * cell + p * perm) with exact dyadics
+            ty = gy.double() * size + py.double() * perm_size
+            tz = gz.double() * size + pz.double() * perm_size
+        dx, dy, dz = pos[:, 0] - tx, pos[:, 1] - ty, pos[:, 2] - tz
+        d2 = (dx * dx + dy * dy) + dz * dz
+        del pos, tx, ty, tz, dx, dy, dz
+        _, cinv = torch.unique_consecutive(cell, return_inverse=True)
+        ncell = int(cinv.max()) + 1
+        dmin = torch.full((ncell,), float("inf"), dtype=torch.float64, device=dev).scatter_reduce(0, cinv, d2, "amin")
+        idx = torch.arange(k.numel(), device=dev)
+        cand_idx = torch.where(d2 == dmin[cinv], idx, torch.full_like(idx, k.numel()))
+        first = torch.full((ncell,), k.numel(), dtype=torch.int64, device=dev).scatter_reduce(0, cinv, cand_idx, "amin")
+        want = torch.zeros_like(taken)
+        want[first] = True
+        bad = (want != taken) & sampling
+        assert not bool(bad.any()), "level %d: %d points decided differently" % (L, int(bad.sum()))
+        checked += int(sampling.sum())
+        del k, node, cell, d2, cinv, dmin, cand_idx, first, want, bad
+    print("%s, %d points: %d point decisions verified" % (sampler_name, n, checked))
+    assert checked >= n

@@ -122,3 +122,33 @@ def test_tileset_tree_of_a_gpu_node_table():
     tree = _check_tileset(nodes["level"], nodes["key"], *UNIT, sp, [0.0, 0.0, 0.0])
     assert all(t["has_content"] for t in tree)          # ACCURATE: every ancestor holds points itself
     assert len(tree) == len(nodes["level"])
+
+
+def test_required_morton_index_depth_matches_the_oracle_near_powers_of_two():
+    """log2f of a ratio narrowed to float decides the depth; spacings whose ratio to the extent
+    is within a few float ulps of a power of two are where a different evaluation order would show."""
+    from schwarzwald_amd.api import required_morton_index_depth
+    rng = np.random.default_rng(9)
+    cases = 0
+    for ext in (1.0, 777.7, 1048576.0, 0.001953125, 3.3e-3):
+        bmin = [-1.5, 2.0, 0.25]
+        bmax = [bmin[0] + ext, bmin[1] + ext, bmin[2] + ext]
+        e = bmax[0] - bmin[0]
+        for k in range(1, 30):
+            base = np.float32(e / 2.0 ** k)
+            for ulps in (-3, -2, -1, 0, 1, 2, 3):
+                sp = float(np.nextafter(base, np.float32(np.inf if ulps > 0 else -np.inf)) if abs(ulps) == 1 else
+                           base * np.float32(1.0 + ulps * 2.0 ** -23))
+                for sampler in (O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED):
+                    for lv in (-1, 0, 1, 5, 13, 14, 19, 20):
+                        want = O.lib().orc_required_morton_index_depth(sampler, lv, O._vec3(bmin), O._vec3(bmax),
+                                                                       O.C.c_float(sp))
+                        assert required_morton_index_depth(sampler, lv, bmin, bmax, sp) == want, (ext, k, ulps, sampler, lv)
+                        cases += 1
+        for _ in range(200):
+            sp = float(np.float32(e * 10.0 ** rng.uniform(-7, 0.5)))
+            for sampler in range(4):
+                lv = int(rng.integers(-1, 21))
+                want = O.lib().orc_required_morton_index_depth(sampler, lv, O._vec3(bmin), O._vec3(bmax), O.C.c_float(sp))
+                assert required_morton_index_depth(sampler, lv, bmin, bmax, sp) == want
+    assert cases > 10000
