@@ -85,6 +85,8 @@ struct LevelResult {
 LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_at_root, uint32_t max_depth,
                     const double bmin[3], const double bmax[3], bool force_sample, bool tiler_rules);
 int alloc_level_buffers(swz_ctx* c, uint32_t m, LevelBuffers* lb);
+// required_morton_index_depth -- core/tiling/Sampling.cpp:29-62, for a root node with this x extent and max_spacing
+int required_depth_host(int sampler, int node_level, double root_extent_x, float root_max_spacing);
 // Samples every node of the level.  When okey/oidx are given the survivors are compacted into them and level_out
 // receives plan.level for the taken points; otherwise only lb.taken is produced.
 int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,

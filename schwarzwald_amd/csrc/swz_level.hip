@@ -457,7 +457,7 @@ static uint32_t prev_pow2_host(uint32_t x) {
   return x - (x >> 1);
 }
 // required_morton_index_depth -- core/tiling/Sampling.cpp:29-62
-static int required_depth_host(int sampler, int node_level, double root_extent_x, float root_max_spacing) {
+int required_depth_host(int sampler, int node_level, double root_extent_x, float root_max_spacing) {
   switch (sampler) {
     case SWZ_RANDOM_GRID:
     case SWZ_GRID_CENTER:

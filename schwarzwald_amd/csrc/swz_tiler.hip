@@ -256,6 +256,51 @@ struct HeadG {
   }
 };
 
+// ---- re-rooting (tile_node, TilingAlgorithms.cpp:444-483)
+// calculate_morton_index<21>(position, new_root.bounds), no clamp (:470-473)
+__global__ __launch_bounds__(256) void rr_encode_kernel(const uint32_t* __restrict__ idx, uint32_t m,
+                                                        const double* __restrict__ X, const double* __restrict__ Y,
+                                                        const double* __restrict__ Z, Box b, uint64_t* __restrict__ keys) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t p = idx[i];
+  keys[i] = morton_in_box(X[p], Y[p], Z[p], b);
+}
+// partition_points_into_child_octants (OctreeAlgorithms.h:240-265): the range of octant o ends at the first element
+// at or behind its start whose octant at the given level is > o (std::find_if) -- on re-rooted keys split at the
+// ABSOLUTE child level (TilingAlgorithms.cpp:124-125) the octants do not ascend, so this is not a digit histogram
+__global__ __launch_bounds__(256) void rr_split_kernel(const uint64_t* __restrict__ keys, uint32_t m, uint32_t shift,
+                                                       uint32_t octant, uint32_t* __restrict__ bounds) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t start = bounds[octant];
+  const bool hit = i < m && i >= start && (uint32_t)((keys[i] >> shift) & 7u) > octant;
+  const uint64_t b = __ballot(hit);
+  if (b && lane_id() == (uint32_t)(__ffsll((unsigned long long)b) - 1)) atomicMin(&bounds[octant + 1], i);
+}
+__global__ void rr_split_init_kernel(uint32_t* bounds, uint32_t m) {
+  if (threadIdx.x < 9) bounds[threadIdx.x] = threadIdx.x == 0 ? 0u : m;
+}
+// bounds[o + 1] must not lie before bounds[o] when nothing was found behind it (it stays m) -- nothing to fix up
+__global__ __launch_bounds__(256) void rr_iota_kernel(uint32_t* __restrict__ out, uint32_t m) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) out[i] = i;
+}
+struct TakeNodeG {  // taken points of ONE node in the order of the range; every entry carries the node's key
+  const uint32_t* idx;
+  const uint32_t* wgid;
+  uint64_t node_key;
+  uint64_t* tkey;
+  uint32_t* tgid;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t t) const {
+    if (!t) return;
+    tkey[excl] = node_key;
+    tgid[excl] = wgid[idx[i]];
+  }
+};
+struct AllF {
+  __device__ uint32_t operator()(uint32_t) const { return 1u; }
+};
+
 __global__ __launch_bounds__(256) void tl_fill_level_kernel(int8_t* __restrict__ out, uint32_t n, int8_t v) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = v;
@@ -460,6 +505,193 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, Active
   return SWZ_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- re-rooting
+// A node whose sampler needs more than 21 key levels below the root becomes the root of a new 21-level index
+// (tile_node, TilingAlgorithms.cpp:444-483): all its points (new ++ cached, unsorted) are re-indexed against the
+// NODE's bounds, sorted, and sampled as that root's level -1 with the node's own max_spacing.  Its children inherit
+// the new root, so every node below re-roots again until the levels run out (level >= min(20, max_depth): terminal).
+// Such nodes are rare (> max_points_per_node points inside a cell 2^-15 of the root's extent at d = 250) and handled
+// one node at a time by the host, every step on the device.  Literal like the oracle, including that the children
+// are split at the ABSOLUTE level of the re-rooted keys (:124-125 via :479-482) and that a point outside the box it
+// is re-indexed against goes through static_cast<uint64_t> of a negative double as x86-64 evaluates it.
+struct RrNode {
+  int level;
+  uint64_t key;
+  double bmin[3], bmax[3];
+  float max_spacing;
+};
+struct RrTotals {
+  uint64_t nodes = 0, visited = 0;
+  int max_level = -1;
+};
+
+static int rr_store_node(swz_tiler* t, int level, const uint64_t* rkey, const uint32_t* rgid, uint32_t nr,
+                         const uint64_t* tkey, const uint32_t* tgid, uint32_t nt) {
+  swz_ctx* c = t->c;
+  StoreLevel& st = t->lv[level + 1];
+  const int dst = st.cur ^ 1;
+  SWZ_TRY(store_reserve(c, st, dst, (size_t)nr + nt));
+  SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey, tgid, nt, level < 0 ? 63u : level_shift(level), 0u, st.key[dst], st.gid[dst]));
+  st.cur = dst;
+  st.cnt = nr + nt;
+  return SWZ_OK;
+}
+
+static int rr_node(swz_tiler* t, BatchWork& w, const RrNode& node, double root_ext_x, float root_max_spacing,
+                   const uint32_t* d_idx, uint32_t cnt, int depth, RrTotals& tot) {
+  swz_ctx* c = t->c;
+  if (depth > 24) return c->fail(SWZ_ERR_INTERNAL, "re-rooting recursed too deep");
+  const uint32_t nsh = level_shift(node.level);
+  uint32_t* counters = nullptr;
+  SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+  // ---- the node's file (read_pnts_from_disk; the re-keying is irrelevant: everything is re-indexed or appended)
+  StoreLevel& st = t->lv[node.level + 1];
+  uint64_t *ckey = nullptr, *rkey = nullptr;
+  uint32_t *cgid = nullptr, *rgid = nullptr;
+  uint32_t nc = 0, nr = 0;
+  if (st.cnt) {
+    uint8_t* touch = nullptr;
+    uint64_t* d_nodekey = nullptr;
+    SWZ_TRY(c->get("tl_touch", (size_t)st.cnt, &touch));
+    SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
+    SWZ_TRY(c->get("tl_cgid", (size_t)st.cnt, &cgid));
+    SWZ_TRY(c->get("tl_rkey", (size_t)st.cnt, &rkey));
+    SWZ_TRY(c->get("tl_rgid", (size_t)st.cnt, &rgid));
+    SWZ_TRY(c->get("rr_nodekey", (size_t)1, &d_nodekey));
+    SWZ_HIP(c, hipMemcpyAsync(d_nodekey, &node.key, 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(tl_touch_kernel, dim3(div_up(st.cnt, 256)), dim3(256), 0, c->stream, st.key[st.cur], st.cnt,
+                       d_nodekey, 1u, nsh, touch);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(fused_scan(c, TouchF{touch}, SplitG{st.key[st.cur], st.gid[st.cur], ckey, cgid, rkey, rgid}, st.cnt, counters, "tl"));
+    SWZ_TRY(read_u32(c, counters, &nc));
+    nr = st.cnt - nc;
+  }
+  const uint32_t m = cnt + nc;
+  tot.nodes += 1;
+  tot.visited += m;
+  tot.max_level = std::max(tot.max_level, node.level);
+  // all = node_data ++ cached (merge_node_data_unsorted), as working-pool indices
+  const std::string sfx = std::to_string(depth);
+  uint32_t* all = nullptr;
+  SWZ_TRY(c->get(("rr_all_" + sfx).c_str(), (size_t)m, &all));
+  SWZ_HIP(c, hipMemcpyAsync(all, d_idx, (size_t)cnt * 4, hipMemcpyDeviceToDevice, c->stream));
+  if (nc) {
+    if (w.wused + nc > w.wcap) return c->fail(SWZ_ERR_INTERNAL, "working pool overflow");
+    hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, cgid, nc, t->pool_xyz,
+                       w.wx + w.wused, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
+    SWZ_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(rr_iota_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, all + cnt, nc);  // 0..nc-1
+    SWZ_LAUNCH_CHECK(c);
+    // shift to the pool positions just filled
+    hipLaunchKernelGGL(tl_wgid_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, all + cnt, nc, w.wused, all + cnt);
+    SWZ_LAUNCH_CHECK(c);
+    w.wused += nc;
+  }
+  uint64_t* tkey = nullptr;
+  uint32_t* tgid = nullptr;
+  SWZ_TRY(c->get("tl_tkey", (size_t)m, &tkey));
+  SWZ_TRY(c->get("tl_tgid", (size_t)m, &tgid));
+
+  const int req = required_depth_host(t->p.sampler, node.level, root_ext_x, root_max_spacing);
+  const int max_level = (int)std::min<uint32_t>(MAX_LEVELS - 1, t->p.max_depth);
+  if (req <= node.level) return c->fail(SWZ_ERR_INTERNAL, "re-rooted subtree reached a node that needs no deeper index");
+  if (node.level >= max_level) {  // tile_terminal_node (:436-442): everything, in this order
+    LevelBuffers lb;
+    SWZ_TRY(alloc_level_buffers(c, m, &lb));
+    SWZ_TRY(fused_scan(c, AllF{}, TakeNodeG{all, w.wgid, node.key, tkey, tgid}, m, counters + 2, "tl"));
+    return rr_store_node(t, node.level, rkey, rgid, nr, tkey, tgid, m);
+  }
+  if (req < (int)MAX_LEVELS) return c->fail(SWZ_ERR_INTERNAL, "re-rooted subtree reached a node that needs no re-rooting");
+
+  // ---- re-index against the node's box, sort, sample as the new root's level -1
+  uint64_t *keys = nullptr, *okey = nullptr;
+  uint32_t* oidx = nullptr;
+  SWZ_TRY(c->get(("rr_keys_" + sfx).c_str(), (size_t)m, &keys));
+  SWZ_TRY(c->get(("rr_okey_" + sfx).c_str(), (size_t)m, &okey));
+  SWZ_TRY(c->get(("rr_oidx_" + sfx).c_str(), (size_t)m, &oidx));
+  const Box nb{node.bmin[0], node.bmin[1], node.bmin[2], node.bmax[0], node.bmax[1], node.bmax[2]};
+  hipLaunchKernelGGL(rr_encode_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, all, m, w.wx, w.wy, w.wz, nb, keys);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(sort_pairs_by_key(c, keys, all, m));  // stable: ties keep the order of `all`
+  LevelPlan plan = make_plan(-1, t->p.sampler, t->p.max_points_per_node, node.max_spacing, t->p.max_depth, node.bmin,
+                             node.bmax, nc > 0, false);
+  LevelBuffers lb;
+  SWZ_TRY(alloc_level_buffers(c, m, &lb));
+  LevelResult r;
+  SWZ_TRY(level_step(c, plan, ActiveSet{keys, all, m}, SortedPoints{w.wx, w.wy, w.wz}, lb, w.wlevel, okey, oidx, &r));
+  const uint32_t nt = m - r.remaining;
+  SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeNodeG{all, w.wgid, node.key, tkey, tgid}, m, counters + 2, "tl"));
+  SWZ_TRY(rr_store_node(t, node.level, rkey, rgid, nr, tkey, tgid, nt));
+  if (r.remaining == 0) return SWZ_OK;
+
+  // ---- children (split_range_into_child_nodes :116-162)
+  const int child_level = node.level + 1;
+  uint32_t* d_bounds = nullptr;
+  SWZ_TRY(c->get(("rr_bounds_" + sfx).c_str(), (size_t)16, &d_bounds));
+  hipLaunchKernelGGL(rr_split_init_kernel, dim3(1), dim3(64), 0, c->stream, d_bounds, r.remaining);
+  for (uint32_t o = 0; o < 8; ++o)
+    hipLaunchKernelGGL(rr_split_kernel, dim3(div_up(r.remaining, 256)), dim3(256), 0, c->stream, okey, r.remaining,
+                       level_shift(child_level), o, d_bounds);
+  SWZ_LAUNCH_CHECK(c);
+  uint32_t b[9];
+  SWZ_HIP(c, hipMemcpyAsync(b, d_bounds, 36, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  const double child_root_ext = node.bmax[0] - node.bmin[0];
+  for (uint32_t o = 0; o < 8; ++o) {
+    if (b[o + 1] <= b[o]) continue;
+    RrNode child;
+    child.level = child_level;
+    child.key = node.key | ((uint64_t)o << level_shift(child_level));
+    for (int ax = 0; ax < 3; ++ax) {  // get_octant_bounds
+      const double e = node.bmax[ax] - node.bmin[ax];
+      const uint32_t bit = ax == 0 ? (o >> 2) & 1u : (ax == 1 ? (o >> 1) & 1u : o & 1u);
+      child.bmin[ax] = bit ? node.bmin[ax] + e / 2 : node.bmin[ax];
+      child.bmax[ax] = child.bmin[ax] + e / 2;
+    }
+    child.max_spacing = node.max_spacing / 2;
+    SWZ_TRY(rr_node(t, w, child, child_root_ext, node.max_spacing, oidx + b[o], b[o + 1] - b[o], depth + 1, tot));
+  }
+  return SWZ_OK;
+}
+
+// every node of the level the active set has reached needs re-rooting
+static int tiler_reroot_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, const ActiveSet& as, RrTotals& tot) {
+  swz_ctx* c = t->c;
+  uint32_t* counters = nullptr;
+  SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+  uint32_t* hp = nullptr;
+  uint64_t* hk = nullptr;
+  SWZ_TRY(c->get("tl_head_pos", (size_t)as.m, &hp));
+  SWZ_TRY(c->get("tl_head_key", (size_t)as.m, &hk));
+  SWZ_TRY(fused_scan(c, HeadF{as.akey, plan.node_shift}, HeadG{as.akey, plan.node_shift, hp, hk}, as.m, counters + 3, "tl"));
+  uint32_t heads = 0;
+  SWZ_TRY(read_u32(c, counters + 3, &heads));
+  std::vector<uint32_t> pos(heads);
+  std::vector<uint64_t> key(heads);
+  SWZ_HIP(c, hipMemcpyAsync(pos.data(), hp, (size_t)heads * 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipMemcpyAsync(key.data(), hk, (size_t)heads * 8, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  const uint32_t* idx = as.aidx;
+  if (!idx) {
+    uint32_t* iota = nullptr;
+    SWZ_TRY(c->get("rr_iota", (size_t)as.m, &iota));
+    hipLaunchKernelGGL(rr_iota_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, iota, as.m);
+    SWZ_LAUNCH_CHECK(c);
+    idx = iota;
+  }
+  for (uint32_t j = 0; j < heads; ++j) {
+    RrNode node;
+    node.level = plan.level;
+    node.key = key[j];
+    swz_node_bounds((int8_t)plan.level, key[j], t->bmin, t->bmax, node.bmin, node.bmax);
+    node.max_spacing = t->p.spacing_at_root;
+    for (int l = 0; l <= plan.level; ++l) node.max_spacing /= 2;  // child_node.max_spacing /= 2 per level (:138)
+    const uint32_t end = j + 1 < heads ? pos[j + 1] : as.m;
+    SWZ_TRY(rr_node(t, w, node, t->bmax[0] - t->bmin[0], t->p.spacing_at_root, idx + pos[j], end - pos[j], 0, tot));
+  }
+  return SWZ_OK;
+}
+
 static void zero_stats(swz_tile_stats* s) {
   if (!s) return;
   std::memset(s, 0, sizeof(*s));
@@ -536,6 +768,15 @@ static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_sta
     LevelPlan plan = make_plan(level, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
                                t->bmin, t->bmax, false, true);
     plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
+    if (plan.reroot && !plan.terminal && t->p.sampler != SWZ_MIN_DISTANCE) {
+      RrTotals tot;
+      SWZ_TRY(tiler_reroot_level(t, w, plan, as, tot));
+      visited += tot.visited;
+      nodes += tot.nodes;
+      max_level = std::max(max_level, tot.max_level);
+      ++nlevels;
+      break;
+    }
     LevelResult r;
     uint32_t merged = 0;
     SWZ_TRY(tiler_level(t, w, plan, as, &r, &merged));

@@ -183,3 +183,54 @@ def test_gpu_multibatch_terminal_nodes(ctx):
         g = _gpu_files(ctx, UNIT, xyz, 3, sampler, 100, sp, O.ACCURATE, 2, staged=False, max_depth=2)
         _compare(g, ex, c)
         assert int(ex["level"].max()) == 2
+
+
+# --------------------------------------------------------------------------------------------------- re-rooting
+def _deep_cloud(rng, n):
+    """All points inside a corner 1e-5 of the root's extent wide: with spacing = extent / 4096 the grid samplers need
+    more than 21 key levels from node level 9 on (tile_node re-roots there, TilingAlgorithms.cpp:444-483) -- the
+    situation of the reference's disabled test "Tiler with deep tree works" (test/TestTiler.cpp:164-190)."""
+    return rng.random((n, 3)) * 0.01
+
+
+DEEP = ([0.0, 0.0, 0.0], [1024.0, 1024.0, 1024.0])
+
+
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.JITTERED])
+def test_oracle_reroots_deep_nodes(sampler):
+    rng = np.random.default_rng(4)
+    n = 60000
+    xyz = _deep_cloud(rng, n)
+    sp = float(np.float32(1024.0 / 4096.0))
+    assert O.lib().orc_required_morton_index_depth(sampler, 9, O._vec3(DEEP[0]), O._vec3(DEEP[1]), O.C.c_float(sp)) >= 21
+    assert O.lib().orc_required_morton_index_depth(sampler, 8, O._vec3(DEEP[0]), O._vec3(DEEP[1]), O.C.c_float(sp)) < 21
+    ex, c = _oracle_files(DEEP, xyz, 2, sampler, 200, sp, O.ACCURATE, 2)
+    assert c["num_stored"] == n and np.array_equal(np.sort(ex["ids"]), np.arange(n, dtype=np.uint32))
+    assert int(ex["level"].max()) > 9          # nodes below the first re-rooted level exist
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.JITTERED])
+@pytest.mark.parametrize("k", [1, 3])
+def test_gpu_reroots_deep_nodes_like_the_oracle(ctx, sampler, k):
+    rng = np.random.default_rng(40 + sampler + k)
+    n = 100000
+    xyz = _deep_cloud(rng, n)
+    sp = float(np.float32(1024.0 / 4096.0))
+    ex, c = _oracle_files(DEEP, xyz, k, sampler, 200, sp, O.ACCURATE, 2)
+    g = _gpu_files(ctx, DEEP, xyz, k, sampler, 200, sp, O.ACCURATE, 2, staged=False)
+    _compare(g, ex, c)
+    assert int(ex["level"].max()) > 9
+
+
+@pytest.mark.gpu
+def test_single_batch_entry_point_reports_reroot(ctx):
+    """swz_tile's output (one level per point of the sorted batch) cannot express the file order of re-rooted nodes:
+    it fails loudly and points to the multi-batch tiler."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(1)
+    xyz = _deep_cloud(rng, 50000)
+    sp = float(np.float32(1024.0 / 4096.0))
+    with pytest.raises(swz.SwzError) as e:
+        ctx.tile(xyz, *DEEP, swz.TileParams(sampler=swz.RANDOM_GRID, max_points_per_node=200, spacing_at_root=sp))
+    assert e.value.code == 5
