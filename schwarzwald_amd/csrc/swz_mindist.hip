@@ -707,12 +707,13 @@ __device__ __forceinline__ void md_wave_push(bool want, uint32_t value, uint32_t
 }
 
 // publish the new frontiers; a cell whose frontier moved wakes the cells sleeping on it
-__global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round) {
+// (wave0: index of this wavefront's first lane among all participating threads, stride: their number)
+__device__ __forceinline__ void md_commit_range(const MdArgs& a, uint32_t round, uint32_t wave0, uint32_t stride) {
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   const uint32_t* qin = a.queue[round & 1];
   uint32_t* qout = a.queue[(round + 1) & 1];
-  for (uint32_t i0 = blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < nq; i0 += gridDim.x * 256) {  // wave-uniform
+  for (uint32_t i0 = wave0; i0 < nq; i0 += stride) {  // wave-uniform
     const uint32_t i = i0 + lane_id();
     const bool valid = i < nq;
     uint32_t c = 0, np = 0, w = NONE32, keep = NONE32;
@@ -747,15 +748,18 @@ __global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round
     if (walk) a.whead[c] = keep;
   }
 }
+__global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round) {
+  md_commit_range(a, round, blockIdx.x * 256 + (threadIdx.x & ~63u), gridDim.x * 256);
+}
 
 // stalled cells go to sleep on their blocker's wait list (or straight back into the queue when the
 // blocker's frontier has already passed the blocking point); yielded cells are re-queued
-__global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t round) {
+__device__ __forceinline__ void md_requeue_range(const MdArgs& a, uint32_t round, uint32_t wave0, uint32_t stride) {
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   const uint32_t* qin = a.queue[round & 1];
   uint32_t* qout = a.queue[(round + 1) & 1];
-  for (uint32_t i0 = blockIdx.x * 256 + (threadIdx.x & ~63u); i0 < nq; i0 += gridDim.x * 256) {  // wave-uniform
+  for (uint32_t i0 = wave0; i0 < nq; i0 += stride) {  // wave-uniform
     const uint32_t i = i0 + lane_id();
     bool push = false;
     uint32_t c = 0;
@@ -774,6 +778,81 @@ __global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t roun
       }
     }
     md_wave_push(push, c, qout, cout);
+  }
+}
+__global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t round) {
+  md_requeue_range(a, round, blockIdx.x * 256 + (threadIdx.x & ~63u), gridDim.x * 256);
+}
+
+// ---- the rounds of one level inside ONE launch ---------------------------------------------------------------------
+// A round of three launches costs about 44 us even when only a few cells are active, and a dense level runs well
+// over a thousand dependent rounds.  Here one workgroup per CU stays resident and the three steps of a round are
+// separated by grid barriers instead: every workgroup releases its stores at agent scope (buffer_wbl2), arrives on one
+// monotonic counter, polls it relaxed, and acquires (buffer_inv) -- cdna_hip_programming.md Guideline 16 in its counter
+// form; the state words are zeroed by the host before every launch and every spin is bounded (a workgroup that is not
+// resident would otherwise hang the others: the launch gives up and the host continues with plain launches).
+struct MdBarrier {
+  uint32_t arrived;   // monotonic over the launch
+  uint32_t timeout;   // set when a spin ran out
+  uint32_t rounds;    // rounds completed in this launch
+  uint32_t pad;
+};
+constexpr int MDP_THREADS = 1024;
+constexpr int MDP_WAVES = MDP_THREADS / WAVE;
+
+__device__ __forceinline__ bool md_grid_barrier(MdBarrier* bar, uint32_t nblocks, uint32_t& epoch, uint32_t* lds_flag) {
+  __syncthreads();  // every wave's stores are issued ...
+  ++epoch;
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... and written back before the arrival is visible
+    __hip_atomic_fetch_add(&bar->arrived, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t target = epoch * nblocks;
+    uint32_t ok = 1;
+    for (uint32_t spins = 0;; ++spins) {
+      if (__hip_atomic_load(&bar->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+      if (spins > (1u << 22) || __hip_atomic_load(&bar->timeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        __hip_atomic_store(&bar->timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = ok;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
+__global__ __launch_bounds__(MDP_THREADS, 4) void md_persistent_kernel(MdArgs a, uint32_t ncells, uint32_t round0,
+                                                                       uint32_t max_rounds, MdBarrier* bar) {
+  __shared__ MdLds lds[MDP_WAVES];
+  __shared__ uint32_t s_flag, s_done;
+  const uint32_t w = threadIdx.x / WAVE;
+  const uint32_t nblocks = gridDim.x;
+  const uint32_t wave0 = blockIdx.x * MDP_THREADS + (threadIdx.x & ~63u);
+  const uint32_t stride = nblocks * MDP_THREADS;
+  uint32_t epoch = 0;
+  for (uint32_t round = round0; round - round0 < max_rounds; ++round) {
+    // sweep
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (round + 2) % 3] = 0;
+    {
+      const uint32_t nq = a.counters[CTR_Q0 + round % 3];
+      const uint32_t* qin = a.queue[round & 1];
+      for (uint32_t i = blockIdx.x * MDP_WAVES + w; i < nq; i += nblocks * MDP_WAVES) md_sweep_cell(a, qin[i], lds[w]);
+    }
+    if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
+    md_commit_range(a, round, wave0, stride);
+    if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
+    md_requeue_range(a, round, wave0, stride);
+    if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
+    if (threadIdx.x == 0) {
+      s_done = __hip_atomic_load(&a.counters[CTR_DONE_CELLS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (blockIdx.x == 0) bar->rounds = round - round0 + 1u;
+    }
+    __syncthreads();
+    if (s_done >= ncells) return;
   }
 }
 
@@ -1037,6 +1116,34 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   const uint32_t sweep_grid = std::min<uint32_t>(sweep_cap, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
   const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
+  // one resident workgroup per CU runs the rounds inside one launch (md_persistent_kernel); SWZ_MD_PERSISTENT=0, a
+  // barrier time-out or a device without room for the grid fall back to three launches per round
+  bool persistent = !getenv("SWZ_MD_PERSISTENT") || atoi(getenv("SWZ_MD_PERSISTENT")) != 0;
+  if (persistent) {
+    int dev = 0, cus = 0, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, md_persistent_kernel, MDP_THREADS, 0) != hipSuccess || per_cu < 1 || cus < 1)
+      persistent = false;
+    MdBarrier* bar = nullptr;
+    if (persistent) SWZ_TRY(c->get("md_barrier", sizeof(MdBarrier), reinterpret_cast<void**>(&bar)));
+    const uint32_t per_launch = getenv("SWZ_MD_ROUNDS_PER_LAUNCH") ? (uint32_t)atoi(getenv("SWZ_MD_ROUNDS_PER_LAUNCH")) : 4096u;
+    while (persistent && done < ncells) {
+      SWZ_HIP(c, hipMemsetAsync(bar, 0, sizeof(MdBarrier), c->stream));
+      hipLaunchKernelGGL(md_persistent_kernel, dim3((uint32_t)cus), dim3(MDP_THREADS), 0, c->stream, a, ncells, round,
+                         per_launch, bar);
+      SWZ_LAUNCH_CHECK(c);
+      MdBarrier hb{};
+      SWZ_HIP(c, hipMemcpyAsync(&hb, bar, sizeof(hb), hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipMemcpyAsync(&done, lb.counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      round += hb.rounds;
+      if (hb.timeout) {  // a round may have been left half done: its steps are idempotent per cell only as a whole
+        return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE: grid barrier timed out (a workgroup of the persistent launch was not resident)");
+      }
+      if (round > 4ull * m + 1024) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE frontier sweep did not terminate");
+    }
+  }
   const uint32_t batch = 32;
   // a level that does not finish is reported, not waited for: points that change while they are being tiled
   // (keys and positions no longer agree) can make single cells arbitrarily expensive
