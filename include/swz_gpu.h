@@ -62,6 +62,10 @@ int swz_abi_version(void);
  * device's default stream (a real stream: PyTorch's default); SWZ_OWN_STREAM restores the own stream. */
 #define SWZ_OWN_STREAM ((void*)(intptr_t)-1)
 int swz_set_stream(swz_ctx* ctx, void* hip_stream);
+/* Debug / tuning switches ("SWZ_DEBUG", "SWZ_MD_*", ...).  A context reads the SWZ_* variables
+ * of the environment once, when it is created; afterwards they change only through this call (value NULL removes the
+ * switch).  None of them changes a result; production code never needs them. */
+int swz_set_option(swz_ctx* ctx, const char* name, const char* value);
 /* Frees all device workspace held by the context (it regrows on demand). */
 int swz_release_workspace(swz_ctx* ctx);
 /* Bytes of device workspace currently held. */

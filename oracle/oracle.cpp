@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -800,10 +801,26 @@ int32_t orc_tile(double* xyz, uint64_t n, const double bmin[3], const double bma
   return orc_tile_mt(xyz, n, bmin, bmax, params, 1, keys_out, perm_out, level_out, dup_mask_out, stats_out);
 }
 
+static thread_local double* g_stage_seconds = nullptr; /* orc_tile_mt_timed: index, sort, tiling */
+static double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int32_t orc_tile_mt_timed(double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                          const orc_tile_params* params, uint32_t threads, uint64_t* keys_out, uint32_t* perm_out,
+                          int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out, double stage_seconds[3]) {
+  g_stage_seconds = stage_seconds;
+  const int32_t st = orc_tile_mt(xyz, n, bmin, bmax, params, threads, keys_out, perm_out, level_out, dup_mask_out, stats_out);
+  g_stage_seconds = nullptr;
+  return st;
+}
+
 int32_t orc_tile_mt(double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
                     const orc_tile_params* params, uint32_t threads, uint64_t* keys_out, uint32_t* perm_out,
                     int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out) {
   if (!params || n > 0xFFFFFFFFull) return ORC_ERR_BAD_ARG;
+  double* stage = g_stage_seconds;
+  const double t_begin = now_seconds();
   if (threads == 0) threads = 1;
   const AABB bounds = make_aabb(bmin, bmax);
   /* index (V1 :588-598 / V3 :1262-1285): chunks of the batch on the indexing threads (Parallel.h:172-213) */
@@ -818,9 +835,16 @@ int32_t orc_tile_mt(double* xyz, uint64_t n, const double bmin[3], const double 
     }
     for (auto& th : ts) th.join();
   }
+  const double t_indexed = now_seconds();
   /* sort (V1 :600-604 / V3 :1292), canonical tie order */
   std::vector<uint32_t> perm(n);
   orc_sort_by_key(keys.data(), n, perm.data());
+  const double t_sorted = now_seconds();
+  if (stage) {
+    stage[0] = t_indexed - t_begin;
+    stage[1] = t_sorted - t_indexed;
+    stage[2] = 0.0;
+  }
   std::vector<IP> sorted(n);
   for (uint64_t i = 0; i < n; ++i) sorted[i] = {perm[i], keys[perm[i]]};
   for (uint64_t i = 0; i < n; ++i) {
@@ -928,6 +952,7 @@ int32_t orc_tile_mt(double* xyz, uint64_t n, const double bmin[3], const double 
     }
   }
   if (stats_out) *stats_out = t.stats;
+  if (stage) stage[2] = now_seconds() - t_sorted;
   return t.error;
 }
 

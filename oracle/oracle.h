@@ -147,6 +147,11 @@ void orc_tiler_stats(const orc_tiler* t, orc_tile_stats* out);
 void orc_tiler_export(const orc_tiler* t, int8_t* node_level, uint64_t* node_key, uint64_t* node_offset,
                       uint64_t* node_count, uint32_t* ids, double* xyz_out);
 
+/* orc_tile_mt that also reports wall seconds per stage: index (all threads), sort (one thread), tiling (node tasks) */
+int32_t orc_tile_mt_timed(double* xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                          const orc_tile_params* params, uint32_t threads, uint64_t* keys_out, uint32_t* perm_out,
+                          int8_t* level_out, uint32_t* dup_mask_out, orc_tile_stats* stats_out, double stage_seconds[3]);
+
 /* util/algorithms/Algorithm.h restatements on int ranges, for the reference's TestAlgorithm vectors */
 int64_t orc_stable_partition_take_multiples(int32_t* values, int64_t n, int32_t modulus);
 void orc_merge_ranges_i32(const int32_t* const* ranges, const int64_t* sizes, int64_t num_ranges,

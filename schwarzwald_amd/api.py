@@ -396,6 +396,11 @@ class Context:
         handle = C.c_void_p(-1) if hip_stream is None else C.c_void_p(int(hip_stream))
         self._check(self._lib.swz_set_stream(self._ctx, handle))
 
+    def set_option(self, name, value):
+        """Debug / tuning switch of this context (what the SWZ_* environment variables seed at creation); None removes it."""
+        self._lib.swz_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+        self._check(self._lib.swz_set_option(self._ctx, name.encode(), None if value is None else str(value).encode()))
+
     def release_workspace(self):
         self._check(self._lib.swz_release_workspace(self._ctx))
 

@@ -27,8 +27,8 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
     }
     b.cap = want;
     // SWZ_POISON=<byte>: fill new workspace memory (hipMalloc does not): shakes out reads of never-written memory
-    if (const char* e = getenv("SWZ_POISON")) {
-      const char* only = getenv("SWZ_POISON_ONLY");
+    if (const char* e = opt("SWZ_POISON")) {
+      const char* only = opt("SWZ_POISON_ONLY");
       if (!only || strstr(name, only)) SWZ_HIP(this, hipMemsetAsync(b.ptr, atoi(e), want, stream));
     }
   }
@@ -158,7 +158,19 @@ int swz_create(swz_ctx** ctx_out, int device) {
     return SWZ_ERR_HIP;
   }
   c->stream = c->own_stream;
+  extern char** environ;
+  for (char** e = environ; e && *e; ++e) {  // the only look at the environment: SWZ_* switches, once per context
+    if (std::strncmp(*e, "SWZ_", 4) != 0) continue;
+    const char* eq = std::strchr(*e, '=');
+    if (eq) c->options[std::string(*e, (size_t)(eq - *e))] = std::string(eq + 1);
+  }
   *ctx_out = c;
+  return SWZ_OK;
+}
+
+int swz_set_option(swz_ctx* c, const char* name, const char* value) {
+  if (!c || !name) return SWZ_ERR_BAD_ARG;
+  if (value) c->options[name] = value; else c->options.erase(name);
   return SWZ_OK;
 }
 
@@ -326,7 +338,7 @@ int swz_tile_device(swz_ctx* c, double* d_xyz, uint64_t n, const double bmin[3],
                     uint32_t* d_dup_mask_out, swz_tile_stats* stats) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
-  if (getenv("SWZ_SYNC_ENTRY")) SWZ_HIP(c, hipDeviceSynchronize());
+  if (c->opt("SWZ_SYNC_ENTRY")) SWZ_HIP(c, hipDeviceSynchronize());
   SWZ_TRY(check_n(c, n));
   SWZ_TRY(check_bounds(c, bmin, bmax));
   SWZ_TRY(check_params(c, params));

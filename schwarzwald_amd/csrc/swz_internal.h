@@ -74,6 +74,13 @@ struct swz_ctx {
   void prof_collect();  // after a stream sync: fold pending events into kstats
   hipEvent_t cur_e0_ = nullptr;
   void* shard = nullptr;  // swz::ShardState of an open sharded batch (swz_level.hip)
+  // Debug / tuning switches ("SWZ_DEBUG", "SWZ_MD_*", ...): read from the environment ONCE, when the context is
+  // created, and changed afterwards only through swz_set_option -- no entry point looks at the environment.
+  std::map<std::string, std::string> options;
+  const char* opt(const char* name) const {
+    const auto it = options.find(name);
+    return it == options.end() ? nullptr : it->second.c_str();
+  }
 };
 
 #define SWZ_HIP(ctx, expr)                                                \
@@ -109,7 +116,7 @@ struct ProfScope {
 // SWZ_TRACE=1: synchronise and report after a stage (debugging hangs; never on in production)
 #define SWZ_STAGE(ctx, what)                                                              \
   do {                                                                                    \
-    if (getenv("SWZ_TRACE")) {                                                            \
+    if ((ctx)->opt("SWZ_TRACE")) {                                                            \
       const hipError_t _e = hipStreamSynchronize((ctx)->stream);                          \
       fprintf(stderr, "[swz trace] %s:%d %s -> %s\n", __FILE__, __LINE__, what, hipGetErrorString(_e)); \
       fflush(stderr);                                                                     \

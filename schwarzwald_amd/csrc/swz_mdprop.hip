@@ -446,7 +446,7 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
     SWZ_LAUNCH_CHECK(c);
   }
   if (phases_out) *phases_out += 8;
-  if (getenv("SWZ_DEBUG")) {
+  if (c->opt("SWZ_DEBUG")) {
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
     fprintf(stderr, "[swz] MIN_DISTANCE property level %d: %u pts in %u nodes, cell levels %d of %d, %u cells (%.1f pts each), "
             "%.1f ms\n", plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, ncells, pts_per_cell,

@@ -298,7 +298,7 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   // points per OCCUPIED cell: clustered data fills a small part of a node's volume
   const double per_cell = (double)sample_points / (double)std::max(1u, occupied[cl]);
   double limit = 2.0;  // per occupied cell; a uniform level with 1.5 points per cell of volume has 1.93
-  if (const char* e = getenv("SWZ_MD_SPARSE_LIMIT")) limit = atof(e);
+  if (const char* e = c->opt("SWZ_MD_SPARSE_LIMIT")) limit = atof(e);
   if (!(per_cell < limit)) return SWZ_OK;
   const uint32_t m = as.m;
 
@@ -345,8 +345,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
   SWZ_LAUNCH_CHECK(c);
-  const uint32_t xcd = getenv("SWZ_MD_XCD") ? ((uint32_t)atoi(getenv("SWZ_MD_XCD")) >> 1) & 1u : 1u;
-  const bool dbg = getenv("SWZ_DEBUG") != nullptr;
+  const uint32_t xcd = c->opt("SWZ_MD_XCD") ? ((uint32_t)atoi(c->opt("SWZ_MD_XCD")) >> 1) & 1u : 1u;
+  const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   if (dbg) {
     ev0 = c->take_event();
@@ -355,7 +355,7 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     (void)hipEventRecord(ev0, c->stream);
   }
   hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nb, 8) * 8 : nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2,
-                     xcd, getenv("SWZ_SP_ITERS") ? atoi(getenv("SWZ_SP_ITERS")) : 8);
+                     xcd, c->opt("SWZ_SP_ITERS") ? atoi(c->opt("SWZ_SP_ITERS")) : 8);
   SWZ_LAUNCH_CHECK(c);
   if (dbg) (void)hipEventRecord(ev1, c->stream);
   uint32_t* uin = u0;
@@ -372,7 +372,7 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     // can be recorded, or long dependency chains.  Both are what the frontier sweep is good at: give up here
     // (every decision taken so far is exact and will simply be taken again).
     if (h[2] > std::max<uint32_t>(1024u, sample_points / 1024u) || rounds >= 512) {
-      if (getenv("SWZ_DEBUG"))
+      if (c->opt("SWZ_DEBUG"))
         fprintf(stderr, "[swz] MIN_DISTANCE level %d sparse path abandoned: %u overflow points, %u rounds, %u undecided\n",
                 plan.level, h[2], rounds, left);
       return SWZ_OK;

@@ -929,7 +929,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   int cl = plan.cell_levels_geo;
   const double avg = (double)sample_points / (double)sample_nodes;
   double per_cell = 8.0;
-  if (const char* e = getenv("SWZ_MD_DENSITY")) per_cell = atof(e);
+  if (const char* e = c->opt("SWZ_MD_DENSITY")) per_cell = atof(e);
   // ... but only while the TYPICAL point would not end up in an oversized cell (points-weighted mean population
   // after the step <= 160): with mixed densities (a dense blob in a sparse background) the average over the cells
   // says little, and cells that are too large for the dense part cost far more (long serial activations) than
@@ -951,14 +951,14 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     for (int k = 0; k < 4; ++k) pop[k] = h[4] ? (double)h[k] / (double)h[4] : 1e30;
   }
   double max_pop = 160.0;
-  if (const char* e = getenv("SWZ_MD_MAX_POP")) max_pop = atof(e);
+  if (const char* e = c->opt("SWZ_MD_MAX_POP")) max_pop = atof(e);
   while (cl > 0 && plan.cell_levels_geo - cl < 3 && (double)sample_points / (double)std::max(1u, occupied[cl]) < per_cell &&
          pop[plan.cell_levels_geo - cl + 1] <= max_pop)
     --cl;
   // the dense [node][cell] map: at most 2^31 entries (8.6 GB; it is memset once per level, a few ms)
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
-  if (const char* e = getenv("SWZ_MD_COARSEN")) {
-    const double thr = getenv("SWZ_MD_COARSEN_MIN") ? atof(getenv("SWZ_MD_COARSEN_MIN")) : 32.0;
+  if (const char* e = c->opt("SWZ_MD_COARSEN")) {
+    const double thr = c->opt("SWZ_MD_COARSEN_MIN") ? atof(c->opt("SWZ_MD_COARSEN_MIN")) : 32.0;
     if (avg / std::pow(8.0, cl) >= thr) cl = std::max(0, cl - atoi(e));
   }
   const uint64_t cells_per_node = 1ull << (3 * cl);
@@ -991,9 +991,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       a.usq[ax] = u * u;
     }
     a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
-    a.ff_min = getenv("SWZ_MD_FF_MIN") ? (uint32_t)atoi(getenv("SWZ_MD_FF_MIN")) : 1024u;
-    a.xcd_chunks = getenv("SWZ_MD_XCD") ? (uint32_t)atoi(getenv("SWZ_MD_XCD")) & 1u : 0u;
-    a.ablate = getenv("SWZ_MD_ABLATE") ? (uint32_t)atoi(getenv("SWZ_MD_ABLATE")) : 0u;
+    a.ff_min = c->opt("SWZ_MD_FF_MIN") ? (uint32_t)atoi(c->opt("SWZ_MD_FF_MIN")) : 1024u;
+    a.xcd_chunks = c->opt("SWZ_MD_XCD") ? (uint32_t)atoi(c->opt("SWZ_MD_XCD")) & 1u : 0u;
+    a.ablate = c->opt("SWZ_MD_ABLATE") ? (uint32_t)atoi(c->opt("SWZ_MD_ABLATE")) : 0u;
     // expected points per spacing-sized cell; far below one almost every candidate is accepted
     a.batch_blockers = (avg / std::pow(8.0, plan.cell_levels_geo) < 0.25) ? 1u : 0u;
   }
@@ -1058,7 +1058,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "md cells");
   hipLaunchKernelGGL(md_nbr_build_kernel,
-                     dim3(std::min<uint32_t>(div_up(ncells, 8), getenv("SWZ_MD_NBR_GRID") ? (uint32_t)atoi(getenv("SWZ_MD_NBR_GRID")) : 1u << 20)),
+                     dim3(std::min<uint32_t>(div_up(ncells, 8), c->opt("SWZ_MD_NBR_GRID") ? (uint32_t)atoi(c->opt("SWZ_MD_NBR_GRID")) : 1u << 20)),
                      dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "md neighbour tables");
@@ -1072,9 +1072,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   a.early_recheck = 0;
   a.latest_first = 0;
   a.patient = many_small ? 1u : 0u;
-  if (const char* e = getenv("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
-  if (const char* e = getenv("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
-  if (const char* e = getenv("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
+  if (const char* e = c->opt("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
+  if (const char* e = c->opt("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
+  if (const char* e = c->opt("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
   // every level starts lazily (no first round in which all cells scan their neighbourhood only to learn that
   // they must wait); levels bound by the number of rounds wake a cell as soon as its latest earlier neighbour has
   // decided its first point (1 B points, root: 147 -> 117 ms), throughput-bound ones once half of it is decided
@@ -1082,8 +1082,8 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   // where an early wake-up only adds expensive activations
   const double typical = pop[std::min(3, plan.cell_levels_geo - cl)];
   bool lazy = many_small || typical <= 1024.0;
-  if (const char* e = getenv("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
-  a.lazy_frac = getenv("SWZ_MD_LAZY_FRAC") ? (float)atof(getenv("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
+  if (const char* e = c->opt("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
+  a.lazy_frac = c->opt("SWZ_MD_LAZY_FRAC") ? (float)atof(c->opt("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
   if (lazy) {
     SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_Q0, 0, 4, c->stream));
     hipLaunchKernelGGL(md_lazy_start_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, a.queue[0],
@@ -1095,7 +1095,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_LAUNCH_CHECK(c);
 
   // rounds; the host only looks at the done counter every `batch` rounds
-  const bool dbg = getenv("SWZ_DEBUG") != nullptr;
+  const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
   if (dbg)
     fprintf(stderr, "[swz] MIN_DISTANCE level %d starts: %u pts in %u nodes, cell levels %d of %d, %u cells (occupied at the finest: %u), "
                     "points-weighted mean cell population at the finest level and coarser %.0f / %.0f / %.0f / %.0f, lazy %d patient %u\n",
@@ -1109,16 +1109,19 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   }
   // grid-stride kernels: whole multiples of the resident workgroups (256 CUs x 5 per CU) avoid a ragged tail
   uint32_t sweep_cap = 2560u, commit_cap = 1280u;
-  if (const char* e = getenv("SWZ_MD_GRID")) {
+  if (const char* e = c->opt("SWZ_MD_GRID")) {
     sweep_cap = (uint32_t)atoi(e);
     commit_cap = std::max(1u, sweep_cap / 2u);
   }
   const uint32_t sweep_grid = std::min<uint32_t>(sweep_cap, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
   const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
-  // one resident workgroup per CU runs the rounds inside one launch (md_persistent_kernel); SWZ_MD_PERSISTENT=0, a
-  // barrier time-out or a device without room for the grid fall back to three launches per round
-  bool persistent = !getenv("SWZ_MD_PERSISTENT") || atoi(getenv("SWZ_MD_PERSISTENT")) != 0;
+  // SWZ_MD_PERSISTENT=1: one resident workgroup per CU runs the rounds inside one launch (md_persistent_kernel).
+  // Measured at 1 B points (round 2): root 169 ms against 117 ms with three launches per round (128 against 89 us
+  // per round), level 0 199 against 129 ms -- a round is bound by its ~15 dependent memory round trips, not by the
+  // launch boundaries (1.5-2 us each), and an agent-scope release (L2 write-back) per workgroup and barrier costs
+  // more than they do.  Off by default; kept selectable for the scheduling tests.
+  bool persistent = c->opt("SWZ_MD_PERSISTENT") && atoi(c->opt("SWZ_MD_PERSISTENT")) != 0;
   if (persistent) {
     int dev = 0, cus = 0, per_cu = 0;
     (void)hipGetDevice(&dev);
@@ -1127,7 +1130,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       persistent = false;
     MdBarrier* bar = nullptr;
     if (persistent) SWZ_TRY(c->get("md_barrier", sizeof(MdBarrier), reinterpret_cast<void**>(&bar)));
-    const uint32_t per_launch = getenv("SWZ_MD_ROUNDS_PER_LAUNCH") ? (uint32_t)atoi(getenv("SWZ_MD_ROUNDS_PER_LAUNCH")) : 4096u;
+    const uint32_t per_launch = c->opt("SWZ_MD_ROUNDS_PER_LAUNCH") ? (uint32_t)atoi(c->opt("SWZ_MD_ROUNDS_PER_LAUNCH")) : 4096u;
     while (persistent && done < ncells) {
       SWZ_HIP(c, hipMemsetAsync(bar, 0, sizeof(MdBarrier), c->stream));
       hipLaunchKernelGGL(md_persistent_kernel, dim3((uint32_t)cus), dim3(MDP_THREADS), 0, c->stream, a, ncells, round,
@@ -1149,9 +1152,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   // (keys and positions no longer agree) can make single cells arbitrarily expensive
   const auto wall0 = std::chrono::steady_clock::now();
   double wall_limit = 900.0;
-  if (const char* e = getenv("SWZ_MD_TIME_LIMIT")) wall_limit = atof(e);
+  if (const char* e = c->opt("SWZ_MD_TIME_LIMIT")) wall_limit = atof(e);
   uint64_t max_rounds = 4ull * m + 1024;
-  if (const char* e = getenv("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
+  if (const char* e = c->opt("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
   while (done < ncells) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
       hipLaunchKernelGGL(md_sweep_kernel, dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
@@ -1161,7 +1164,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     SWZ_LAUNCH_CHECK(c);
     SWZ_HIP(c, hipMemcpyAsync(&done, lb.counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    if (dbg && getenv("SWZ_MD_TIMELINE")) {
+    if (dbg && c->opt("SWZ_MD_TIMELINE")) {
       float t = 0.f;
       hipEvent_t e = c->take_event();
       (void)hipEventRecord(e, c->stream);

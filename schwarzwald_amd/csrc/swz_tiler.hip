@@ -511,7 +511,7 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, Active
 // NODE's bounds, sorted, and sampled as that root's level -1 with the node's own max_spacing.  Its children inherit
 // the new root, so every node below re-roots again until the levels run out (level >= min(20, max_depth): terminal).
 // Such nodes are rare (> max_points_per_node points inside a cell 2^-15 of the root's extent at d = 250) and handled
-// one node at a time by the host, every step on the device.  Literal like the oracle, including that the children
+// one node at a time by the host, every step on the device.  Literal, including that the children
 // are split at the ABSOLUTE level of the re-rooted keys (:124-125 via :479-482) and that a point outside the box it
 // is re-indexed against goes through static_cast<uint64_t> of a negative double as x86-64 evaluates it.
 struct RrNode {

@@ -88,6 +88,9 @@ def lib():
         L.orc_tile_mt.restype = C.c_int32
         L.orc_tile_mt.argtypes = [_dp, C.c_uint64, _dp, _dp, C.POINTER(TileParams), C.c_uint32, _u64p, _u32p, _i8p, _u32p,
                                   C.POINTER(TileStats)]
+        L.orc_tile_mt_timed.restype = C.c_int32
+        L.orc_tile_mt_timed.argtypes = [_dp, C.c_uint64, _dp, _dp, C.POINTER(TileParams), C.c_uint32, _u64p, _u32p, _i8p, _u32p,
+                                        C.POINTER(TileStats), _dp]
         L.orc_stable_partition_take_multiples.restype = C.c_int64
         L.orc_stable_partition_take_multiples.argtypes = [C.POINTER(C.c_int32), C.c_int64, C.c_int32]
         L.orc_merge_ranges_i32.restype = None
@@ -230,9 +233,11 @@ def tile(xyz, bmin, bmax, sampler, max_points_per_node, spacing_at_root, max_dep
     dup = np.zeros(n, dtype=np.uint32)
     params = TileParams(sampler, max_points_per_node, spacing_at_root, max_depth, strategy, fast_concurrency)
     stats = TileStats()
-    st = lib().orc_tile_mt(_ptr(x, _dp), n, _vec3(bmin), _vec3(bmax), C.byref(params), int(threads), _ptr(keys, _u64p),
-                           _ptr(perm, _u32p), _ptr(level, _i8p), _ptr(dup, _u32p), C.byref(stats))
+    stage = (C.c_double * 3)()
+    st = lib().orc_tile_mt_timed(_ptr(x, _dp), n, _vec3(bmin), _vec3(bmax), C.byref(params), int(threads), _ptr(keys, _u64p),
+                                 _ptr(perm, _u32p), _ptr(level, _i8p), _ptr(dup, _u32p), C.byref(stats), stage)
     return dict(status=int(st), keys=keys, perm=perm, level=level, dup=dup, xyz_clamped=x,
+                stage_seconds=dict(index=float(stage[0]), sort=float(stage[1]), tiling=float(stage[2])),
                 stats=dict(num_nodes=int(stats.num_nodes), points_visited=int(stats.points_visited),
                            max_level=int(stats.max_level), fast_start_levels=int(stats.fast_start_levels)))
 

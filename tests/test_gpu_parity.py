@@ -283,12 +283,15 @@ def test_min_distance_sparse_path_and_its_fallback(ctx, monkeypatch):
     rng = np.random.default_rng(321)
     xyz = np.vstack([rng.random((120000, 3)), 0.5 + 0.004 * rng.standard_normal((30000, 3))])  # a dense blob inside
     xyz = np.clip(xyz, 0.0, 1.0)
-    for limit, d in (("1000", 250), ("1000", 60), ("0", 250)):
-        monkeypatch.setenv("SWZ_MD_SPARSE_LIMIT", limit)
-        spacing = O.spacing_from_diagonal(*UNIT, d)
-        o = O.tile(xyz, *UNIT, O.MIN_DISTANCE, 300, spacing)
-        g = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=300, spacing_at_root=spacing))
-        assert np.array_equal(g.level, o["level"])
+    try:
+        for limit, d in (("1000", 250), ("1000", 60), ("0", 250)):
+            ctx.set_option("SWZ_MD_SPARSE_LIMIT", limit)
+            spacing = O.spacing_from_diagonal(*UNIT, d)
+            o = O.tile(xyz, *UNIT, O.MIN_DISTANCE, 300, spacing)
+            g = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=300, spacing_at_root=spacing))
+            assert np.array_equal(g.level, o["level"])
+    finally:
+        ctx.set_option("SWZ_MD_SPARSE_LIMIT", None)
 
 
 @pytest.mark.gpu
@@ -300,24 +303,29 @@ def test_min_distance_sparse_path_and_its_fallback(ctx, monkeypatch):
     {"SWZ_MD_EARLY": "0", "SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "1"},
     {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "1", "SWZ_MD_ABLATE": "8"},  # 8: no dead-point test
     {"SWZ_MD_NBR_GRID": "3", "SWZ_MD_GRID": "40"},  # tiny launch grids: the grid-stride loops must cover every cell
+    {"SWZ_MD_PERSISTENT": "1", "SWZ_MD_ROUNDS_PER_LAUNCH": "7"},  # the rounds inside persistent launches of 7 rounds
 ], ids=lambda m: "-".join("%s%s" % (k[7:10], v) for k, v in m.items()))
 def test_min_distance_sweep_scheduling_modes(ctx, monkeypatch, mode):
     """The frontier sweep picks its scheduling per level from the cell statistics (early re-check, patient stalls,
     lazy start, scan order); the big-level choices never trigger on test-sized inputs, so they are forced here.
     Scheduling must never change the result."""
     import schwarzwald_amd as swz
-    monkeypatch.setenv("SWZ_MD_SPARSE_LIMIT", "0")  # keep every level on the sweep
-    for k, v in mode.items():
-        monkeypatch.setenv(k, v)
     rng = np.random.default_rng(99)
     xyz = np.vstack([rng.random((400000, 3)), 0.25 + 0.01 * rng.standard_normal((50000, 3))])
     xyz = np.clip(xyz, 0.0, 1.0)
-    for d, mppn in ((250, 2000), (40, 500)):
-        spacing = O.spacing_from_diagonal(*UNIT, d)
-        o = O.tile(xyz, *UNIT, O.MIN_DISTANCE, mppn, spacing)
-        g = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=mppn, spacing_at_root=spacing))
-        assert np.array_equal(g.keys, o["keys"]) and np.array_equal(g.perm, o["perm"])
-        assert np.array_equal(g.level, o["level"])
+    try:
+        ctx.set_option("SWZ_MD_SPARSE_LIMIT", "0")  # keep every level on the sweep
+        for k, v in mode.items():
+            ctx.set_option(k, v)
+        for d, mppn in ((250, 2000), (40, 500)):
+            spacing = O.spacing_from_diagonal(*UNIT, d)
+            o = O.tile(xyz, *UNIT, O.MIN_DISTANCE, mppn, spacing)
+            g = ctx.tile(xyz, *UNIT, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=mppn, spacing_at_root=spacing))
+            assert np.array_equal(g.keys, o["keys"]) and np.array_equal(g.perm, o["perm"])
+            assert np.array_equal(g.level, o["level"])
+    finally:
+        for k in list(mode) + ["SWZ_MD_SPARSE_LIMIT"]:
+            ctx.set_option(k, None)
 
 
 @pytest.mark.parametrize("presort", [False, True])
