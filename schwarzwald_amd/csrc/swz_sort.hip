@@ -8,6 +8,8 @@
 // digit), prefix-sums per-wave digit counts in LDS, exchanges the tile through LDS so that global
 // stores of one digit run are contiguous, and is stable (ties keep their input order), which makes
 // the final order (key, original index).
+#include <algorithm>
+
 #include "swz_device.h"
 #include "swz_internal.h"
 
@@ -268,19 +270,208 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
   }
 }
 
+
+// ------------------------------------------------------------------------------------- one-sweep passes
+// The three-kernel pass above reads the keys twice (tile histograms, then the scatter) and scans a [digit][tile]
+// table in between.  For n < 2^30 the passes run "one sweep" instead: ONE kernel computes the eight digit histograms
+// of the whole input up front (the multiset of keys is the same in every pass), and each pass is a single scatter
+// kernel in which a tile learns where its digit runs start by decoupled look-back over the tiles in front of it:
+// thread d of tile t publishes the tile's count of digit d (flag LOCAL), walks back over earlier tiles adding their
+// counts until it meets an INCLUSIVE prefix, then publishes its own inclusive prefix.  Tiles take their index from
+// an atomic ticket, so every tile only ever waits for tiles that are already running.  Status words carry flag and
+// value together (one relaxed agent-scope 32-bit access, no ordering needed): 2 flag bits + 30 value bits.
+constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;
+
+__global__ __launch_bounds__(RS_THREADS) void radix_ghist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+                                                                 uint32_t* __restrict__ ghist /*[8][256]*/) {
+  __shared__ uint32_t h[RADIX_PASSES][RADIX];
+  for (uint32_t i = threadIdx.x; i < RADIX_PASSES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
+  __syncthreads();
+  for (uint64_t base = (uint64_t)blockIdx.x * RS_TILE; base < n; base += (uint64_t)gridDim.x * RS_TILE) {
+#pragma unroll 4
+    for (int k = 0; k < RS_KPT; ++k) {
+      const uint64_t i = base + (uint64_t)k * RS_THREADS + threadIdx.x;
+      if (i < n) {
+        const uint64_t key = keys[i];
+#pragma unroll
+        for (int p = 0; p < RADIX_PASSES; ++p) atomicAdd(&h[p][(uint32_t)(key >> (p * RADIX_BITS)) & (RADIX - 1)], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < RADIX_PASSES * RADIX; i += RS_THREADS) {
+    const uint32_t v = (&h[0][0])[i];
+    if (v) atomicAdd(&ghist[i], v);
+  }
+}
+// exclusive scan of each pass's 256-bin histogram (one block per pass)
+__global__ __launch_bounds__(RADIX) void radix_gscan_kernel(uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t lds[RADIX / WAVE];
+  uint32_t* hrow = ghist + blockIdx.x * RADIX;
+  const uint32_t v = hrow[threadIdx.x];
+  uint32_t total;
+  const uint32_t ex = block_excl_sum<RADIX>(v, lds, total);
+  hrow[threadIdx.x] = ex;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64_t* __restrict__ keys_in,
+                                                                    const uint32_t* __restrict__ vals_in,
+                                                                    uint64_t* __restrict__ keys_out,
+                                                                    uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                                    const uint32_t* __restrict__ gstart /*[256]*/,
+                                                                    uint32_t* __restrict__ status /*[ntiles][256]*/,
+                                                                    uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t whist[RS_WAVES][RADIX];
+  __shared__ uint32_t dstart[RADIX];
+  __shared__ uint32_t gbase[RADIX];
+  __shared__ uint32_t scan_lds[RS_WAVES];
+  __shared__ uint64_t xkeys[RS_TILE];
+  __shared__ uint32_t xvals[RS_TILE];
+  __shared__ uint32_t s_tile;
+
+  const uint32_t tid = threadIdx.x, w = tid / WAVE, l = lane_id();
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) whist[i][tid] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint64_t tile_base = (uint64_t)tile * RS_TILE;
+  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)RS_TILE ? (n - tile_base) : RS_TILE);
+
+  uint64_t key[RS_KPT];
+  uint32_t val[RS_KPT];
+  uint32_t rank[RS_KPT];
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+    if (e < tile_n) {
+      key[k] = keys_in[tile_base + e];
+      val[k] = vals_in ? vals_in[tile_base + e] : (uint32_t)(tile_base + e);
+    } else {
+      key[k] = ~0ull;
+      val[k] = 0;
+    }
+  }
+  volatile uint32_t* wh = whist[w];
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+    const bool ok = e < tile_n;
+    const uint64_t valid = __ballot(ok);
+    const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+    const uint64_t peers = match_digit(d, valid);
+    uint32_t pre = 0;
+    if (ok) {
+      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+      if (l == leader) {
+        pre = wh[d];
+        wh[d] = pre + (uint32_t)__popcll(peers);
+      }
+      pre = __shfl(pre, leader, WAVE);
+      rank[k] = pre + (uint32_t)__popcll(peers & lanemask_lt());
+    } else {
+      rank[k] = 0;
+    }
+  }
+  __syncthreads();
+
+  // thread tid owns digit tid: exclusive prefix over the waves, the tile's count of the digit
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int i = 0; i < RS_WAVES; ++i) {
+    const uint32_t t = whist[i][tid];
+    whist[i][tid] = cnt;
+    cnt += t;
+  }
+  // publish the tile's own count right away: later tiles can walk over it while this one is still busy
+  uint32_t* my_status = status + (size_t)tile * RADIX + tid;
+  __hip_atomic_store(my_status, (tile == 0 ? OS_FLAG_INCL : OS_FLAG_LOCAL) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t total;
+  const uint32_t ds = block_excl_sum<RS_THREADS>(cnt, scan_lds, total);
+  dstart[tid] = ds;
+  __syncthreads();
+
+  // exchange through LDS: position inside the digit-sorted tile
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+    if (e < tile_n) {
+      const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+      const uint32_t p = dstart[d] + whist[w][d] + rank[k];
+      xkeys[p] = key[k];
+      xvals[p] = val[k];
+    }
+  }
+
+  // decoupled look-back for digit tid
+  uint32_t excl = 0;
+  if (tile > 0) {
+    for (uint32_t p = tile; p-- > 0;) {
+      const uint32_t* ps = status + (size_t)p * RADIX + tid;
+      uint32_t v;
+      while (((v = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
+      excl += v & OS_VALUE_MASK;
+      if (v & OS_FLAG_INCL) break;
+    }
+    __hip_atomic_store(my_status, OS_FLAG_INCL | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  gbase[tid] = gstart[tid] + excl;
+  __syncthreads();
+
+  // contiguous stores per digit run
+#pragma unroll
+  for (int k = 0; k < RS_KPT; ++k) {
+    const uint32_t j = k * RS_THREADS + tid;
+    if (j < tile_n) {
+      const uint64_t kk = xkeys[j];
+      const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
+      const uint32_t dst = gbase[d] + (j - dstart[d]);
+      keys_out[dst] = kk;
+      vals_out[dst] = xvals[j];
+    }
+  }
+}
+
 bool radix_result_in_second() { return (RADIX_PASSES & 1) != 0; }
 
 int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint64_t* d_keys_out,
                      uint32_t* d_vals_out, uint32_t n, bool vals_identity) {
   if (n == 0) return SWZ_OK;
   const uint32_t ntiles = div_up(n, RS_TILE);
-  uint32_t* d_hist = nullptr;
-  SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
   // the data ping-pongs first -> second -> first ...; radix_result_in_second() tells where it ends
   uint64_t* kin = d_keys_in;
   uint32_t* vin = d_vals_tmp;
   uint64_t* kout = d_keys_out;
   uint32_t* vout = d_vals_out;
+  const char* os_opt = c->opt("SWZ_SORT_ONESWEEP");
+  if (n < (1u << 30) && !(os_opt && atoi(os_opt) == 0)) {
+    static_assert(RADIX == RS_THREADS, "one thread per digit");
+    uint32_t *d_ghist = nullptr, *d_status = nullptr, *d_ticket = nullptr;
+    SWZ_TRY(c->get("radix_ghist", (size_t)RADIX_PASSES * RADIX, &d_ghist));
+    SWZ_TRY(c->get("radix_status", (size_t)ntiles * RADIX, &d_status));
+    SWZ_TRY(c->get("radix_ticket", (size_t)RADIX_PASSES, &d_ticket));
+    {
+      ProfScope ps(c, "radix_hist", (uint64_t)n * 8ull);
+      SWZ_HIP(c, hipMemsetAsync(d_ghist, 0, sizeof(uint32_t) * RADIX_PASSES * RADIX, c->stream));
+      SWZ_HIP(c, hipMemsetAsync(d_ticket, 0, sizeof(uint32_t) * RADIX_PASSES, c->stream));
+      hipLaunchKernelGGL(radix_ghist_kernel, dim3(std::min<uint32_t>(ntiles, 256u * 8u)), dim3(RS_THREADS), 0, c->stream, kin, n, d_ghist);
+      hipLaunchKernelGGL(radix_gscan_kernel, dim3(RADIX_PASSES), dim3(RADIX), 0, c->stream, d_ghist);
+      SWZ_LAUNCH_CHECK(c);
+    }
+    for (int pass = 0; pass < RADIX_PASSES; ++pass) {
+      ProfScope ps(c, "radix_scatter", (uint64_t)n * 24ull);
+      SWZ_HIP(c, hipMemsetAsync(d_status, 0, (size_t)ntiles * RADIX * sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, kin,
+                         (pass == 0 && vals_identity) ? (const uint32_t*)nullptr : vin, kout, vout, n, pass * RADIX_BITS,
+                         d_ghist + pass * RADIX, d_status, d_ticket + pass);
+      SWZ_LAUNCH_CHECK(c);
+      uint64_t* tk = kin; kin = kout; kout = tk;
+      uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    return SWZ_OK;
+  }
+  uint32_t* d_hist = nullptr;
+  SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
   for (int pass = 0; pass < RADIX_PASSES; ++pass) {
     const int shift = pass * RADIX_BITS;
     {
