@@ -321,9 +321,9 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
                                                                     const uint32_t* __restrict__ gstart /*[256]*/,
                                                                     uint32_t* __restrict__ status /*[ntiles][256]*/,
                                                                     uint32_t* __restrict__ ticket) {
-  __shared__ uint32_t whist[RS_WAVES][RADIX];
-  __shared__ uint32_t dstart[RADIX];
-  __shared__ uint32_t gbase[RADIX];
+  // 52 KB of LDS: three workgroups per CU (the per-wave counters fit 16 bits: a wave holds 1024 keys)
+  __shared__ uint16_t whist[RS_WAVES][RADIX];
+  __shared__ uint32_t doff[RADIX];  // start of the digit's run inside the tile, later: global start minus that
   __shared__ uint32_t scan_lds[RS_WAVES];
   __shared__ uint64_t xkeys[RS_TILE];
   __shared__ uint32_t xvals[RS_TILE];
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
       val[k] = 0;
     }
   }
-  volatile uint32_t* wh = whist[w];
+  volatile uint16_t* wh = whist[w];
 #pragma unroll
   for (int k = 0; k < RS_KPT; ++k) {
     const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
       const uint32_t leader = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
       if (l == leader) {
         pre = wh[d];
-        wh[d] = pre + (uint32_t)__popcll(peers);
+        wh[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
       }
       pre = __shfl(pre, leader, WAVE);
       rank[k] = pre + (uint32_t)__popcll(peers & lanemask_lt());
@@ -380,15 +380,18 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
 #pragma unroll
   for (int i = 0; i < RS_WAVES; ++i) {
     const uint32_t t = whist[i][tid];
-    whist[i][tid] = cnt;
+    whist[i][tid] = (uint16_t)cnt;
     cnt += t;
   }
   // publish the tile's own count right away: later tiles can walk over it while this one is still busy
   uint32_t* my_status = status + (size_t)tile * RADIX + tid;
   __hip_atomic_store(my_status, (tile == 0 ? OS_FLAG_INCL : OS_FLAG_LOCAL) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // first look at the tile in front: by the time the exchange below is done its answer has arrived
+  uint32_t look = OS_FLAG_INCL;
+  if (tile > 0) look = __hip_atomic_load(status + (size_t)(tile - 1) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint32_t total;
   const uint32_t ds = block_excl_sum<RS_THREADS>(cnt, scan_lds, total);
-  dstart[tid] = ds;
+  doff[tid] = ds;
   __syncthreads();
 
   // exchange through LDS: position inside the digit-sorted tile
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
     const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
     if (e < tile_n) {
       const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
-      const uint32_t p = dstart[d] + whist[w][d] + rank[k];
+      const uint32_t p = doff[d] + whist[w][d] + rank[k];
       xkeys[p] = key[k];
       xvals[p] = val[k];
     }
@@ -406,16 +409,22 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
   // decoupled look-back for digit tid
   uint32_t excl = 0;
   if (tile > 0) {
-    for (uint32_t p = tile; p-- > 0;) {
-      const uint32_t* ps = status + (size_t)p * RADIX + tid;
-      uint32_t v;
-      while (((v = __hip_atomic_load(ps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 30) == 0u) __builtin_amdgcn_s_sleep(1);
+    uint32_t p = tile - 1;
+    uint32_t v = look;
+    for (;;) {
+      while ((v >> 30) == 0u) {
+        __builtin_amdgcn_s_sleep(1);
+        v = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       excl += v & OS_VALUE_MASK;
-      if (v & OS_FLAG_INCL) break;
+      if ((v & OS_FLAG_INCL) || p == 0) break;
+      --p;
+      v = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __hip_atomic_store(my_status, OS_FLAG_INCL | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  gbase[tid] = gstart[tid] + excl;
+  __syncthreads();  // every thread has read doff for the exchange
+  doff[tid] = gstart[tid] + excl - ds;
   __syncthreads();
 
   // contiguous stores per digit run
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
     if (j < tile_n) {
       const uint64_t kk = xkeys[j];
       const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
-      const uint32_t dst = gbase[d] + (j - dstart[d]);
+      const uint32_t dst = doff[d] + j;
       keys_out[dst] = kk;
       vals_out[dst] = xvals[j];
     }
