@@ -280,6 +280,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
 // counts until it meets an INCLUSIVE prefix, then publishes its own inclusive prefix.  Tiles take their index from
 // an atomic ticket, so every tile only ever waits for tiles that are already running.  Status words carry flag and
 // value together (one relaxed agent-scope 32-bit access, no ordering needed): 2 flag bits + 30 value bits.
+constexpr int OS_BATCH = 4;  // consecutive tiles per ticket (one atomic word serves only ~90 tickets per microsecond)
+__device__ __forceinline__ uint32_t div_up_dev(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;
 
 __global__ __launch_bounds__(RS_THREADS) void radix_ghist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
@@ -330,114 +332,126 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
   __shared__ uint32_t s_tile;
 
   const uint32_t tid = threadIdx.x, w = tid / WAVE, l = lane_id();
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-#pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) whist[i][tid] = 0;
+  if (tid == 0) s_tile = atomicAdd(ticket, (uint32_t)OS_BATCH);
   __syncthreads();
-  const uint32_t tile = s_tile;
-  const uint64_t tile_base = (uint64_t)tile * RS_TILE;
-  const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)RS_TILE ? (n - tile_base) : RS_TILE);
+  const uint32_t tile0 = s_tile;
+  const uint32_t ntiles = div_up_dev(n, RS_TILE);
+  uint32_t carry = 0;  // digit tid: keys with this digit in all tiles in front of the current one
+  for (uint32_t b = 0; b < (uint32_t)OS_BATCH; ++b) {
+    const uint32_t tile = tile0 + b;
+    if (tile >= ntiles) break;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) whist[i][tid] = 0;
+    __syncthreads();
+    const uint64_t tile_base = (uint64_t)tile * RS_TILE;
+    const uint32_t tile_n = (uint32_t)((n - tile_base) < (uint64_t)RS_TILE ? (n - tile_base) : RS_TILE);
 
-  uint64_t key[RS_KPT];
-  uint32_t val[RS_KPT];
-  uint32_t rank[RS_KPT];
+    uint64_t key[RS_KPT];
+    uint32_t val[RS_KPT];
+    uint32_t rank[RS_KPT];
 #pragma unroll
-  for (int k = 0; k < RS_KPT; ++k) {
-    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
-    if (e < tile_n) {
-      key[k] = keys_in[tile_base + e];
-      val[k] = vals_in ? vals_in[tile_base + e] : (uint32_t)(tile_base + e);
-    } else {
-      key[k] = ~0ull;
-      val[k] = 0;
-    }
-  }
-  volatile uint16_t* wh = whist[w];
-#pragma unroll
-  for (int k = 0; k < RS_KPT; ++k) {
-    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
-    const bool ok = e < tile_n;
-    const uint64_t valid = __ballot(ok);
-    const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
-    const uint64_t peers = match_digit(d, valid);
-    uint32_t pre = 0;
-    if (ok) {
-      const uint32_t leader = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
-      if (l == leader) {
-        pre = wh[d];
-        wh[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
+    for (int k = 0; k < RS_KPT; ++k) {
+      const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+      if (e < tile_n) {
+        key[k] = keys_in[tile_base + e];
+        val[k] = vals_in ? vals_in[tile_base + e] : (uint32_t)(tile_base + e);
+      } else {
+        key[k] = ~0ull;
+        val[k] = 0;
       }
-      pre = __shfl(pre, leader, WAVE);
-      rank[k] = pre + (uint32_t)__popcll(peers & lanemask_lt());
-    } else {
-      rank[k] = 0;
     }
-  }
-  __syncthreads();
-
-  // thread tid owns digit tid: exclusive prefix over the waves, the tile's count of the digit
-  uint32_t cnt = 0;
+    volatile uint16_t* wh = whist[w];
 #pragma unroll
-  for (int i = 0; i < RS_WAVES; ++i) {
-    const uint32_t t = whist[i][tid];
-    whist[i][tid] = (uint16_t)cnt;
-    cnt += t;
-  }
-  // publish the tile's own count right away: later tiles can walk over it while this one is still busy
-  uint32_t* my_status = status + (size_t)tile * RADIX + tid;
-  __hip_atomic_store(my_status, (tile == 0 ? OS_FLAG_INCL : OS_FLAG_LOCAL) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  // first look at the tile in front: by the time the exchange below is done its answer has arrived
-  uint32_t look = OS_FLAG_INCL;
-  if (tile > 0) look = __hip_atomic_load(status + (size_t)(tile - 1) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t total;
-  const uint32_t ds = block_excl_sum<RS_THREADS>(cnt, scan_lds, total);
-  doff[tid] = ds;
-  __syncthreads();
-
-  // exchange through LDS: position inside the digit-sorted tile
-#pragma unroll
-  for (int k = 0; k < RS_KPT; ++k) {
-    const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
-    if (e < tile_n) {
+    for (int k = 0; k < RS_KPT; ++k) {
+      const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+      const bool ok = e < tile_n;
+      const uint64_t valid = __ballot(ok);
       const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
-      const uint32_t p = doff[d] + whist[w][d] + rank[k];
-      xkeys[p] = key[k];
-      xvals[p] = val[k];
+      const uint64_t peers = match_digit(d, valid);
+      uint32_t pre = 0;
+      if (ok) {
+        const uint32_t leader = (uint32_t)__ffsll((unsigned long long)peers) - 1u;
+        if (l == leader) {
+          pre = wh[d];
+          wh[d] = (uint16_t)(pre + (uint32_t)__popcll(peers));
+        }
+        pre = __shfl(pre, leader, WAVE);
+        rank[k] = pre + (uint32_t)__popcll(peers & lanemask_lt());
+      } else {
+        rank[k] = 0;
+      }
     }
-  }
+    __syncthreads();
 
-  // decoupled look-back for digit tid
-  uint32_t excl = 0;
-  if (tile > 0) {
-    uint32_t p = tile - 1;
-    uint32_t v = look;
-    for (;;) {
-      while ((v >> 30) == 0u) {
-        __builtin_amdgcn_s_sleep(1);
+    // thread tid owns digit tid: exclusive prefix over the waves, the tile's count of the digit
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < RS_WAVES; ++i) {
+      const uint32_t t = whist[i][tid];
+      whist[i][tid] = (uint16_t)cnt;
+      cnt += t;
+    }
+    uint32_t* my_status = status + (size_t)tile * RADIX + tid;
+    const bool look_back = b == 0 && tile > 0;  // the tiles in front belong to other workgroups
+    uint32_t look = 0;
+    if (look_back) {
+      // publish the tile's own count right away: later tiles can walk over it while this one is still busy; and take
+      // a first look at the tile in front: by the time the exchange below is done its answer has arrived
+      __hip_atomic_store(my_status, OS_FLAG_LOCAL | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      look = __hip_atomic_load(status + (size_t)(tile - 1) * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      __hip_atomic_store(my_status, OS_FLAG_INCL | (carry + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    uint32_t total;
+    const uint32_t ds = block_excl_sum<RS_THREADS>(cnt, scan_lds, total);
+    doff[tid] = ds;
+    __syncthreads();
+
+    // exchange through LDS: position inside the digit-sorted tile
+#pragma unroll
+    for (int k = 0; k < RS_KPT; ++k) {
+      const uint32_t e = w * RS_WAVE_SPAN + k * WAVE + l;
+      if (e < tile_n) {
+        const uint32_t d = (uint32_t)(key[k] >> shift) & (RADIX - 1);
+        const uint32_t p = doff[d] + whist[w][d] + rank[k];
+        xkeys[p] = key[k];
+        xvals[p] = val[k];
+      }
+    }
+
+    if (look_back) {  // decoupled look-back for digit tid
+      uint32_t p = tile - 1;
+      uint32_t v = look;
+      for (;;) {
+        while ((v >> 30) == 0u) {
+          __builtin_amdgcn_s_sleep(1);
+          v = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        carry += v & OS_VALUE_MASK;
+        if ((v & OS_FLAG_INCL) || p == 0) break;
+        --p;
         v = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      excl += v & OS_VALUE_MASK;
-      if ((v & OS_FLAG_INCL) || p == 0) break;
-      --p;
-      v = __hip_atomic_load(status + (size_t)p * RADIX + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(my_status, OS_FLAG_INCL | (carry + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __hip_atomic_store(my_status, OS_FLAG_INCL | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  __syncthreads();  // every thread has read doff for the exchange
-  doff[tid] = gstart[tid] + excl - ds;
-  __syncthreads();
+    __syncthreads();  // every thread has read doff for the exchange
+    doff[tid] = gstart[tid] + carry - ds;
+    __syncthreads();
 
-  // contiguous stores per digit run
+    // contiguous stores per digit run
 #pragma unroll
-  for (int k = 0; k < RS_KPT; ++k) {
-    const uint32_t j = k * RS_THREADS + tid;
-    if (j < tile_n) {
-      const uint64_t kk = xkeys[j];
-      const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
-      const uint32_t dst = doff[d] + j;
-      keys_out[dst] = kk;
-      vals_out[dst] = xvals[j];
+    for (int k = 0; k < RS_KPT; ++k) {
+      const uint32_t j = k * RS_THREADS + tid;
+      if (j < tile_n) {
+        const uint64_t kk = xkeys[j];
+        const uint32_t d = (uint32_t)(kk >> shift) & (RADIX - 1);
+        const uint32_t dst = doff[d] + j;
+        keys_out[dst] = kk;
+        vals_out[dst] = xvals[j];
+      }
     }
+    carry += cnt;
+    __syncthreads();  // the tile's LDS image is free again
   }
 }
 
@@ -470,7 +484,7 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
     for (int pass = 0; pass < RADIX_PASSES; ++pass) {
       ProfScope ps(c, "radix_scatter", (uint64_t)n * 24ull);
       SWZ_HIP(c, hipMemsetAsync(d_status, 0, (size_t)ntiles * RADIX * sizeof(uint32_t), c->stream));
-      hipLaunchKernelGGL(radix_onesweep_kernel, dim3(ntiles), dim3(RS_THREADS), 0, c->stream, kin,
+      hipLaunchKernelGGL(radix_onesweep_kernel, dim3(div_up(ntiles, OS_BATCH)), dim3(RS_THREADS), 0, c->stream, kin,
                          (pass == 0 && vals_identity) ? (const uint32_t*)nullptr : vin, kout, vout, n, pass * RADIX_BITS,
                          d_ghist + pass * RADIX, d_status, d_ticket + pass);
       SWZ_LAUNCH_CHECK(c);
