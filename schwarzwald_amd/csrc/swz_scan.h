@@ -48,17 +48,20 @@ __global__ __launch_bounds__(FS_THREADS) void fscan_apply_kernel(F f, G g, uint3
   }
 }
 
-// ---- one-pass form: the inputs are read ONCE.  A tile (2048 elements, taken in ticket order) computes its values and
+// ---- one-pass form: the inputs are read ONCE.  A tile (4096 elements, taken in ticket order) computes its values and
 // their sum, publishes the sum, learns the sum of everything in front of it by decoupled look-back -- one wavefront
 // looks at the 64 tiles in front at a time and adds their sums up to the nearest tile whose INCLUSIVE prefix is
 // known -- publishes its own inclusive prefix and applies.  A status word carries flag and value together (one
 // relaxed agent-scope 64-bit access), tiles only wait for tiles that already run.
 constexpr int FO_THREADS = 256;
-constexpr int FO_IPT = 8;
+constexpr int FO_IPT = 16;
 constexpr int FO_TILE = FO_THREADS * FO_IPT;
 constexpr unsigned long long FO_LOCAL = 1ull << 32, FO_INCL = 2ull << 32;
 
-constexpr int FO_BATCH = 8;  // consecutive tiles per ticket: one atomic word serves only ~90 tickets per microsecond
+// One tile per ticket.  (Handing out batches of consecutive tiles per ticket was tried: a workgroup then publishes its
+// tiles one after the other, so the workgroup behind it waits for its LAST tile -- a serial chain, 100x slower.  Large
+// tiles keep the number of tickets, which all hit one atomic word, small instead.)
+constexpr int FO_BATCH = 1;
 
 template <typename F, typename G>
 __global__ __launch_bounds__(FO_THREADS) void fscan_onepass_kernel(F f, G g, uint32_t n, uint32_t ntiles,
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(FO_THREADS) void fscan_onepass_kernel(F f, G g, uin
   for (uint32_t b = 0; b < (uint32_t)FO_BATCH; ++b) {
     const uint32_t tile = tile0 + b;
     if (tile >= ntiles) break;
-    // wave w owns elements [w * 512, (w + 1) * 512) of the tile in 8 chunks of 64 consecutive elements
+    // wave w owns FO_IPT chunks of 64 consecutive elements
     const uint32_t wbase = tile * FO_TILE + w * (WAVE * FO_IPT);
     uint32_t v[FO_IPT], ex[FO_IPT];
     uint32_t run = 0;

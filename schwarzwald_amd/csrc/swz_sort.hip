@@ -280,7 +280,7 @@ __global__ __launch_bounds__(RS_THREADS) void radix_scatter_kernel(const uint64_
 // counts until it meets an INCLUSIVE prefix, then publishes its own inclusive prefix.  Tiles take their index from
 // an atomic ticket, so every tile only ever waits for tiles that are already running.  Status words carry flag and
 // value together (one relaxed agent-scope 32-bit access, no ordering needed): 2 flag bits + 30 value bits.
-constexpr int OS_BATCH = 4;  // consecutive tiles per ticket (one atomic word serves only ~90 tickets per microsecond)
+constexpr int OS_BATCH = 1;  // tiles per ticket: batches serialise the workgroups (each waits for the LAST tile of the one in front)
 __device__ __forceinline__ uint32_t div_up_dev(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;
 
