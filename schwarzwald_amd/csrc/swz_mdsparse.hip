@@ -10,6 +10,9 @@
 //      table holds {first, end} of every cell's run, the active points are gathered into 32-byte
 //      records, and the 27 cells are taken nine at a time with all nine table lookups, then the j-th
 //      record of all nine runs, in flight together;
+//      (Round 2 also built the search per BLOCK of 8 x 8 x 8 cells out of LDS -- table entries and records of the
+//      block and its one-cell halo copied in once: at these densities, 0.4-0.8 points per cell, the 1000-cell region
+//      costs more than the ~400 points it serves: level 2 of the 1 B run 219 ms against 162 ms.  Dropped.)
 //   2. fixpoint rounds over the still undecided points: rejected when a recorded neighbour is accepted,
 //      accepted when all of them are rejected, otherwise wait.  States only move undecided -> final, so a
 //      stale read is conservative; the number of rounds is the dependency depth (tens).
