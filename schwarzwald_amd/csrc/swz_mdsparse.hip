@@ -22,7 +22,6 @@
 #include <cstdlib>
 
 #include "swz_level.h"
-#include "swz_scan.h"
 
 namespace swz {
 
@@ -49,10 +48,6 @@ struct SpArgs {
   uint8_t* ncount;          // recorded neighbours, SP_K + 1 = overflow
   uint8_t* state;
   uint8_t* taken;
-  const uint32_t* nstart;   // node -> first active index (nstart[node + 1] = end)
-  uint32_t block_levels;    // a block = 2^block_levels cells per axis (blocked search, below)
-  const uint32_t* bstart;   // first active index of every block
-  uint32_t nblocks;
 };
 
 // states are polled while other wavefronts publish them: agent-scope relaxed atomics (served by L2)
@@ -249,214 +244,6 @@ __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* 
   if (undecided) ulist[wave_base[w] + (uint32_t)__popcll(bm & lanemask_lt())] = p;
 }
 
-
-// ---- phase 1, blocked: the neighbour search out of LDS -------------------------------------------------------------
-// The per-point search above is a chain of dependent global loads per point (table entries, then records).  Points
-// are Morton sorted, so the points of a BLOCK of 8 x 8 x 8 cells are one contiguous run; a workgroup loads the table
-// entries of the block and of the one-cell layer around it (10^3 cells), copies the records of those cells into LDS
-// once, and every point of the block then finds its neighbours there.  Same neighbours, same records, one tenth of
-// the memory round trips.  Blocks with more points than fit (locally dense data) search the old way.
-constexpr int SPB_THREADS = 256;
-constexpr int SPB_CAP = 1536;    // points of block + halo held in LDS
-constexpr int SPB_REGION = 1000; // (8 + 2)^3 cells
-
-struct SpbHeadF {
-  SpArgs a;
-  uint32_t bshift;
-  __device__ uint32_t operator()(uint32_t i) const {
-    if (!sp_sampled(a, i)) return 0u;
-    return (i == 0 || !sp_sampled(a, i - 1) || (a.akey[i] >> bshift) != (a.akey[i - 1] >> bshift)) ? 1u : 0u;
-  }
-};
-struct SpbHeadG {
-  uint32_t* bstart;
-  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t h) const {
-    if (h) bstart[excl] = i;
-  }
-};
-
-__device__ __forceinline__ uint32_t sp_dilate3(uint32_t v) {  // 10 bits -> every third bit
-  v &= 0x3FFu;
-  v = (v | (v << 16)) & 0x030000FFu;
-  v = (v | (v << 8)) & 0x0300F00Fu;
-  v = (v | (v << 4)) & 0x030C30C3u;
-  v = (v | (v << 2)) & 0x09249249u;
-  return v;
-}
-
-__global__ __launch_bounds__(SPB_THREADS) void sp_neighbours_blocked_kernel(SpArgs a, uint32_t* __restrict__ ulist,
-                                                                            uint32_t* __restrict__ ucount,
-                                                                            uint32_t* __restrict__ overflow, uint32_t xcd,
-                                                                            int iters) {
-  __shared__ double lx[SPB_CAP], ly[SPB_CAP], lz[SPB_CAP];
-  __shared__ uint32_t lg[SPB_CAP];            // active index of the LDS record
-  __shared__ uint32_t rfirst[SPB_REGION];     // per region cell: first active index of its run
-  __shared__ uint16_t rcnt[SPB_REGION];       // points in the cell
-  __shared__ uint16_t roff[SPB_REGION + 1];   // where they sit in LDS
-  __shared__ uint32_t scan_lds[SPB_THREADS / WAVE];
-  __shared__ uint32_t wave_count[4], wave_base[4];
-  __shared__ uint32_t s_total;
-
-  const uint32_t tid = threadIdx.x;
-  const uint32_t blk = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  if (blk >= a.nblocks) return;  // whole workgroup
-  const uint32_t bs = a.bstart[blk];
-  const uint32_t node = a.nid[bs];
-  const uint32_t node_end = a.nstart[node + 1];
-  const uint32_t next = blk + 1 < a.nblocks ? a.bstart[blk + 1] : a.m;
-  const uint32_t be = next < node_end ? next : node_end;
-  const uint32_t B = 1u << a.block_levels, R = B + 2u, R3 = R * R * R;
-  const uint32_t cpa = 1u << a.cell_levels;  // cells per axis of the node
-  const uint64_t base = (uint64_t)a.snode_of[node] * a.cells_per_node;
-  const uint2* __restrict__ tab = a.table + base;
-  // block origin in cell coordinates of the node
-  const uint32_t code0 = (uint32_t)((a.akey[bs] >> a.cell_shift) & (a.cells_per_node - 1ull));
-  const uint32_t ox = ((uint32_t)contract_bits_by_3(code0 >> 2) >> a.block_levels) << a.block_levels;
-  const uint32_t oy = ((uint32_t)contract_bits_by_3(code0 >> 1) >> a.block_levels) << a.block_levels;
-  const uint32_t oz = ((uint32_t)contract_bits_by_3(code0) >> a.block_levels) << a.block_levels;
-
-  // region cells: table entries -> counts, LDS offsets
-  uint32_t my_total = 0;
-  for (uint32_t r0 = 0; r0 < R3; r0 += SPB_THREADS) {
-    const uint32_t r = r0 + tid;
-    uint32_t cnt = 0, first = 0;
-    if (r < R3) {
-      const uint32_t ix = r % R, iy = (r / R) % R, iz = r / (R * R);
-      const int x = (int)(ox + ix) - 1, y = (int)(oy + iy) - 1, z = (int)(oz + iz) - 1;
-      if (x >= 0 && y >= 0 && z >= 0 && (uint32_t)x < cpa && (uint32_t)y < cpa && (uint32_t)z < cpa) {
-        const uint2 e = tab[(sp_dilate3((uint32_t)x) << 2) | (sp_dilate3((uint32_t)y) << 1) | sp_dilate3((uint32_t)z)];
-        if (e.x != SP_NONE) {
-          first = e.x;
-          cnt = e.y - e.x;
-        }
-      }
-    }
-    uint32_t total;
-    const uint32_t ex = block_excl_sum<SPB_THREADS>(cnt, scan_lds, total);
-    if (r < R3) {
-      rfirst[r] = first;
-      rcnt[r] = (uint16_t)(cnt < 0xFFFFu ? cnt : 0xFFFFu);
-      const uint32_t o = my_total + ex;
-      roff[r] = (uint16_t)(o < 0xFFFFu ? o : 0xFFFFu);
-    }
-    my_total += total;
-  }
-  if (tid == 0) s_total = my_total;
-  __syncthreads();
-  const uint32_t T = s_total;
-  const bool in_lds = T <= (uint32_t)SPB_CAP;
-  if (in_lds) {
-    // records of the region into LDS: entry t belongs to the cell whose offset range holds t (binary search in roff)
-    if (tid == 0) roff[R3] = (uint16_t)T;
-    __syncthreads();
-    for (uint32_t t = tid; t < T; t += SPB_THREADS) {
-      uint32_t lo = 0, hi = R3;  // last cell with roff <= t and a non-empty range
-      while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if ((uint32_t)roff[mid] <= t) lo = mid; else hi = mid;
-      }
-      const uint32_t src = rfirst[lo] + (t - (uint32_t)roff[lo]);
-      const double4* rp = a.rec + src;
-      const double2 xy = *reinterpret_cast<const double2*>(rp);
-      lx[t] = xy.x;
-      ly[t] = xy.y;
-      lz[t] = rp->z;
-      lg[t] = src;
-    }
-    __syncthreads();
-  }
-
-  for (uint32_t p0 = bs; p0 < be; p0 += SPB_THREADS) {  // uniform trip count
-    const uint32_t p = p0 + tid;
-    bool undecided = false;
-    if (p < be) {
-      uint32_t cnt = 0;
-      uint32_t* mine = a.nbr + (size_t)p * SP_K;
-      if (!in_lds) {
-        sp_visit_earlier(a, p, [&](uint32_t q) {
-          if (cnt < (uint32_t)SP_K) mine[cnt] = q;
-          ++cnt;
-          return cnt <= (uint32_t)SP_K;
-        });
-      } else {
-        const double4 me = a.rec[p];
-        const uint64_t key = sp_key(me);
-        const uint32_t code = (uint32_t)((key >> a.cell_shift) & (a.cells_per_node - 1ull));
-        const uint32_t cx = (uint32_t)contract_bits_by_3(code >> 2) - ox + 1u, cy = (uint32_t)contract_bits_by_3(code >> 1) - oy + 1u,
-                       cz = (uint32_t)contract_bits_by_3(code) - oz + 1u;  // region coordinates, 1 .. B
-        // adjacent cells this point cannot reach are skipped: squared gap between its slab and the neighbour
-        uint32_t reach = 0;
-        {
-          const uint64_t sub = (key >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
-          const int smax = (1 << a.sub_levels) - 1;
-          const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1), sz = (int)contract_bits_by_3(sub);
-          const double lxs = (double)sx, hxs = (double)(smax - sx), lys = (double)sy, hys = (double)(smax - sy), lzs = (double)sz,
-                       hzs = (double)(smax - sz);
-          const double gx[3] = {lxs * lxs * a.usq[0], 0.0, hxs * hxs * a.usq[0]};
-          const double gy[3] = {lys * lys * a.usq[1], 0.0, hys * hys * a.usq[1]};
-          const double gz[3] = {lzs * lzs * a.usq[2], 0.0, hzs * hzs * a.usq[2]};
-#pragma unroll
-          for (int k = 0; k < 27; ++k)
-            if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) reach |= 1u << k;
-        }
-        bool full = false;
-        for (uint32_t k = 0; k < 27u && !full; ++k) {
-          if (!((reach >> k) & 1u)) continue;
-          const uint32_t r = (cz + k / 9u - 1u) * R * R + (cy + (k / 3u) % 3u - 1u) * R + (cx + k % 3u - 1u);
-          const uint32_t n = rcnt[r], o = roff[r];
-          for (uint32_t j = 0; j < n; ++j) {
-            const uint32_t q = lg[o + j];
-            if (q >= p) break;  // runs ascend: the rest of this cell is not earlier either
-            if (sq_dist(me.x, me.y, me.z, lx[o + j], ly[o + j], lz[o + j]) < a.sq_spacing) {
-              if (cnt < (uint32_t)SP_K) mine[cnt] = q;
-              ++cnt;
-              if (cnt > (uint32_t)SP_K) {
-                full = true;
-                break;
-              }
-            }
-          }
-        }
-      }
-      a.ncount[p] = (uint8_t)cnt;
-      if (cnt > (uint32_t)SP_K) atomicAdd(overflow, 1u);
-      if (cnt == 0) {
-        sp_store(a.state, p, SP_A);
-        a.taken[p] = 1;
-      } else {
-        undecided = true;
-      }
-    }
-    for (int it = 0; it < iters; ++it) {
-      if (!__ballot(undecided)) break;
-      if (undecided && a.ncount[p] <= (uint8_t)SP_K) {
-        const uint8_t r = sp_eval(a.state, a.nbr + (size_t)p * SP_K, a.ncount[p]);
-        if (r != SP_U) {
-          sp_store(a.state, p, r);
-          if (r == SP_A) a.taken[p] = 1;
-          undecided = false;
-        }
-      }
-    }
-    const uint64_t bm = __ballot(undecided);
-    const uint32_t w = tid / WAVE;
-    if (lane_id() == 0) wave_count[w] = (uint32_t)__popcll(bm);
-    __syncthreads();
-    if (tid == 0) {
-      const uint32_t c0 = wave_count[0], c1 = wave_count[1], c2 = wave_count[2], c3 = wave_count[3];
-      const uint32_t total = c0 + c1 + c2 + c3;
-      const uint32_t b0 = total ? atomicAdd(ucount, total) : 0u;
-      wave_base[0] = b0;
-      wave_base[1] = b0 + c0;
-      wave_base[2] = b0 + c0 + c1;
-      wave_base[3] = b0 + c0 + c1 + c2;
-    }
-    __syncthreads();
-    if (undecided) ulist[wave_base[w] + (uint32_t)__popcll(bm & lanemask_lt())] = p;
-    __syncthreads();
-  }
-}
-
 // phase 2: one fixpoint round over the undecided points
 __global__ __launch_bounds__(256) void sp_round_kernel(SpArgs a, const uint32_t* __restrict__ uin, const uint32_t* __restrict__ nin,
                                                        uint32_t* __restrict__ uout, uint32_t* __restrict__ nout) {
@@ -539,7 +326,6 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
   }
   a.taken = lb.taken;
-  a.nstart = lb.nstart;
   const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
   SWZ_TRY(c->get("sp_table", (size_t)entries, &a.table));
   double4* rec = nullptr;
@@ -571,29 +357,9 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     ev2 = c->take_event();
     (void)hipEventRecord(ev0, c->stream);
   }
-  const int sp_iters = c->opt("SWZ_SP_ITERS") ? atoi(c->opt("SWZ_SP_ITERS")) : 8;
-  const bool blocked = !(c->opt("SWZ_SP_BLOCKED") && atoi(c->opt("SWZ_SP_BLOCKED")) == 0);
-  if (blocked) {
-    // blocks of 8 x 8 x 8 cells (fewer when the node has fewer): runs of the block prefix inside sampled nodes
-    a.block_levels = std::min<uint32_t>(3u, (uint32_t)cl);
-    uint32_t* d_bstart = nullptr;
-    SWZ_TRY(c->get("sp_bstart", (size_t)m, &d_bstart));
-    SWZ_TRY(fused_scan(c, SpbHeadF{a, a.cell_shift + 3u * a.block_levels}, SpbHeadG{d_bstart}, m, cnt + 3, "spb"));
-    uint32_t nblocks = 0;
-    SWZ_HIP(c, hipMemcpyAsync(&nblocks, cnt + 3, 4, hipMemcpyDeviceToHost, c->stream));
-    SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    a.bstart = d_bstart;
-    a.nblocks = nblocks;
-    if (nblocks) {
-      hipLaunchKernelGGL(sp_neighbours_blocked_kernel, dim3(xcd ? div_up(nblocks, 8) * 8 : nblocks), dim3(SPB_THREADS), 0,
-                         c->stream, a, u0, cnt, cnt + 2, xcd, sp_iters);
-      SWZ_LAUNCH_CHECK(c);
-    }
-  } else {
-    hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nb, 8) * 8 : nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2,
-                       xcd, sp_iters);
-    SWZ_LAUNCH_CHECK(c);
-  }
+  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nb, 8) * 8 : nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2,
+                     xcd, c->opt("SWZ_SP_ITERS") ? atoi(c->opt("SWZ_SP_ITERS")) : 8);
+  SWZ_LAUNCH_CHECK(c);
   if (dbg) (void)hipEventRecord(ev1, c->stream);
   uint32_t* uin = u0;
   uint32_t* uout = u1;
