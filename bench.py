@@ -92,12 +92,16 @@ def algorithmic_bytes_per_point(sampler, visit_factor):
 
 def measured_traffic(kernel_class, n, sampler):
     """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
-    (profiles/r01/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
+    (profiles/rNN/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
     command, corrected as MI355X_MICROARCH.md prescribes).  None when no matching profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
-    try:
-        t = json.load(open(path))
-    except Exception:
+    t = None
+    for rnd in ("r02", "r01"):  # the newest committed profile of this configuration
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
+            break
+        except Exception:
+            continue
+    if t is None:
         return None
     if t.get("points") != n or t.get("sampler") != sampler:
         return None
