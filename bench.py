@@ -229,6 +229,10 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # SWZ_BENCH_FORCE_SHARDED=1: run the sharded driver (RCCL init, exchange, shard API) even with one rank
     distributed = world > 1 or os.environ.get("SWZ_BENCH_FORCE_SHARDED") == "1"
+    if distributed and "RANK" not in os.environ:  # SWZ_BENCH_FORCE_SHARDED=1 outside torchrun: a group of one
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)

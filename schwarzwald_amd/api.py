@@ -616,7 +616,8 @@ class Tiler:
 
     def close(self):
         if getattr(self, "_t", None):
-            self._lib.swz_tiler_destroy(self._t)
+            if getattr(self._ctx, "_ctx", None):  # a context that is gone took the tiler's memory with it
+                self._lib.swz_tiler_destroy(self._t)
             self._t = None
 
     def __del__(self):

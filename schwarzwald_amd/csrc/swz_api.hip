@@ -199,6 +199,7 @@ int swz_set_stream(swz_ctx* c, void* hip_stream) {
 int swz_release_workspace(swz_ctx* c) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
+  if (c->tiler_active) return c->fail(SWZ_ERR_BAD_ARG, "swz_release_workspace: a tiler of this context keeps its node store in the workspace");
   swz::shard_free(c);  // an open or presorted sharded batch points into the workspace that goes away
   c->release_all();
   return SWZ_OK;

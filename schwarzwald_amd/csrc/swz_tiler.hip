@@ -309,28 +309,22 @@ __global__ __launch_bounds__(256) void tl_fill_level_kernel(int8_t* __restrict__
 // ---------------------------------------------------------------------------------------------- host helpers
 static Box root_box(const swz_tiler* t) { return Box{t->bmin[0], t->bmin[1], t->bmin[2], t->bmax[0], t->bmax[1], t->bmax[2]}; }
 
-static int store_reserve(swz_ctx* c, StoreLevel& s, int which, size_t count) {
-  if (s.cap[which] >= count) return SWZ_OK;
-  if (s.key[which]) {
-    SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    SWZ_HIP(c, hipFree(s.key[which]));
-    SWZ_HIP(c, hipFree(s.gid[which]));
-    s.key[which] = nullptr;
-    s.gid[which] = nullptr;
-    s.cap[which] = 0;
-  }
+// The node store and the pools live in the context's grow-only workspace under fixed names, so a tiler created after
+// another one on the same context reuses the memory (hipMalloc / hipFree of multi-GB blocks were measured to stall for
+// seconds now and then).  One tiler per context at a time.
+static int store_reserve(swz_ctx* c, StoreLevel& s, int level_index, int which, size_t count) {
+  if (s.cap[which] >= count && s.key[which]) return SWZ_OK;
   const size_t want = count + count / 4 + 1024;
-  hipError_t e = hipMalloc((void**)&s.key[which], want * sizeof(uint64_t));
-  if (e == hipSuccess) e = hipMalloc((void**)&s.gid[which], want * sizeof(uint32_t));
-  if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(node store): ") + hipGetErrorString(e));
-  s.cap[which] = want;
+  const std::string kn = "tiler_store_key_" + std::to_string(level_index) + "_" + std::to_string(which);
+  const std::string gn = "tiler_store_gid_" + std::to_string(level_index) + "_" + std::to_string(which);
+  SWZ_TRY(c->get(kn.c_str(), want, &s.key[which]));  // the side being written holds nothing that is still needed
+  SWZ_TRY(c->get(gn.c_str(), want, &s.gid[which]));
+  s.cap[which] = std::min(c->bufs[kn].cap / sizeof(uint64_t), c->bufs[gn].cap / sizeof(uint32_t));
   return SWZ_OK;
 }
 
 static void store_free(StoreLevel& s) {
   for (int w = 0; w < 2; ++w) {
-    if (s.key[w]) (void)hipFree(s.key[w]);
-    if (s.gid[w]) (void)hipFree(s.gid[w]);
     s.key[w] = nullptr;
     s.gid[w] = nullptr;
     s.cap[w] = 0;
@@ -338,29 +332,42 @@ static void store_free(StoreLevel& s) {
   s.cnt = 0;
 }
 
+// grows a named workspace buffer keeping its first `keep` bytes
+static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t keep, void** out) {
+  swz::DevBuf& b = c->bufs[name];
+  if (b.cap < bytes) {
+    void* np = nullptr;
+    const size_t want = (bytes + 255) & ~size_t(255);
+    const hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(") + name + "): " + hipGetErrorString(e));
+    if (b.ptr && keep) SWZ_HIP(c, hipMemcpy(np, b.ptr, keep, hipMemcpyDeviceToDevice));
+    if (b.ptr) SWZ_HIP(c, hipFree(b.ptr));
+    b.ptr = np;
+    b.cap = want;
+  }
+  *out = b.ptr;
+  return SWZ_OK;
+}
+
 // makes room for `points` points in the pools (positions and the attribute columns in use); keeps the content
 static int pool_reserve(swz_tiler* t, size_t points) {
   swz_ctx* c = t->c;
-  if (points <= t->pool_cap) return SWZ_OK;
+  if (points <= t->pool_cap && t->pool_xyz) return SWZ_OK;
   // nothing may still be writing into or reading from the old pools
   if (t->copy_stream) SWZ_HIP(c, hipStreamSynchronize(t->copy_stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
-  const size_t want = std::max(points, t->pool_cap + t->pool_cap / 2);
+  size_t have = c->bufs["tiler_pool_xyz"].cap / 24;  // what an earlier tiler of this context left behind
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (t->attr_mask & (1u << a)) have = std::min(have, c->bufs["tiler_pool_attr" + std::to_string(a)].cap / TILER_ATTR_BYTES[a]);
+  const size_t want = points <= have ? have : std::max(points, t->pool_cap + t->pool_cap / 2);
   const size_t used = t->staged_total;
-  double* nx = nullptr;
-  hipError_t e = hipMalloc((void**)&nx, want * 24);
-  if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(position pool): ") + hipGetErrorString(e));
-  if (used) SWZ_HIP(c, hipMemcpy(nx, t->pool_xyz, used * 24, hipMemcpyDeviceToDevice));
-  if (t->pool_xyz) SWZ_HIP(c, hipFree(t->pool_xyz));
-  t->pool_xyz = nx;
+  void* px = nullptr;
+  SWZ_TRY(grow_preserving(c, "tiler_pool_xyz", want * 24, used * 24, &px));
+  t->pool_xyz = static_cast<double*>(px);
   for (int a = 0; a < SWZ_ATTR_COUNT; ++a) {
     if (!(t->attr_mask & (1u << a))) continue;
-    void* na = nullptr;
-    e = hipMalloc(&na, want * TILER_ATTR_BYTES[a]);
-    if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(attribute pool): ") + hipGetErrorString(e));
-    if (used && t->pool_attr[a]) SWZ_HIP(c, hipMemcpy(na, t->pool_attr[a], used * TILER_ATTR_BYTES[a], hipMemcpyDeviceToDevice));
-    if (t->pool_attr[a]) SWZ_HIP(c, hipFree(t->pool_attr[a]));
-    t->pool_attr[a] = na;
+    const std::string name = "tiler_pool_attr" + std::to_string(a);
+    SWZ_TRY(grow_preserving(c, name.c_str(), want * TILER_ATTR_BYTES[a], used * TILER_ATTR_BYTES[a], &t->pool_attr[a]));
   }
   t->pool_cap = want;
   return SWZ_OK;
@@ -495,7 +502,7 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, Active
   SWZ_TRY(c->get("tl_tgid", (size_t)nt, &tgid));
   SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{ms.akey, ms.aidx, w.wgid, tkey, tgid}, ms.m, counters + 2, "tl"));
   const int dst = st.cur ^ 1;
-  SWZ_TRY(store_reserve(c, st, dst, (size_t)nr + nt));
+  SWZ_TRY(store_reserve(c, st, plan.level + 1, dst, (size_t)nr + nt));
   SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey, tgid, nt, nsh, 0u, st.key[dst], st.gid[dst]));
   st.cur = dst;
   st.cnt = nr + nt;
@@ -530,7 +537,7 @@ static int rr_store_node(swz_tiler* t, int level, const uint64_t* rkey, const ui
   swz_ctx* c = t->c;
   StoreLevel& st = t->lv[level + 1];
   const int dst = st.cur ^ 1;
-  SWZ_TRY(store_reserve(c, st, dst, (size_t)nr + nt));
+  SWZ_TRY(store_reserve(c, st, level + 1, dst, (size_t)nr + nt));
   SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey, tgid, nt, level < 0 ? 63u : level_shift(level), 0u, st.key[dst], st.gid[dst]));
   st.cur = dst;
   st.cnt = nr + nt;
@@ -862,7 +869,7 @@ static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats) {
     uint32_t nt = 0;
     SWZ_TRY(read_u32(c, counters + 2, &nt));
     const int w = dst.cur ^ 1;
-    SWZ_TRY(store_reserve(c, dst, w, nt));
+    SWZ_TRY(store_reserve(c, dst, lv, w, nt));
     SWZ_HIP(c, hipMemcpyAsync(dst.key[w], tkey, (size_t)nt * 8, hipMemcpyDeviceToDevice, c->stream));
     SWZ_HIP(c, hipMemcpyAsync(dst.gid[w], tgid, (size_t)nt * 4, hipMemcpyDeviceToDevice, c->stream));
     dst.cur = w;
@@ -939,6 +946,7 @@ int swz_tiler_create(swz_ctx* c, const double bmin[3], const double bmax[3], con
   if (params->strategy == SWZ_FAST && params->fast_concurrency == 0)
     return c->fail(SWZ_ERR_BAD_ARG, "FAST needs fast_concurrency >= 1");
   if (capacity_hint > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
+  if (c->tiler_active) return c->fail(SWZ_ERR_BAD_ARG, "this context already has a tiler (one per context; use one context per data set)");
   swz_tiler* t = new swz_tiler();
   t->c = c;
   for (int a = 0; a < 3; ++a) {
@@ -959,6 +967,7 @@ int swz_tiler_create(swz_ctx* c, const double bmin[3], const double bmax[3], con
       return st;
     }
   }
+  c->tiler_active = true;
   *out = t;
   return SWZ_OK;
 }
@@ -969,10 +978,8 @@ int swz_tiler_destroy(swz_tiler* t) {
   if (t->copy_stream) (void)hipStreamSynchronize(t->copy_stream);
   (void)hipStreamSynchronize(t->c->stream);
   for (hipEvent_t e : t->staged_events) (void)hipEventDestroy(e);
-  for (int l = 0; l < 22; ++l) store_free(t->lv[l]);
-  if (t->pool_xyz) (void)hipFree(t->pool_xyz);
-  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
-    if (t->pool_attr[a]) (void)hipFree(t->pool_attr[a]);
+  for (int l = 0; l < 22; ++l) store_free(t->lv[l]);  // the memory stays in the context's workspace (swz_release_workspace)
+  t->c->tiler_active = false;
   if (t->copy_stream) (void)hipStreamDestroy(t->copy_stream);
   delete t;
   return SWZ_OK;
@@ -1011,7 +1018,6 @@ int swz_tiler_stage_batch(swz_tiler* t, const double* xyz_host, uint64_t n, cons
     if (mask && t->pool_cap) {  // the pools were presized before the columns were known
       const size_t cap = t->pool_cap;
       t->pool_cap = 0;
-      if (t->pool_xyz) SWZ_HIP(c, hipFree(t->pool_xyz));
       t->pool_xyz = nullptr;
       SWZ_TRY(pool_reserve(t, cap));
     }
