@@ -30,15 +30,24 @@ def bytes_of(pred):
     return ks, b
 
 
-calib = 2.0 * fetch["swz::radix_hist_kernel"][1] * 1024.0 / (8 * 8.0 * points)
+# calibration on a kernel whose reads are known exactly: the one-sweep histogram reads every key once (8 B x points);
+# (round 1: radix_hist_kernel, eight passes over the keys)
+if "swz::radix_ghist_kernel" in fetch:
+    calib = 2.0 * fetch["swz::radix_ghist_kernel"][1] * 1024.0 / (8.0 * points)
+else:
+    calib = 2.0 * fetch["swz::radix_hist_kernel"][1] * 1024.0 / (8 * 8.0 * points)
 md_k, md_b = bytes_of(lambda k: k.startswith("swz::md_") or k.startswith("swz::sp_"))
-rs_k, rs_b = bytes_of(lambda k: k == "swz::radix_scatter_kernel")
+rs_k, rs_b = bytes_of(lambda k: k in ("swz::radix_scatter_kernel", "swz::radix_onesweep_kernel"))
+md_lo = sum((fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1]) * 1024.0 for k in md_k)
 out = {
     "points": points, "sampler": "MIN_DISTANCE",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0`; "
               "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md); "
-              "check: corrected radix_hist_kernel reads / (64 B x points) = %.4f" % calib,
+              "check: corrected reads of the radix histogram kernel / its exact key bytes = %.4f.  The factor 2 is calibrated "
+              "for wide coalesced loads only: for the scattered 8-byte loads of the MIN_DISTANCE kernels it is an UPPER bound; "
+              "FETCH_SIZE + WRITE_SIZE uncorrected (a lower bound) is given as bytes_per_launch_lower_bound" % calib,
     "bytes_per_launch": {"sample_min_distance": md_b / levels, "radix_scatter": rs_b / 8},
+    "bytes_per_launch_lower_bound": {"sample_min_distance": md_lo / levels},
     "detail": {
         "sample_min_distance": {"kernels": md_k, "launches_per_step": levels, "bytes_per_step": md_b},
         "radix_scatter": {"kernels": rs_k, "launches_per_step": 8, "bytes_per_step": rs_b},
