@@ -28,8 +28,10 @@ namespace swz {
 constexpr uint32_t PM_NONE = 0xFFFFFFFFu;
 constexpr int PM_THREADS = 256;
 constexpr int PM_WAVES = PM_THREADS / WAVE;
-constexpr int PM_WIN = 128;    // taken points of the neighbourhood held in LDS at a time
-constexpr int PM_FRESH = 192;  // taken points of the cell itself held in LDS (more spill to memory reads)
+constexpr int PM_WIN = 256;    // taken points of the neighbourhood held in LDS at a time
+constexpr int PM_FRESH = 128;  // taken points of the cell itself held in LDS (more spill to memory reads)
+constexpr uint32_t PM_BIG = 4096;   // cells with more points: neighbour tests in parallel first (pm_big_reject_kernel)
+constexpr uint32_t PM_UNIT = 256;   // points per unit of that pass (one wavefront, four chunks)
 
 struct PmArgs {
   const uint64_t* akey;
@@ -50,6 +52,7 @@ struct PmArgs {
   double* acc;        // taken positions of cell c at slots [cell.x, cell.x + ccnt), 3 doubles each
   const uint32_t* snode_of;
   uint32_t* ticket;   // work distribution of the running phase
+  uint8_t* rej;       // big cells: 1 = struck out by a taken point of an adjacent cell (pm_big_reject_kernel)
   uint32_t cell_shift;
   uint64_t cells_per_node;
   double sq_spacing;
@@ -154,30 +157,103 @@ __device__ __forceinline__ uint32_t pm_fill_window(const PmArgs& a, PmLds& lds, 
   return wn;
 }
 
+struct PmHood {  // the taken points of the 26 adjacent cells as one flattened list; lane k < 27 owns cell k's part
+  uint32_t n_cnt, n_start, off, T, maxcnt;
+};
+__device__ __forceinline__ PmHood pm_hood(const PmArgs& a, uint32_t c) {
+  const uint32_t l = lane_id();
+  PmHood h{0, 0, 0, 0, 0};
+  if (l < 27u && l != 13u) {
+    const uint32_t nb = a.nbr[(size_t)c * 27 + l];
+    if (nb != PM_NONE) {
+      h.n_cnt = a.ccnt[nb];
+      h.n_start = a.cell[nb].x;
+    }
+  }
+  const uint32_t incl = wave_incl_sum(h.n_cnt);
+  h.off = incl - h.n_cnt;
+  h.T = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+  h.maxcnt = h.n_cnt;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t o = __shfl_xor(h.maxcnt, d, WAVE);
+    h.maxcnt = o > h.maxcnt ? o : h.maxcnt;
+  }
+  return h;
+}
+
+// Big cells (dense blobs: tens of thousands of points in one cell): testing every point against the taken points of
+// the neighbourhood is the bulk of the work and does not depend on the order inside the cell, so it runs first, 256
+// points per wavefront, and leaves a flag per point; the cell's own wavefront then only walks the unflagged points.
+__global__ __launch_bounds__(PM_THREADS) void pm_big_reject_kernel(PmArgs a, const uint2* __restrict__ units, uint32_t nunits) {
+  __shared__ PmLds lds_all[PM_WAVES];
+  const uint32_t w = threadIdx.x / WAVE, l = lane_id();
+  PmLds& lds = lds_all[w];
+  const double t = a.sq_spacing;
+  for (uint32_t u = blockIdx.x * PM_WAVES + w; u < nunits; u += gridDim.x * PM_WAVES) {
+    const uint2 unit = units[u];  // {cell, first point}
+    const uint32_t c = unit.x;
+    const uint32_t e = a.cell[c].y;
+    const uint32_t end = unit.y + PM_UNIT < e ? unit.y + PM_UNIT : e;
+    const PmHood h = pm_hood(a, c);
+    if (h.T == 0) continue;
+    bool rej[PM_UNIT / WAVE];
+    double px[PM_UNIT / WAVE], py[PM_UNIT / WAVE], pz[PM_UNIT / WAVE];
+#pragma unroll
+    for (int k = 0; k < (int)(PM_UNIT / WAVE); ++k) {
+      const uint32_t p = unit.y + (uint32_t)k * WAVE + l;
+      rej[k] = false;
+      px[k] = py[k] = pz[k] = 0.0;
+      if (p < end) {
+        px[k] = a.X[p];
+        py[k] = a.Y[p];
+        pz[k] = a.Z[p];
+      }
+    }
+    for (uint32_t base = 0; base < h.T; base += PM_WIN) {
+      const uint32_t wn = pm_fill_window(a, lds, base, h.T, h.maxcnt, h.n_cnt, h.n_start, h.off);
+      for (uint32_t ti = 0; ti < wn; ++ti) {
+        const double qx = lds.wx[ti], qy = lds.wy[ti], qz = lds.wz[ti];
+#pragma unroll
+        for (int k = 0; k < (int)(PM_UNIT / WAVE); ++k)
+          if (sq_dist(px[k], py[k], pz[k], qx, qy, qz) < t) rej[k] = true;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < (int)(PM_UNIT / WAVE); ++k) {
+      const uint32_t p = unit.y + (uint32_t)k * WAVE + l;
+      if (p < end && rej[k]) a.rej[p] = 1;
+    }
+  }
+}
+// units of the big cells: first the counts per colour, then the units themselves behind per-colour cursors
+__global__ __launch_bounds__(256) void pm_big_count_kernel(PmArgs a, uint32_t ncells, uint32_t* __restrict__ counts) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const uint2 r = a.cell[c];
+  if (r.y - r.x > PM_BIG) atomicAdd(&counts[a.crel[c] & 7u], (r.y - r.x + PM_UNIT - 1u) / PM_UNIT);
+}
+__global__ __launch_bounds__(256) void pm_big_units_kernel(PmArgs a, uint32_t ncells, uint32_t* __restrict__ cursors,
+                                                           uint2* __restrict__ units) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const uint2 r = a.cell[c];
+  if (r.y - r.x <= PM_BIG) return;
+  const uint32_t nu = (r.y - r.x + PM_UNIT - 1u) / PM_UNIT;
+  const uint32_t at = atomicAdd(&cursors[a.crel[c] & 7u], nu);
+  for (uint32_t j = 0; j < nu; ++j) units[at + j] = make_uint2(c, r.x + j * PM_UNIT);
+}
+
 // one wavefront decides all points of one cell
 __device__ void pm_cell(const PmArgs& a, uint32_t c, PmLds& lds) {
   const uint32_t l = lane_id();
   const uint2 me = a.cell[c];
   const uint32_t s0 = me.x, e = me.y;
   const double t = a.sq_spacing;
-  // lane k < 27, k != 13: adjacent cell in direction slot k
-  uint32_t n_cnt = 0, n_start = 0;
-  if (l < 27u && l != 13u) {
-    const uint32_t nb = a.nbr[(size_t)c * 27 + l];
-    if (nb != PM_NONE) {
-      n_cnt = a.ccnt[nb];
-      n_start = a.cell[nb].x;
-    }
-  }
-  const uint32_t incl = wave_incl_sum(n_cnt);
-  const uint32_t off = incl - n_cnt;
-  const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
-  uint32_t maxcnt = n_cnt;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const uint32_t o = __shfl_xor(maxcnt, d, WAVE);
-    maxcnt = o > maxcnt ? o : maxcnt;
-  }
+  const bool big = e - s0 > PM_BIG;  // the neighbourhood has been dealt with (a.rej)
+  PmHood h{0, 0, 0, 0, 0};
+  if (!big) h = pm_hood(a, c);
+  const uint32_t n_cnt = h.n_cnt, n_start = h.n_start, off = h.off, T = h.T, maxcnt = h.maxcnt;
   uint32_t wn0 = 0;
   if (T > 0) wn0 = pm_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
   uint32_t fresh = 0;
@@ -190,7 +266,8 @@ __device__ void pm_cell(const PmArgs& a, uint32_t c, PmLds& lds) {
       py = a.Y[p];
       pz = a.Z[p];
     }
-    bool rej = !valid;
+    bool rej = !valid || (big && a.rej[p] != 0);
+    if (big && !__ballot(!rej)) continue;  // a stretch struck out completely
     // against the taken points of the adjacent cells, window by window
     for (uint32_t base = 0; base < T; base += PM_WIN) {
       const uint32_t wn = (T <= (uint32_t)PM_WIN) ? wn0 : pm_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off);
@@ -321,6 +398,36 @@ __global__ __launch_bounds__(256) void pm_cell_hist_kernel(const uint64_t* __res
   if (threadIdx.x < 16 && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
+// points-weighted mean cell population at cell level cl_geo (out[0]) and one level coarser (out[1]); out[2] = samples:
+// the population of the cell of every 65536-th point, by binary search for the cell's run in the sorted keys
+__global__ __launch_bounds__(256) void pm_cell_pop_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ nid,
+                                                          const uint8_t* __restrict__ nmode, uint32_t m, uint32_t node_shift,
+                                                          uint32_t cl_geo, unsigned long long* __restrict__ out) {
+  const uint32_t tsample = blockIdx.x * 256 + threadIdx.x;
+  if (tsample >= 65536u) return;
+  const uint32_t i = (uint32_t)(((uint64_t)tsample * m) / 65536u);
+  if (i >= m || nmode[nid[i]] != MODE_SAMPLE) return;
+  const uint64_t key = akey[i];
+  for (uint32_t k = 0; k <= 1u && k <= cl_geo; ++k) {
+    const uint32_t sh = node_shift - 3u * (cl_geo - k);
+    const uint64_t pre = key >> sh;
+    uint32_t lo = 0, hi = i;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2u;
+      if ((akey[mid] >> sh) < pre) lo = mid + 1u; else hi = mid;
+    }
+    const uint32_t first = lo;
+    lo = i;
+    hi = m;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2u;
+      if ((akey[mid] >> sh) <= pre) lo = mid + 1u; else hi = mid;
+    }
+    atomicAdd(&out[k], (unsigned long long)(lo - first));
+  }
+  atomicAdd(&out[2], 1ull);
+}
+
 int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                                 const LevelBuffers& lb, uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points,
                                 uint32_t* phases_out) {
@@ -354,7 +461,20 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   // finest cells are poorly filled and the coarser ones still hold few taken points WHATEVER their population (real
   // data is clustered: an average says nothing about the dense parts).
   int cl = plan.cell_levels_geo;
-  if (cl > 0 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0 && 0.75 * 8.0 * r0 * r0 * r0 <= 48.0) --cl;
+  if (cl > 0 && (double)sample_points / (double)std::max(1u, occupied[cl]) < 24.0 && 0.75 * 8.0 * r0 * r0 * r0 <= 48.0) {
+    // ... and only while the TYPICAL point would not sit in an oversized cell afterwards (points-weighted mean
+    // population: a dense blob in a sparse background keeps the plain average low)
+    unsigned long long* d_pop = nullptr;
+    SWZ_TRY(c->get("md_pop", (size_t)8, &d_pop));
+    SWZ_HIP(c, hipMemsetAsync(d_pop, 0, 64, c->stream));
+    hipLaunchKernelGGL(pm_cell_pop_kernel, dim3(256), dim3(256), 0, c->stream, as.akey, lb.nid, lb.nmode, m, nsh,
+                       (uint32_t)plan.cell_levels_geo, d_pop);
+    SWZ_LAUNCH_CHECK(c);
+    unsigned long long hp[3];
+    SWZ_HIP(c, hipMemcpyAsync(hp, d_pop, 24, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (hp[2] && (double)hp[1] / (double)hp[2] <= 1024.0) --cl;
+  }
   while (cl > 0 && (double)sample_nodes * std::pow(8.0, cl) > 2147483648.0) --cl;
   const double pts_per_cell = (double)sample_points / (double)std::max(1u, occupied[cl]);
   const uint64_t cells_per_node = 1ull << (3 * cl);
@@ -438,8 +558,32 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   uint32_t h[8];
   SWZ_HIP(c, hipMemcpyAsync(h, counts, 32, hipMemcpyDeviceToHost, c->stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  // big cells: their units of 256 points per colour
+  uint32_t ucount[8], uoff[9] = {0};
+  uint2* d_units = nullptr;
+  {
+    SWZ_HIP(c, hipMemsetAsync(counts, 0, 32, c->stream));
+    hipLaunchKernelGGL(pm_big_count_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, counts);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_HIP(c, hipMemcpyAsync(ucount, counts, 32, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 8; ++k) uoff[k + 1] = uoff[k] + ucount[k];
+    if (uoff[8]) {
+      SWZ_TRY(c->get("pm_units", (size_t)uoff[8], &d_units));
+      SWZ_TRY(c->get("pm_rej", (size_t)m, &a.rej));
+      SWZ_HIP(c, hipMemsetAsync(a.rej, 0, (size_t)m, c->stream));
+      SWZ_HIP(c, hipMemcpyAsync(counts, uoff, 32, hipMemcpyHostToDevice, c->stream));  // cursors start at the offsets
+      hipLaunchKernelGGL(pm_big_units_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, counts, d_units);
+      SWZ_LAUNCH_CHECK(c);
+    }
+  }
   for (uint32_t colour = 0; colour < 8; ++colour) {
     if (!h[colour]) continue;
+    if (ucount[colour]) {
+      hipLaunchKernelGGL(pm_big_reject_kernel, dim3(std::min<uint32_t>(256u * 4u, div_up(ucount[colour], PM_WAVES))),
+                         dim3(PM_THREADS), 0, c->stream, a, d_units + uoff[colour], ucount[colour]);
+      SWZ_LAUNCH_CHECK(c);
+    }
     const uint32_t grid = std::min<uint32_t>(256u * 5u, std::max(1u, div_up(h[colour], 16u * PM_WAVES)));
     SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
     hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, lists + (size_t)colour * ncells, h[colour]);
