@@ -28,8 +28,8 @@ namespace swz {
 constexpr uint32_t PM_NONE = 0xFFFFFFFFu;
 constexpr int PM_THREADS = 256;
 constexpr int PM_WAVES = PM_THREADS / WAVE;
-constexpr int PM_WIN = 256;    // taken points of the neighbourhood held in LDS at a time
-constexpr int PM_FRESH = 128;  // taken points of the cell itself held in LDS (more spill to memory reads)
+constexpr int PM_WIN = 128;    // taken points of the neighbourhood held in LDS at a time
+constexpr int PM_FRESH = 64;  // taken points of the cell itself held in LDS (more spill to memory reads)
 constexpr uint32_t PM_BIG = 4096;   // cells with more points: neighbour tests in parallel first (pm_big_reject_kernel)
 constexpr uint32_t PM_UNIT = 256;   // points per unit of that pass (one wavefront, four chunks)
 
@@ -584,7 +584,7 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
                          dim3(PM_THREADS), 0, c->stream, a, d_units + uoff[colour], ucount[colour]);
       SWZ_LAUNCH_CHECK(c);
     }
-    const uint32_t grid = std::min<uint32_t>(256u * 5u, std::max(1u, div_up(h[colour], 16u * PM_WAVES)));
+    const uint32_t grid = std::min<uint32_t>(256u * 8u, std::max(1u, div_up(h[colour], 16u * PM_WAVES)));
     SWZ_HIP(c, hipMemsetAsync(a.ticket, 0, 4, c->stream));
     hipLaunchKernelGGL(pm_phase_kernel, dim3(grid), dim3(PM_THREADS), 0, c->stream, a, lists + (size_t)colour * ncells, h[colour]);
     SWZ_LAUNCH_CHECK(c);
