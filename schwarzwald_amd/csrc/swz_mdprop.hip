@@ -244,15 +244,57 @@ __global__ __launch_bounds__(256) void pm_big_units_kernel(PmArgs a, uint32_t nc
   for (uint32_t j = 0; j < nu; ++j) units[at + j] = make_uint2(c, r.x + j * PM_UNIT);
 }
 
-// one wavefront decides all points of one cell
-__device__ void pm_cell(const PmArgs& a, uint32_t c, PmLds& lds) {
+// What a wavefront requests for the NEXT cell of its ticket while it works on the current one: the cell record and the
+// row of adjacent cells first, then (they depend on those) the adjacent cells' counts and starts and the first 64
+// points -- a cell is a chain of five dependent memory round trips otherwise, for often fewer than 64 points.
+struct PmPre {
+  uint2 me;
+  uint32_t nb;              // lane k < 27, k != 13: adjacent cell in direction slot k
+  uint32_t n_cnt, n_start;  // ... its taken points
+  double px, py, pz;        // the lane's point of the first chunk
+};
+__device__ __forceinline__ void pm_prefetch1(const PmArgs& a, uint32_t c, PmPre& q) {
   const uint32_t l = lane_id();
-  const uint2 me = a.cell[c];
+  q.me = a.cell[c];
+  q.nb = (l < 27u && l != 13u) ? a.nbr[(size_t)c * 27 + l] : PM_NONE;
+}
+__device__ __forceinline__ void pm_prefetch2(const PmArgs& a, PmPre& q) {
+  q.n_cnt = 0;
+  q.n_start = 0;
+  if (q.nb != PM_NONE) {
+    q.n_cnt = a.ccnt[q.nb];
+    q.n_start = a.cell[q.nb].x;
+  }
+  const uint32_t p = q.me.x + lane_id();
+  q.px = q.py = q.pz = 0.0;
+  if (p < q.me.y) {
+    q.px = a.X[p];
+    q.py = a.Y[p];
+    q.pz = a.Z[p];
+  }
+}
+
+// one wavefront decides all points of one cell
+__device__ void pm_cell(const PmArgs& a, uint32_t c, const PmPre& pre, PmLds& lds) {
+  const uint32_t l = lane_id();
+  const uint2 me = pre.me;
   const uint32_t s0 = me.x, e = me.y;
   const double t = a.sq_spacing;
   const bool big = e - s0 > PM_BIG;  // the neighbourhood has been dealt with (a.rej)
   PmHood h{0, 0, 0, 0, 0};
-  if (!big) h = pm_hood(a, c);
+  if (!big) {
+    h.n_cnt = pre.n_cnt;
+    h.n_start = pre.n_start;
+    const uint32_t incl = wave_incl_sum(h.n_cnt);
+    h.off = incl - h.n_cnt;
+    h.T = (uint32_t)__builtin_amdgcn_readlane((int)incl, WAVE - 1);
+    h.maxcnt = h.n_cnt;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t o = __shfl_xor(h.maxcnt, d, WAVE);
+      h.maxcnt = o > h.maxcnt ? o : h.maxcnt;
+    }
+  }
   const uint32_t n_cnt = h.n_cnt, n_start = h.n_start, off = h.off, T = h.T, maxcnt = h.maxcnt;
   uint32_t wn0 = 0;
   if (T > 0) wn0 = pm_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
@@ -260,11 +302,14 @@ __device__ void pm_cell(const PmArgs& a, uint32_t c, PmLds& lds) {
   for (uint32_t cur = s0; cur < e; cur += WAVE) {
     const uint32_t p = cur + l;
     const bool valid = p < e;
-    double px = 0, py = 0, pz = 0;
-    if (valid) {
-      px = a.X[p];
-      py = a.Y[p];
-      pz = a.Z[p];
+    double px = pre.px, py = pre.py, pz = pre.pz;
+    if (cur != s0) {
+      px = py = pz = 0.0;
+      if (valid) {
+        px = a.X[p];
+        py = a.Y[p];
+        pz = a.Z[p];
+      }
     }
     bool rej = !valid || (big && a.rej[p] != 0);
     if (big && !__ballot(!rej)) continue;  // a stretch struck out completely
@@ -328,7 +373,20 @@ __global__ __launch_bounds__(PM_THREADS) void pm_phase_kernel(PmArgs a, const ui
     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
     if (base >= count) return;
     const uint32_t end = base + 16u < count ? base + 16u : count;
-    for (uint32_t i = base; i < end; ++i) pm_cell(a, list[i], lds[w]);
+    PmPre nxt;
+    uint32_t cn = list[base];
+    pm_prefetch1(a, cn, nxt);
+    pm_prefetch2(a, nxt);
+    for (uint32_t i = base; i < end; ++i) {
+      const PmPre cur = nxt;
+      const uint32_t c = cn;
+      if (i + 1 < end) {
+        cn = list[i + 1];
+        pm_prefetch1(a, cn, nxt);
+        pm_prefetch2(a, nxt);
+      }
+      pm_cell(a, c, cur, lds[w]);
+    }
   }
 }
 
