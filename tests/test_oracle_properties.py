@@ -139,3 +139,90 @@ def test_threaded_oracle_gives_the_same_tiles(sampler, strategy):
     for k in ("keys", "perm", "level", "dup"):
         assert np.array_equal(a[k], b[k]), k
     assert a["stats"] == b["stats"]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Independent characterisation of GRID_CENTER and JITTERED (no reference vector pins them): in the unit cube every
+# box edge is a dyadic rational, so the cell centre / jitter target is exact in ANY evaluation order and a few lines of
+# numpy say what sample_points must return -- in every run of equal key prefix at the grid level exactly one point,
+# the FIRST (Morton order) with the smallest (dx*dx + dy*dy) + dz*dz to the target (std::min_element,
+# Sampling.h:392-403 / :741-750).  The jitter tables are the reference's constants (Sampling.h:14-138).
+def _compact3(v):
+    out = np.zeros_like(v)
+    for b in range(21):
+        out |= ((v >> np.uint64(3 * b)) & np.uint64(1)) << np.uint64(b)
+    return out
+
+
+def _jitter_tables():
+    import os
+    import re
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "jitter_tables.inc")).read()
+    out = {}
+    for w in (16, 32, 64):
+        body = text.split("SWZ_JITTER_TABLE(%d)" % w)[1].split("};")[0]
+        nums = [int(x) for x in re.findall(r"\b\d+\b", body)]
+        out[w] = np.array(nums[-16 * w:], dtype=np.int64).reshape(16, w)
+    return out
+
+
+def _expected_grid_sample(keys, pos, sampler, node_level, spacing_at_root):
+    """taken flags of a sampled node at node_level whose points are keys/pos (Morton order), unit-cube root"""
+    s_node = float(np.float32(spacing_at_root)) / 2.0 ** (node_level + 1)
+    node_ext = 0.5 ** (node_level + 1)
+    if sampler == O.GRID_CENTER:
+        grid_level = max(-1, int(np.floor(np.log2(np.float32(1.0 / s_node)))) - 1)  # candidate_level_in_octree
+    else:
+        cells = 1 << int(np.floor(np.log2(np.uint32(node_ext / s_node))))            # prev_pow2((uint32) perfect count)
+        levels = int(np.log2(cells))
+        grid_level = node_level + levels
+    depth = grid_level + 1
+    cell = keys >> np.uint64(3 * (20 - grid_level))
+    gx, gy, gz = _compact3(cell >> np.uint64(2)), _compact3(cell >> np.uint64(1)), _compact3(cell)
+    size = 0.5 ** depth
+    if sampler == O.GRID_CENTER:
+        t = np.stack([(gx + 0.5) * size, (gy + 0.5) * size, (gz + 0.5) * size], axis=1)
+    else:
+        m = np.uint64(cells - 1)
+        lx, ly, lz = (gx & m).astype(np.int64), (gy & m).astype(np.int64), (gz & m).astype(np.int64)
+        tab = _jitter_tables()[16 if cells <= 16 else (32 if cells <= 32 else 64)]
+        plen = min(cells, 64)
+        start = (3 * (node_level + 1)) % 16
+        px = tab[start][(ly + lz) % plen] - 1
+        py = tab[(start + 1) % 16][(lx + lz) % plen] - 1
+        pz = tab[(start + 2) % 16][(lx + ly) % plen] - 1
+        perm_size = size / cells
+        t = np.stack([gx * size + px * perm_size, gy * size + py * perm_size, gz * size + pz * perm_size], axis=1)
+    d = pos - t
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    taken = np.zeros(len(keys), dtype=bool)
+    starts = np.nonzero(np.r_[True, cell[1:] != cell[:-1]])[0]
+    ends = np.r_[starts[1:], len(keys)]
+    for a, b in zip(starts, ends):
+        taken[a + int(np.argmin(d2[a:b]))] = True      # np.argmin returns the FIRST minimum
+    return taken
+
+
+@pytest.mark.parametrize("sampler", [O.GRID_CENTER, O.JITTERED])
+@pytest.mark.parametrize("d", [250, 40])
+def test_grid_center_and_jittered_against_an_independent_characterisation(sampler, d):
+    rng = np.random.default_rng(31 + d)
+    n = 60000
+    xyz = np.vstack([rng.random((n - 5000, 3)), 0.4 + 0.01 * rng.standard_normal((5000, 3))]).clip(0.0, 1.0)
+    xyz[::17] = xyz[5]                                   # exact duplicates: ties in distance
+    sp = O.spacing_from_diagonal(*UNIT, d)
+    keys, clamped = O.index_points(xyz, *UNIT)
+    order = O.sort_by_key(keys)
+    ks, pos = keys[order], clamped[order]
+    # the root node (level -1) and one level-0 node
+    cases = [(-1, np.arange(n))]
+    in0 = np.nonzero((ks >> np.uint64(60)) == np.uint64(5))[0]
+    cases.append((0, in0))
+    for level, sel in cases:
+        node_key = int(ks[sel[0]]) >> (3 * (20 - level)) << (3 * (20 - level)) if level >= 0 else 0
+        cnt, k2, i2 = O.sample_points(sampler, 10, ks[sel], order[sel], clamped, node_key, level, *UNIT, sp, O.ALWAYS_ADHERE)
+        assert cnt > 0
+        want = _expected_grid_sample(ks[sel], pos[sel], sampler, level, sp)
+        assert cnt == int(want.sum())
+        assert np.array_equal(i2[:cnt], order[sel][want])          # taken points, in Morton order
+        assert np.array_equal(i2[cnt:], order[sel][~want])         # the rest keeps its order (stable partition)
