@@ -384,6 +384,31 @@ int swz_tiler_node_table(swz_tiler* tiler, uint64_t max_nodes, int8_t* node_leve
                          uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out);
 /* the pools by point id: positions (num_points x 3, clamped) and the attribute columns staged so far */
 int swz_tiler_pools_device(swz_tiler* tiler, const double** d_xyz_out, swz_attribute_columns* d_attrs_out);
+/* ---- one tiler per GPU of a multi-GPU run (BASELINE config 5: sharded + multi-batch).  Points are owned by their
+ * level-0 octant as in swz_shard_* above; every shard keeps the subtrees of its octants and ITS part of the root's
+ * file.  Per batch, after the exchange of the batch's points (and attribute columns) by octant:
+ *   swz_tiler_shard_begin_device: d_xyz / d_attrs (device; attrs may be NULL) are the points this shard received
+ *     (n may be 0).  Indexes + sorts them and decides the ROOT node: take-all / sample from the counts of the whole
+ *     root (tile_internal_node, TilingAlgorithms.cpp:272-275: global_root_stored > 0 forces sampling); the whole
+ *     local part of the root's file takes part whenever the batch has points anywhere; for MIN_DISTANCE
+ *     d_ghost_xyz are the positions of what the root holds on all LOWER shards after their begin of THIS batch
+ *     (swz_tiler_level_positions_device(tiler, -1, ...) there): they sort first and are taken again.
+ *     *root_file_count_out = points of the root's file on this shard afterwards.
+ *   swz_tiler_shard_finish: the levels >= 0 (local).
+ * ACCURATE and exact MIN_DISTANCE only.  The node table of a shard lists the root with the shard's part of its file;
+ * the root's file is the concatenation over the shards in rank order. */
+typedef struct {
+  uint64_t global_new_points;  /* points of this batch over all shards */
+  uint64_t global_root_stored; /* points in the root's file over all shards before this batch */
+  const double* d_ghost_xyz;   /* device, num_ghosts x 3 */
+  uint64_t num_ghosts;
+} swz_tiler_shard_info;
+int swz_tiler_shard_begin_device(swz_tiler* tiler, double* d_xyz, uint64_t n, const swz_attribute_columns* d_attrs,
+                                 const swz_tiler_shard_info* info, uint64_t* root_file_count_out);
+int swz_tiler_shard_finish(swz_tiler* tiler, swz_tile_stats* stats);
+/* points stored in the files of one octree level (-1 = root) and their positions in file order */
+int swz_tiler_level_count(swz_tiler* tiler, int level, uint64_t* count_out);
+int swz_tiler_level_positions_device(swz_tiler* tiler, int level, double* d_xyz_out);
 /* page-locked host memory for the staging entry points (hipHostMalloc / hipHostFree) */
 int swz_host_alloc_pinned(uint64_t bytes, void** out);
 int swz_host_free_pinned(void* p);

@@ -50,6 +50,11 @@ class _TilerInfo(C.Structure):
                 ("staged_bytes", C.c_uint64), ("staged_wait_ms", C.c_double)]
 
 
+class _TilerShardInfo(C.Structure):
+    _fields_ = [("global_new_points", C.c_uint64), ("global_root_stored", C.c_uint64), ("d_ghost_xyz", C.c_void_p),
+                ("num_ghosts", C.c_uint64)]
+
+
 class _KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double),
                 ("algorithmic_bytes", C.c_uint64)]
@@ -326,6 +331,10 @@ def load_library():
     L.swz_tiler_export_device.argtypes = [vp, vp, vp, vp]
     L.swz_tiler_node_table.argtypes = [vp, C.c_uint64, _i8p, _u64p, _u64p, _u64p, _u64p]
     L.swz_tiler_pools_device.argtypes = [vp, C.POINTER(vp), cols]
+    L.swz_tiler_shard_begin_device.argtypes = [vp, vp, C.c_uint64, cols, C.POINTER(_TilerShardInfo), _u64p]
+    L.swz_tiler_shard_finish.argtypes = [vp, C.POINTER(_TileStats)]
+    L.swz_tiler_level_count.argtypes = [vp, C.c_int, _u64p]
+    L.swz_tiler_level_positions_device.argtypes = [vp, C.c_int, vp]
     L.swz_host_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(vp)]
     L.swz_host_free_pinned.argtypes = [vp]
     L.swz_profile_enable.argtypes = [vp, C.c_int]
@@ -342,7 +351,9 @@ def load_library():
                  "swz_node_from_entwine_name", "swz_node_bounds", "swz_tiler_create", "swz_tiler_destroy",
                  "swz_tiler_add_batch_device", "swz_tiler_stage_batch", "swz_tiler_tile_staged", "swz_tiler_add_batch",
                  "swz_tiler_finalize", "swz_tiler_get_info", "swz_tiler_export_device", "swz_tiler_node_table",
-                 "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned"):
+                 "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned",
+                 "swz_tiler_shard_begin_device", "swz_tiler_shard_finish", "swz_tiler_level_count",
+                 "swz_tiler_level_positions_device"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -400,6 +411,13 @@ class Context:
         """Debug / tuning switch of this context (what the SWZ_* environment variables seed at creation); None removes it."""
         self._lib.swz_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
         self._check(self._lib.swz_set_option(self._ctx, name.encode(), None if value is None else str(value).encode()))
+
+    def copy_to_host(self, d_ptr, nbytes):
+        """nbytes of device memory as a numpy uint8 array (swz_copy_to_host: for pointers the library hands out)"""
+        out = np.empty(int(nbytes), dtype=np.uint8)
+        self._lib.swz_copy_to_host.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+        self._check(self._lib.swz_copy_to_host(self._ctx, out.ctypes.data_as(C.c_void_p), C.c_void_p(int(d_ptr)), int(nbytes)))
+        return out
 
     def release_workspace(self):
         self._check(self._lib.swz_release_workspace(self._ctx))
@@ -680,6 +698,30 @@ class Tiler:
     def export_device(self, d_keys, d_ids, d_level):
         self._ctx._check(self._lib.swz_tiler_export_device(self._t, C.c_void_p(d_keys), C.c_void_p(d_ids),
                                                            C.c_void_p(d_level)))
+
+    # -- one tiler per GPU of a multi-GPU run (schwarzwald_amd/sharded.py drives these)
+    def shard_begin_device(self, d_xyz, n, d_attrs, global_new_points, global_root_stored, d_ghost_xyz=None, num_ghosts=0):
+        """Indexes + sorts this shard's part of the batch and decides the root node.  Returns the points of the
+        root's file on this shard afterwards."""
+        info = _TilerShardInfo(int(global_new_points), int(global_root_stored), C.c_void_p(d_ghost_xyz), int(num_ghosts))
+        cols = device_columns(d_attrs)
+        out = C.c_uint64()
+        self._ctx._check(self._lib.swz_tiler_shard_begin_device(self._t, C.c_void_p(d_xyz), int(n), C.byref(cols),
+                                                                C.byref(info), C.byref(out)))
+        return int(out.value)
+
+    def shard_finish(self):
+        stats = _TileStats()
+        self._ctx._check(self._lib.swz_tiler_shard_finish(self._t, C.byref(stats)))
+        return _stats_dict(stats)
+
+    def level_count(self, level):
+        out = C.c_uint64()
+        self._ctx._check(self._lib.swz_tiler_level_count(self._t, int(level), C.byref(out)))
+        return int(out.value)
+
+    def level_positions_device(self, level, d_xyz_out):
+        self._ctx._check(self._lib.swz_tiler_level_positions_device(self._t, int(level), C.c_void_p(d_xyz_out)))
 
     def pools_device(self):
         """(device pointer of the clamped positions by point id, dict name -> device pointer of the attribute pools)"""

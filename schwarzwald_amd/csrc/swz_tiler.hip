@@ -38,6 +38,28 @@ struct StoreLevel {
   uint32_t cnt = 0;
 };
 
+// One batch on its way through the levels.  `as` (kept beside it) is the active set handed down -- new points and
+// displaced old ones --, Morton sorted.
+struct BatchWork {
+  uint32_t n = 0;          // points of the batch
+  uint32_t wused = 0;      // working-pool entries in use
+  uint32_t wcap = 0;
+  double *wx = nullptr, *wy = nullptr, *wz = nullptr;
+  int8_t* wlevel = nullptr;
+  uint32_t* wgid = nullptr;
+  uint64_t* surv_key[2] = {nullptr, nullptr};
+  uint32_t* surv_idx[2] = {nullptr, nullptr};
+  int which = 0;
+};
+
+// what a shard of a multi-GPU batch knows about the other shards (root node only)
+struct ShardRoot {
+  bool active = false;
+  bool sample = false;        // the root samples (global counts), else it takes everything
+  const double* ghost_xyz = nullptr;
+  uint32_t ghosts = 0;
+};
+
 }  // namespace swz
 
 struct swz_tiler {
@@ -61,6 +83,14 @@ struct swz_tiler {
   uint64_t rekey_inversions = 0;
   uint64_t staged_bytes = 0;
   double staged_wait_ms = 0.0;  // time swz_tiler_tile_staged had to WAIT for its copy (0 when fully overlapped)
+  // a batch between swz_tiler_shard_begin_device and swz_tiler_shard_finish
+  bool batch_open = false;
+  swz::BatchWork bw;
+  swz::ActiveSet as;
+  int next_level = -1;
+  uint64_t acc_visited = 0, acc_nodes = 0;
+  uint32_t acc_rounds = 0, acc_levels = 0;
+  int acc_max_level = -1;
 };
 
 namespace swz {
@@ -410,33 +440,53 @@ static int sort_pairs_by_key(swz_ctx* c, uint64_t* key, uint32_t* gid, uint32_t 
   return SWZ_OK;
 }
 
-// One level of one batch.  `as` is the active set handed down (new points and displaced old ones), Morton sorted;
-// on return *next is the active set of the next level.
-struct BatchWork {
-  uint32_t n = 0;          // points of the batch
-  uint32_t wused = 0;      // working-pool entries in use
-  uint32_t wcap = 0;
-  double *wx = nullptr, *wy = nullptr, *wz = nullptr;
-  int8_t* wlevel = nullptr;
-  uint32_t* wgid = nullptr;
-  uint64_t* surv_key[2] = {nullptr, nullptr};
-  uint32_t* surv_idx[2] = {nullptr, nullptr};
-  int which = 0;
-};
+__global__ __launch_bounds__(256) void tl_rows_kernel(const uint32_t* __restrict__ gid, uint32_t n, const double* __restrict__ pool,
+                                                      double* __restrict__ out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const size_t g = gid[i];
+  out[3 * (size_t)i] = pool[3 * g];
+  out[3 * (size_t)i + 1] = pool[3 * g + 1];
+  out[3 * (size_t)i + 2] = pool[3 * g + 2];
+}
+__global__ __launch_bounds__(256) void tl_iota_base_kernel(uint32_t* __restrict__ out, uint32_t n, uint32_t base) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = base + i;
+}
+__global__ __launch_bounds__(256) void tl_count_untaken_kernel(const uint8_t* __restrict__ taken, uint32_t n,
+                                                               uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  const uint64_t b = __ballot(i < n && !taken[i]);
+  if (lane_id() == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
+}
 
-static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, ActiveSet& as, LevelResult* res,
-                       uint32_t* merged_out) {
+// sr != nullptr: the ROOT level of a sharded batch (the node spans all shards: its take-all / sample decision is
+// the global one, its whole local file takes part even without new local points, and for MIN_DISTANCE what the root
+// took on lower shards in this batch sorts first as ghosts -- swz_tiler_shard_begin_device)
+static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, ActiveSet& as, LevelResult* res,
+                       uint32_t* merged_out, const ShardRoot* sr = nullptr) {
   swz_ctx* c = t->c;
+  LevelPlan plan = plan_in;
   StoreLevel& st = t->lv[plan.level + 1];
   const uint32_t nsh = plan.node_shift;
   uint32_t* counters = nullptr;
   SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+  const uint32_t ng = sr ? sr->ghosts : 0u;
+  if (sr) {
+    if (sr->sample) plan.force_sample = true; else plan.max_points = ~0ull;
+  }
 
   // ---- pull the files of the nodes this level's active set reaches
   uint64_t *ckey = nullptr, *rkey = nullptr;
   uint32_t *cgid = nullptr, *rgid = nullptr;
   uint32_t nc = 0, nr = 0;
-  if (st.cnt) {
+  if (st.cnt && sr) {  // the root is reached by the batch as a whole: all of its local file
+    SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
+    SWZ_TRY(c->get("tl_cgid", (size_t)st.cnt, &cgid));
+    SWZ_HIP(c, hipMemcpyAsync(ckey, st.key[st.cur], (size_t)st.cnt * 8, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_HIP(c, hipMemcpyAsync(cgid, st.gid[st.cur], (size_t)st.cnt * 4, hipMemcpyDeviceToDevice, c->stream));
+    nc = st.cnt;
+  } else if (st.cnt) {
     uint8_t* touch = nullptr;
     SWZ_TRY(c->get("tl_touch", (size_t)st.cnt, &touch));
     SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
@@ -452,7 +502,7 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, Active
     nr = st.cnt - nc;
   }
   ActiveSet ms = as;
-  if (nc) {
+  if (nc || ng) {
     hipLaunchKernelGGL(tl_rekey_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, cgid, nc, t->pool_xyz,
                        root_box(t), plan.level);
     SWZ_LAUNCH_CHECK(c);
@@ -467,22 +517,54 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, Active
         SWZ_TRY(sort_pairs_by_key(c, ckey, cgid, nc));
       }
     }
-    if (w.wused + nc > w.wcap) return c->fail(SWZ_ERR_INTERNAL, "working pool overflow");
-    hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, cgid, nc, t->pool_xyz,
-                       w.wx + w.wused, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
-    SWZ_LAUNCH_CHECK(c);
+    if (w.wused + nc + ng > w.wcap) return c->fail(SWZ_ERR_INTERNAL, "working pool overflow");
+    if (nc) {
+      hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, cgid, nc, t->pool_xyz,
+                         w.wx + w.wused, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
+      SWZ_LAUNCH_CHECK(c);
+    }
     uint64_t* mkey = nullptr;
     uint32_t* midx = nullptr;
-    SWZ_TRY(c->get("tl_mkey", (size_t)as.m + nc, &mkey));
-    SWZ_TRY(c->get("tl_midx", (size_t)as.m + nc, &midx));
-    // tile_node :421-442: terminal nodes append (new ++ cached), the others std::merge by key
-    SWZ_TRY(merge_pairs(c, as.akey, as.aidx, as.m, ckey, nullptr, nc, plan.terminal ? nsh : 0u, w.wused, mkey, midx));
+    SWZ_TRY(c->get("tl_mkey", (size_t)as.m + nc + ng, &mkey));
+    SWZ_TRY(c->get("tl_midx", (size_t)as.m + nc + ng, &midx));
+    // tile_node :421-442: terminal nodes append (new ++ cached), the others std::merge by key; ghosts lie in lower
+    // octants, so their keys are smaller than every local key: sorted ghosts ++ merged locals is the merged whole
+    SWZ_TRY(merge_pairs(c, as.akey, as.aidx, as.m, ckey, nullptr, nc, plan.terminal ? nsh : 0u, w.wused, mkey + ng, midx + ng));
     w.wused += nc;
+    if (ng) {
+      uint64_t *gk = nullptr, *gkb = nullptr;
+      uint32_t *gp = nullptr, *gpb = nullptr;
+      SWZ_TRY(c->get("tl_gkey", (size_t)ng, &gk));
+      SWZ_TRY(c->get("tl_gkey_b", (size_t)ng, &gkb));
+      SWZ_TRY(c->get("tl_gperm", (size_t)ng, &gp));
+      SWZ_TRY(c->get("tl_gperm_b", (size_t)ng, &gpb));
+      double* gx = const_cast<double*>(sr->ghost_xyz);  // inside the bounds already: the clamp of the encode is a no-op
+      uint64_t* sorted_k = gk;
+      uint32_t* sorted_p = gp;
+      if (radix_result_in_second()) {
+        SWZ_TRY(encode_device(c, gx, ng, t->bmin, t->bmax, gkb));
+        SWZ_TRY(radix_sort_pairs(c, gkb, gpb, gk, gp, ng, true));
+      } else {
+        SWZ_TRY(encode_device(c, gx, ng, t->bmin, t->bmax, gk));
+        SWZ_TRY(radix_sort_pairs(c, gk, gp, gkb, gpb, ng, true));
+      }
+      SWZ_TRY(gather_positions(c, sr->ghost_xyz, sorted_p, ng, w.wx + w.wused, w.wy + w.wused, w.wz + w.wused));
+      SWZ_HIP(c, hipMemsetAsync(w.wgid + w.wused, 0xFF, (size_t)ng * 4, c->stream));
+      SWZ_HIP(c, hipMemcpyAsync(mkey, sorted_k, (size_t)ng * 8, hipMemcpyDeviceToDevice, c->stream));
+      hipLaunchKernelGGL(tl_iota_base_kernel, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, midx, ng, w.wused);
+      SWZ_LAUNCH_CHECK(c);
+      w.wused += ng;
+    }
     ms.akey = mkey;
     ms.aidx = midx;
-    ms.m = as.m + nc;
-    ms.ckey = ckey;
-    ms.nc = nc;
+    ms.m = as.m + nc + ng;
+    ms.ckey = sr ? nullptr : ckey;  // a sharded root decides from the global counts
+    ms.nc = sr ? 0u : nc;
+  }
+  if (ms.m == 0) {  // a shard without new points and without a root file
+    res->remaining = 0;
+    *merged_out = 0;
+    return SWZ_OK;
   }
   *merged_out = ms.m;
 
@@ -501,11 +583,20 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan, Active
   SWZ_TRY(c->get("tl_tkey", (size_t)nt, &tkey));
   SWZ_TRY(c->get("tl_tgid", (size_t)nt, &tgid));
   SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{ms.akey, ms.aidx, w.wgid, tkey, tgid}, ms.m, counters + 2, "tl"));
+  if (ng) {  // the ghosts lead the merged range and are all taken again: they are not part of the local file
+    SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
+    hipLaunchKernelGGL(tl_count_untaken_kernel, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, lb.taken, ng, counters + 1);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t lost = 0;
+    SWZ_TRY(read_u32(c, counters + 1, &lost));
+    if (lost) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: " + std::to_string(lost) + " ghost points were not taken again "
+                                              "(they must be what the root took on LOWER shards in this batch)");
+  }
   const int dst = st.cur ^ 1;
-  SWZ_TRY(store_reserve(c, st, plan.level + 1, dst, (size_t)nr + nt));
-  SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey, tgid, nt, nsh, 0u, st.key[dst], st.gid[dst]));
+  SWZ_TRY(store_reserve(c, st, plan.level + 1, dst, (size_t)nr + nt - ng));
+  SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey + ng, tgid + ng, nt - ng, nsh, 0u, st.key[dst], st.gid[dst]));
   st.cur = dst;
-  st.cnt = nr + nt;
+  st.cnt = nr + nt - ng;
 
   as = ActiveSet{w.surv_key[w.which], w.surv_idx[w.which], res->remaining};
   w.which ^= 1;
@@ -712,42 +803,41 @@ static uint64_t stored_total(const swz_tiler* t) {
   return s;
 }
 
-// d_xyz: the batch inside the position pool (already there) or anywhere else on the device (copied in)
-static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_stats* stats) {
+// d_xyz: the batch inside the position pool (already there) or anywhere else on the device (copied in).
+// Index + sort + positions into Morton order (K1, K2, gather), exactly like a single batch; leaves the batch open.
+static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t extra_pool) {
   swz_ctx* c = t->c;
-  zero_stats(stats);
   if (t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
-  if (n == 0) {
-    ++t->batches;
-    return SWZ_OK;
-  }
+  if (t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: the previous batch is still open (swz_tiler_shard_finish)");
   // parallel::scatter throws for a batch with fewer points than indexing threads (util/threading/Parallel.h:181-186)
   if (t->p.strategy == SWZ_FAST && n < t->p.fast_concurrency)
     return c->fail(SWZ_ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points");
   const uint32_t base = t->total;
-  double* slot = t->pool_xyz + (size_t)base * 3;
-  const bool in_pool = d_xyz == slot;
-
-  // ---- index + sort + positions into Morton order (K1, K2, gather), exactly like a single batch
-  uint64_t *keys = nullptr, *keys_b = nullptr;
-  uint32_t *perm = nullptr, *vals_b = nullptr;
-  SWZ_TRY(c->get("tl_keys", (size_t)n, &keys));
-  SWZ_TRY(c->get("tl_perm", (size_t)n, &perm));
-  SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
-  SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vals_b));
-  if (radix_result_in_second()) {
-    SWZ_TRY(encode_device(c, d_xyz, n, t->bmin, t->bmax, keys_b));
-    SWZ_TRY(radix_sort_pairs(c, keys_b, vals_b, keys, perm, n, true));
-  } else {
-    SWZ_TRY(encode_device(c, d_xyz, n, t->bmin, t->bmax, keys));
-    SWZ_TRY(radix_sort_pairs(c, keys, perm, keys_b, vals_b, n, true));
+  uint64_t* keys = nullptr;
+  uint32_t* perm = nullptr;
+  if (n) {
+    double* slot = t->pool_xyz + (size_t)base * 3;
+    const bool in_pool = d_xyz == slot;
+    uint64_t* keys_b = nullptr;
+    uint32_t* vals_b = nullptr;
+    SWZ_TRY(c->get("tl_keys", (size_t)n, &keys));
+    SWZ_TRY(c->get("tl_perm", (size_t)n, &perm));
+    SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
+    SWZ_TRY(c->get("sort_vals_b", (size_t)n, &vals_b));
+    if (radix_result_in_second()) {
+      SWZ_TRY(encode_device(c, d_xyz, n, t->bmin, t->bmax, keys_b));
+      SWZ_TRY(radix_sort_pairs(c, keys_b, vals_b, keys, perm, n, true));
+    } else {
+      SWZ_TRY(encode_device(c, d_xyz, n, t->bmin, t->bmax, keys));
+      SWZ_TRY(radix_sort_pairs(c, keys, perm, keys_b, vals_b, n, true));
+    }
+    if (!in_pool)  // clamped positions (index_point clamps in place, OctreeAlgorithms.h:167-169) into the pool
+      SWZ_HIP(c, hipMemcpyAsync(slot, d_xyz, (size_t)n * 24, hipMemcpyDeviceToDevice, c->stream));
   }
-  if (!in_pool)  // clamped positions (index_point clamps in place, OctreeAlgorithms.h:167-169) into the pool
-    SWZ_HIP(c, hipMemcpyAsync(slot, d_xyz, (size_t)n * 24, hipMemcpyDeviceToDevice, c->stream));
-
-  BatchWork w;
+  BatchWork& w = t->bw;
+  w = BatchWork{};
   w.n = n;
-  const uint64_t wcap64 = (uint64_t)n + stored_total(t);
+  const uint64_t wcap64 = (uint64_t)n + stored_total(t) + extra_pool;
   if (wcap64 > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "batch + stored points exceed 2^32-65536");
   w.wcap = (uint32_t)wcap64;
   SWZ_TRY(c->get("tl_wx", (size_t)w.wcap, &w.wx));
@@ -755,22 +845,34 @@ static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_sta
   SWZ_TRY(c->get("tl_wz", (size_t)w.wcap, &w.wz));
   SWZ_TRY(c->get("tl_wlevel", (size_t)w.wcap, &w.wlevel));
   SWZ_TRY(c->get("tl_wgid", (size_t)w.wcap, &w.wgid));
-  SWZ_TRY(gather_positions(c, d_xyz, perm, n, w.wx, w.wy, w.wz));
-  hipLaunchKernelGGL(tl_wgid_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, perm, n, base, w.wgid);
-  SWZ_LAUNCH_CHECK(c);
-  SWZ_HIP(c, hipMemsetAsync(w.wlevel, 0x80, (size_t)w.wcap, c->stream));
+  if (n) {
+    SWZ_TRY(gather_positions(c, d_xyz, perm, n, w.wx, w.wy, w.wz));
+    hipLaunchKernelGGL(tl_wgid_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, perm, n, base, w.wgid);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  SWZ_HIP(c, hipMemsetAsync(w.wlevel, 0x80, (size_t)std::max<uint32_t>(w.wcap, 1u), c->stream));
   w.wused = n;
-
-  int first_level = -1;
+  t->next_level = -1;
   if (t->p.strategy == SWZ_FAST) {
     if (t->fast_start < 0) SWZ_TRY(fast_start_level(c, keys, n, t->p.fast_concurrency, &t->fast_start));
-    first_level = t->fast_start - 1;
+    t->next_level = t->fast_start - 1;
   }
-  ActiveSet as{keys, nullptr, n};
-  uint64_t visited = 0, nodes = 0;
-  uint32_t rounds = 0, nlevels = 0;
-  int max_level = -1;
-  for (int level = first_level; as.m > 0; ++level) {
+  t->as = ActiveSet{keys, nullptr, n};
+  t->acc_visited = t->acc_nodes = 0;
+  t->acc_rounds = t->acc_levels = 0;
+  t->acc_max_level = -1;
+  t->batch_open = true;
+  return SWZ_OK;
+}
+
+// the level loop from t->next_level to last_level (sr: the root level of a sharded batch)
+static int tiler_batch_run(swz_tiler* t, int last_level, const ShardRoot* sr) {
+  swz_ctx* c = t->c;
+  BatchWork& w = t->bw;
+  ActiveSet& as = t->as;
+  for (int level = t->next_level; level <= last_level; ++level) {
+    const bool shard_root = sr && sr->active && level == -1;
+    if (as.m == 0 && !shard_root) break;
     if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
     LevelPlan plan = make_plan(level, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
                                t->bmin, t->bmax, false, true);
@@ -778,32 +880,56 @@ static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_sta
     if (plan.reroot && !plan.terminal && t->p.sampler != SWZ_MIN_DISTANCE) {
       RrTotals tot;
       SWZ_TRY(tiler_reroot_level(t, w, plan, as, tot));
-      visited += tot.visited;
-      nodes += tot.nodes;
-      max_level = std::max(max_level, tot.max_level);
-      ++nlevels;
-      break;
+      t->acc_visited += tot.visited;
+      t->acc_nodes += tot.nodes;
+      t->acc_max_level = std::max(t->acc_max_level, tot.max_level);
+      ++t->acc_levels;
+      as.m = 0;
+      t->next_level = 21;
+      return SWZ_OK;
     }
     LevelResult r;
     uint32_t merged = 0;
-    SWZ_TRY(tiler_level(t, w, plan, as, &r, &merged));
-    visited += merged;
-    nodes += r.num_nodes;
-    rounds += r.md_rounds;
-    max_level = level;
-    ++nlevels;
+    SWZ_TRY(tiler_level(t, w, plan, as, &r, &merged, shard_root ? sr : nullptr));
+    t->acc_visited += merged;
+    t->acc_nodes += r.num_nodes;
+    t->acc_rounds += r.md_rounds;
+    if (merged) t->acc_max_level = level;
+    ++t->acc_levels;
+    t->next_level = level + 1;
   }
-  t->total += n;
+  return SWZ_OK;
+}
+
+static void tiler_batch_close(swz_tiler* t, swz_tile_stats* stats) {
+  t->total += t->bw.n;
   if (t->staged_total < t->total) t->staged_total = t->total;
   ++t->batches;
+  t->batch_open = false;
   if (stats) {
-    stats->num_nodes = nodes;
-    stats->points_visited = visited;
-    stats->max_level = max_level;
+    stats->num_nodes = t->acc_nodes;
+    stats->points_visited = t->acc_visited;
+    stats->max_level = t->acc_max_level;
     stats->fast_start_levels = t->fast_start;
-    stats->num_levels = nlevels;
-    stats->min_distance_rounds = rounds;
+    stats->num_levels = t->acc_levels;
+    stats->min_distance_rounds = t->acc_rounds;
   }
+}
+
+static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_stats* stats) {
+  zero_stats(stats);
+  if (n == 0) {
+    if (t->finalized) return t->c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
+    ++t->batches;
+    return SWZ_OK;
+  }
+  int st = tiler_batch_prepare(t, d_xyz, n, 0);
+  if (st == SWZ_OK) st = tiler_batch_run(t, 20, nullptr);
+  if (st != SWZ_OK) {
+    t->batch_open = false;
+    return st;
+  }
+  tiler_batch_close(t, stats);
   return SWZ_OK;
 }
 
@@ -999,6 +1125,101 @@ int swz_tiler_add_batch_device(swz_tiler* t, double* d_xyz, uint64_t n, swz_tile
   c->prof_collect();
   if (st != SWZ_OK) return st;
   SWZ_HIP(c, e);
+  return SWZ_OK;
+}
+
+// ---- a tiler per GPU of a multi-GPU run: the shard owns the subtrees of its level-0 octants and ITS part of the root's
+// file; the root node itself spans the shards (swz_shard_* for the single-batch form)
+int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const swz_attribute_columns* d_attrs,
+                                 const swz_tiler_shard_info* info, uint64_t* root_file_count_out) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (!info) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL shard info");
+  if (t->p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  if ((t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && t->p.sampler == SWZ_MIN_DISTANCE)
+    return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
+  if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: staged batches are pending");
+  if ((n && !d_xyz) || (info->num_ghosts && !info->d_ghost_xyz)) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL buffer");
+  if ((uint64_t)t->total + n > 0xFFFF0000ull || info->num_ghosts > 0x7FFFFFFFull)
+    return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
+  uint32_t mask = 0;
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (d_attrs && d_attrs->column[a]) mask |= 1u << a;
+  if (t->total == 0 && t->batches == 0) {
+    t->attr_mask = mask;
+    if (mask && t->pool_cap) {
+      const size_t cap = t->pool_cap;
+      t->pool_cap = 0;
+      t->pool_xyz = nullptr;
+      SWZ_TRY(pool_reserve(t, cap));
+    }
+  } else if (mask != t->attr_mask && n) {
+    return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: every batch must carry the same attribute columns");
+  }
+  SWZ_TRY(pool_reserve(t, (size_t)t->total + n));
+  for (int a = 0; a < SWZ_ATTR_COUNT && n; ++a) {
+    if (!(t->attr_mask & (1u << a))) continue;
+    const size_t rb = TILER_ATTR_BYTES[a];
+    SWZ_HIP(c, hipMemcpyAsync((char*)t->pool_attr[a] + (size_t)t->total * rb, d_attrs->column[a], (size_t)n * rb,
+                              hipMemcpyDeviceToDevice, c->stream));
+  }
+  int st = tiler_batch_prepare(t, d_xyz, (uint32_t)n, (uint32_t)info->num_ghosts);
+  if (st == SWZ_OK && info->global_new_points > 0) {
+    ShardRoot sr;
+    sr.active = true;
+    // tile_internal_node :272-275 with the counts of the WHOLE root: cached points force sampling, else count <= max takes all
+    sr.sample = info->global_root_stored > 0 || info->global_new_points + info->global_root_stored > t->p.max_points_per_node;
+    sr.ghost_xyz = info->d_ghost_xyz;
+    sr.ghosts = sr.sample ? (uint32_t)info->num_ghosts : 0u;
+    st = tiler_batch_run(t, -1, &sr);
+  }
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  c->prof_collect();
+  if (st != SWZ_OK) {
+    t->batch_open = false;
+    return st;
+  }
+  SWZ_HIP(c, e);
+  if (root_file_count_out) *root_file_count_out = t->lv[0].cnt;
+  return SWZ_OK;
+}
+
+int swz_tiler_shard_finish(swz_tiler* t, swz_tile_stats* stats) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  zero_stats(stats);
+  if (!t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_finish: no batch is open");
+  if (t->next_level < 0) t->next_level = 0;  // the root was skipped (an empty batch)
+  const int st = tiler_batch_run(t, 20, nullptr);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  c->prof_collect();
+  if (st != SWZ_OK) {
+    t->batch_open = false;
+    return st;
+  }
+  SWZ_HIP(c, e);
+  tiler_batch_close(t, stats);
+  return SWZ_OK;
+}
+
+int swz_tiler_level_count(swz_tiler* t, int level, uint64_t* count_out) {
+  if (!t || !count_out || level < -1 || level > 20) return SWZ_ERR_BAD_ARG;
+  *count_out = t->lv[level + 1].cnt;
+  return SWZ_OK;
+}
+
+int swz_tiler_level_positions_device(swz_tiler* t, int level, double* d_xyz_out) {
+  if (!t || level < -1 || level > 20) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  const StoreLevel& s = t->lv[level + 1];
+  if (!s.cnt) return SWZ_OK;
+  if (!d_xyz_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_level_positions_device: NULL buffer");
+  hipLaunchKernelGGL(tl_rows_kernel, dim3(div_up(s.cnt, 256)), dim3(256), 0, c->stream, s.gid[s.cur], s.cnt, t->pool_xyz, d_xyz_out);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
   return SWZ_OK;
 }
 

@@ -278,3 +278,113 @@ class ShardedTiler:
         self._keepalive = buf  # the context reads the points until shard_finish returned
         stats["shard_points"] = m
         return stats
+
+
+class ShardedBatchTiler:
+    """A data set that arrives in several batches, tiled by all ranks of a process group (BASELINE config 5): every
+    rank runs one api.Tiler for the subtrees of its level-0 octants and its part of the root's file.  Per batch:
+    encode, group by destination, ONE exchange step of the point rows and of every attribute column, then the root
+    node -- decided from global counts, for MIN_DISTANCE rank by rank with the lower ranks' root files as ghosts --
+    and, without communication, the levels below it."""
+
+    def __init__(self, ctx, device, bmin, bmax, params, group=None, capacity_hint=0):
+        self.ctx, self.device, self.bmin, self.bmax, self.params, self.group = ctx, device, bmin, bmax, params, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        if self.world not in (1, 2, 4, 8):
+            raise ValueError("world size must be 1, 2, 4 or 8 (octants are dealt out in contiguous blocks)")
+        if device.type == "cuda":
+            ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
+        self.tiler = api.Tiler(ctx, bmin, bmax, params, capacity_hint)
+        self._keep = None
+
+    def close(self):
+        self.tiler.close()
+
+    def _all_sum(self, value):
+        t = torch.tensor([int(value)], dtype=torch.int64,
+                         device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(t, group=self.group)
+        return int(t.item())
+
+    def _bcast(self, tensor, src):
+        if dist.get_backend(self.group) == "nccl" or tensor.device.type == "cpu":
+            dist.broadcast(tensor, src, group=self.group)
+            return tensor
+        t = tensor.cpu()
+        dist.broadcast(t, src, group=self.group)
+        tensor.copy_(t)
+        return tensor
+
+    def add_batch(self, xyz, attrs=None):
+        """xyz: [n, 3] float64 on this rank's GPU (any points of the batch), attrs: dict name -> tensor with n rows.
+        Returns the tile stats of this rank's shard for the batch."""
+        ctx, dev, world = self.ctx, self.device, self.world
+        attrs = attrs or {}
+        n = xyz.shape[0]
+        keys = torch.empty(n, dtype=torch.int64, device=dev)
+        ctx.morton_encode_device(xyz.data_ptr(), n, self.bmin, self.bmax, keys.data_ptr())
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        octant_counts = ctx.partition_by_octant_device(keys.data_ptr(), n, perm.data_ptr())
+        del keys
+        send_counts = rank_send_counts(octant_counts, world)
+        order = perm.long()
+        del perm
+        global_new = self._all_sum(n)
+        recv, recv_counts = exchange_rows(xyz.index_select(0, order), send_counts, self.group)
+        m = recv.shape[0]
+        cols = {}
+        for name, t in attrs.items():  # the same exchange, column by column
+            rows = t.index_select(0, order).reshape(n, -1)
+            got, rc = exchange_rows(rows, send_counts, self.group)
+            assert rc == recv_counts
+            cols[name] = got.contiguous()
+        del order
+        root_stored = self._all_sum(self.tiler.level_count(-1))
+        sample = root_stored > 0 or global_new + root_stored > self.params.max_points_per_node
+        sequential_root = self.params.sampler == api.MIN_DISTANCE and sample and global_new > 0
+        ptrs = {name: t.data_ptr() for name, t in cols.items()}
+        failure = []
+
+        def guarded(fn, default):
+            if failure:
+                return default
+            try:
+                return fn()
+            except api.SwzError as e:
+                failure.append(e)
+                return default
+
+        if not sequential_root:
+            guarded(lambda: self.tiler.shard_begin_device(recv.data_ptr(), m, ptrs, global_new, root_stored), 0)
+        else:
+            ghosts = []
+            for r in range(world):
+                cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+                mine = None
+                if r == self.rank:
+                    gbuf = torch.cat(ghosts) if ghosts else None
+                    g = gbuf.shape[0] if gbuf is not None else 0
+                    have = guarded(lambda: self.tiler.shard_begin_device(recv.data_ptr(), m, ptrs, global_new, root_stored,
+                                                                         gbuf.data_ptr() if g else None, g), 0)
+                    mine = torch.empty((have, 3), dtype=torch.float64, device=dev)
+                    if have:
+                        guarded(lambda: self.tiler.level_positions_device(-1, mine.data_ptr()), None)
+                    cnt[0] = have
+                if r == world - 1:
+                    break
+                self._bcast(cnt, r)
+                b = mine if r == self.rank else torch.empty((int(cnt.item()), 3), dtype=torch.float64, device=dev)
+                if b.shape[0]:
+                    self._bcast(b, r)
+                if self.rank > r:
+                    ghosts.append(b)
+        zero = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
+        stats = guarded(lambda: self.tiler.shard_finish(), zero)
+        if self._all_sum(1 if failure else 0):
+            if failure:
+                raise failure[0]
+            raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
+        self._keep = (recv, cols)
+        stats["shard_points"] = m
+        return stats

@@ -231,3 +231,88 @@ def test_sharded_tile_with_empty_shards(sampler, world):
     rec = lambda k, lv, p: np.sort(np.rec.fromarrays([k, lv, p[:, 0], p[:, 1], p[:, 2]], names="k,l,x,y,z"),
                                    order=["k", "x", "y", "z", "l"])
     assert np.array_equal(rec(got[0][1], got[0][3], pos), rec(ref["keys"], ref["level"], ref_xyz))
+
+
+# ------------------------------------------------------------------ GPU: sharded AND multi-batch (BASELINE config 5's shape)
+def _mb_cloud(n, batch, rank, corner_world=0):
+    xyz = _cloud(n, 500 + 10 * batch + rank)
+    if corner_world:          # rank 0's octants only: every other shard stays empty
+        xyz[:, 0] *= 0.5
+        if corner_world > 2:
+            xyz[:, 1] *= 0.5
+    return xyz
+
+
+def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner):
+    _init(rank, world, port)
+    import schwarzwald_amd as swz
+    from schwarzwald_amd import sharded
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ctx = swz.Context(0)
+    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
+    st = sharded.ShardedBatchTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
+    for b in range(k):
+        xyz = torch.from_numpy(_mb_cloud(n, b, rank, world if corner else 0)).to(dev)
+        ids = torch.arange(n, dtype=torch.int64) + (b * world * n + rank * n)     # id in the single-process batch order
+        attrs = {"intensity": (ids & 0xFFFF).to(torch.int16).to(dev), "point_source_id": (ids >> 16).to(torch.int16).to(dev)}
+        st.add_batch(xyz, attrs)
+    st.tiler.finalize()
+    info = st.tiler.info()
+    table = st.tiler.node_table()
+    ns = int(info["num_stored"])
+    d_ids = torch.empty(max(ns, 1), dtype=torch.int32, device=dev)
+    st.tiler.export_device(0, d_ids.data_ptr(), 0)
+    local = d_ids.cpu().numpy().view(np.uint32)[:ns].astype(np.int64)
+    _, pools = st.tiler.pools_device()
+    npts = int(info["num_points"])
+    lo = ctx.copy_to_host(pools["intensity"], 2 * npts).view(np.uint16).astype(np.int64) if npts else np.zeros(0, np.int64)
+    hi = ctx.copy_to_host(pools["point_source_id"], 2 * npts).view(np.uint16).astype(np.int64) if npts else np.zeros(0, np.int64)
+    gids = (lo | (hi << 16))[local] if ns else np.zeros(0, np.int64)
+    q.put((rank, {kk: np.asarray(v) for kk, v in table.items()}, gids, npts))
+    st.close()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("corner", [False, True])
+def test_sharded_multibatch_matches_the_multibatch_oracle(sampler, corner):
+    """Two ranks (sharing cuda:0, collectives over gloo), three batches each: the union of the shards' node files must
+    be the single-process multi-batch oracle's, file by file and in file order; the root's file is the concatenation of
+    the shards' parts in rank order.  corner: rank 1 never owns a point."""
+    world, n, k, max_pts = 2, 20000, 3, 400
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_mb_worker, args=(r, world, port, n, k, sampler, max_pts, spacing, q, corner)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    oracle = O.Tiler([0, 0, 0], [1, 1, 1], sampler, max_pts, spacing)
+    for b in range(k):
+        assert oracle.add_batch(np.vstack([_mb_cloud(n, b, r, world if corner else 0) for r in range(world)])) == 0
+    assert oracle.finalize() == 0
+    ex = oracle.export()
+    want = {(int(l), int(key)): ex["ids"][int(o):int(o + c)].astype(np.int64)
+            for l, key, o, c in zip(ex["level"], ex["key"], ex["offset"], ex["count"])}
+    have = {}
+    for r in range(world):
+        table, gids, npts = got[r]
+        for l, key, o, c in zip(table["level"], table["key"], table["offset"], table["count"]):
+            have.setdefault((int(l), int(key)), []).append(gids[int(o):int(o + c)])
+    assert sum(got[r][2] for r in range(world)) == world * n * k
+    if corner:
+        assert got[1][2] == 0
+    assert set(have) == set(want)
+    for node, parts in have.items():
+        assert node[0] == -1 or len(parts) == 1          # only the root spans shards
+        assert np.array_equal(np.concatenate(parts), want[node]), node
