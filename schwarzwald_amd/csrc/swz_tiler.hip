@@ -503,10 +503,12 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   }
   ActiveSet ms = as;
   if (nc || ng) {
-    hipLaunchKernelGGL(tl_rekey_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, cgid, nc, t->pool_xyz,
-                       root_box(t), plan.level);
-    SWZ_LAUNCH_CHECK(c);
-    if (!plan.terminal) {
+    if (nc) {
+      hipLaunchKernelGGL(tl_rekey_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, cgid, nc, t->pool_xyz,
+                         root_box(t), plan.level);
+      SWZ_LAUNCH_CHECK(c);
+    }
+    if (nc && !plan.terminal) {
       SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
       hipLaunchKernelGGL(tl_inversion_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, nc, nsh, counters + 1);
       SWZ_LAUNCH_CHECK(c);
