@@ -257,7 +257,60 @@ def main():
     ctx.generate_uniform_device(SEED + 3, rank * n, n, xyz.data_ptr())
 
     mb = None
-    if distributed:
+    if distributed and args.batches > 1:
+        # BASELINE config 5's shape: every rank feeds its points in `batches` batches (attribute columns of --payload
+        # along) to a sharded multi-batch tiler; with --staged the batches come from pinned host memory, the copy of
+        # batch i+1 on a side stream under the tiling of batch i
+        from schwarzwald_amd import sharded
+        k = args.batches
+        cuts = [(i * n) // k for i in range(k + 1)]
+        names = [a for a in args.payload.split(",") if a]
+        cols = {}
+        for a in names:
+            idx, dt, width = swz.ATTRIBUTES[a]
+            tdt = {"uint8": torch.uint8, "int8": torch.int8, "uint16": torch.int16, "float32": torch.float32,
+                   "float64": torch.float64}[np.dtype(dt).name]
+            t = torch.empty((n, width) if width > 1 else (n,), dtype=tdt, device=dev)
+            t.random_(0, 100) if not t.is_floating_point() else t.normal_()
+            cols[a] = t
+        host_xyz = host_cols = None
+        if args.staged:
+            host_xyz = torch.empty((n, 3), dtype=torch.float64, pin_memory=True)
+            host_xyz.copy_(xyz)
+            host_cols = {a: torch.empty(t.shape, dtype=t.dtype, pin_memory=True).copy_(t) for a, t in cols.items()}
+            torch.cuda.synchronize(dev)
+        copy_stream = torch.cuda.Stream(device=dev)
+
+        def fetch(i):
+            lo, hi = cuts[i], cuts[i + 1]
+            if not args.staged:
+                return xyz[lo:hi], {a: t[lo:hi] for a, t in cols.items()}, None
+            with torch.cuda.stream(copy_stream):
+                bx = host_xyz[lo:hi].to(dev, non_blocking=True)
+                bc = {a: t[lo:hi].to(dev, non_blocking=True) for a, t in host_cols.items()}
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return bx, bc, ev
+
+        def step():
+            runner = sharded.ShardedBatchTiler(ctx, dev, bmin, bmax, params, capacity_hint=int(1.3 * n) + 1024)
+            tot = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
+            nxt = fetch(0)
+            for i in range(k):
+                bx, bc, ev = nxt
+                if i + 1 < k:
+                    nxt = fetch(i + 1)
+                if ev is not None:
+                    torch.cuda.current_stream(dev).wait_event(ev)
+                st = runner.add_batch(bx, bc)
+                for key in ("points_visited", "num_levels", "min_distance_rounds"):
+                    tot[key] += st[key]
+                tot["max_level"] = max(tot["max_level"], st["max_level"])
+            runner.tiler.finalize()
+            tot["num_nodes"] = int(runner.tiler.info()["num_nodes"])
+            runner.close()
+            return tot
+    elif distributed:
         from schwarzwald_amd import sharded
         runner = sharded.ShardedTiler(ctx, dev, bmin, bmax, params)
 
@@ -335,6 +388,8 @@ def main():
                        "points_per_gpu": n, "sampler": args.sampler, "strategy": args.strategy,
                        "min_distance_mode": ("property" if args.md_mode == "property" else "exact") if args.sampler == "MIN_DISTANCE" else None,
                        "batches": args.batches,
+                       "staged_from_pinned_host": bool(args.staged and distributed and args.batches > 1) or None,
+                       "payload_columns": [a for a in args.payload.split(",") if a] if (distributed and args.batches > 1) else None,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
             "ranks_in_process_group": dist.get_world_size() if distributed else 1,
             "visit_factor": round(visit, 4),
