@@ -356,7 +356,9 @@ int swz_shard_finish_device(swz_ctx* ctx, uint64_t* d_keys_out, uint32_t* d_perm
  *   rekey_inversions: re-keyed file contents whose order was not ascending any more (a point within an ulp of a
  *     cell boundary); the reference merges them unsorted for a lossless persistence (:103-106), this library sorts
  *     them like the reference does for a lossy one -- results may differ from the reference only when > 0.
- *   A node that needs Morton re-rooting (:444-483) fails the batch with SWZ_ERR_REROOT_UNSUPPORTED. */
+ *   A node that needs Morton re-rooting (:444-483) is re-rooted like the reference does (its subtree's files are
+ *     ordered by the re-rooted keys); only the single-batch swz_tile*, whose outputs cannot express that order,
+ *     returns SWZ_ERR_REROOT_UNSUPPORTED there. */
 typedef struct swz_tiler swz_tiler;
 typedef struct {
   uint64_t num_points;       /* points added so far */
@@ -409,12 +411,47 @@ int swz_tiler_shard_finish(swz_tiler* tiler, swz_tile_stats* stats);
 /* points stored in the files of one octree level (-1 = root) and their positions in file order */
 int swz_tiler_level_count(swz_tiler* tiler, int level, uint64_t* count_out);
 int swz_tiler_level_positions_device(swz_tiler* tiler, int level, double* d_xyz_out);
+/* ---- one batch sharded over several GPUs from ONE host process (the reference's host is a
+ * single C++ process, so this is its multi-GPU drop-in: TilingAlgorithmBase::build_execution_graph,
+ * core/tiling/TilingAlgorithms.cpp:1362-1784, for a batch whose points lie on several devices).
+ *   swz_group_create: one context per shard on devices[shard] (1, 2, 4 or 8 shards; shard s owns the level-0 octants
+ *     o with o * num_shards / 8 == s).  transport 0 = peer copies (hipMemcpyPeerAsync; several shards may share a
+ *     device), 1 = RCCL grouped ncclSend / ncclRecv on communicators made by ncclCommInitAll (distinct devices only;
+ *     librccl is loaded on demand, the library does not link it).
+ *   swz_group_tile: d_xyz[s] / n[s] are the points that currently lie on shard s's device (any octants; clamped in
+ *     place), d_attrs (may be NULL) is an array of num_shards column sets: d_attrs[s] holds shard s's attribute
+ *     columns (device, n[s] rows; the same attributes on every shard), which travel with the points.  One host thread per shard: encode, group by destination, ONE exchange step, root node (for
+ *     MIN_DISTANCE the chain of ghosts from lower to higher shards), levels.  results[s] describes what shard s
+ *     ended up with, exactly as swz_shard_finish_device does: device pointers owned by the shard's context, valid
+ *     until the group's next call.  ACCURATE strategy, exact samplers.
+ *   swz_group_ctx: the shard's context, e.g. for swz_copy_to_host, swz_build_node_lists_device or
+ *     swz_gather_payload_device on that shard's results. */
+typedef struct swz_group swz_group;
+typedef struct {
+  const double* d_xyz;     /* the shard's points after the exchange (num_points x 3) */
+  const uint64_t* d_keys;  /* ascending */
+  const uint32_t* d_perm;  /* index into d_xyz */
+  const int8_t* d_level;
+  swz_attribute_columns attrs; /* the attribute columns that travelled with the points (rows like d_xyz) */
+  uint64_t num_points;
+  swz_tile_stats stats;
+} swz_group_result;
+int swz_group_create(int num_shards, const int* devices, int transport, swz_group** group_out);
+int swz_group_destroy(swz_group* group);
+const char* swz_group_last_error(const swz_group* group);
+int swz_group_num_shards(const swz_group* group);
+swz_ctx* swz_group_ctx(swz_group* group, int shard);
+int swz_group_tile(swz_group* group, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n,
+                   const double bounds_min[3], const double bounds_max[3], const swz_tile_params* params,
+                   swz_group_result* results);
+
 /* page-locked host memory for the staging entry points (hipHostMalloc / hipHostFree) */
 int swz_host_alloc_pinned(uint64_t bytes, void** out);
 int swz_host_free_pinned(void* p);
 /* device memory and copies for host code that does not include HIP headers itself (hipMalloc / hipFree on the
  * current device; the copies run on the context's stream and return when done) */
 int swz_device_alloc(uint64_t bytes, void** d_out);
+int swz_device_alloc_on(swz_ctx* ctx, uint64_t bytes, void** d_out); /* on the context's device (several GPUs) */
 int swz_device_free(void* d_ptr);
 int swz_copy_to_host(swz_ctx* ctx, void* dst_host, const void* d_src, uint64_t bytes);
 int swz_copy_to_device(swz_ctx* ctx, void* d_dst, const void* src_host, uint64_t bytes);

@@ -1,0 +1,406 @@
+// swz_group.hip -- a batch sharded over several GPUs, driven from ONE host process in C++ (SURVEY.md section 8(e);
+// BASELINE north star: "host code stays C++ ... points shard across the GPUs of one node by the top-3 Morton bits
+// with a single RCCL all-to-all after the encode step").
+//
+// Schwarzwald is a single process, so its drop-in for several GPUs is one object that owns one context per shard and
+// one host thread per shard: encode -> group the rows by destination -> ONE exchange step -> root node -> levels,
+// every step through the same C ABI the single-GPU path uses (swz_morton_encode_device, swz_partition_by_octant_device,
+// swz_shard_*).  The exchange is either grouped RCCL send/recv (ncclCommInitAll in this process; librccl is loaded
+// on demand so that nothing else depends on it) or peer copies (hipMemcpyPeerAsync), which also work with several
+// shards on one GPU -- that is how the shard logic is tested on a one-GPU box.  The Python driver (sharded.py) is the
+// multi-process counterpart used by bench.py.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "swz_internal.h"
+
+namespace {
+
+// the few RCCL entry points the exchange needs (rccl.h: ncclCommInitAll :236, ncclCommDestroy :260, ncclSend :700,
+// ncclRecv :722, ncclGroupStart :923, ncclGroupEnd :933), resolved with dlsym
+struct Rccl {
+  void* lib = nullptr;
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*Send)(const void* buf, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
+  int (*Recv)(void* buf, size_t count, int datatype, int peer, void* comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  static constexpr int kUint8 = 1;  // ncclUint8, rccl.h:460
+  bool load(std::string& err) {
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+      lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (lib) break;
+    }
+    if (!lib) {
+      err = std::string("cannot load librccl: ") + dlerror();
+      return false;
+    }
+    CommInitAll = reinterpret_cast<decltype(CommInitAll)>(dlsym(lib, "ncclCommInitAll"));
+    CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
+    Send = reinterpret_cast<decltype(Send)>(dlsym(lib, "ncclSend"));
+    Recv = reinterpret_cast<decltype(Recv)>(dlsym(lib, "ncclRecv"));
+    GroupStart = reinterpret_cast<decltype(GroupStart)>(dlsym(lib, "ncclGroupStart"));
+    GroupEnd = reinterpret_cast<decltype(GroupEnd)>(dlsym(lib, "ncclGroupEnd"));
+    GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+    if (!CommInitAll || !CommDestroy || !Send || !Recv || !GroupStart || !GroupEnd) {
+      err = "librccl lacks an expected symbol";
+      return false;
+    }
+    return true;
+  }
+};
+
+struct Barrier {  // all shard threads meet here between the steps
+  std::mutex m;
+  std::condition_variable cv;
+  int count = 0, generation = 0, parties = 1;
+  void wait() {
+    std::unique_lock<std::mutex> g(m);
+    const int gen = generation;
+    if (++count == parties) {
+      count = 0;
+      ++generation;
+      cv.notify_all();
+    } else {
+      cv.wait(g, [&] { return gen != generation; });
+    }
+  }
+};
+
+constexpr size_t kChunkBytes = size_t(1) << 30;  // per message: RCCL 2.26 was measured to lose the tail of one > 2 GB block
+constexpr uint64_t kGhostHeadroom = 4u << 20;    // rows kept free in front of the received points (MIN_DISTANCE root ghosts)
+
+}  // namespace
+
+struct swz_group {
+  int n = 0;
+  int transport = 0;
+  std::vector<int> devices;
+  std::vector<swz_ctx*> ctx;
+  std::vector<void*> comms;
+  Rccl rccl;
+  std::string err;
+  Barrier barrier;
+  // per batch, shared between the shard threads
+  std::vector<std::vector<uint64_t>> send_counts;  // [source][destination]
+  std::vector<double*> recv_rows;                  // device buffers of every shard: positions ...
+  std::vector<std::vector<char*>> recv_attr;       // ... and attribute columns [shard][attribute]
+  std::vector<uint64_t> recv_total;
+  std::vector<double*> root_taken;                 // positions the root took on every shard (ghosts of the higher ones)
+  std::vector<uint64_t> root_taken_count;
+  std::vector<int> status;
+  std::vector<std::string> status_msg;
+  int turn = 0;  // MIN_DISTANCE root: the shard whose turn it is
+  std::mutex turn_m;
+  std::condition_variable turn_cv;
+};
+
+namespace {
+
+int owner_of_octant(int octant, int shards) { return octant * shards / 8; }
+
+struct ShardCall {
+  swz_group* g;
+  int r;
+  double* d_xyz;
+  uint64_t n;
+  const double* bmin;
+  const double* bmax;
+  const swz_tile_params* params;
+  const swz_attribute_columns* attrs;  // may be NULL
+  swz_group_result* result;
+};
+
+bool fail(swz_group* g, int r, int code, const std::string& msg) {
+  g->status[r] = code;
+  g->status_msg[r] = msg;
+  return false;
+}
+#define GRP_TRY(expr)                                                                  \
+  do {                                                                                 \
+    if (ok) {                                                                          \
+      const int _s = (expr);                                                           \
+      if (_s != SWZ_OK) ok = fail(g, r, _s, swz_last_error(c));                        \
+    }                                                                                  \
+  } while (0)
+#define GRP_HIP(expr)                                                                  \
+  do {                                                                                 \
+    if (ok) {                                                                          \
+      const hipError_t _e = (expr);                                                    \
+      if (_e != hipSuccess) ok = fail(g, r, SWZ_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    }                                                                                  \
+  } while (0)
+
+// One shard's part of a batch.  A failing shard keeps walking through the barriers (with nothing to contribute) so
+// that the others are not stranded; swz_group_tile reports the first failure.
+void shard_thread(ShardCall a) {
+  swz_group* g = a.g;
+  const int r = a.r, N = g->n;
+  swz_ctx* c = g->ctx[r];
+  bool ok = true;
+  (void)hipSetDevice(g->devices[r]);
+  const uint64_t n = a.n;
+
+  // 1. encode locally, group the rows by destination shard
+  uint64_t* d_keys = nullptr;
+  uint32_t* d_perm = nullptr;
+  if (ok && c->get("grp_keys", (size_t)n, &d_keys) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  if (ok && c->get("grp_perm", (size_t)n, &d_perm) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  uint64_t oct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (n) {
+    GRP_TRY(swz_morton_encode_device(c, a.d_xyz, n, a.bmin, a.bmax, d_keys));
+    GRP_TRY(swz_partition_by_octant_device(c, d_keys, n, d_perm, oct));
+  }
+  std::fill(g->send_counts[r].begin(), g->send_counts[r].end(), 0);
+  for (int o = 0; o < 8; ++o) g->send_counts[r][owner_of_octant(o, N)] += ok ? oct[o] : 0;
+  double* send = nullptr;
+  if (ok && c->get("grp_send", (size_t)n * 3, &send) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  swz_attribute_columns send_attr{};
+  uint32_t row_bytes[SWZ_ATTR_COUNT];
+  for (int t = 0; t < SWZ_ATTR_COUNT; ++t) {
+    row_bytes[t] = (a.attrs && a.attrs->column[t]) ? swz_attribute_row_bytes(t) : 0;
+    if (!row_bytes[t]) continue;
+    const std::string name = "grp_send_attr" + std::to_string(t);
+    if (ok && c->get(name.c_str(), (size_t)n * row_bytes[t], &send_attr.column[t]) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  }
+  if (n) GRP_TRY(swz_gather_payload_device(c, d_perm, nullptr, n, a.d_xyz, a.attrs, send, a.attrs ? &send_attr : nullptr));
+  g->barrier.wait();  // ---- every shard knows every count
+
+  // 2. the one exchange step
+  uint64_t m = 0;
+  std::vector<uint64_t> recv_off(N, 0), send_off(N, 0);
+  for (int s = 0; s < N; ++s) {
+    recv_off[s] = m;
+    m += g->send_counts[s][r];
+  }
+  for (int d = 1; d < N; ++d) send_off[d] = send_off[d - 1] + g->send_counts[r][d - 1];
+  uint64_t global_points = 0;
+  for (int s = 0; s < N; ++s)
+    for (int d = 0; d < N; ++d) global_points += g->send_counts[s][d];
+  double* buf = nullptr;
+  if (ok && c->get("grp_recv", (size_t)(m + kGhostHeadroom) * 3, &buf) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  double* recv = buf ? buf + kGhostHeadroom * 3 : nullptr;
+  g->recv_rows[r] = recv;
+  g->recv_total[r] = m;
+  swz_attribute_columns recv_attr{};
+  for (int t = 0; t < SWZ_ATTR_COUNT; ++t) {
+    g->recv_attr[r][t] = nullptr;
+    if (!row_bytes[t]) continue;
+    const std::string name = "grp_recv_attr" + std::to_string(t);
+    if (ok && c->get(name.c_str(), (size_t)std::max<uint64_t>(m, 1) * row_bytes[t], &recv_attr.column[t]) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    g->recv_attr[r][t] = ok ? (char*)recv_attr.column[t] : nullptr;
+  }
+  // the columns of one row travel as separate blocks: [0] positions, [1 + t] attribute t
+  struct Column {
+    const char* src;
+    char* dst_here;
+    uint32_t bytes;
+    int attr;
+  };
+  std::vector<Column> columns{{(const char*)send, (char*)recv, 24u, -1}};
+  for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+    if (row_bytes[t]) columns.push_back({(const char*)send_attr.column[t], (char*)recv_attr.column[t], row_bytes[t], t});
+  g->barrier.wait();  // ---- every receive buffer exists
+  if (g->transport == 1 && N > 1) {
+    // grouped RCCL point-to-point = the all-to-all(v): bounded messages, both sides cut their block the same way
+    if (ok && g->rccl.GroupStart() != 0) ok = fail(g, r, SWZ_ERR_HIP, "ncclGroupStart failed");
+    for (const Column& col : columns)
+      for (int p = 0; p < N && ok; ++p) {
+        if (p == r) continue;
+        const size_t sb = (size_t)g->send_counts[r][p] * col.bytes, rb = (size_t)g->send_counts[p][r] * col.bytes;
+        for (size_t at = 0; at < sb && ok; at += kChunkBytes)
+          if (g->rccl.Send(col.src + send_off[p] * col.bytes + at, std::min(kChunkBytes, sb - at), Rccl::kUint8, p, g->comms[r], c->stream) != 0)
+            ok = fail(g, r, SWZ_ERR_HIP, "ncclSend failed");
+        for (size_t at = 0; at < rb && ok; at += kChunkBytes)
+          if (g->rccl.Recv(col.dst_here + recv_off[p] * col.bytes + at, std::min(kChunkBytes, rb - at), Rccl::kUint8, p, g->comms[r], c->stream) != 0)
+            ok = fail(g, r, SWZ_ERR_HIP, "ncclRecv failed");
+      }
+    if (g->rccl.GroupEnd() != 0 && ok) ok = fail(g, r, SWZ_ERR_HIP, "ncclGroupEnd failed");
+    for (const Column& col : columns)
+      if (ok && g->send_counts[r][r])
+        GRP_HIP(hipMemcpyAsync(col.dst_here + recv_off[r] * col.bytes, col.src + send_off[r] * col.bytes,
+                               (size_t)g->send_counts[r][r] * col.bytes, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    // peer copies: every source pushes its blocks
+    for (int d = 0; d < N && ok; ++d) {
+      const uint64_t cnt = g->send_counts[r][d];
+      if (!cnt || !g->recv_rows[d]) continue;
+      uint64_t off = 0;  // where this source's block starts on the destination
+      for (int s = 0; s < r; ++s) off += g->send_counts[s][d];
+      for (const Column& col : columns) {
+        char* dst = col.attr < 0 ? (char*)g->recv_rows[d] : g->recv_attr[d][col.attr];
+        if (!dst) continue;
+        GRP_HIP(hipMemcpyPeerAsync(dst + off * col.bytes, g->devices[d], col.src + send_off[d] * col.bytes, g->devices[r],
+                                   (size_t)cnt * col.bytes, c->stream));
+      }
+    }
+  }
+  GRP_HIP(hipStreamSynchronize(c->stream));
+  g->barrier.wait();  // ---- all rows have arrived everywhere
+
+  // 3. the root node
+  const bool sequential_root = a.params->sampler == SWZ_MIN_DISTANCE && global_points > a.params->max_points_per_node;
+  uint64_t taken = 0;
+  g->root_taken_count[r] = 0;
+  if (!sequential_root) {
+    swz_shard_info info{global_points, nullptr, 0};
+    GRP_TRY(swz_shard_begin_device(c, recv, m, a.bmin, a.bmax, a.params, &info, &taken));
+  } else {
+    if (m) GRP_TRY(swz_shard_presort_device(c, recv, m, a.bmin, a.bmax, a.params, kGhostHeadroom));
+    {
+      std::unique_lock<std::mutex> lk(g->turn_m);
+      g->turn_cv.wait(lk, [&] { return g->turn == r; });
+    }
+    // ghosts: what the root took on all lower shards, right in front of the received points
+    uint64_t gh = 0;
+    for (int s = 0; s < r; ++s) gh += g->root_taken_count[s];
+    if (gh > kGhostHeadroom && ok) ok = fail(g, r, SWZ_ERR_TOO_MANY_POINTS, "more root samples on lower shards than the ghost headroom holds");
+    double* gp = recv ? recv - gh * 3 : nullptr;
+    uint64_t at = 0;
+    for (int s = 0; s < r && ok && m; ++s) {
+      if (!g->root_taken_count[s]) continue;
+      GRP_HIP(hipMemcpyPeerAsync(gp + at * 3, g->devices[r], g->root_taken[s], g->devices[s], (size_t)g->root_taken_count[s] * 24, c->stream));
+      at += g->root_taken_count[s];
+    }
+    GRP_HIP(hipStreamSynchronize(c->stream));
+    swz_shard_info info{global_points, m ? gp : nullptr, m ? gh : 0};
+    GRP_TRY(swz_shard_begin_device(c, recv, m, a.bmin, a.bmax, a.params, &info, &taken));
+    double* mine = nullptr;
+    if (ok && c->get("grp_root_taken", (size_t)std::max<uint64_t>(taken, 1) * 3, &mine) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    if (taken) GRP_TRY(swz_shard_root_taken_device(c, mine));
+    g->root_taken[r] = mine;
+    g->root_taken_count[r] = ok ? taken : 0;
+    {
+      std::lock_guard<std::mutex> lk(g->turn_m);
+      g->turn = r + 1;
+    }
+    g->turn_cv.notify_all();
+  }
+
+  // 4. everything below the root is local
+  uint64_t* okeys = nullptr;
+  uint32_t* operm = nullptr;
+  int8_t* olevel = nullptr;
+  if (ok && c->get("grp_out_keys", (size_t)m, &okeys) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  if (ok && c->get("grp_out_perm", (size_t)m, &operm) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  if (ok && c->get("grp_out_level", (size_t)m, &olevel) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+  swz_tile_stats stats{};
+  GRP_TRY(swz_shard_finish_device(c, okeys, operm, olevel, &stats));
+  if (a.result) {
+    a.result->d_xyz = recv;
+    a.result->d_keys = okeys;
+    a.result->d_perm = operm;
+    a.result->d_level = olevel;
+    a.result->attrs = recv_attr;
+    a.result->num_points = ok ? m : 0;
+    a.result->stats = stats;
+  }
+  g->barrier.wait();  // ---- nobody reads a neighbour's buffers any more
+}
+
+}  // namespace
+
+extern "C" {
+
+int swz_group_create(int num_shards, const int* devices, int transport, swz_group** out) {
+  if (!out || !devices || num_shards < 1 || (num_shards != 1 && num_shards != 2 && num_shards != 4 && num_shards != 8)) return SWZ_ERR_BAD_ARG;
+  *out = nullptr;
+  swz_group* g = new swz_group();
+  g->n = num_shards;
+  g->devices.assign(devices, devices + num_shards);
+  g->transport = transport;
+  g->barrier.parties = num_shards;
+  bool distinct = true;
+  for (int i = 0; i < num_shards; ++i)
+    for (int j = 0; j < i; ++j) distinct &= devices[i] != devices[j];
+  if (transport == 1 && !distinct) {
+    delete g;
+    return SWZ_ERR_BAD_ARG;  // RCCL refuses two ranks on one GPU; use peer copies (0)
+  }
+  for (int i = 0; i < num_shards; ++i) {
+    swz_ctx* c = nullptr;
+    if (swz_create(&c, devices[i]) != SWZ_OK) {
+      for (swz_ctx* x : g->ctx) swz_destroy(x);
+      delete g;
+      return SWZ_ERR_HIP;
+    }
+    g->ctx.push_back(c);
+  }
+  if (transport == 1) {
+    g->comms.assign(num_shards, nullptr);
+    if (!g->rccl.load(g->err) || g->rccl.CommInitAll(g->comms.data(), num_shards, devices) != 0) {
+      if (g->err.empty()) g->err = "ncclCommInitAll failed";
+      for (swz_ctx* x : g->ctx) swz_destroy(x);
+      delete g;
+      return SWZ_ERR_HIP;
+    }
+  } else if (distinct && num_shards > 1) {
+    for (int i = 0; i < num_shards; ++i) {  // peer copies between distinct devices want peer access enabled
+      (void)hipSetDevice(devices[i]);
+      for (int j = 0; j < num_shards; ++j)
+        if (i != j) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+    }
+  }
+  g->send_counts.assign(num_shards, std::vector<uint64_t>(num_shards, 0));
+  g->recv_rows.assign(num_shards, nullptr);
+  g->recv_attr.assign(num_shards, std::vector<char*>(SWZ_ATTR_COUNT, nullptr));
+  g->recv_total.assign(num_shards, 0);
+  g->root_taken.assign(num_shards, nullptr);
+  g->root_taken_count.assign(num_shards, 0);
+  g->status.assign(num_shards, SWZ_OK);
+  g->status_msg.assign(num_shards, "");
+  *out = g;
+  return SWZ_OK;
+}
+
+int swz_group_destroy(swz_group* g) {
+  if (!g) return SWZ_OK;
+  for (void* comm : g->comms)
+    if (comm && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(comm);
+  for (swz_ctx* c : g->ctx) swz_destroy(c);
+  delete g;
+  return SWZ_OK;
+}
+
+const char* swz_group_last_error(const swz_group* g) { return g ? g->err.c_str() : "swz_group_create failed"; }
+int swz_group_num_shards(const swz_group* g) { return g ? g->n : 0; }
+swz_ctx* swz_group_ctx(swz_group* g, int shard) { return (g && shard >= 0 && shard < g->n) ? g->ctx[shard] : nullptr; }
+
+int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n, const double bmin[3],
+                   const double bmax[3], const swz_tile_params* params, swz_group_result* results) {
+  if (!g || !d_xyz || !n || !bmin || !bmax || !params) return SWZ_ERR_BAD_ARG;
+  if (params->strategy != SWZ_ACCURATE || (params->flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY)) {
+    g->err = "sharded batches support the ACCURATE strategy and exact MIN_DISTANCE";
+    return SWZ_ERR_BAD_ARG;
+  }
+  if (d_attrs)
+    for (int r = 1; r < g->n; ++r)
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+        if ((d_attrs[r].column[t] != nullptr) != (d_attrs[0].column[t] != nullptr)) {
+          g->err = "every shard must hand over the same attribute columns";
+          return SWZ_ERR_BAD_ARG;
+        }
+  g->turn = 0;
+  std::fill(g->status.begin(), g->status.end(), SWZ_OK);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < g->n; ++r)
+    threads.emplace_back(shard_thread, ShardCall{g, r, d_xyz[r], n[r], bmin, bmax, params, d_attrs ? &d_attrs[r] : nullptr, results ? &results[r] : nullptr});
+  for (auto& t : threads) t.join();
+  for (int r = 0; r < g->n; ++r)
+    if (g->status[r] != SWZ_OK) {
+      g->err = "shard " + std::to_string(r) + ": " + g->status_msg[r];
+      return g->status[r];
+    }
+  return SWZ_OK;
+}
+
+}  // extern "C"

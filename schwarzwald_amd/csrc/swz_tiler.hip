@@ -1385,6 +1385,13 @@ int swz_device_alloc(uint64_t bytes, void** d_out) {
   *d_out = nullptr;
   return hipMalloc(d_out, bytes ? bytes : 1) == hipSuccess ? SWZ_OK : SWZ_ERR_HIP;
 }
+int swz_device_alloc_on(swz_ctx* c, uint64_t bytes, void** d_out) {
+  if (!c || !d_out) return SWZ_ERR_BAD_ARG;
+  *d_out = nullptr;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_HIP(c, hipMalloc(d_out, bytes ? bytes : 1));
+  return SWZ_OK;
+}
 int swz_device_free(void* d_ptr) { return (!d_ptr || hipFree(d_ptr) == hipSuccess) ? SWZ_OK : SWZ_ERR_HIP; }
 int swz_copy_to_host(swz_ctx* c, void* dst_host, const void* d_src, uint64_t bytes) {
   if (!c) return SWZ_ERR_BAD_ARG;

@@ -166,6 +166,13 @@ struct PointsSink {
   // PointReferences, core/tiling/TilingAlgorithms.cpp:232-236, 316-322).
   virtual void persist_points(const uint32_t* ids_begin, const uint32_t* ids_end, const double* positions,
                               const AABB& node_bounds, const std::string& node_name) = 0;
+  // Sharded batches (ShardedTilingAlgorithmGPU): the attribute columns travelled with the points between the
+  // GPUs, so a node's file arrives as rows instead of ids: count positions plus every attribute column present
+  // (host memory, count rows each, in file order).
+  virtual void persist_rows(size_t /*count*/, const double* /*positions*/, const swz_attribute_columns& /*attributes*/,
+                            const AABB& /*node_bounds*/, const std::string& /*node_name*/) {
+    throw std::runtime_error{"PointsSink::persist_rows is not implemented by this sink"};
+  }
 };
 
 // The shape of TilingAlgorithmBase (core/tiling/TilingAlgorithms.h:70-116): one object per Tiler, fed one batch at
@@ -268,6 +275,141 @@ private:
   swz_tiler* _tiler = nullptr;
   AABB _bounds;
   bool _finalized = false;
+};
+
+// One batch over several GPUs from this one process (swz_group_*): the batch is cut into equal pieces in input
+// order, one per GPU, the library exchanges the points (and their attribute columns) by level-0 octant, tiles, and
+// every shard hands the files of its subtrees to the persistence; the root node's file is the concatenation of the
+// shards' parts in shard order (= Morton order).  transport: 0 peer copies, 1 RCCL.
+class ShardedTilingAlgorithmGPU {
+public:
+  ShardedTilingAlgorithmGPU(SamplingStrategy sampling_strategy, PointsSink& persistence, TilerMetaParameters meta,
+                            const std::vector<int>& devices, int transport = 0)
+    : _sampling_strategy(sampling_strategy), _persistence(persistence), _meta(meta), _shards(static_cast<int>(devices.size())) {
+    if (swz_group_create(_shards, devices.data(), transport, &_group) != SWZ_OK)
+      throw std::runtime_error{std::string("swz_group_create: ") + swz_group_last_error(nullptr)};
+  }
+  ~ShardedTilingAlgorithmGPU() { swz_group_destroy(_group); }
+  ShardedTilingAlgorithmGPU(const ShardedTilingAlgorithmGPU&) = delete;
+  ShardedTilingAlgorithmGPU& operator=(const ShardedTilingAlgorithmGPU&) = delete;
+
+  // positions: n x 3 doubles, attributes: host columns of n rows (may be NULL).  Returns the number of node files.
+  size_t tile_batch(const double* positions, const swz_attribute_columns* attributes, size_t n, const AABB& bounds) {
+    swz_tile_params p{};
+    p.sampler = _sampling_strategy.kind;
+    p.max_points_per_node = _sampling_strategy.max_points_per_node;
+    p.spacing_at_root = _meta.spacing_at_root;
+    p.max_depth = _meta.max_depth;
+    p.strategy = SWZ_ACCURATE;
+    const double mn[3] = {bounds.min.x, bounds.min.y, bounds.min.z}, mx[3] = {bounds.max.x, bounds.max.y, bounds.max.z};
+    std::vector<std::vector<Scratch>> owned(_shards);
+    std::vector<double*> d_xyz(_shards, nullptr);
+    std::vector<swz_attribute_columns> d_attrs(_shards);
+    std::vector<uint64_t> cnt(_shards, 0);
+    for (int s = 0; s < _shards; ++s) {
+      const size_t lo = n * s / _shards, hi = n * (s + 1) / _shards;
+      cnt[s] = hi - lo;
+      swz_ctx* c = swz_group_ctx(_group, s);
+      d_attrs[s] = swz_attribute_columns{};
+      d_xyz[s] = static_cast<double*>(upload(owned[s], c, positions + 3 * lo, cnt[s] * 24));
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+        if (attributes && attributes->column[t]) {
+          const uint32_t rb = swz_attribute_row_bytes(t);
+          d_attrs[s].column[t] = upload(owned[s], c, static_cast<const char*>(attributes->column[t]) + lo * rb, cnt[s] * rb);
+        }
+    }
+    std::vector<swz_group_result> res(_shards);
+    if (swz_group_tile(_group, d_xyz.data(), attributes ? d_attrs.data() : nullptr, cnt.data(), mn, mx, &p, res.data()) != SWZ_OK)
+      throw std::runtime_error{std::string("swz_group_tile: ") + swz_group_last_error(_group)};
+
+    // node files: per shard on its device, the root's parts joined afterwards
+    size_t files = 0;
+    std::vector<double> root_xyz;
+    std::vector<std::vector<char>> root_attr(SWZ_ATTR_COUNT);
+    for (int s = 0; s < _shards; ++s) {
+      const uint64_t m = res[s].num_points;
+      if (!m) continue;
+      swz_ctx* c = swz_group_ctx(_group, s);
+      std::vector<Scratch> tmp;
+      uint32_t* d_order = static_cast<uint32_t*>(alloc(tmp, c, m * 4));
+      std::vector<int8_t> nl(m);
+      std::vector<uint64_t> nk(m), no(m), nc(m);
+      uint64_t nn = 0;
+      check(c, swz_build_node_lists_device(c, res[s].d_keys, res[s].d_level, m, d_order, m, nl.data(), nk.data(), no.data(), nc.data(), &nn));
+      double* d_rows = static_cast<double*>(alloc(tmp, c, m * 24));
+      swz_attribute_columns d_out{}, h_out{};
+      std::vector<std::vector<char>> host_cols(SWZ_ATTR_COUNT);
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+        if (res[s].attrs.column[t]) d_out.column[t] = alloc(tmp, c, m * swz_attribute_row_bytes(t));
+      check(c, swz_gather_payload_device(c, res[s].d_perm, d_order, m, res[s].d_xyz, &res[s].attrs, d_rows, &d_out));
+      std::vector<double> rows(m * 3);
+      check(c, swz_copy_to_host(c, rows.data(), d_rows, m * 24));
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+        if (d_out.column[t]) {
+          host_cols[t].resize(m * swz_attribute_row_bytes(t));
+          check(c, swz_copy_to_host(c, host_cols[t].data(), d_out.column[t], host_cols[t].size()));
+        }
+      for (uint64_t j = 0; j < nn; ++j) {
+        if (nl[j] < 0) {  // this shard's part of the root
+          root_xyz.insert(root_xyz.end(), rows.begin() + 3 * no[j], rows.begin() + 3 * (no[j] + nc[j]));
+          for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+            if (d_out.column[t]) {
+              const uint32_t rb = swz_attribute_row_bytes(t);
+              root_attr[t].insert(root_attr[t].end(), host_cols[t].begin() + no[j] * rb, host_cols[t].begin() + (no[j] + nc[j]) * rb);
+            }
+          continue;
+        }
+        std::string name = "r";
+        AABB b = bounds;
+        for (int l = 0; l <= nl[j]; ++l) {
+          const uint8_t o = get_octant_at_level(nk[j], static_cast<uint32_t>(l));
+          name.push_back(static_cast<char>('0' + o));
+          b = get_octant_bounds(o, b);
+        }
+        for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+          h_out.column[t] = d_out.column[t] ? host_cols[t].data() + no[j] * swz_attribute_row_bytes(t) : nullptr;
+        _persistence.persist_rows(nc[j], rows.data() + 3 * no[j], h_out, b, name);
+        ++files;
+      }
+    }
+    if (!root_xyz.empty()) {
+      swz_attribute_columns h_out{};
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t) h_out.column[t] = root_attr[t].empty() ? nullptr : root_attr[t].data();
+      _persistence.persist_rows(root_xyz.size() / 3, root_xyz.data(), h_out, bounds, "r");
+      ++files;
+    }
+    return files;
+  }
+
+private:
+  struct Scratch {
+    void* ptr = nullptr;
+    Scratch() = default;
+    Scratch(Scratch&& o) noexcept : ptr(o.ptr) { o.ptr = nullptr; }
+    Scratch(const Scratch&) = delete;
+    ~Scratch() { swz_device_free(ptr); }
+  };
+  static void* alloc(std::vector<Scratch>& owner, swz_ctx* c, uint64_t bytes) {
+    Scratch s;
+    if (swz_device_alloc_on(c, bytes ? bytes : 1, &s.ptr) != SWZ_OK) throw std::runtime_error{"swz_device_alloc_on failed"};
+    void* p = s.ptr;
+    owner.push_back(std::move(s));
+    return p;
+  }
+  static void check(swz_ctx* c, int status) {
+    if (status != SWZ_OK) throw std::runtime_error{std::string("swz: ") + swz_last_error(c)};
+  }
+  static void* upload(std::vector<Scratch>& owner, swz_ctx* c, const void* src, uint64_t bytes) {
+    void* d = alloc(owner, c, bytes);
+    if (bytes) check(c, swz_copy_to_device(c, d, src, bytes));
+    return d;
+  }
+
+  SamplingStrategy _sampling_strategy;
+  PointsSink& _persistence;
+  TilerMetaParameters _meta;
+  int _shards;
+  swz_group* _group = nullptr;
 };
 
 }  // namespace swz_host

@@ -1,0 +1,219 @@
+// One batch sharded over several contexts from ONE C++ process (swz_group_*, include/swz_gpu.h): the points start
+// scattered over the shards in uneven pieces (one piece empty), the library exchanges them by level-0 octant and
+// tiles; the union of the shards' results must equal the single-process oracle's result point for point
+// (Morton key and node level of every position), every shard's keys ascend and lie in its own octants.
+// Usage: test_group [transport]   (0 = peer copies, default; 1 = RCCL, one shard per visible GPU)
+// Exit code 0 = pass.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/swz_gpu.h"
+#include "../../oracle/oracle.h"
+#include "../../schwarzwald_amd/host/swz_tiling.hpp"
+
+static int fail(const char* msg, const char* detail = "") {
+  std::fprintf(stderr, "FAIL: %s %s\n", msg, detail);
+  return 1;
+}
+
+// collects the node files a ShardedTilingAlgorithmGPU hands over: name -> the input index of every row (GPS time column)
+struct RowSink : swz_host::PointsSink {
+  std::map<std::string, std::vector<uint32_t>> nodes;
+  const std::vector<double>* xyz = nullptr;
+  bool rows_match = true;
+  void persist_points(const uint32_t*, const uint32_t*, const double*, const swz_host::AABB&, const std::string&) override {}
+  void persist_rows(size_t count, const double* positions, const swz_attribute_columns& attrs, const swz_host::AABB& b,
+                    const std::string& name) override {
+    const double* gps = static_cast<const double*>(attrs.column[SWZ_ATTR_GPS_TIME]);
+    std::vector<uint32_t>& ids = nodes[name];
+    for (size_t i = 0; i < count; ++i) {
+      const uint32_t src = (uint32_t)gps[i];
+      ids.push_back(src);
+      for (int d = 0; d < 3; ++d) rows_match &= positions[3 * i + d] == (*xyz)[3 * (size_t)src + d];
+      rows_match &= positions[3 * i] >= b.min.x && positions[3 * i] <= b.max.x && positions[3 * i + 1] >= b.min.y &&
+                    positions[3 * i + 1] <= b.max.y && positions[3 * i + 2] >= b.min.z && positions[3 * i + 2] <= b.max.z;
+    }
+  }
+};
+
+using Row = std::tuple<uint64_t, double, double, double, int>;  // key, x, y, z, level
+
+int main(int argc, char** argv) {
+  const int transport = argc > 1 ? std::atoi(argv[1]) : 0;
+  const size_t n = 300000;
+  const double mn[3] = {0, 0, 0}, mx[3] = {1, 1, 1};
+  const float spacing = (float)(std::sqrt(3.0) / 250.0);
+  const char* names[] = {"RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED"};
+  std::vector<double> xyz(n * 3);
+  orc_generate_uniform(7, 0, n, xyz.data());
+  // two attribute columns that identify the point they belong to: GPS time = its index, RGB = the index's low bytes
+  std::vector<double> gps(n);
+  std::vector<uint8_t> rgb(n * 3);
+  for (size_t i = 0; i < n; ++i) {
+    gps[i] = (double)i;
+    rgb[3 * i] = (uint8_t)i, rgb[3 * i + 1] = (uint8_t)(i >> 8), rgb[3 * i + 2] = (uint8_t)(i >> 16);
+  }
+
+  for (int shards : {1, 2, 4, 8}) {
+    if (transport == 1 && shards > 1) {
+      // RCCL wants one GPU per rank; run what the box offers
+      swz_group* probe = nullptr;
+      std::vector<int> dev(shards);
+      for (int i = 0; i < shards; ++i) dev[i] = i;
+      if (swz_group_create(shards, dev.data(), 1, &probe) != SWZ_OK) {
+        std::printf("RCCL with %d shards skipped: not that many GPUs\n", shards);
+        continue;
+      }
+      swz_group_destroy(probe);
+    }
+    std::vector<int> devices(shards, 0);
+    if (transport == 1)
+      for (int i = 0; i < shards; ++i) devices[i] = i;
+    swz_group* g = nullptr;
+    if (swz_group_create(shards, devices.data(), transport, &g) != SWZ_OK) return fail("swz_group_create", swz_group_last_error(nullptr));
+    // uneven pieces in input order; the second piece is empty
+    std::vector<size_t> cut(shards + 1, 0);
+    for (int s = 1; s <= shards; ++s) cut[s] = (s == 2 && shards > 2) ? cut[1] : std::min(n, (size_t)((double)n * s * s / ((double)shards * shards)));
+    cut[shards] = n;
+    for (int sampler = 0; sampler < 4; ++sampler) {
+      std::vector<double*> d_xyz(shards, nullptr);
+      std::vector<swz_attribute_columns> d_attrs(shards);
+      std::vector<uint64_t> cnt(shards, 0);
+      for (int s = 0; s < shards; ++s) {
+        cnt[s] = cut[s + 1] - cut[s];
+        d_attrs[s] = swz_attribute_columns{};
+        const uint64_t rows = std::max<uint64_t>(cnt[s], 1);
+        swz_ctx* c = swz_group_ctx(g, s);
+        if (swz_device_alloc_on(c, rows * 24, (void**)&d_xyz[s]) != SWZ_OK || swz_device_alloc_on(c, rows * 8, &d_attrs[s].column[SWZ_ATTR_GPS_TIME]) != SWZ_OK ||
+            swz_device_alloc_on(c, rows * 3, &d_attrs[s].column[SWZ_ATTR_RGB]) != SWZ_OK)
+          return fail("device alloc");
+        if (!cnt[s]) continue;
+        if (swz_copy_to_device(c, d_xyz[s], xyz.data() + 3 * cut[s], cnt[s] * 24) != SWZ_OK ||
+            swz_copy_to_device(c, d_attrs[s].column[SWZ_ATTR_GPS_TIME], gps.data() + cut[s], cnt[s] * 8) != SWZ_OK ||
+            swz_copy_to_device(c, d_attrs[s].column[SWZ_ATTR_RGB], rgb.data() + 3 * cut[s], cnt[s] * 3) != SWZ_OK)
+          return fail("upload");
+      }
+      swz_tile_params p{};
+      p.sampler = sampler;
+      p.max_points_per_node = 2000;
+      p.spacing_at_root = spacing;
+      p.max_depth = 100;
+      p.strategy = SWZ_ACCURATE;
+      p.fast_concurrency = 8;
+      std::vector<swz_group_result> res(shards);
+      if (swz_group_tile(g, d_xyz.data(), d_attrs.data(), cnt.data(), mn, mx, &p, res.data()) != SWZ_OK) return fail("swz_group_tile", swz_group_last_error(g));
+
+      std::vector<Row> got;
+      for (int s = 0; s < shards; ++s) {
+        const uint64_t m = res[s].num_points;
+        std::vector<double> px(m * 3);
+        std::vector<uint64_t> k(m);
+        std::vector<uint32_t> perm(m);
+        std::vector<int8_t> lv(m);
+        std::vector<double> got_gps(m);
+        std::vector<uint8_t> got_rgb(m * 3);
+        swz_ctx* c = swz_group_ctx(g, s);
+        if (m) {
+          if (!res[s].attrs.column[SWZ_ATTR_GPS_TIME] || !res[s].attrs.column[SWZ_ATTR_RGB]) return fail("attribute columns missing in the result");
+          if (swz_copy_to_host(c, got_gps.data(), res[s].attrs.column[SWZ_ATTR_GPS_TIME], m * 8) ||
+              swz_copy_to_host(c, got_rgb.data(), res[s].attrs.column[SWZ_ATTR_RGB], m * 3))
+            return fail("download of the attributes");
+          if (swz_copy_to_host(c, px.data(), res[s].d_xyz, m * 24) || swz_copy_to_host(c, k.data(), res[s].d_keys, m * 8) ||
+              swz_copy_to_host(c, perm.data(), res[s].d_perm, m * 4) || swz_copy_to_host(c, lv.data(), res[s].d_level, m))
+            return fail("download");
+        }
+        for (uint64_t i = 0; i < m; ++i) {
+          if (i && k[i] < k[i - 1]) return fail("keys of a shard do not ascend");
+          const int octant = (int)(k[i] >> 60);
+          if (octant * shards / 8 != s) return fail("point on a shard that does not own its octant");
+          const uint32_t q = perm[i];
+          if (q >= m) return fail("perm out of range");
+          const size_t src = (size_t)got_gps[q];  // the attributes name the input point this row came from
+          if (src >= n || xyz[3 * src] != px[3 * q] || xyz[3 * src + 1] != px[3 * q + 1] || xyz[3 * src + 2] != px[3 * q + 2])
+            return fail("GPS time column did not travel with its point");
+          if (got_rgb[3 * q] != (uint8_t)src || got_rgb[3 * q + 1] != (uint8_t)(src >> 8) || got_rgb[3 * q + 2] != (uint8_t)(src >> 16))
+            return fail("RGB column did not travel with its point");
+          got.emplace_back(k[i], px[3 * q], px[3 * q + 1], px[3 * q + 2], (int)lv[i]);
+        }
+      }
+      if (got.size() != n) return fail("points lost or duplicated in the exchange");
+
+      std::vector<double> copy(xyz);
+      std::vector<uint64_t> ok(n);
+      std::vector<uint32_t> operm(n);
+      std::vector<int8_t> olv(n);
+      orc_tile_params op{sampler, 2000, spacing, 100, ORC_ACCURATE, 8};
+      orc_tile_stats ost;
+      if (orc_tile(copy.data(), n, mn, mx, &op, ok.data(), operm.data(), olv.data(), nullptr, &ost) != 0) return fail("oracle");
+      std::vector<Row> want;
+      want.reserve(n);
+      for (size_t i = 0; i < n; ++i) {
+        const uint32_t q = operm[i];
+        want.emplace_back(ok[i], copy[3 * q], copy[3 * q + 1], copy[3 * q + 2], (int)olv[i]);
+      }
+      std::sort(got.begin(), got.end());
+      std::sort(want.begin(), want.end());
+      if (got != want) {
+        size_t bad = 0, first = n;
+        for (size_t i = 0; i < n; ++i)
+          if (got[i] != want[i]) {
+            ++bad;
+            if (first == n) first = i;
+          }
+        std::fprintf(stderr, "%s, %d shards: %zu rows differ, first at %zu (level %d vs %d)\n", names[sampler], shards, bad, first,
+                     std::get<4>(got[first]), std::get<4>(want[first]));
+        return fail("sharded result differs from the oracle");
+      }
+      std::printf("%-12s %d shard(s) ok\n", names[sampler], shards);
+      for (int s = 0; s < shards; ++s) {
+        swz_device_free(d_xyz[s]);
+        swz_device_free(d_attrs[s].column[SWZ_ATTR_GPS_TIME]);
+        swz_device_free(d_attrs[s].column[SWZ_ATTR_RGB]);
+      }
+    }
+    swz_group_destroy(g);
+
+    // the reference-shaped C++ class on top: node files (names, contents, order) equal the oracle's
+    if (transport == 0)
+      for (int sampler = 0; sampler < 4; ++sampler) {
+        RowSink sink;
+        sink.xyz = &xyz;
+        swz_host::TilerMetaParameters meta;
+        meta.spacing_at_root = spacing;
+        meta.max_points_per_node = 2000;
+        swz_host::ShardedTilingAlgorithmGPU tiler(swz_host::make_sampling_strategy_from_name(names[sampler], 2000), sink, meta, devices, 0);
+        swz_attribute_columns cols{};
+        cols.column[SWZ_ATTR_GPS_TIME] = gps.data();
+        cols.column[SWZ_ATTR_RGB] = rgb.data();
+        const swz_host::AABB bounds{{0, 0, 0}, {1, 1, 1}};
+        const size_t files = tiler.tile_batch(xyz.data(), &cols, n, bounds);
+        if (!sink.rows_match) return fail("a row of a node file is not the point its attributes name, or lies outside the node");
+        orc_tile_params op{sampler, 2000, spacing, 100, ORC_ACCURATE, 8};
+        orc_tiler* oracle = orc_tiler_create(mn, mx, &op);
+        std::vector<double> copy(xyz);
+        if (orc_tiler_add_batch(oracle, copy.data(), n) != 0 || orc_tiler_finalize(oracle) != 0) return fail("oracle tiler");
+        uint64_t nn = 0, ns = 0;
+        orc_tiler_counts(oracle, &nn, &ns, nullptr, nullptr);
+        std::vector<int8_t> nl(nn);
+        std::vector<uint64_t> nk(nn), no(nn), nc(nn);
+        std::vector<uint32_t> ids(ns);
+        orc_tiler_export(oracle, nl.data(), nk.data(), no.data(), nc.data(), ids.data(), nullptr);
+        orc_tiler_destroy(oracle);
+        std::map<std::string, std::vector<uint32_t>> expect;
+        for (uint64_t j = 0; j < nn; ++j) {
+          std::string name = "r";
+          for (int l = 0; l <= nl[j]; ++l) name.push_back((char)('0' + swz_host::get_octant_at_level(nk[j], (uint32_t)l)));
+          expect[name].assign(ids.begin() + no[j], ids.begin() + no[j] + nc[j]);
+        }
+        if (files != expect.size() || expect != sink.nodes) return fail("node files of the sharded C++ tiler differ from the oracle");
+        std::printf("%-12s %d shard(s) files ok: %zu nodes\n", names[sampler], shards, files);
+      }
+  }
+  return 0;
+}
