@@ -22,7 +22,8 @@ enum {
   CTR_DBG_SCAN = 12,     //   64-point chunks read by blocker scans,
   CTR_DBG_RTEST = 13,    //   accepted points tested per chunk by the rejection pass,
   CTR_DBG_STALL = 14,    //   activations that ended stalled
-  CTR_COUNT = 16
+  CTR_DBG_CHUNK = 16, CTR_DBG_CAND = 17, CTR_DBG_RANKS = 18, CTR_DBG_STEPS = 19, CTR_DBG_TIME = 20, CTR_DBG_TMAX = 21, CTR_DBG_HIST = 22,
+  CTR_COUNT = 40
 };
 
 // The active set of one level: Morton-sorted survivors.  aidx == nullptr means identity (level -1).

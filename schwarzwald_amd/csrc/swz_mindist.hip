@@ -62,8 +62,8 @@ struct MdArgs {
   uint32_t* blk_slot;
   uint32_t* blk_q;
   uint32_t* blk_cell;
-  uint32_t* whead;     // wait list of cells sleeping on this cell
-  uint32_t* wnext;
+  uint32_t* sleeper;   // [cell][28], 27 used: the adjacent cell in direction k that sleeps on this cell (NONE32 = nobody); a cell
+                       // is the only writer of its entry and the cell it sleeps on the only one who clears it
   double* acc_xyz;     // per cell: positions of its accepted points, 3 doubles each, at slots [start, start+cnt)
   uint32_t* gridmap;   // [sample node][cell code] -> cell index (build time only)
   // per cell, built once: its earlier adjacent cells, latest (largest Morton code) first
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void md_cell_build_kernel(MdArgs a, const uint
   a.cell[c] = make_uint4(i, 0u, i, 0u);
   a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
   a.csnode[c] = a.snode_of[a.nid[i]];
-  a.whead[c] = NONE32;
+  a.npos[c] = i;  // the frontier as the round bookkeeping sees it (a cell that never ran has not moved)
   a.blk_p[c] = NONE32;
 }
 
@@ -297,6 +297,25 @@ __device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, 
   return wn;
 }
 
+// true when (x, y, z) is closer than the spacing to one of n points in LDS.  The next entry is requested before the
+// current one is tested: written as a plain loop every iteration waits for its own LDS reads (~175 cycles per
+// entry; measured at 1 B points, level 1: 77 entries per chunk of 64 points, 11.6 us per chunk).
+__device__ __forceinline__ bool md_near_any(const double* ex, const double* ey, const double* ez, uint32_t n, double x, double y,
+                                            double z, double t) {
+  if (n == 0u) return false;
+  bool hit = false;
+  double cx = ex[0], cy = ey[0], cz = ez[0];
+  for (uint32_t i = 1; i < n; ++i) {
+    const double nx = ex[i], ny = ey[i], nz = ez[i];
+    hit |= sq_dist(x, y, z, cx, cy, cz) < t;
+    cx = nx;
+    cy = ny;
+    cz = nz;
+  }
+  hit |= sq_dist(x, y, z, cx, cy, cz) < t;
+  return hit;
+}
+
 // squared slab distance from a point with slab coordinates (sx,sy,sz) to the adjacent cell in slot k
 __device__ __forceinline__ bool md_culled(const MdArgs& a, int k, int sx, int sy, int sz) {
   const int smax = (1 << a.sub_levels) - 1;
@@ -316,8 +335,7 @@ __device__ __forceinline__ uint64_t md_live_hits(const MdArgs& a, const MdLds& l
                                                  double y, double z) {
   uint64_t hb = __ballot(hit);
   if (hb && wn) {
-    for (uint32_t ti = 0; ti < wn; ++ti)
-      if (sq_dist(x, y, z, lds.ex[ti], lds.ey[ti], lds.ez[ti]) < a.sq_spacing) hit = false;
+    if (md_near_any(lds.ex, lds.ey, lds.ez, wn, x, y, z, a.sq_spacing)) hit = false;
     hb = __ballot(hit);
   }
   return hb;
@@ -355,6 +373,9 @@ __device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& l
 // One wavefront advances the frontier of one active cell as far as it can.
 __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t l = lane_id();
+#ifdef SWZ_MD_STATS
+  const uint64_t dbg_t0 = wall_clock64();
+#endif
   const uint4 me = a.cell[c];
   const uint32_t s0 = me.x, e = me.y;
   const double t = a.sq_spacing;
@@ -456,7 +477,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t live_wn = (T <= (uint32_t)MD_EXT_CAP && !(a.ablate & 8u)) ? wn0 : 0u;
   uint32_t fresh = 0;
 #ifdef SWZ_MD_STATS
-  uint32_t dbg_scan = 0, dbg_rtest = 0;
+  uint32_t dbg_scan = 0, dbg_rtest = 0, dbg_chunk = 0, dbg_cand = 0, dbg_ranks = 0;
+  uint64_t dbg_tscan = 0, dbg_tchunk = 0;
+  const uint64_t dbg_t1 = wall_clock64();  // prologue done (records, window)
 #endif
   uint32_t cur = P;
   uint32_t out_pos = e, out_status = ST_FINISHED;
@@ -478,10 +501,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       bool alive_l = false;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        bool rej_u = false;
-        for (uint32_t ti = 0; ti < live_wn; ++ti)
-          if (sq_dist(x[u], y[u], z[u], lds.ex[ti], lds.ey[ti], lds.ez[ti]) < t) rej_u = true;
-        alive_l |= !rej_u;
+        alive_l |= !md_near_any(lds.ex, lds.ey, lds.ez, live_wn, x[u], y[u], z[u], t);
       }
       if (__ballot(alive_l)) break;
       cur += 4u * WAVE;
@@ -489,6 +509,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   }
 
   while (cur < e && !stop) {
+#ifdef SWZ_MD_STATS
+    const uint64_t dbg_tc = wall_clock64();
+#endif
     const uint32_t p = cur + l;
     const bool valid = p < e;
     int sx = 0, sy = 0, sz = 0;
@@ -517,6 +540,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       for (int k = 0; k < 27; ++k)
         if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) needmask |= 1u << k;
     }
+#ifdef SWZ_MD_STATS
+    ++dbg_chunk;
+#endif
     uint32_t needrank = 0;  // the same in scan order, restricted to cells that may hold undecided points
     for (uint32_t r = 0; r < nnb; ++r)
       if ((emask_r >> r) & 1u) needrank |= ((needmask >> bcast_u32(slot_of_rank, (int)r)) & 1u) << r;
@@ -529,15 +555,16 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 #ifdef SWZ_MD_STATS
       dbg_rtest += wn;
 #endif
-      for (uint32_t ti = 0; ti < wn; ++ti)
-        if (sq_dist(px, py, pz, lds.ex[ti], lds.ey[ti], lds.ez[ti]) < t) rej = true;
+      rej |= md_near_any(lds.ex, lds.ey, lds.ez, wn, px, py, pz, t);
       if (!__ballot(!rej)) break;
     }
     // ... and against the points accepted earlier in this activation
-    for (uint32_t ti = 0; ti < fresh; ++ti)
-      if (sq_dist(px, py, pz, lds.fx[ti], lds.fy[ti], lds.fz[ti]) < t) rej = true;
+    rej |= md_near_any(lds.fx, lds.fy, lds.fz, fresh, px, py, pz, t);
 
     uint64_t alive = __ballot(!rej);
+#ifdef SWZ_MD_STATS
+    dbg_tchunk += wall_clock64() - dbg_tc;
+#endif
     // (A) for many survivors at once: one pass over the possibly-undecided points of the earlier
     // adjacent cells, every surviving lane testing its own point against the broadcast one
     bool pre = false;          // blocker flags of this chunk were precomputed for all lanes
@@ -605,13 +632,24 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       } else {
         // few survivors: scan the earlier adjacent cells for this candidate, 64 points at a time
         uint32_t nm = bcast_u32(needrank, j);
+#ifdef SWZ_MD_STATS
+        ++dbg_cand;
+#endif
         if ((a.ablate & 1u) || (p_clear && cand == P)) nm = 0;
         while (nm && !blocked) {
           const int r = md_next_rank(nm, a.latest_first);
           nm &= ~(1u << r);
           const uint32_t qs = bcast_u32(n_pos, r);
           const uint32_t qe = bcast_u32(n_end, r);
+#ifdef SWZ_MD_STATS
+          const uint64_t dbg_ts = wall_clock64();
+#endif
           const uint32_t hq = md_first_hit(a, lds, live_wn, qs, qe, bx, by, bz);
+#ifdef SWZ_MD_STATS
+          dbg_tscan += wall_clock64() - dbg_ts;
+          ++dbg_ranks;
+          dbg_scan += (qe - qs + 255u) / 256u;
+#endif
           if (hq != NONE32) {
             blocked = true;
             b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
@@ -657,10 +695,17 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   }
   if (l == 0) {
 #ifdef SWZ_MD_STATS
-    atomicAdd(&a.counters[CTR_DBG_ACT], 1u);
-    atomicAdd(&a.counters[CTR_DBG_SCAN], dbg_scan);
-    atomicAdd(&a.counters[CTR_DBG_RTEST], dbg_rtest);
-    if (out_status == ST_STALLED) atomicAdd(&a.counters[CTR_DBG_STALL], 1u);
+    if ((c & 63u) == 0u) {  // a sample of the cells: the atomics themselves disturb the timing
+      const uint32_t dt = (uint32_t)(wall_clock64() - dbg_t0);  // 100 MHz
+      atomicAdd(&a.counters[CTR_DBG_TIME], dt);
+      atomicMax(&a.counters[CTR_DBG_TMAX], dt);
+      atomicAdd(&a.counters[CTR_DBG_HIST + 0], 1u);
+      atomicAdd(&a.counters[CTR_DBG_HIST + 1], (uint32_t)(dbg_t1 - dbg_t0));
+      atomicAdd(&a.counters[CTR_DBG_HIST + 2], (uint32_t)dbg_tchunk);
+      atomicAdd(&a.counters[CTR_DBG_HIST + 3], (uint32_t)dbg_tscan);
+      atomicAdd(&a.counters[CTR_DBG_HIST + 4], dbg_chunk);
+      atomicAdd(&a.counters[CTR_DBG_HIST + 5], dbg_ranks);
+    }
 #endif
     a.npos[c] = out_pos;
     a.ncnt[c] = CNT + fresh;
@@ -706,9 +751,19 @@ __device__ __forceinline__ void md_wave_push(bool want, uint32_t value, uint32_t
   if (want) qout[base + (uint32_t)__popcll(m & lanemask_lt())] = value;
 }
 
-// publish the new frontiers; a cell whose frontier moved wakes the cells sleeping on it
+// After the sweep of a round, for every cell that took part (one lane per cell):
+//  * publish its new frontier and number of accepted points (the record the next round's activations read);
+//  * if the frontier moved, wake the adjacent cells that sleep on it and whose blocking point it has passed;
+//  * if the cell itself ended the round stalled, put it to sleep on the blocking cell -- or straight back into the
+//    queue when that cell's frontier has already passed the blocking point; yielded cells are re-queued.
+// One launch does all three: a cell that goes to sleep decides from the blocker's PENDING frontier (npos, final since
+// the sweep ended), so it does not depend on the blocker's record having been published in this launch; and a sleeper
+// is an entry in the blocker's 27-slot array written by the sleeper alone and cleared by the blocker alone, so the
+// blocker's lane may see the entry now or in its next round, either is right (the wake test is the same data the
+// sleeper decided on).  (Until round 2 this was two launches, commit and requeue, with linked wait lists: 18 us per
+// round at 1 B points, now ~13.)
 // (wave0: index of this wavefront's first lane among all participating threads, stride: their number)
-__device__ __forceinline__ void md_commit_range(const MdArgs& a, uint32_t round, uint32_t wave0, uint32_t stride) {
+__device__ __forceinline__ void md_commit_requeue_range(const MdArgs& a, uint32_t round, uint32_t wave0, uint32_t stride) {
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
   const uint32_t* qin = a.queue[round & 1];
@@ -716,72 +771,68 @@ __device__ __forceinline__ void md_commit_range(const MdArgs& a, uint32_t round,
   for (uint32_t i0 = wave0; i0 < nq; i0 += stride) {  // wave-uniform
     const uint32_t i = i0 + lane_id();
     const bool valid = i < nq;
-    uint32_t c = 0, np = 0, w = NONE32, keep = NONE32;
-    bool fin = false;
+    // everything that depends on the cell alone is requested together: its records and its sleepers' entries
+    uint32_t c = 0, np = 0, st = ST_FINISHED, old = 0, cnt_new = 0, b = 0, bq = 0, bslot = 0;
+    uint4 sl[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) sl[k] = make_uint4(NONE32, NONE32, NONE32, NONE32);
     if (valid) {
       c = qin[i];
-      const uint32_t old = a.cell[c].z;
+      old = a.cell[c].z;
       np = a.npos[c];
+      st = a.status[c];
+      cnt_new = a.ncnt[c];
+      b = a.blk_cell[c];
+      bq = a.blk_q[c];
+      bslot = a.blk_slot[c] & 0xFFu;
+      const uint4* row = reinterpret_cast<const uint4*>(a.sleeper + (size_t)c * 28);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) sl[k] = row[k];
+    }
+    const bool fin = valid && st == ST_FINISHED;
+    const bool moved = valid && (np > old || fin);
+    const bool stalled = valid && st == ST_STALLED;
+    if (valid) {
       a.cell[c].z = np;
-      a.cell[c].w = a.ncnt[c];
-      fin = a.status[c] == ST_FINISHED;
-      if (np > old || fin) w = a.whead[c];
+      a.cell[c].w = cnt_new;
     }
     const uint64_t fm = __ballot(fin);
     if (fm && lane_id() == 0) atomicAdd(&a.counters[CTR_DONE_CELLS], (uint32_t)__popcll(fm));
-    const bool walk = valid && w != NONE32;
-    // wake the sleepers whose blocking point the frontier has passed; the others stay on the list
-    while (__ballot(w != NONE32)) {
-      bool wake = false;
-      uint32_t cur = w;
-      if (w != NONE32) {
-        const uint32_t nx = a.wnext[w];
-        wake = fin || a.blk_q[w] < np;
-        if (!wake) {
-          a.wnext[w] = keep;
-          keep = w;
-        }
-        w = nx;
-      }
-      md_wave_push(wake, cur, qout, cout);
+    // second round trip: the blocker's pending frontier, the blocking points of the sleepers
+    uint32_t w[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const uint4 v = sl[k / 4];
+      w[k] = moved ? (k % 4 == 0 ? v.x : (k % 4 == 1 ? v.y : (k % 4 == 2 ? v.z : v.w))) : NONE32;
     }
-    if (walk) a.whead[c] = keep;
+    const uint32_t bpos = stalled ? a.npos[b] : 0u;
+    uint32_t wake = 0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k)
+      if (w[k] != NONE32 && (fin || a.blk_q[w[k]] < np)) wake |= 1u << k;
+    // the cell's own fate
+    const bool push = (valid && st == ST_YIELD) || (stalled && bpos > bq);
+    if (stalled && !push) a.sleeper[(size_t)b * 28 + (26u - bslot)] = c;  // the direction from b to c
+    // one queue reservation for the wavefront: the cells themselves, then the sleepers they wake
+    const uint32_t cnt = (push ? 1u : 0u) + (uint32_t)__popc(wake);
+    const uint32_t incl = wave_incl_sum(cnt);
+    const uint32_t total = bcast_u32(incl, WAVE - 1);
+    if (total) {
+      uint32_t base = 0;
+      if (lane_id() == 0) base = atomicAdd(cout, total);
+      uint32_t off = bcast_u32(base, 0) + incl - cnt;
+      if (push) qout[off++] = c;
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if ((wake >> k) & 1u) {
+          qout[off++] = w[k];
+          a.sleeper[(size_t)c * 28 + k] = NONE32;
+        }
+    }
   }
 }
-__global__ __launch_bounds__(256) void md_commit_kernel(MdArgs a, uint32_t round) {
-  md_commit_range(a, round, blockIdx.x * 256 + (threadIdx.x & ~63u), gridDim.x * 256);
-}
-
-// stalled cells go to sleep on their blocker's wait list (or straight back into the queue when the
-// blocker's frontier has already passed the blocking point); yielded cells are re-queued
-__device__ __forceinline__ void md_requeue_range(const MdArgs& a, uint32_t round, uint32_t wave0, uint32_t stride) {
-  const uint32_t nq = a.counters[CTR_Q0 + round % 3];
-  uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
-  const uint32_t* qin = a.queue[round & 1];
-  uint32_t* qout = a.queue[(round + 1) & 1];
-  for (uint32_t i0 = wave0; i0 < nq; i0 += stride) {  // wave-uniform
-    const uint32_t i = i0 + lane_id();
-    bool push = false;
-    uint32_t c = 0;
-    if (i < nq) {
-      c = qin[i];
-      const uint32_t st = a.status[c];
-      if (st == ST_YIELD) {
-        push = true;
-      } else if (st == ST_STALLED) {
-        const uint32_t b = a.blk_cell[c];
-        if (a.cell[b].z > a.blk_q[c]) {
-          push = true;
-        } else {
-          a.wnext[c] = atomicExch(&a.whead[b], c);
-        }
-      }
-    }
-    md_wave_push(push, c, qout, cout);
-  }
-}
-__global__ __launch_bounds__(256) void md_requeue_kernel(MdArgs a, uint32_t round) {
-  md_requeue_range(a, round, blockIdx.x * 256 + (threadIdx.x & ~63u), gridDim.x * 256);
+__global__ __launch_bounds__(256) void md_commit_requeue_kernel(MdArgs a, uint32_t round) {
+  md_commit_requeue_range(a, round, blockIdx.x * 256 + (threadIdx.x & ~63u), gridDim.x * 256);
 }
 
 // ---- the rounds of one level inside ONE launch ---------------------------------------------------------------------
@@ -843,9 +894,7 @@ __global__ __launch_bounds__(MDP_THREADS, 4) void md_persistent_kernel(MdArgs a,
       for (uint32_t i = blockIdx.x * MDP_WAVES + w; i < nq; i += nblocks * MDP_WAVES) md_sweep_cell(a, qin[i], lds[w]);
     }
     if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
-    md_commit_range(a, round, wave0, stride);
-    if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
-    md_requeue_range(a, round, wave0, stride);
+    md_commit_requeue_range(a, round, wave0, stride);
     if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
     if (threadIdx.x == 0) {
       s_done = __hip_atomic_load(&a.counters[CTR_DONE_CELLS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -891,7 +940,7 @@ __global__ __launch_bounds__(256) void md_lazy_start_kernel(MdArgs a, uint32_t n
       const uint4 o = a.cell[b];
       a.blk_q[c] = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
       a.status[c] = ST_STALLED;
-      a.wnext[c] = atomicExch(&a.whead[b], c);
+      a.sleeper[(size_t)b * 28 + (26u - a.nbr_slot[(size_t)c * 32])] = c;
     }
   }
   md_wave_push(push, c, q, counter);
@@ -1036,11 +1085,12 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   if (ncells == 0) return SWZ_OK;
 
-  uint32_t* cellbuf = nullptr;  // 11 per-cell u32 arrays + the packed {start,end,pos,cnt} records
-  SWZ_TRY(c->get("md_cells", (size_t)ncells * 11, &cellbuf));
-  uint32_t** fields[] = {&a.crel,     &a.csnode, &a.npos,     &a.ncnt,  &a.status, &a.blk_p,
-                         &a.blk_slot, &a.blk_q,  &a.blk_cell, &a.whead, &a.wnext};
-  for (size_t f = 0; f < 11; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
+  uint32_t* cellbuf = nullptr;  // 9 per-cell u32 arrays + the packed {start,end,pos,cnt} records
+  SWZ_TRY(c->get("md_cells", (size_t)ncells * 9, &cellbuf));
+  uint32_t** fields[] = {&a.crel, &a.csnode, &a.npos, &a.ncnt, &a.status, &a.blk_p, &a.blk_slot, &a.blk_q, &a.blk_cell};
+  for (size_t f = 0; f < 9; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
+  SWZ_TRY(c->get("md_sleeper", (size_t)ncells * 28, &a.sleeper));  // 27 directions, rows of 7 x 16 bytes
+  SWZ_HIP(c, memset_large(a.sleeper, 0xFF, (size_t)ncells * 28 * 4, c->stream));
   SWZ_TRY(c->get("md_cell4", (size_t)ncells, &a.cell));
   SWZ_TRY(c->get("md_nbr_id", (size_t)ncells * 27, &a.nbr_id));
   SWZ_TRY(c->get("md_nbr_slot", (size_t)ncells * 32, &a.nbr_slot));
@@ -1158,8 +1208,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   while (done < ncells) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
       hipLaunchKernelGGL(md_sweep_kernel, dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
-      hipLaunchKernelGGL(md_commit_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
-      hipLaunchKernelGGL(md_requeue_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
+      hipLaunchKernelGGL(md_commit_requeue_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
     }
     SWZ_LAUNCH_CHECK(c);
     SWZ_HIP(c, hipMemcpyAsync(&done, lb.counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
@@ -1200,9 +1249,16 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     uint32_t h[CTR_COUNT];
     SWZ_HIP(c, hipMemcpy(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[swz] MIN_DISTANCE level %d: %u pts in %u nodes, cell_levels %d, %u cells, %u rounds, %u activations "
-                    "(%u stalled), %u scan chunks, %u rtests\n",
+                    "(%u stalled), %u scan steps, %u rtests, %u chunks, %u candidates scanned, %u ranks scanned, mean activation %.1f us, max %.1f us, hist(<1,2,4..us):",
             plan.level, sample_points, sample_nodes, cl, ncells, round, h[CTR_DBG_ACT], h[CTR_DBG_STALL],
-            h[CTR_DBG_SCAN], h[CTR_DBG_RTEST]);
+            h[CTR_DBG_SCAN], h[CTR_DBG_RTEST], h[CTR_DBG_CHUNK], h[CTR_DBG_CAND], h[CTR_DBG_RANKS],
+            0.0, h[CTR_DBG_TMAX] / 100.0);
+    {
+      const double ns = std::max(1u, h[CTR_DBG_HIST]);
+      fprintf(stderr, " sampled %u activations: mean total %.2f us, prologue %.2f us, chunks %.2f us (%.2f chunks), scans %.2f us (%.2f ranks)\n",
+              h[CTR_DBG_HIST], h[CTR_DBG_TIME] / ns / 100.0, h[CTR_DBG_HIST + 1] / ns / 100.0, h[CTR_DBG_HIST + 2] / ns / 100.0,
+              h[CTR_DBG_HIST + 4] / ns, h[CTR_DBG_HIST + 3] / ns / 100.0, h[CTR_DBG_HIST + 5] / ns);
+    }
   }
   return SWZ_OK;
 }
