@@ -78,7 +78,6 @@ struct MdArgs {
   // blocker-scan culling: a cell is cut into 2^sub_levels slabs per axis; usq[a] = squared slab width
   uint32_t sub_levels;
   uint32_t batch_blockers;   // very sparse level: test all surviving lanes in one pass over the neighbours
-  uint32_t early_recheck;    // re-activated cells first continue the stalled candidate's blocker scan
   uint32_t latest_first;     // blocker scans visit the latest adjacent cell first (else the earliest)
   uint32_t patient;          // 1 = a stalled cell sleeps until the blocking CELL is finished, not just the blocking point
   float lazy_frac;           // lazy start: sleep until this fraction of the latest earlier neighbour is decided
@@ -341,28 +340,30 @@ __device__ __forceinline__ uint64_t md_live_hits(const MdArgs& a, const MdLds& l
   return hb;
 }
 
+// (U: chunks of 64 points requested together; the small-cell variant of the kernel uses 1 and saves the registers)
+template <int U>
 __device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& lds, uint32_t wn, uint32_t qs, uint32_t qe,
                                                  double bx, double by, double bz) {
   const uint32_t l = lane_id();
   const double t = a.sq_spacing;
   uint32_t q0 = qs;
   while (qe - q0 > (uint32_t)WAVE) {  // qe > q0 always
-    double x[4], y[4], z[4];
+    double x[U], y[U], z[U];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const uint32_t q = min(q0 + (uint32_t)u * WAVE + l, qe - 1u);
       x[u] = a.X[q];
       y[u] = a.Y[q];
       z[u] = a.Z[q];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < U; ++u) {
       const uint32_t q = q0 + (uint32_t)u * WAVE + l;
       const uint64_t hb = md_live_hits(a, lds, wn, q < qe && sq_dist(bx, by, bz, x[u], y[u], z[u]) < t, x[u], y[u], z[u]);
       if (hb) return q0 + (uint32_t)u * WAVE + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
     }
-    if (qe - q0 <= 4u * WAVE) return NONE32;
-    q0 += 4u * WAVE;
+    if (qe - q0 <= (uint32_t)U * WAVE) return NONE32;
+    q0 += (uint32_t)U * WAVE;
   }
   const uint32_t q = min(q0 + l, qe - 1u);
   const double x = a.X[q], y = a.Y[q], z = a.Z[q];
@@ -371,6 +372,11 @@ __device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& l
 }
 
 // One wavefront advances the frontier of one active cell as far as it can.
+// U = 4: cells of hundreds of points and more (blocker scans and the fast-forward take four chunks per memory round
+// trip); U = 1: levels of small cells, which never need either and run better with the registers it saves.
+// BATCH: very sparse levels (almost every candidate is accepted) test all surviving lanes of a chunk in one pass over
+// the neighbours' undecided points.
+template <int U, bool BATCH>
 __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t l = lane_id();
 #ifdef SWZ_MD_STATS
@@ -419,57 +425,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t r_group = r_packed >> 8;    // rank (scan position) of that cell: earlier ranks were scanned clean
   const uint32_t r_q = resume ? a.blk_q[c] : 0u;
 
-  // Re-activation of a stalled cell: before paying for the accepted-points window and the rejection
-  // tests of the whole chunk, continue the blocker scan of the stalled candidate P where it stopped.
-  // Going back to sleep on a new blocker is always safe (a rejection of P is simply found later).
-  bool p_clear = false;  // P has no possibly-undecided earlier neighbour in this activation's snapshot
-  if (resume && a.early_recheck && !(a.ablate & 1u)) {
-    const double bx = a.X[P], by = a.Y[P], bz = a.Z[P];
-    uint32_t pmask = 0;
-    {
-      const uint64_t sub = (a.akey[P] >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
-      const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1),
-                sz = (int)contract_bits_by_3(sub);
-      const int smax = (1 << a.sub_levels) - 1;
-      const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
-                   lz = (double)sz, hz = (double)(smax - sz);
-      const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
-      const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
-      const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
-#pragma unroll
-      for (int k = 0; k < 27; ++k)
-        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) pmask |= 1u << k;
-    }
-    uint32_t nm = (uint32_t)__ballot(earlier && n_pos < n_end && ((pmask >> slot_of_rank) & 1u));
-    bool blocked = false;
-    uint32_t b_slot = 0, b_q = 0, b_cell = 0;
-    while (nm && !blocked) {
-      const int r = md_next_rank(nm, a.latest_first);
-      nm &= ~(1u << r);
-      const uint32_t qs = bcast_u32(n_pos, r);
-      const uint32_t qe = bcast_u32(n_end, r);
-      const uint32_t hq = md_first_hit(a, lds, 0u, qs, qe, bx, by, bz);
-      if (hq != NONE32) {
-        blocked = true;
-        b_slot = bcast_u32(slot_of_rank, r) | ((uint32_t)r << 8);
-        b_q = a.patient ? qe - 1u : hq;
-        b_cell = bcast_u32(nb, r);
-      }
-    }
-    if (blocked && !(a.ablate & 4u)) {
-      if (l == 0) {
-        a.npos[c] = P;
-        a.ncnt[c] = CNT;
-        a.status[c] = ST_STALLED;
-        a.blk_slot[c] = b_slot;
-        a.blk_q[c] = b_q;
-        a.blk_cell[c] = b_cell;
-      }
-      return;
-    }
-    p_clear = true;
-  }
-
   uint32_t wn0 = 0;
   if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
 
@@ -488,7 +443,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 
   // Very large cells (dense blobs: thousands of points per cell): skip stretches in which every point is already
   // rejected by the committed accepted points, four chunks per memory round trip.
-  if (live_wn && e - cur > a.ff_min && !(a.ablate & 16u)) {
+  if (U > 1 && live_wn && e - cur > a.ff_min && !(a.ablate & 16u)) {
     while (e - cur > 4u * WAVE) {
       double x[4], y[4], z[4];
 #pragma unroll
@@ -572,7 +527,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     uint32_t blk_slot_l = 0, blk_q_l = 0;
     const int first_alive = alive ? __ffsll((unsigned long long)alive) - 1 : 0;
     bool still = false;  // the stalled candidate of the last activation is still blocked by the same point
-    if (!p_clear && resume && cur == P && (alive & 1ull) && ((emask_r >> r_group) & 1u) &&
+    if (resume && cur == P && (alive & 1ull) && ((emask_r >> r_group) & 1u) &&
         bcast_u32(n_pos, (int)r_group) <= r_q) {
       still = true;
       blk = (l == 0);
@@ -580,7 +535,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       blk_q_l = r_q;
       pre = true;
     }
-    if (!still && a.batch_blockers && __popcll(alive) > 8) {
+    if (BATCH && !still && __popcll(alive) > 8) {
       pre = true;
       uint32_t mm = emask_r;
       bool first_blocked = false;
@@ -635,7 +590,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 #ifdef SWZ_MD_STATS
         ++dbg_cand;
 #endif
-        if ((a.ablate & 1u) || (p_clear && cand == P)) nm = 0;
+        if (a.ablate & 1u) nm = 0;
         while (nm && !blocked) {
           const int r = md_next_rank(nm, a.latest_first);
           nm &= ~(1u << r);
@@ -644,7 +599,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 #ifdef SWZ_MD_STATS
           const uint64_t dbg_ts = wall_clock64();
 #endif
-          const uint32_t hq = md_first_hit(a, lds, live_wn, qs, qe, bx, by, bz);
+          const uint32_t hq = md_first_hit<U>(a, lds, live_wn, qs, qe, bx, by, bz);
 #ifdef SWZ_MD_STATS
           dbg_tscan += wall_clock64() - dbg_ts;
           ++dbg_ranks;
@@ -722,7 +677,8 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 #ifndef SWZ_MD_MIN_WAVES
 #define SWZ_MD_MIN_WAVES 5
 #endif
-__global__ __launch_bounds__(MD_THREADS, SWZ_MD_MIN_WAVES) void md_sweep_kernel(MdArgs a, uint32_t round) {
+template <int U, bool BATCH>
+__global__ __launch_bounds__(MD_THREADS, U == 1 ? SWZ_MD_MIN_WAVES : 4) void md_sweep_kernel(MdArgs a, uint32_t round) {
   __shared__ MdLds lds[MD_WAVES];
   const uint32_t w = threadIdx.x / WAVE;
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (round + 2) % 3] = 0;
@@ -734,10 +690,10 @@ __global__ __launch_bounds__(MD_THREADS, SWZ_MD_MIN_WAVES) void md_sweep_kernel(
     const uint32_t seg = (nq + 7u) / 8u, x = blockIdx.x & 7u;
     const uint32_t end = min(nq, (x + 1u) * seg);
     for (uint32_t i = x * seg + (blockIdx.x >> 3) * MD_WAVES + w; i < end; i += (gridDim.x >> 3) * MD_WAVES)
-      md_sweep_cell(a, qin[i], lds[w]);
+      md_sweep_cell<U, BATCH>(a, qin[i], lds[w]);
     return;
   }
-  for (uint32_t i = blockIdx.x * MD_WAVES + w; i < nq; i += gridDim.x * MD_WAVES) md_sweep_cell(a, qin[i], lds[w]);
+  for (uint32_t i = blockIdx.x * MD_WAVES + w; i < nq; i += gridDim.x * MD_WAVES) md_sweep_cell<U, BATCH>(a, qin[i], lds[w]);
 }
 
 // append `value` of every lane with want == true to the queue: one atomic per wavefront
@@ -891,7 +847,7 @@ __global__ __launch_bounds__(MDP_THREADS, 4) void md_persistent_kernel(MdArgs a,
     {
       const uint32_t nq = a.counters[CTR_Q0 + round % 3];
       const uint32_t* qin = a.queue[round & 1];
-      for (uint32_t i = blockIdx.x * MDP_WAVES + w; i < nq; i += nblocks * MDP_WAVES) md_sweep_cell(a, qin[i], lds[w]);
+      for (uint32_t i = blockIdx.x * MDP_WAVES + w; i < nq; i += nblocks * MDP_WAVES) md_sweep_cell<1, true>(a, qin[i], lds[w]);
     }
     if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
     md_commit_requeue_range(a, round, wave0, stride);
@@ -1115,14 +1071,12 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   // With many small cells a level is bound by activation throughput: start lazily and let a stalled cell sleep
   // until the whole blocking cell is finished (fewer, later wake-ups; measured at 1 B points, level 1:
   // 302 -> 173 ms).  With few large cells it is bound by the latency of a round times the number of rounds:
-  // wake up as early as possible.  The cheap re-check of a stalled candidate and the latest-first scan order
-  // (both from before blocker scans could tell dead points) no longer pay and stay off; they remain
-  // selectable for the scheduling tests.
+  // wake up as early as possible.  The latest-first scan order (from before blocker scans could tell dead points)
+  // no longer pays and stays off; it remains selectable for the scheduling tests.  (A cheap re-check of the stalled
+  // candidate before the full activation, from the same time, was removed in round 2: it cost the kernel registers.)
   const bool many_small = ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0;
-  a.early_recheck = 0;
   a.latest_first = 0;
   a.patient = many_small ? 1u : 0u;
-  if (const char* e = c->opt("SWZ_MD_EARLY")) a.early_recheck = (uint32_t)atoi(e);
   if (const char* e = c->opt("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
   if (const char* e = c->opt("SWZ_MD_LATEST_FIRST")) a.latest_first = (uint32_t)atoi(e);
   // every level starts lazily (no first round in which all cells scan their neighbourhood only to learn that
@@ -1198,6 +1152,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     }
   }
   const uint32_t batch = 32;
+  // two builds of the sweep: for cells of hundreds of points and more (four chunks per memory round trip in blocker
+  // scans and the fast-forward, 4 wavefronts per SIMD) and for levels of small cells (neither, 5 per SIMD)
+  bool big_cells = typical > 128.0;
+  if (const char* e = c->opt("SWZ_MD_BIG")) big_cells = atoi(e) != 0;
   // a level that does not finish is reported, not waited for: points that change while they are being tiled
   // (keys and positions no longer agree) can make single cells arbitrarily expensive
   const auto wall0 = std::chrono::steady_clock::now();
@@ -1207,7 +1165,12 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   if (const char* e = c->opt("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
   while (done < ncells) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
-      hipLaunchKernelGGL(md_sweep_kernel, dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
+      if (a.batch_blockers)
+        hipLaunchKernelGGL((md_sweep_kernel<1, true>), dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
+      else if (big_cells)
+        hipLaunchKernelGGL((md_sweep_kernel<4, false>), dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
+      else
+        hipLaunchKernelGGL((md_sweep_kernel<1, false>), dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
       hipLaunchKernelGGL(md_commit_requeue_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
     }
     SWZ_LAUNCH_CHECK(c);

@@ -296,18 +296,22 @@ def test_min_distance_sparse_path_and_its_fallback(ctx, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [
-    {"SWZ_MD_EARLY": "0", "SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_LATEST_FIRST": "0"},
-    {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_LATEST_FIRST": "1"},
-    {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LATEST_FIRST": "1"},
-    {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "0", "SWZ_MD_LATEST_FIRST": "0"},
-    {"SWZ_MD_EARLY": "0", "SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "1"},
-    {"SWZ_MD_EARLY": "1", "SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "1", "SWZ_MD_ABLATE": "8"},  # 8: no dead-point test
+    {"SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_LATEST_FIRST": "0"},
+    {"SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_LATEST_FIRST": "1", "SWZ_MD_BIG": "1"},
+    {"SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LATEST_FIRST": "1"},
+    {"SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "0", "SWZ_MD_LATEST_FIRST": "0", "SWZ_MD_BIG": "0"},
+    {"SWZ_MD_PATIENT": "1", "SWZ_MD_LAZY": "1", "SWZ_MD_LAZY_FRAC": "1", "SWZ_MD_BIG": "1"},
+    {"SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "1", "SWZ_MD_ABLATE": "8"},  # 8: no dead-point test
     {"SWZ_MD_NBR_GRID": "3", "SWZ_MD_GRID": "40"},  # tiny launch grids: the grid-stride loops must cover every cell
     {"SWZ_MD_PERSISTENT": "1", "SWZ_MD_ROUNDS_PER_LAUNCH": "7"},  # the rounds inside persistent launches of 7 rounds
+    # the build for cells of hundreds of points (four chunks per round trip, fast-forward) on cells that large
+    {"SWZ_MD_BIG": "1", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_FF_MIN": "64"},
+    {"SWZ_MD_BIG": "0", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0"},  # ... and the small-cell build on them
 ], ids=lambda m: "-".join("%s%s" % (k[7:10], v) for k, v in m.items()))
 def test_min_distance_sweep_scheduling_modes(ctx, monkeypatch, mode):
-    """The frontier sweep picks its scheduling per level from the cell statistics (early re-check, patient stalls,
-    lazy start, scan order); the big-level choices never trigger on test-sized inputs, so they are forced here.
+    """The frontier sweep picks its scheduling per level from the cell statistics (patient stalls, lazy start, scan
+    order, the kernel build for large or small cells); the big-level choices never trigger on test-sized inputs, so
+    they are forced here.
     Scheduling must never change the result."""
     import schwarzwald_amd as swz
     rng = np.random.default_rng(99)
