@@ -18,11 +18,12 @@ enum {
   CTR_NUM_CELLS = 5,     // MIN_DISTANCE: cells
   CTR_DONE_CELLS = 6,    // MIN_DISTANCE: cells finished
   CTR_Q0 = 8,            // MIN_DISTANCE: three rotating queue counters
-  CTR_DBG_ACT = 11,      // MIN_DISTANCE statistics (SWZ_DEBUG=1): cell activations,
-  CTR_DBG_SCAN = 12,     //   64-point chunks read by blocker scans,
-  CTR_DBG_RTEST = 13,    //   accepted points tested per chunk by the rejection pass,
-  CTR_DBG_STALL = 14,    //   activations that ended stalled
-  CTR_DBG_CHUNK = 16, CTR_DBG_CAND = 17, CTR_DBG_RANKS = 18, CTR_DBG_STEPS = 19, CTR_DBG_TIME = 20, CTR_DBG_TMAX = 21, CTR_DBG_HIST = 22,
+  // MIN_DISTANCE sweep, builds with -DSWZ_MD_STATS only (printed with SWZ_DEBUG=1): timings of a sample of the
+  // activations in 10 ns ticks
+  CTR_DBG_TIME = 20,     // total
+  CTR_DBG_TMAX = 21,     // longest
+  CTR_DBG_HIST = 22,     // +0 activations sampled, +1 prologue, +2 chunk loads and rejection tests, +3 blocker scans,
+                         // +4 chunks, +5 cells scanned
   CTR_COUNT = 40
 };
 

@@ -296,22 +296,21 @@ __device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, 
   return wn;
 }
 
-// true when (x, y, z) is closer than the spacing to one of n points in LDS.  The next entry is requested before the
-// current one is tested: written as a plain loop every iteration waits for its own LDS reads (~175 cycles per
-// entry; measured at 1 B points, level 1: 77 entries per chunk of 64 points, 11.6 us per chunk).
+// true when (x, y, z) is closer than the spacing to one of n points in LDS.  Two entries per step with independent
+// chains: as a plain loop every iteration waits for its own LDS reads and its own chain of dependent double operations
+// (~130 cycles per entry; measured at 1 B points, level 1: 77 entries per chunk of 64 points, 9.8 us per chunk;
+// four per step cost more in spilled registers than it gained).
 __device__ __forceinline__ bool md_near_any(const double* ex, const double* ey, const double* ez, uint32_t n, double x, double y,
                                             double z, double t) {
-  if (n == 0u) return false;
   bool hit = false;
-  double cx = ex[0], cy = ey[0], cz = ez[0];
-  for (uint32_t i = 1; i < n; ++i) {
-    const double nx = ex[i], ny = ey[i], nz = ez[i];
-    hit |= sq_dist(x, y, z, cx, cy, cz) < t;
-    cx = nx;
-    cy = ny;
-    cz = nz;
+  uint32_t i = 0;
+  for (; i + 2u <= n; i += 2u) {
+    const double x0 = ex[i], y0 = ey[i], z0 = ez[i];
+    const double x1 = ex[i + 1], y1 = ey[i + 1], z1 = ez[i + 1];
+    const double d0 = sq_dist(x, y, z, x0, y0, z0), d1 = sq_dist(x, y, z, x1, y1, z1);
+    hit |= (d0 < t) | (d1 < t);
   }
-  hit |= sq_dist(x, y, z, cx, cy, cz) < t;
+  if (i < n) hit |= sq_dist(x, y, z, ex[i], ey[i], ez[i]) < t;
   return hit;
 }
 
@@ -432,7 +431,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t live_wn = (T <= (uint32_t)MD_EXT_CAP && !(a.ablate & 8u)) ? wn0 : 0u;
   uint32_t fresh = 0;
 #ifdef SWZ_MD_STATS
-  uint32_t dbg_scan = 0, dbg_rtest = 0, dbg_chunk = 0, dbg_cand = 0, dbg_ranks = 0;
+  uint32_t dbg_chunk = 0, dbg_ranks = 0;
   uint64_t dbg_tscan = 0, dbg_tchunk = 0;
   const uint64_t dbg_t1 = wall_clock64();  // prologue done (records, window)
 #endif
@@ -507,9 +506,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       const uint32_t wn = (base == 0 && T <= (uint32_t)MD_EXT_CAP && cur == P)
                             ? wn0
                             : ((T <= (uint32_t)MD_EXT_CAP) ? wn0 : md_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off));
-#ifdef SWZ_MD_STATS
-      dbg_rtest += wn;
-#endif
       rej |= md_near_any(lds.ex, lds.ey, lds.ez, wn, px, py, pz, t);
       if (!__ballot(!rej)) break;
     }
@@ -546,9 +542,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
         if (!__ballot(need)) continue;
         const uint32_t qs = bcast_u32(n_pos, k), qe = bcast_u32(n_end, k);
         for (uint32_t q0 = qs; q0 < qe; q0 += WAVE) {
-#ifdef SWZ_MD_STATS
-          ++dbg_scan;
-#endif
           double qx = 0, qy = 0, qz = 0;
           if (q0 + l < qe) {
             qx = a.X[q0 + l];
@@ -587,9 +580,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
       } else {
         // few survivors: scan the earlier adjacent cells for this candidate, 64 points at a time
         uint32_t nm = bcast_u32(needrank, j);
-#ifdef SWZ_MD_STATS
-        ++dbg_cand;
-#endif
         if (a.ablate & 1u) nm = 0;
         while (nm && !blocked) {
           const int r = md_next_rank(nm, a.latest_first);
@@ -603,7 +593,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
 #ifdef SWZ_MD_STATS
           dbg_tscan += wall_clock64() - dbg_ts;
           ++dbg_ranks;
-          dbg_scan += (qe - qs + 255u) / 256u;
 #endif
           if (hq != NONE32) {
             blocked = true;
@@ -1211,17 +1200,16 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     fprintf(stderr, "[swz] MIN_DISTANCE level %d sweep: %.2f ms\n", plan.level, ms);
     uint32_t h[CTR_COUNT];
     SWZ_HIP(c, hipMemcpy(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost));
-    fprintf(stderr, "[swz] MIN_DISTANCE level %d: %u pts in %u nodes, cell_levels %d, %u cells, %u rounds, %u activations "
-                    "(%u stalled), %u scan steps, %u rtests, %u chunks, %u candidates scanned, %u ranks scanned, mean activation %.1f us, max %.1f us, hist(<1,2,4..us):",
-            plan.level, sample_points, sample_nodes, cl, ncells, round, h[CTR_DBG_ACT], h[CTR_DBG_STALL],
-            h[CTR_DBG_SCAN], h[CTR_DBG_RTEST], h[CTR_DBG_CHUNK], h[CTR_DBG_CAND], h[CTR_DBG_RANKS],
-            0.0, h[CTR_DBG_TMAX] / 100.0);
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d: %u pts in %u nodes, cell_levels %d, %u cells, %u rounds\n", plan.level, sample_points,
+            sample_nodes, cl, ncells, round);
+#ifdef SWZ_MD_STATS
     {
       const double ns = std::max(1u, h[CTR_DBG_HIST]);
-      fprintf(stderr, " sampled %u activations: mean total %.2f us, prologue %.2f us, chunks %.2f us (%.2f chunks), scans %.2f us (%.2f ranks)\n",
-              h[CTR_DBG_HIST], h[CTR_DBG_TIME] / ns / 100.0, h[CTR_DBG_HIST + 1] / ns / 100.0, h[CTR_DBG_HIST + 2] / ns / 100.0,
-              h[CTR_DBG_HIST + 4] / ns, h[CTR_DBG_HIST + 3] / ns / 100.0, h[CTR_DBG_HIST + 5] / ns);
+      fprintf(stderr, "[swz]   sampled %u activations: mean %.2f us (max %.1f): prologue %.2f, chunks %.2f (%.2f chunks), scans %.2f (%.2f ranks)\n",
+              h[CTR_DBG_HIST], h[CTR_DBG_TIME] / ns / 100.0, h[CTR_DBG_TMAX] / 100.0, h[CTR_DBG_HIST + 1] / ns / 100.0,
+              h[CTR_DBG_HIST + 2] / ns / 100.0, h[CTR_DBG_HIST + 4] / ns, h[CTR_DBG_HIST + 3] / ns / 100.0, h[CTR_DBG_HIST + 5] / ns);
     }
+#endif
   }
   return SWZ_OK;
 }
