@@ -27,6 +27,7 @@
 #include <cstdlib>
 
 #include "swz_level.h"
+#include "swz_scan.h"
 
 namespace swz {
 
@@ -107,15 +108,17 @@ __device__ __forceinline__ bool md_is_head(const MdArgs& a, uint32_t i) {
 // digit b (1-based); occupied(cl) = hist[0] + ... + hist[cl].
 __global__ __launch_bounds__(256) void md_cell_hist_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ nid,
                                                            const uint8_t* __restrict__ nmode, uint32_t m, uint32_t node_shift,
-                                                           uint32_t cl_geo, uint32_t* __restrict__ hist) {
+                                                           uint32_t cl_geo, uint32_t skip, uint32_t* __restrict__ hist) {
   __shared__ uint32_t lh[16];
   if (threadIdx.x < 16) lh[threadIdx.x] = 0;
   __syncthreads();
   uint32_t mine = 0;  // lane b accumulates the wavefront's count of bin b
-  for (uint32_t i0 = blockIdx.x * 256; i0 < m; i0 += gridDim.x * 256) {  // few workgroups: one flush each at the end
-    const uint32_t i = i0 + threadIdx.x;
+  // every skip-th tile of 256 points (the counts only steer the choice of cell size and algorithm: on large levels a
+  // sample of some million points says the same as all of them and saves a pass over the keys)
+  for (uint64_t i0 = (uint64_t)blockIdx.x * skip * 256u; i0 < m; i0 += (uint64_t)gridDim.x * skip * 256u) {
+    const uint32_t i = (uint32_t)i0 + threadIdx.x;
     uint32_t bin = 0xFFu;
-    if (i < m && nmode[nid[i]] == MODE_SAMPLE) {
+    if (i0 + threadIdx.x < m && nmode[nid[i]] == MODE_SAMPLE) {
       if (i == 0 || nid[i - 1] != nid[i]) {
         bin = 0;
       } else if (cl_geo) {
@@ -166,21 +169,22 @@ __global__ __launch_bounds__(256) void md_cell_pop_kernel(const uint64_t* __rest
   atomicAdd(&out[4], 1ull);
 }
 
-__global__ __launch_bounds__(256) void md_cell_head_kernel(MdArgs a, uint32_t* __restrict__ flags) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < a.m) flags[i] = md_is_head(a, i) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void md_cell_build_kernel(MdArgs a, const uint32_t* __restrict__ excl) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.m || !md_is_head(a, i)) return;
-  const uint32_t c = excl[i];
-  a.cell[c] = make_uint4(i, 0u, i, 0u);
-  a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
-  a.csnode[c] = a.snode_of[a.nid[i]];
-  a.npos[c] = i;  // the frontier as the round bookkeeping sees it (a cell that never ran has not moved)
-  a.blk_p[c] = NONE32;
-}
+// cells = runs of the cell prefix inside sampled nodes: counted and built by one fused scan (swz_scan.h)
+struct CellHeadF {
+  MdArgs a;
+  __device__ uint32_t operator()(uint32_t i) const { return md_is_head(a, i) ? 1u : 0u; }
+};
+struct CellBuildG {
+  MdArgs a;
+  __device__ void operator()(uint32_t i, uint32_t c, uint32_t head) const {
+    if (!head) return;
+    a.cell[c] = make_uint4(i, 0u, i, 0u);
+    a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
+    a.csnode[c] = a.snode_of[a.nid[i]];
+    a.npos[c] = i;  // the frontier as the round bookkeeping sees it (a cell that never ran has not moved)
+    a.blk_p[c] = NONE32;
+  }
+};
 
 __global__ __launch_bounds__(256) void md_cell_end_kernel(MdArgs a, uint32_t ncells) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
@@ -462,6 +466,21 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     }
   }
 
+  // large cells: the next chunk is requested before this one is worked on (most chunks of a large cell only find
+  // every point rejected, and each would otherwise cost a memory round trip of its own)
+  double nx = 0, ny = 0, nz = 0;
+  uint64_t nkey = 0;
+  uint32_t nat = NONE32;  // the chunk (nx, ny, nz, nkey) belongs to
+  auto request = [&](uint32_t at) {
+    nat = at;
+    if (at + l < e) {
+      nx = a.X[at + l];
+      ny = a.Y[at + l];
+      nz = a.Z[at + l];
+      nkey = a.akey[at + l];
+    }
+  };
+  if (U > 1 && cur < e) request(cur);
   while (cur < e && !stop) {
 #ifdef SWZ_MD_STATS
     const uint64_t dbg_tc = wall_clock64();
@@ -470,12 +489,23 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     const bool valid = p < e;
     int sx = 0, sy = 0, sz = 0;
     double px = 0, py = 0, pz = 0;
-    if (valid) {
+    uint64_t key = 0;
+    if (U > 1) {
+      if (nat != cur) request(cur);
+      px = nx;
+      py = ny;
+      pz = nz;
+      key = nkey;
+      if (cur + WAVE < e) request(cur + WAVE);
+    } else if (valid) {
       px = a.X[p];
       py = a.Y[p];
       pz = a.Z[p];
+      key = a.akey[p];
+    }
+    if (valid) {
       // slab coordinates inside the cell (culling of blocker scans)
-      const uint64_t sub = (a.akey[p] >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+      const uint64_t sub = (key >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
       sx = (int)contract_bits_by_3(sub >> 2);
       sy = (int)contract_bits_by_3(sub >> 1);
       sz = (int)contract_bits_by_3(sub);
@@ -673,16 +703,17 @@ __global__ __launch_bounds__(MD_THREADS, U == 1 ? SWZ_MD_MIN_WAVES : 4) void md_
   if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (round + 2) % 3] = 0;
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   const uint32_t* qin = a.queue[round & 1];
+  // one loop for both mappings (the body is large: a second inlined copy doubles the kernel)
+  uint32_t first = blockIdx.x * MD_WAVES + w, end = nq, step = gridDim.x * MD_WAVES;
   if (a.xcd_chunks && (gridDim.x & 7u) == 0) {
     // workgroups go round-robin over the 8 XCDs: give every XCD one contiguous eighth of the queue so that
     // neighbouring cells (which read each other's records and accepted points) share an L2
     const uint32_t seg = (nq + 7u) / 8u, x = blockIdx.x & 7u;
-    const uint32_t end = min(nq, (x + 1u) * seg);
-    for (uint32_t i = x * seg + (blockIdx.x >> 3) * MD_WAVES + w; i < end; i += (gridDim.x >> 3) * MD_WAVES)
-      md_sweep_cell<U, BATCH>(a, qin[i], lds[w]);
-    return;
+    first = x * seg + (blockIdx.x >> 3) * MD_WAVES + w;
+    end = min(nq, (x + 1u) * seg);
+    step = (gridDim.x >> 3) * MD_WAVES;
   }
-  for (uint32_t i = blockIdx.x * MD_WAVES + w; i < nq; i += gridDim.x * MD_WAVES) md_sweep_cell<U, BATCH>(a, qin[i], lds[w]);
+  for (uint32_t i = first; i < end; i += step) md_sweep_cell<U, BATCH>(a, qin[i], lds[w]);
 }
 
 // append `value` of every lane with want == true to the queue: one atomic per wavefront
@@ -903,18 +934,22 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     SWZ_TRY(c->get("md_hist", (size_t)16, &d_hist));
     SWZ_HIP(c, hipMemsetAsync(d_hist, 0, 64, c->stream));
     const uint32_t nsh = plan.node_shift == 63u ? 63u : plan.node_shift;
-    hipLaunchKernelGGL(md_cell_hist_kernel, dim3(std::min<uint32_t>(div_up(m, 256), 4096u)), dim3(256), 0, c->stream, as.akey,
-                       lb.nid, lb.nmode, m, nsh,
-                       (uint32_t)plan.cell_levels_geo, d_hist);
+    const uint32_t tiles = div_up(m, 256);
+    uint32_t skip = std::max(1u, m >> 23);  // about 8 M points are looked at
+    if (const char* e = c->opt("SWZ_MD_HIST_SKIP")) skip = std::max(1, atoi(e));
+    const uint32_t sampled_tiles = div_up(tiles, skip);
+    hipLaunchKernelGGL(md_cell_hist_kernel, dim3(std::min<uint32_t>(sampled_tiles, 4096u)), dim3(256), 0, c->stream, as.akey,
+                       lb.nid, lb.nmode, m, nsh, (uint32_t)plan.cell_levels_geo, skip, d_hist);
     SWZ_LAUNCH_CHECK(c);
     SWZ_STAGE(c, "md cell hist");
     uint32_t h[16];
     SWZ_HIP(c, hipMemcpyAsync(h, d_hist, 64, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    uint32_t run = 0;
+    const double scale = skip == 1 ? 1.0 : (double)m / (double)std::min<uint64_t>(m, (uint64_t)sampled_tiles * 256u);
+    double run = 0;
     for (int b = 0; b < 12; ++b) {
       run += h[b];
-      occupied[b] = run;
+      occupied[b] = (uint32_t)std::min<double>(run * scale, (double)m);
     }
   }
   // cell size: as fine as the spacing allows, but coarse enough that an OCCUPIED cell holds >= 8 points on
@@ -995,7 +1030,6 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   uint32_t* snode = nullptr;
   SWZ_TRY(c->get("md_snode", (size_t)nnodes, &snode));
   a.snode_of = snode;
-  const uint32_t nb = div_up(m, 256);
   hipLaunchKernelGGL(md_node_flag_kernel, dim3(div_up(nnodes, 256)), dim3(256), 0, c->stream, lb.nmode, nnodes, snode);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, snode, snode, nnodes, nullptr, "mdn"));
@@ -1021,10 +1055,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   }
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
 
-  // cells = runs of the cell prefix inside sampled nodes
-  hipLaunchKernelGGL(md_cell_head_kernel, dim3(nb), dim3(256), 0, c->stream, a, lb.flags);
-  SWZ_LAUNCH_CHECK(c);
-  SWZ_TRY(scan_exclusive_u32(c, lb.flags, lb.flags, m, lb.counters + CTR_NUM_CELLS, "mdc"));
+  // cells = runs of the cell prefix inside sampled nodes: count them, size the per-cell arrays, build them
+  uint32_t* d_cell_sums = nullptr;
+  SWZ_TRY(fused_scan_sums(c, CellHeadF{a}, m, lb.counters + CTR_NUM_CELLS, "mdc", &d_cell_sums));
   uint32_t ncells = 0;
   SWZ_HIP(c, hipMemcpyAsync(&ncells, lb.counters + CTR_NUM_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -1046,8 +1079,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_TRY(c->get("md_gridmap", (size_t)grid_entries, &a.gridmap));
   SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
 
-  hipLaunchKernelGGL(md_cell_build_kernel, dim3(nb), dim3(256), 0, c->stream, a, lb.flags);
-  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(fused_scan_apply(c, CellHeadF{a}, CellBuildG{a}, m, d_cell_sums));
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(md_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);

@@ -51,8 +51,11 @@ __global__ __launch_bounds__(FS_THREADS) void fscan_apply_kernel(F f, G g, uint3
 }
 
 // f: uint32_t(uint32_t i)   g: void(uint32_t i, uint32_t exclusive_prefix, uint32_t value)
-template <typename F, typename G>
-int fused_scan(swz_ctx* c, F f, G g, uint32_t n, uint32_t* d_total, const char* tag) {
+// In two steps for callers that need the total on the host before they can build g (buffers sized by it):
+// fused_scan_sums leaves the scanned tile sums in *d_partial_out and the total in d_total, fused_scan_apply consumes them.
+template <typename F>
+int fused_scan_sums(swz_ctx* c, F f, uint32_t n, uint32_t* d_total, const char* tag, uint32_t** d_partial_out) {
+  *d_partial_out = nullptr;
   if (n == 0) {
     if (d_total) SWZ_HIP(c, hipMemsetAsync(d_total, 0, sizeof(uint32_t), c->stream));
     return SWZ_OK;
@@ -64,10 +67,22 @@ int fused_scan(swz_ctx* c, F f, G g, uint32_t n, uint32_t* d_total, const char* 
   hipLaunchKernelGGL(HIP_KERNEL_NAME(fscan_partial_kernel<F>), dim3(nb), dim3(FS_THREADS), 0, c->stream, f, n, d_partial);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, d_partial, d_partial, nb, d_total, tag));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(fscan_apply_kernel<F, G>), dim3(nb), dim3(FS_THREADS), 0, c->stream, f, g, n,
+  *d_partial_out = d_partial;
+  return SWZ_OK;
+}
+template <typename F, typename G>
+int fused_scan_apply(swz_ctx* c, F f, G g, uint32_t n, const uint32_t* d_partial) {
+  if (n == 0) return SWZ_OK;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(fscan_apply_kernel<F, G>), dim3(div_up(n, FS_TILE)), dim3(FS_THREADS), 0, c->stream, f, g, n,
                      d_partial);
   SWZ_LAUNCH_CHECK(c);
   return SWZ_OK;
+}
+template <typename F, typename G>
+int fused_scan(swz_ctx* c, F f, G g, uint32_t n, uint32_t* d_total, const char* tag) {
+  uint32_t* d_partial = nullptr;
+  SWZ_TRY(fused_scan_sums(c, f, n, d_total, tag, &d_partial));
+  return fused_scan_apply(c, f, g, n, d_partial);
 }
 
 }  // namespace swz
