@@ -7,9 +7,13 @@
 //   1. every point looks up its 27 adjacent cells once (dense [node][cell] table of run starts) and
 //      records its EARLIER neighbours closer than the spacing (exact compare, usually 0-3 of them).
 //      The search is a chain of dependent loads (table -> points), so it is laid out for latency: the
-//      table holds {first, end} of every cell's run, the active points are gathered into 32-byte
+//      table holds {first, end} of every cell's run, the active points are gathered into 16-byte
 //      records, and the 27 cells are taken nine at a time with all nine table lookups, then the j-th
-//      record of all nine runs, in flight together;
+//      record of all nine runs, in flight together.  The kernel is bound by the L1's outstanding misses
+//      (rocprofv3: TCP_PENDING_STALL 60 % of the cycles, 2.5 L1 misses per point, HBM at 0.6 TB/s), and most of the
+//      lines it touches are records: a record holds the position as three floats relative to the node's corner, which
+//      decides all but ~1 in 1000 compares (|d2 - s2| beyond the float error bound, sp_filter_eps); the rest are
+//      repeated in double on the original positions, so the result is the exact one;
 //      (Round 2 also built the search per BLOCK of 8 x 8 x 8 cells out of LDS -- table entries and records of the
 //      block and its one-cell halo copied in once: at these densities, 0.4-0.8 points per cell, the 1000-cell region
 //      costs more than the ~400 points it serves: level 2 of the 1 B run 219 ms against 162 ms.  Dropped.)
@@ -34,7 +38,12 @@ struct SpArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* snode_of;
-  const double4* rec;  // active order: {x, y, z, key bits}
+  const float4* rec;   // active order: position relative to the node's min corner, rounded to float; w unused
+  const uint32_t* aidx;      // exact positions of active point i: X[aidx ? aidx[i] : i]
+  const double* X;
+  const double* Y;
+  const double* Z;
+  float f_lo, f_hi;          // float squared distance < f_lo: closer than the spacing for sure, >= f_hi: farther for sure
   uint32_t m;
   uint32_t cell_shift;      // key >> cell_shift = node prefix + cell code
   uint32_t cell_levels;
@@ -86,20 +95,27 @@ __global__ __launch_bounds__(256) void sp_table_kernel(SpArgs a) {
 
 __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t* __restrict__ aidx, const uint64_t* __restrict__ akey,
                                                         uint32_t m, const double* __restrict__ X, const double* __restrict__ Y,
-                                                        const double* __restrict__ Z, double4* __restrict__ rec) {
+                                                        const double* __restrict__ Z, Box root, int node_depth,
+                                                        float4* __restrict__ rec) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
   const uint32_t s = aidx ? aidx[i] : i;
-  rec[i] = make_double4(X[s], Y[s], Z[s], __longlong_as_double((long long)akey[i]));
+  const Box nb = bounds_from_key(akey[i], root, node_depth);  // the point's node (level + 1 octants of its key)
+  rec[i] = make_float4((float)(X[s] - nb.minx), (float)(Y[s] - nb.miny), (float)(Z[s] - nb.minz), 0.f);
 }
 
-__device__ __forceinline__ uint64_t sp_key(const double4& r) { return (uint64_t)__double_as_longlong(r.w); }
+// the exact compare of the reference on the original positions (GridCell.cpp:52)
+__device__ __forceinline__ bool sp_exact_near(const SpArgs& a, uint32_t p, uint32_t q) {
+  const uint32_t sp = a.aidx ? a.aidx[p] : p, sq = a.aidx ? a.aidx[q] : q;
+  return sq_dist(a.X[sp], a.Y[sp], a.Z[sp], a.X[sq], a.Y[sq], a.Z[sq]) < a.sq_spacing;
+}
 
 // Visits every EARLIER point closer than the spacing to point p.  f(q) returns false to stop.
 template <typename F>
 __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F f) {
-  const double4 me = a.rec[p];
-  const uint64_t pre = sp_key(me) >> a.cell_shift;
+  const float4 me = a.rec[p];
+  const uint64_t mykey = a.akey[p];
+  const uint64_t pre = mykey >> a.cell_shift;
   const uint32_t code = (uint32_t)(pre & (a.cells_per_node - 1ull));
   const uint64_t base = (uint64_t)a.snode_of[a.nid[p]] * a.cells_per_node;
   // neighbour cell codes by arithmetic on the dilated coordinates (code = x bits | y bits | z bits, every
@@ -117,7 +133,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   // (conservative: a slab never overstates the gap).
   uint32_t reach = 0;  // bit k: adjacent cell k (x fastest) can hold a point closer than the spacing
   {
-    const uint64_t sub = (sp_key(me) >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+    const uint64_t sub = (mykey >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
     const int smax = (1 << a.sub_levels) - 1;
     const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1), sz = (int)contract_bits_by_3(sub);
     const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy), lz = (double)sz,
@@ -159,16 +175,15 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
       }
     }
     for (;;) {
-      double rx[9], ry[9], rz[9];
+      float rx[9], ry[9], rz[9];
       bool any = false;
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         if (q[i] < qe[i]) {
-          const double4* r = a.rec + q[i];
-          const double2 xy = *reinterpret_cast<const double2*>(r);
-          rx[i] = xy.x;
-          ry[i] = xy.y;
-          rz[i] = r->z;
+          const float4 r = a.rec[q[i]];
+          rx[i] = r.x;
+          ry[i] = r.y;
+          rz[i] = r.z;
           any = true;
         }
       }
@@ -176,7 +191,9 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
 #pragma unroll
       for (int i = 0; i < 9; ++i) {
         if (q[i] < qe[i]) {
-          if (sq_dist(me.x, me.y, me.z, rx[i], ry[i], rz[i]) < a.sq_spacing) {
+          const float dx = me.x - rx[i], dy = me.y - ry[i], dz = me.z - rz[i];
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          if (d2 < a.f_hi && (d2 < a.f_lo || sp_exact_near(a, p, q[i]))) {
             if (!f(q[i])) return;
           }
           ++q[i];
@@ -328,9 +345,31 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.taken = lb.taken;
   const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
   SWZ_TRY(c->get("sp_table", (size_t)entries, &a.table));
-  double4* rec = nullptr;
-  SWZ_TRY(c->get("md_pos", (size_t)m * 4, reinterpret_cast<double**>(&rec)));  // shared with the sweep
+  float4* rec = nullptr;
+  SWZ_TRY(c->get("md_pos", (size_t)m * 4, reinterpret_cast<double**>(&rec)));  // shared with the sweep (half of it used)
   a.rec = rec;
+  a.aidx = as.aidx;
+  a.X = sp.X;
+  a.Y = sp.Y;
+  a.Z = sp.Z;
+  {
+    // Float filter.  A record coordinate is fl(x - corner) with |x - corner| <= E (the node's extent; twice that is
+    // assumed): error <= 2^-24 * 2E; the float difference of two of them adds 2^-24 * 2E: |dxf - dx| <= delta =
+    // 2^-22 * E.  |sum dxf^2 - d^2| <= 2 sqrt(3) d delta + 3 delta^2, plus 3 roundings of the sum (2^-22 relative, generous).
+    // Around d = s: relative to s^2 at most 2 sqrt(3) r + 3 r^2 + 2^-22 with r = delta / s.  Four times that is used.
+    const double ext = std::max({plan.root.maxx - plan.root.minx, plan.root.maxy - plan.root.miny, plan.root.maxz - plan.root.minz});
+    const double E = std::ldexp(ext, -(plan.level + 1));
+    const double r = std::ldexp(E, -22) / std::sqrt(plan.sq_spacing);
+    double eps = 4.0 * (2.0 * std::sqrt(3.0) * r * 1.001 + 3.0 * r * r + std::ldexp(1.0, -22));
+    if (const char* e = c->opt("SWZ_SP_FILTER_EPS")) eps = atof(e);  // tests: 1e30 sends every compare to the exact path
+    if (!(eps < 0.5)) {  // the filter decides nothing: everything that is not far beyond reach is compared exactly
+      a.f_lo = 0.f;
+      a.f_hi = INFINITY;
+    } else {
+      a.f_lo = std::nextafterf((float)(plan.sq_spacing * (1.0 - eps)), 0.f);
+      a.f_hi = std::nextafterf((float)(plan.sq_spacing * (1.0 + eps)), INFINITY);
+    }
+  }
   static_assert(SP_K * sizeof(uint32_t) == 4 * sizeof(double), "md_acc holds 32 bytes per point");
   SWZ_TRY(c->get("md_acc", (size_t)m * 4, reinterpret_cast<double**>(&a.nbr)));  // shared with the sweep
   SWZ_TRY(c->get("sp_ncount", (size_t)m, &a.ncount));
@@ -344,7 +383,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
   SWZ_HIP(c, memset_large(a.state, SP_U, (size_t)m, c->stream));
   const uint32_t nb = div_up(m, 256);
-  hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, rec);
+  hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, plan.root,
+                     plan.level + 1, rec);
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
   SWZ_LAUNCH_CHECK(c);
