@@ -204,13 +204,14 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
 }
 
 // phase 1: record the earlier neighbours; points without any are accepted right away
-__global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ ulist,
+constexpr int SP_NB_THREADS = 256;
+__global__ __launch_bounds__(SP_NB_THREADS) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ ulist,
                                                             uint32_t* __restrict__ ucount,
                                                             uint32_t* __restrict__ overflow, uint32_t xcd, int iters) {
   // workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the points, so the
   // neighbourhoods a workgroup reads were mostly fetched into the same L2 by the workgroups just before it
   const uint32_t blk = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
-  const uint32_t p = blk * 256 + threadIdx.x;
+  const uint32_t p = blk * SP_NB_THREADS + threadIdx.x;
   bool undecided = false;
   if (p < a.m && sp_sampled(a, p)) {
     uint32_t cnt = 0;
@@ -243,19 +244,20 @@ __global__ __launch_bounds__(256) void sp_neighbours_kernel(SpArgs a, uint32_t* 
     }
   }
   // append the undecided points to the list: one atomic per workgroup
-  __shared__ uint32_t wave_count[4], wave_base[4];
+  constexpr int NW = SP_NB_THREADS / WAVE;
+  __shared__ uint32_t wave_count[NW], wave_base[NW];
   const uint64_t bm = __ballot(undecided);
   const uint32_t w = threadIdx.x / WAVE;
   if (lane_id() == 0) wave_count[w] = (uint32_t)__popcll(bm);
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t c0 = wave_count[0], c1 = wave_count[1], c2 = wave_count[2], c3 = wave_count[3];
-    const uint32_t total = c0 + c1 + c2 + c3;
-    const uint32_t base = total ? atomicAdd(ucount, total) : 0u;
-    wave_base[0] = base;
-    wave_base[1] = base + c0;
-    wave_base[2] = base + c0 + c1;
-    wave_base[3] = base + c0 + c1 + c2;
+    uint32_t total = 0;
+    for (int k = 0; k < NW; ++k) total += wave_count[k];
+    uint32_t base = total ? atomicAdd(ucount, total) : 0u;
+    for (int k = 0; k < NW; ++k) {
+      wave_base[k] = base;
+      base += wave_count[k];
+    }
   }
   __syncthreads();
   if (undecided) ulist[wave_base[w] + (uint32_t)__popcll(bm & lanemask_lt())] = p;
@@ -397,7 +399,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     ev2 = c->take_event();
     (void)hipEventRecord(ev0, c->stream);
   }
-  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nb, 8) * 8 : nb), dim3(256), 0, c->stream, a, u0, cnt, cnt + 2,
+  const uint32_t nbn = div_up(m, SP_NB_THREADS);
+  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nbn, 8) * 8 : nbn), dim3(SP_NB_THREADS), 0, c->stream, a, u0, cnt, cnt + 2,
                      xcd, c->opt("SWZ_SP_ITERS") ? atoi(c->opt("SWZ_SP_ITERS")) : 8);
   SWZ_LAUNCH_CHECK(c);
   if (dbg) (void)hipEventRecord(ev1, c->stream);
