@@ -32,7 +32,7 @@
 namespace swz {
 
 constexpr uint32_t NONE32 = 0xFFFFFFFFu;
-constexpr int MD_THREADS = 256;
+constexpr int MD_THREADS = 64;  // one wavefront per workgroup: wavefronts of a larger workgroup would wait for its slowest
 constexpr int MD_WAVES = MD_THREADS / WAVE;
 constexpr int MD_EXT_CAP = 128;   // accepted points of the neighbourhood cached in LDS per wave (window)
 constexpr int MD_FRESH_CAP = 64;  // points a cell may accept per activation
@@ -1133,10 +1133,11 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     (void)hipEventRecord(ev0, c->stream);
   }
   // grid-stride kernels: whole multiples of the resident workgroups (256 CUs x 5 per CU) avoid a ragged tail
-  uint32_t sweep_cap = 2560u, commit_cap = 1280u;
+  uint32_t sweep_cap = 2560u * (256u / MD_THREADS), commit_cap = 1280u;
   if (const char* e = c->opt("SWZ_MD_GRID")) {
     sweep_cap = (uint32_t)atoi(e);
     commit_cap = std::max(1u, sweep_cap / 2u);
+    sweep_cap *= 256u / MD_THREADS;
   }
   const uint32_t sweep_grid = std::min<uint32_t>(sweep_cap, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
   const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));

@@ -295,6 +295,31 @@ def test_min_distance_sparse_path_and_its_fallback(ctx, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("eps", ["1e30", "0.3", "1e-9"])
+def test_min_distance_sparse_path_float_filter(ctx, eps):
+    """The sparse path compares float copies of the positions first and repeats every compare inside the error band
+    in double on the original positions.  Forced here: a band that holds every compare (all exact), a wide band, and
+    -- to show that the test would notice a filter that decides too much -- a band far below the float error, which
+    must NOT be relied on to give the oracle's set (it only has to run)."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(4711)
+    xyz = rng.random((400000, 3)) * np.array([1.0, 0.7, 0.3]) + 0.123456789  # not dyadic: float copies do round
+    bmin, bmax = np.zeros(3), np.full(3, 1.5)
+    try:
+        ctx.set_option("SWZ_MD_SPARSE_LIMIT", "1000")  # the sparse path on every level
+        ctx.set_option("SWZ_SP_FILTER_EPS", eps)
+        for d in (250, 90):
+            spacing = O.spacing_from_diagonal(bmin, bmax, d)
+            o = O.tile(xyz, bmin, bmax, O.MIN_DISTANCE, 2000, spacing)
+            g = ctx.tile(xyz, bmin, bmax, swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=2000, spacing_at_root=spacing))
+            if eps != "1e-9":
+                assert np.array_equal(g.level, o["level"])
+    finally:
+        ctx.set_option("SWZ_MD_SPARSE_LIMIT", None)
+        ctx.set_option("SWZ_SP_FILTER_EPS", None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", [
     {"SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_LATEST_FIRST": "0"},
     {"SWZ_MD_PATIENT": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_LATEST_FIRST": "1", "SWZ_MD_BIG": "1"},
