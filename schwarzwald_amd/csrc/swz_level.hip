@@ -577,12 +577,14 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     SWZ_LAUNCH_CHECK(c);
   } else {  // MIN_DISTANCE
     SWZ_HIP(c, hipMemsetAsync(lb.taken, 0, m, c->stream));
-    hipLaunchKernelGGL(take_all_kernel, dim3(nb), dim3(256), 0, c->stream, m, lb.nid, lb.nmode, lb.taken);
-    SWZ_LAUNCH_CHECK(c);
     uint32_t h[CTR_COUNT];
     SWZ_HIP(c, hipMemcpyAsync(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
     if (h[CTR_ERROR]) return c->fail((int)h[CTR_ERROR], "node needs Morton re-rooting (unsupported)");
+    if (h[CTR_SAMPLE_NODES] < h[CTR_NUM_NODES]) {  // only levels that have take-all nodes pay for the pass
+      hipLaunchKernelGGL(take_all_kernel, dim3(nb), dim3(256), 0, c->stream, m, lb.nid, lb.nmode, lb.taken);
+      SWZ_LAUNCH_CHECK(c);
+    }
     if (h[CTR_SAMPLE_NODES] > 0) {
       if (plan.md_property)
         SWZ_TRY(min_distance_property_level(c, plan, as, sp, lb, h[CTR_NUM_NODES], h[CTR_SAMPLE_NODES],

@@ -1133,7 +1133,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     (void)hipEventRecord(ev0, c->stream);
   }
   // grid-stride kernels: whole multiples of the resident workgroups (256 CUs x 5 per CU) avoid a ragged tail
-  uint32_t sweep_cap = 2560u * (256u / MD_THREADS), commit_cap = 1280u;
+  uint32_t sweep_cap = 2560u * (256u / MD_THREADS), commit_cap = 256u;
   if (const char* e = c->opt("SWZ_MD_GRID")) {
     sweep_cap = (uint32_t)atoi(e);
     commit_cap = std::max(1u, sweep_cap / 2u);
