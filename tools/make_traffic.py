@@ -36,7 +36,8 @@ if "swz::radix_ghist_kernel" in fetch:
     calib = 2.0 * fetch["swz::radix_ghist_kernel"][1] * 1024.0 / (8.0 * points)
 else:
     calib = 2.0 * fetch["swz::radix_hist_kernel"][1] * 1024.0 / (8 * 8.0 * points)
-md_k, md_b = bytes_of(lambda k: k.startswith("swz::md_") or k.startswith("swz::sp_"))
+# (templated kernels are listed as "void swz::md_sweep_kernel<1, false>"; the fused cell scan belongs to the class too)
+md_k, md_b = bytes_of(lambda k: "swz::md_" in k or "swz::sp_" in k or "swz::CellHeadF" in k)
 rs_k, rs_b = bytes_of(lambda k: k in ("swz::radix_scatter_kernel", "swz::radix_onesweep_kernel"))
 md_lo = sum((fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1]) * 1024.0 for k in md_k)
 out = {
