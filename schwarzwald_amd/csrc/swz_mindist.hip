@@ -379,7 +379,7 @@ __device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& l
 // trip); U = 1: levels of small cells, which never need either and run better with the registers it saves.
 // BATCH: very sparse levels (almost every candidate is accepted) test all surviving lanes of a chunk in one pass over
 // the neighbours' undecided points.
-template <int U, bool BATCH>
+template <int U, bool BATCH, bool EARLY = false>
 __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t l = lane_id();
 #ifdef SWZ_MD_STATS
@@ -389,6 +389,24 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
   const uint32_t s0 = me.x, e = me.y;
   const double t = a.sq_spacing;
   const uint32_t P = me.z, CNT = me.w;
+
+  // Large cells (U > 1) request the next chunk before the current one is worked on (most chunks of a large cell only
+  // find every point rejected).  EARLY requests the chunk at the frontier here, so that it travels with the neighbour
+  // records instead of costing a round trip of its own -- measured twice at 1 B points, slower both times (levels
+  // 0 / 1: 108 / 135 ms against 103 / 131), so it is off.
+  double nx = 0, ny = 0, nz = 0;
+  uint64_t nkey = 0;
+  uint32_t nat = NONE32;  // the chunk (nx, ny, nz, nkey) belongs to
+  auto request = [&](uint32_t at) {
+    nat = at;
+    if (at + l < e) {
+      nx = a.X[at + l];
+      ny = a.Y[at + l];
+      nz = a.Z[at + l];
+      nkey = a.akey[at + l];
+    }
+  };
+  if (EARLY) request(P);
 
   // lane r < nnb: the r-th earlier adjacent cell, latest (largest Morton code) first -- decisions arrive
   // roughly in Morton order, so the blocker found first tends to be decided last and one sleep covers the
@@ -466,21 +484,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     }
   }
 
-  // large cells: the next chunk is requested before this one is worked on (most chunks of a large cell only find
-  // every point rejected, and each would otherwise cost a memory round trip of its own)
-  double nx = 0, ny = 0, nz = 0;
-  uint64_t nkey = 0;
-  uint32_t nat = NONE32;  // the chunk (nx, ny, nz, nkey) belongs to
-  auto request = [&](uint32_t at) {
-    nat = at;
-    if (at + l < e) {
-      nx = a.X[at + l];
-      ny = a.Y[at + l];
-      nz = a.Z[at + l];
-      nkey = a.akey[at + l];
-    }
-  };
-  if (U > 1 && cur < e) request(cur);
   while (cur < e && !stop) {
 #ifdef SWZ_MD_STATS
     const uint64_t dbg_tc = wall_clock64();
@@ -490,19 +493,12 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     int sx = 0, sy = 0, sz = 0;
     double px = 0, py = 0, pz = 0;
     uint64_t key = 0;
-    if (U > 1) {
-      if (nat != cur) request(cur);
-      px = nx;
-      py = ny;
-      pz = nz;
-      key = nkey;
-      if (cur + WAVE < e) request(cur + WAVE);
-    } else if (valid) {
-      px = a.X[p];
-      py = a.Y[p];
-      pz = a.Z[p];
-      key = a.akey[p];
-    }
+    if (nat != cur) request(cur);
+    px = nx;
+    py = ny;
+    pz = nz;
+    key = nkey;
+    if (U > 1 && cur + WAVE < e) request(cur + WAVE);
     if (valid) {
       // slab coordinates inside the cell (culling of blocker scans)
       const uint64_t sub = (key >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
