@@ -455,13 +455,163 @@ __global__ __launch_bounds__(RS_THREADS) void radix_onesweep_kernel(const uint64
   }
 }
 
-bool radix_result_in_second() { return (RADIX_PASSES & 1) != 0; }
+// ---- hybrid: LSD passes over the TOP digits only, then one pass that orders the runs of equal top bits -----------------
+// Eight LSD passes move every (key, value) pair eight times.  After K passes over the top K digits the pairs are sorted by
+// the top 8K bits and, inside a run of equal top bits, still in input order; what is left is a stable sort of every run
+// by the whole key.  For Morton keys of a big cloud those runs are short (1 B uniform points: 0.23 points per 2^-32 of the
+// volume, longest run ~10), so one more pass in which every element finds its run, counts the run's elements that have
+// to precede it and writes itself to run start + that rank finishes the sort: 4 + 1 moves instead of 8.  K is chosen
+// from a sorted sample of the keys (no tie in the top 32 bits -> 4 passes, none in the top 48 -> 6, else all 8); a run
+// longer than a thread wants to walk goes to a workgroup (rank sort out of LDS), one longer than that makes the whole
+// sort fall back to eight passes -- the choice of K only ever costs time.
+constexpr uint32_t FIX_SHORT = 16;    // longest run its own elements rank themselves in
+constexpr uint32_t FIX_LONG = 4096;   // longest run a workgroup ranks out of LDS
+
+__global__ __launch_bounds__(256) void radix_sample_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t samples,
+                                                           uint64_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < samples) out[j] = keys[(uint64_t)j * n / samples];
+}
+// ties[0] / ties[1]: adjacent pairs of the sorted sample that agree in the top 32 / 48 bits of the 63-bit key
+__global__ __launch_bounds__(256) void radix_sample_ties_kernel(const uint64_t* __restrict__ sorted, uint32_t samples,
+                                                                uint32_t* __restrict__ ties) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j == 0 || j >= samples) return;
+  const uint64_t a = sorted[j - 1], b = sorted[j];
+  if ((a >> 32) == (b >> 32)) atomicAdd(&ties[0], 1u);
+  if ((a >> 16) == (b >> 16)) atomicAdd(&ties[1], 1u);
+}
+
+// Every element of a run of at most short_max equal prefixes writes itself to its place; the first element of a longer
+// run reports the run.  in: sorted by key >> shift, stable; out: the final order.  A workgroup stages its 1024 keys and
+// a halo of short_max + 1 on either side in LDS: the walks along the run are chains of dependent reads.
+constexpr int FIX_TILE = 1024, FIX_HALO = FIX_SHORT + 1;
+__global__ __launch_bounds__(256) void radix_fix_short_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                              uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
+                                                              int shift, uint32_t short_max, uint32_t* __restrict__ long_runs,
+                                                              uint32_t* __restrict__ counters /*[0] long runs*/) {
+  __shared__ uint64_t lk[FIX_TILE + 2 * FIX_HALO];
+  const uint64_t base = (uint64_t)blockIdx.x * FIX_TILE;  // lk[j] = kin[base - FIX_HALO + j]
+  for (uint32_t j = threadIdx.x; j < FIX_TILE + 2 * FIX_HALO; j += 256u) {
+    const uint64_t g = base + j;
+    if (g >= FIX_HALO && g - FIX_HALO < n) lk[j] = kin[g - FIX_HALO];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < FIX_TILE / 256; ++u) {
+    const uint32_t t = (uint32_t)u * 256u + threadIdx.x;  // coalesced reads of the values, neighbouring writes
+    const uint64_t gi = base + t;
+    if (gi >= n) continue;
+    const uint32_t i = (uint32_t)gi;
+    const uint32_t c = t + FIX_HALO;  // own slot
+    const uint64_t key = lk[c];
+    const uint64_t pre = key >> shift;
+    // the run [s, e) around i, as far as it matters (never farther than the halo reaches)
+    uint32_t s = i, e = i + 1u, rank = 0;
+    while (s > 0 && i - s <= short_max) {
+      const uint64_t o = lk[c - (i - s) - 1u];
+      if ((o >> shift) != pre) break;
+      --s;
+      rank += o <= key ? 1u : 0u;  // an earlier element precedes unless its key is larger
+    }
+    while (e < n && e - s <= short_max && e - i <= short_max) {
+      const uint64_t o = lk[c + (e - i)];
+      if ((o >> shift) != pre) break;
+      ++e;
+      rank += o < key ? 1u : 0u;   // a later element precedes only with a smaller key
+    }
+    const bool more_right = e < n && e - i > short_max && (lk[c + (e - i)] >> shift) == pre;  // the walk ran out of halo
+    if (e - s > short_max || more_right) {  // a long run: its first element reports it
+      if (s == i && (i == 0 || (lk[c - 1u] >> shift) != pre)) long_runs[atomicAdd(&counters[0], 1u)] = i;
+      continue;
+    }
+    kout[s + rank] = key;
+    vout[s + rank] = vin[i];
+  }
+}
+
+// one workgroup per long run: rank sort out of LDS; a run longer than long_max raises counters[1]
+__global__ __launch_bounds__(256) void radix_fix_long_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                             uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
+                                                             int shift, uint32_t long_max, const uint32_t* __restrict__ long_runs,
+                                                             uint32_t* __restrict__ counters) {
+  __shared__ uint64_t lk[FIX_LONG];
+  const uint32_t nruns = counters[0];
+  for (uint32_t r = blockIdx.x; r < nruns; r += gridDim.x) {
+    const uint32_t s = long_runs[r];
+    const uint64_t pre = kin[s] >> shift;
+    __syncthreads();
+    // length: every thread probes a stride of positions until the prefix changes (runs are contiguous)
+    uint32_t len = 0;
+    for (uint32_t base = 0;; base += 256u) {
+      const uint32_t j = s + base + threadIdx.x;
+      const bool in = j < n && base + threadIdx.x <= long_max && (kin[j] >> shift) == pre;
+      if (in) lk[(base + threadIdx.x) < FIX_LONG ? (base + threadIdx.x) : 0u] = kin[j];
+      const uint32_t cnt = __syncthreads_count(in ? 1 : 0);
+      len += cnt;
+      if (cnt < 256u) break;
+    }
+    if (len > long_max) {
+      if (threadIdx.x == 0) atomicAdd(&counters[1], 1u);
+      continue;
+    }
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < len; j += 256u) {
+      const uint64_t key = lk[j];
+      uint32_t rank = 0;
+      for (uint32_t m = 0; m < len; ++m) {
+        const uint64_t o = lk[m];
+        rank += (o < key || (o == key && m < j)) ? 1u : 0u;
+      }
+      kout[s + rank] = key;
+      vout[s + rank] = vin[s + j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void radix_copy_pairs_kernel(const uint64_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+                                                               uint64_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    kout[i] = kin[i];
+    vout[i] = vin[i];
+  }
+}
+
+// The sorted pairs always end in the SECOND buffer pair: the hybrid moves the data an odd number of times (4 or 6 passes
+// and the run pass); the plain eight passes end in the first pair and are copied over (small inputs, 2^30 points and
+// more, keys with long runs of equal top bits).
+bool radix_result_in_second() { return true; }
+
+static int radix_lsd_passes(swz_ctx* c, uint64_t*& kin, uint32_t*& vin, uint64_t*& kout, uint32_t*& vout, uint32_t n, int first_pass,
+                            int last_pass, bool first_synthesises_values, uint32_t* d_ghist, uint32_t* d_status, uint32_t* d_ticket) {
+  const uint32_t ntiles = div_up(n, RS_TILE);
+  SWZ_HIP(c, hipMemsetAsync(d_ticket, 0, sizeof(uint32_t) * RADIX_PASSES, c->stream));
+  for (int pass = first_pass; pass <= last_pass; ++pass) {
+    ProfScope ps(c, "radix_scatter", (uint64_t)n * 24ull);
+    SWZ_HIP(c, hipMemsetAsync(d_status, 0, (size_t)ntiles * RADIX * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(radix_onesweep_kernel, dim3(div_up(ntiles, OS_BATCH)), dim3(RS_THREADS), 0, c->stream, kin,
+                       (pass == first_pass && first_synthesises_values) ? (const uint32_t*)nullptr : vin, kout, vout, n,
+                       pass * RADIX_BITS, d_ghist + pass * RADIX, d_status, d_ticket + pass);
+    SWZ_LAUNCH_CHECK(c);
+    std::swap(kin, kout);
+    std::swap(vin, vout);
+  }
+  return SWZ_OK;
+}
+
+static int radix_copy_pairs(swz_ctx* c, const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout, uint32_t n) {
+  ProfScope ps(c, "radix_copy", (uint64_t)n * 24ull);
+  hipLaunchKernelGGL(radix_copy_pairs_kernel, dim3(std::min<uint32_t>(div_up(n, 256), 16384u)), dim3(256), 0, c->stream, kin, vin,
+                     kout, vout, n);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}
 
 int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint64_t* d_keys_out,
                      uint32_t* d_vals_out, uint32_t n, bool vals_identity) {
   if (n == 0) return SWZ_OK;
   const uint32_t ntiles = div_up(n, RS_TILE);
-  // the data ping-pongs first -> second -> first ...; radix_result_in_second() tells where it ends
+  // the data ping-pongs first -> second -> first ...
   uint64_t* kin = d_keys_in;
   uint32_t* vin = d_vals_tmp;
   uint64_t* kout = d_keys_out;
@@ -476,22 +626,73 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
     {
       ProfScope ps(c, "radix_hist", (uint64_t)n * 8ull);
       SWZ_HIP(c, hipMemsetAsync(d_ghist, 0, sizeof(uint32_t) * RADIX_PASSES * RADIX, c->stream));
-      SWZ_HIP(c, hipMemsetAsync(d_ticket, 0, sizeof(uint32_t) * RADIX_PASSES, c->stream));
       hipLaunchKernelGGL(radix_ghist_kernel, dim3(std::min<uint32_t>(ntiles, 256u * 8u)), dim3(RS_THREADS), 0, c->stream, kin, n, d_ghist);
       hipLaunchKernelGGL(radix_gscan_kernel, dim3(RADIX_PASSES), dim3(RADIX), 0, c->stream, d_ghist);
       SWZ_LAUNCH_CHECK(c);
     }
-    for (int pass = 0; pass < RADIX_PASSES; ++pass) {
-      ProfScope ps(c, "radix_scatter", (uint64_t)n * 24ull);
-      SWZ_HIP(c, hipMemsetAsync(d_status, 0, (size_t)ntiles * RADIX * sizeof(uint32_t), c->stream));
-      hipLaunchKernelGGL(radix_onesweep_kernel, dim3(div_up(ntiles, OS_BATCH)), dim3(RS_THREADS), 0, c->stream, kin,
-                         (pass == 0 && vals_identity) ? (const uint32_t*)nullptr : vin, kout, vout, n, pass * RADIX_BITS,
-                         d_ghist + pass * RADIX, d_status, d_ticket + pass);
+    // how many top digits: from a sorted sample of the keys
+    int top = RADIX_PASSES;
+    uint32_t min_n = 1u << 24, short_max = FIX_SHORT, long_max = FIX_LONG;
+    if (const char* e = c->opt("SWZ_SORT_HYBRID_MIN_N")) min_n = (uint32_t)atoll(e);
+    if (const char* e = c->opt("SWZ_SORT_FIX_SHORT")) short_max = std::max(1u, std::min<uint32_t>(FIX_SHORT, (uint32_t)atoi(e)));
+    if (const char* e = c->opt("SWZ_SORT_FIX_LONG")) long_max = std::max(short_max, std::min<uint32_t>(FIX_LONG, (uint32_t)atoi(e)));
+    uint32_t* d_fix = nullptr;  // [0] long runs, [1] runs too long, [2..3] sample ties
+    SWZ_TRY(c->get("radix_fix_counters", (size_t)4, &d_fix));
+    if (n >= min_n) {
+      const uint32_t samples = std::min<uint32_t>(n, 32768u);
+      uint64_t *d_sk = nullptr, *d_sk2 = nullptr;
+      uint32_t *d_sv = nullptr, *d_sv2 = nullptr;
+      SWZ_TRY(c->get("radix_sample_k", (size_t)samples, &d_sk));
+      SWZ_TRY(c->get("radix_sample_k2", (size_t)samples, &d_sk2));
+      SWZ_TRY(c->get("radix_sample_v", (size_t)samples, &d_sv));
+      SWZ_TRY(c->get("radix_sample_v2", (size_t)samples, &d_sv2));
+      uint32_t* d_sghist = nullptr;
+      SWZ_TRY(c->get("radix_sample_ghist", (size_t)RADIX_PASSES * RADIX, &d_sghist));
+      hipLaunchKernelGGL(radix_sample_kernel, dim3(div_up(samples, 256)), dim3(256), 0, c->stream, kin, n, samples, d_sk);
+      SWZ_HIP(c, hipMemsetAsync(d_sghist, 0, sizeof(uint32_t) * RADIX_PASSES * RADIX, c->stream));
+      hipLaunchKernelGGL(radix_ghist_kernel, dim3(div_up(samples, RS_TILE)), dim3(RS_THREADS), 0, c->stream, d_sk, samples, d_sghist);
+      hipLaunchKernelGGL(radix_gscan_kernel, dim3(RADIX_PASSES), dim3(RADIX), 0, c->stream, d_sghist);
       SWZ_LAUNCH_CHECK(c);
-      uint64_t* tk = kin; kin = kout; kout = tk;
-      uint32_t* tv = vin; vin = vout; vout = tv;
+      uint64_t *a = d_sk, *b = d_sk2;
+      uint32_t *va = d_sv, *vb = d_sv2;
+      SWZ_TRY(radix_lsd_passes(c, a, va, b, vb, samples, 0, RADIX_PASSES - 1, true, d_sghist, d_status, d_ticket));
+      SWZ_HIP(c, hipMemsetAsync(d_fix, 0, 16, c->stream));
+      hipLaunchKernelGGL(radix_sample_ties_kernel, dim3(div_up(samples, 256)), dim3(256), 0, c->stream, a, samples, d_fix + 2);
+      SWZ_LAUNCH_CHECK(c);
+      uint32_t h[4];
+      SWZ_HIP(c, hipMemcpyAsync(h, d_fix, 16, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      // (two tied pairs are tolerated: 32768 samples of 1 B uniform points tie in the top 32 bits with probability 0.12)
+      top = h[2] <= 2u ? 4 : (h[3] <= 2u ? 6 : RADIX_PASSES);
     }
-    return SWZ_OK;
+    if (const char* e = c->opt("SWZ_SORT_HYBRID_TOP")) top = std::max(2, std::min(RADIX_PASSES, atoi(e) & ~1));
+    if (top < RADIX_PASSES) {
+      const int first_pass = RADIX_PASSES - top;
+      SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, first_pass, RADIX_PASSES - 1, vals_identity, d_ghist, d_status, d_ticket));
+      // an even number of passes: the data is back in the first pair; the run pass writes the second
+      uint32_t* d_long = nullptr;
+      SWZ_TRY(c->get("radix_fix_long", (size_t)div_up(n, short_max + 1u) + 1u, &d_long));
+      {
+        ProfScope ps(c, "radix_runs", (uint64_t)n * 24ull);
+        SWZ_HIP(c, hipMemsetAsync(d_fix, 0, 8, c->stream));
+        hipLaunchKernelGGL(radix_fix_short_kernel, dim3(div_up(n, FIX_TILE)), dim3(256), 0, c->stream, kin, vin, kout, vout, n,
+                           first_pass * RADIX_BITS, short_max, d_long, d_fix);
+        hipLaunchKernelGGL(radix_fix_long_kernel, dim3(1024), dim3(256), 0, c->stream, kin, vin, kout, vout, n,
+                           first_pass * RADIX_BITS, long_max, d_long, d_fix);
+        SWZ_LAUNCH_CHECK(c);
+      }
+      uint32_t h[2];
+      SWZ_HIP(c, hipMemcpyAsync(h, d_fix, 8, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      if (h[1] == 0) return SWZ_OK;
+      // runs of equal top bits too long to rank: all eight passes over what the top passes left in the first pair
+      // (equal keys are still in input order there, so the result is the same stable order)
+      if (c->opt("SWZ_DEBUG")) fprintf(stderr, "[swz] sort: %u runs of equal top %d bits longer than %u, falling back to eight passes\n", h[1], 8 * top - 1, long_max);
+      SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, 0, RADIX_PASSES - 1, false, d_ghist, d_status, d_ticket));
+      return radix_copy_pairs(c, kin, vin, kout, vout, n);
+    }
+    SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, 0, RADIX_PASSES - 1, vals_identity, d_ghist, d_status, d_ticket));
+    return radix_copy_pairs(c, kin, vin, kout, vout, n);
   }
   uint32_t* d_hist = nullptr;
   SWZ_TRY(c->get("radix_hist", (size_t)ntiles * RADIX, &d_hist));
@@ -517,7 +718,7 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
     uint64_t* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
-  return SWZ_OK;
+  return radix_copy_pairs(c, kin, vin, kout, vout, n);
 }
 
 __global__ __launch_bounds__(RADIX) void digit_starts_kernel(const uint32_t* __restrict__ offs, uint32_t ntiles,

@@ -93,6 +93,39 @@ def test_sort_is_stable_on_ties(ctx):
     assert np.all(np.diff(ks.astype(np.float64)) >= 0)
 
 
+@pytest.mark.parametrize("opts", [
+    {"SWZ_SORT_HYBRID_TOP": "4"},                                                     # top 32 bits, then the run pass
+    {"SWZ_SORT_HYBRID_TOP": "6"},
+    {"SWZ_SORT_HYBRID_TOP": "2", "SWZ_SORT_FIX_SHORT": "3", "SWZ_SORT_FIX_LONG": "4096"},   # most runs go to workgroups
+    {"SWZ_SORT_HYBRID_TOP": "4", "SWZ_SORT_FIX_SHORT": "2", "SWZ_SORT_FIX_LONG": "5"},      # runs too long: eight passes after all
+    {},                                                                               # K from the sample of the keys
+], ids=lambda o: "-".join(v for v in o.values()) or "sampled")
+def test_sort_hybrid_top_digits_then_runs(ctx, opts):
+    """Large inputs are sorted by LSD passes over the top digits only and one pass that orders the runs of equal top
+    bits (swz_sort.hip); forced here onto small inputs, with run-length limits that send runs through the per-element
+    ranking, the workgroup ranking and the fallback to eight passes.  Order and tie order must be the oracle's."""
+    rng = np.random.default_rng(2024)
+    n = 300_000
+    cases = {
+        "random": rng.integers(0, 1 << 63, size=n, dtype=np.uint64),
+        # clusters: few distinct top bits, random low bits, plus exact duplicates (ties by index)
+        "clustered": (rng.integers(0, 40, size=n, dtype=np.uint64) << np.uint64(45)) | rng.integers(0, 1 << 20, size=n, dtype=np.uint64),
+        "one_run": rng.integers(0, 1 << 12, size=n, dtype=np.uint64),   # all top bits equal: one run of n
+    }
+    cases["clustered"][::5] = cases["clustered"][0]
+    try:
+        ctx.set_option("SWZ_SORT_HYBRID_MIN_N", "1")
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        for name, keys in cases.items():
+            perm, ks = ctx.sort_by_key(keys)
+            assert np.array_equal(perm, O.sort_by_key(keys)), name
+            assert np.array_equal(ks, keys[perm]), name
+    finally:
+        for k in list(opts) + ["SWZ_SORT_HYBRID_MIN_N"]:
+            ctx.set_option(k, None)
+
+
 # ----------------------------------------------------------------------------------------- sample_points
 def _sorted_cloud(xyz, bmin, bmax):
     keys, clamped = O.index_points(xyz, bmin, bmax)
