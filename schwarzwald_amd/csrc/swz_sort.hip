@@ -666,6 +666,7 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
       top = h[2] <= 2u ? 4 : (h[3] <= 2u ? 6 : RADIX_PASSES);
     }
     if (const char* e = c->opt("SWZ_SORT_HYBRID_TOP")) top = std::max(2, std::min(RADIX_PASSES, atoi(e) & ~1));
+    if (c->opt("SWZ_DEBUG") && n >= min_n) fprintf(stderr, "[swz] sort: %u keys, passes over the top %d digits\n", n, top);
     if (top < RADIX_PASSES) {
       const int first_pass = RADIX_PASSES - top;
       SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, first_pass, RADIX_PASSES - 1, vals_identity, d_ghist, d_status, d_ticket));
