@@ -68,12 +68,20 @@ __device__ __forceinline__ void sp_store(uint8_t* st, uint32_t i, uint8_t v) {
 }
 
 // one evaluation of point p from its recorded neighbours: 0 = still waiting, SP_A, SP_R
+// (all states are requested before the first is looked at: one memory round trip per evaluation, not one per neighbour --
+// as a plain loop the eight in-kernel evaluations cost 55 of level 2's 148 ms at 1 B points)
 __device__ __forceinline__ uint8_t sp_eval(const uint8_t* st, const uint32_t* mine, uint32_t cnt) {
+  uint32_t q[SP_K];
+  uint8_t s[SP_K];
+  const uint4 lo = *reinterpret_cast<const uint4*>(mine), hi = *reinterpret_cast<const uint4*>(mine + 4);
+  q[0] = lo.x, q[1] = lo.y, q[2] = lo.z, q[3] = lo.w, q[4] = hi.x, q[5] = hi.y, q[6] = hi.z, q[7] = hi.w;
+#pragma unroll
+  for (int j = 0; j < SP_K; ++j) s[j] = (uint32_t)j < cnt ? sp_load(st, q[j]) : (uint8_t)SP_R;
   bool rej = false, wait = false;
-  for (uint32_t j = 0; j < cnt; ++j) {
-    const uint8_t s = sp_load(st, mine[j]);
-    rej |= s == SP_A;
-    wait |= s == SP_U;
+#pragma unroll
+  for (int j = 0; j < SP_K; ++j) {
+    rej |= s[j] == SP_A;
+    wait |= s[j] == SP_U;
   }
   return rej ? SP_R : (wait ? SP_U : SP_A);
 }
@@ -205,62 +213,126 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
 
 // phase 1: record the earlier neighbours; points without any are accepted right away
 constexpr int SP_NB_THREADS = 256;
-__global__ __launch_bounds__(SP_NB_THREADS) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ ulist,
-                                                            uint32_t* __restrict__ ucount,
-                                                            uint32_t* __restrict__ overflow, uint32_t xcd, int iters) {
+__global__ __launch_bounds__(SP_NB_THREADS) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ overflow, uint32_t xcd) {
   // workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the points, so the
   // neighbourhoods a workgroup reads were mostly fetched into the same L2 by the workgroups just before it
   const uint32_t blk = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
   const uint32_t p = blk * SP_NB_THREADS + threadIdx.x;
-  bool undecided = false;
-  if (p < a.m && sp_sampled(a, p)) {
-    uint32_t cnt = 0;
+  if (p >= a.m) return;
+  uint32_t cnt = 0;
+  if (sp_sampled(a, p)) {
     uint32_t* mine = a.nbr + (size_t)p * SP_K;
     sp_visit_earlier(a, p, [&](uint32_t q) {
       if (cnt < (uint32_t)SP_K) mine[cnt] = q;
       ++cnt;
       return cnt <= (uint32_t)SP_K;  // one past the capacity marks the overflow, then stop
     });
-    a.ncount[p] = (uint8_t)cnt;
     if (cnt > (uint32_t)SP_K) atomicAdd(overflow, 1u);
     if (cnt == 0) {
       sp_store(a.state, p, SP_A);
       a.taken[p] = 1;
-    } else {
-      undecided = true;
     }
   }
-  // A few fixpoint iterations right here: workgroups run roughly in Morton order, so most earlier
-  // neighbours are already final (or become final in this wavefront within an iteration or two).
-  for (int it = 0; it < iters; ++it) {
-    if (!__ballot(undecided)) break;
-    if (undecided && a.ncount[p] <= (uint8_t)SP_K) {
-      const uint8_t r = sp_eval(a.state, a.nbr + (size_t)p * SP_K, a.ncount[p]);
-      if (r != SP_U) {
-        sp_store(a.state, p, r);
-        if (r == SP_A) a.taken[p] = 1;
-        undecided = false;
+  a.ncount[p] = (uint8_t)cnt;  // 0 also for the points of nodes that are not sampled: nothing left to decide
+}
+
+// phase 1b: the decisions, in one light pass in Morton order.  A point depends on earlier points only, and workgroups
+// are dispatched in the order of their index, so most of what a point waits for was decided by a workgroup that started
+// before its own: a few polls of the neighbours' states (agent-scope atomics) settle almost every point; what is
+// still open after max_polls goes to the list of the rounds below (so nothing here can wait forever).
+// (Until round 2 the search kernel polled eight times itself: the polls kept its wavefronts -- with all their
+// registers -- resident for 50 of level 2's 148 ms at 1 B points.  A strictly ordered variant -- stretches of points
+// handed out by an atomic ticket, polling until decided -- was no faster: 1.3 M tickets on one word and a chain of
+// five dependent round trips per stretch.)
+__global__ __launch_bounds__(256) void sp_resolve_kernel(SpArgs a, uint32_t max_polls, uint32_t* __restrict__ ulist,
+                                                         uint32_t* __restrict__ ucount) {
+  const uint64_t pp = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+  const uint32_t p = (uint32_t)pp;
+  const uint32_t wave_first = p - lane_id();
+  const uint32_t cnt = pp < a.m ? a.ncount[p] : 0u;
+  // this lane's state as the other lanes of the wavefront see it (a point without recorded neighbours was accepted by
+  // the search kernel; points of nodes that are not sampled are nobody's neighbour)
+  uint32_t mystate = cnt != 0u ? (uint32_t)SP_U : (uint32_t)SP_A;
+  const bool recorded = cnt <= (uint32_t)SP_K;
+  uint4 lo = make_uint4(0, 0, 0, 0), hi = lo;
+  if (cnt != 0u && recorded) {
+    const uint4* mine = reinterpret_cast<const uint4*>(a.nbr + (size_t)p * SP_K);
+    lo = mine[0];
+    if (cnt > 4u) hi = mine[1];
+  }
+  const uint32_t q[SP_K] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  // neighbours in this wavefront are read from the lanes' registers, never from memory; of the others only those
+  // that were still undecided at the last look are polled again
+  uint32_t inwave = 0, open = 0;  // bit j: neighbour j is a lane of this wavefront / is outside and not known final
+  bool ext_acc = false;           // an outside neighbour is accepted
+  if (recorded) {
+#pragma unroll
+    for (int j = 0; j < SP_K; ++j)
+      if ((uint32_t)j < cnt) {
+        if (q[j] >= wave_first) inwave |= 1u << j; else open |= 1u << j;   // neighbours are earlier points: q < p
+      }
+  }
+  for (uint32_t polls = 0; polls < max_polls; ++polls) {
+    if (!__ballot(mystate == (uint32_t)SP_U)) break;
+    if (mystate == (uint32_t)SP_U && !recorded) {  // too many neighbours to record (rare): search again, looking at their states
+      bool rej = false, wait = false;
+      sp_visit_earlier(a, p, [&](uint32_t qq) {
+        const uint8_t sq = sp_load(a.state, qq);
+        rej |= sq == SP_A;
+        wait |= sq == SP_U;
+        return !rej;
+      });
+      if (rej || !wait) {
+        mystate = rej ? SP_R : SP_A;
+        sp_store(a.state, p, (uint8_t)mystate);
+        if (!rej) a.taken[p] = 1;
       }
     }
-  }
-  // append the undecided points to the list: one atomic per workgroup
-  constexpr int NW = SP_NB_THREADS / WAVE;
-  __shared__ uint32_t wave_count[NW], wave_base[NW];
-  const uint64_t bm = __ballot(undecided);
-  const uint32_t w = threadIdx.x / WAVE;
-  if (lane_id() == 0) wave_count[w] = (uint32_t)__popcll(bm);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-    for (int k = 0; k < NW; ++k) total += wave_count[k];
-    uint32_t base = total ? atomicAdd(ucount, total) : 0u;
-    for (int k = 0; k < NW; ++k) {
-      wave_base[k] = base;
-      base += wave_count[k];
+    if (mystate == (uint32_t)SP_U && recorded && open) {
+      uint8_t st[SP_K];
+#pragma unroll
+      for (int j = 0; j < SP_K; ++j) st[j] = ((open >> j) & 1u) ? sp_load(a.state, q[j]) : (uint8_t)SP_R;
+#pragma unroll
+      for (int j = 0; j < SP_K; ++j)
+        if ((open >> j) & 1u) {
+          ext_acc |= st[j] == SP_A;
+          if (st[j] != SP_U) open &= ~(1u << j);
+        }
+    }
+    // the wavefront's own chains, without memory: every lane shows its state, every undecided lane looks
+    for (;;) {
+      bool in_acc = false, in_wait = false;
+#pragma unroll
+      for (int j = 0; j < SP_K; ++j) {
+        const uint32_t sj = (uint32_t)__shfl((int)mystate, (int)((q[j] - wave_first) & 63u), WAVE);
+        if ((inwave >> j) & 1u) {
+          in_acc |= sj == (uint32_t)SP_A;
+          in_wait |= sj == (uint32_t)SP_U;
+        }
+      }
+      bool changed = false;
+      if (mystate == (uint32_t)SP_U && recorded) {
+        const bool rej = ext_acc || in_acc;
+        if (rej || (!in_wait && !open)) {
+          mystate = rej ? SP_R : SP_A;
+          sp_store(a.state, p, (uint8_t)mystate);
+          if (!rej) a.taken[p] = 1;
+          changed = true;
+        }
+      }
+      if (!__ballot(changed)) break;
     }
   }
-  __syncthreads();
-  if (undecided) ulist[wave_base[w] + (uint32_t)__popcll(bm & lanemask_lt())] = p;
+  // leftovers: one atomic per wavefront
+  const bool undecided = mystate == (uint32_t)SP_U;
+  const uint64_t bm = __ballot(undecided);
+  if (bm) {
+    const int leader = __ffsll((unsigned long long)bm) - 1;
+    uint32_t off = 0;
+    if ((int)lane_id() == leader) off = atomicAdd(ucount, (uint32_t)__popcll(bm));
+    off = __shfl(off, leader, WAVE);
+    if (undecided) ulist[off + (uint32_t)__popcll(bm & lanemask_lt())] = p;
+  }
 }
 
 // phase 2: one fixpoint round over the undecided points
@@ -400,9 +472,13 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     (void)hipEventRecord(ev0, c->stream);
   }
   const uint32_t nbn = div_up(m, SP_NB_THREADS);
-  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nbn, 8) * 8 : nbn), dim3(SP_NB_THREADS), 0, c->stream, a, u0, cnt, cnt + 2,
-                     xcd, c->opt("SWZ_SP_ITERS") ? atoi(c->opt("SWZ_SP_ITERS")) : 8);
+  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nbn, 8) * 8 : nbn), dim3(SP_NB_THREADS), 0, c->stream, a, cnt + 2, xcd);
   SWZ_LAUNCH_CHECK(c);
+  {
+    const uint32_t max_polls = c->opt("SWZ_SP_POLLS") ? (uint32_t)atoi(c->opt("SWZ_SP_POLLS")) : 16u;
+    hipLaunchKernelGGL(sp_resolve_kernel, dim3(nb), dim3(256), 0, c->stream, a, max_polls, u0, cnt);
+    SWZ_LAUNCH_CHECK(c);
+  }
   if (dbg) (void)hipEventRecord(ev1, c->stream);
   uint32_t* uin = u0;
   uint32_t* uout = u1;
