@@ -56,15 +56,15 @@ struct MdArgs {
                        // committed number of accepted points -- one 16-byte load per adjacent cell
   uint32_t* crel;
   uint32_t* csnode;
-  uint32_t* npos;      // pending frontier / count / status written by the sweep kernel
-  uint32_t* ncnt;
-  uint32_t* status;
-  uint32_t* blk_p;     // stalled candidate and where its blocker scan stopped
+  uint32_t* npos;      // pending frontier written by the sweep kernel (what a cell that goes to sleep compares with)
+  uint4* result;       // [queue slot][2]: what the activation in that slot of the round's queue ended with --
+                       // {cell, new frontier, new count, status | moved << 8}, {blocking cell, blocking point, its slot, -}
+  uint32_t* blk_p;     // stalled candidate and where its blocker scan stopped (read by the cell's next activation)
   uint32_t* blk_slot;
   uint32_t* blk_q;
-  uint32_t* blk_cell;
-  uint32_t* sleeper;   // [cell][28], 27 used: the adjacent cell in direction k that sleeps on this cell (NONE32 = nobody); a cell
-                       // is the only writer of its entry and the cell it sleeps on the only one who clears it
+  uint2* sleeper;      // [cell][28], 27 used: {the adjacent cell in direction k that sleeps on this cell (NONE32 = nobody),
+                       // the point it waits for}; a cell is the only writer of its entry and the cell it sleeps on the
+                       // only one who clears it
   double* acc_xyz;     // per cell: positions of its accepted points, 3 doubles each, at slots [start, start+cnt)
   uint32_t* gridmap;   // [sample node][cell code] -> cell index (build time only)
   // per cell, built once: its earlier adjacent cells, latest (largest Morton code) first
@@ -380,7 +380,7 @@ __device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& l
 // BATCH: very sparse levels (almost every candidate is accepted) test all surviving lanes of a chunk in one pass over
 // the neighbours' undecided points.
 template <int U, bool BATCH, bool EARLY = false>
-__device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
+__device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds& lds) {
   const uint32_t l = lane_id();
 #ifdef SWZ_MD_STATS
   const uint64_t dbg_t0 = wall_clock64();
@@ -678,13 +678,13 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t c, MdLds& lds) {
     }
 #endif
     a.npos[c] = out_pos;
-    a.ncnt[c] = CNT + fresh;
-    a.status[c] = out_status;
+    const uint32_t moved = (out_pos > P || out_status == ST_FINISHED) ? 1u : 0u;
+    a.result[(size_t)slot * 2] = make_uint4(c, out_pos, CNT + fresh, out_status | (moved << 8));
     if (out_status == ST_STALLED) {
+      a.result[(size_t)slot * 2 + 1] = make_uint4(b_cell, b_q, b_slot & 0xFFu, 0u);
       a.blk_p[c] = out_pos;
       a.blk_slot[c] = b_slot;
       a.blk_q[c] = b_q;
-      a.blk_cell[c] = b_cell;
     }
   }
 }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(MD_THREADS, U == 1 ? SWZ_MD_MIN_WAVES : 4) void md_
     end = min(nq, (x + 1u) * seg);
     step = (gridDim.x >> 3) * MD_WAVES;
   }
-  for (uint32_t i = first; i < end; i += step) md_sweep_cell<U, BATCH>(a, qin[i], lds[w]);
+  for (uint32_t i = first; i < end; i += step) md_sweep_cell<U, BATCH>(a, i, qin[i], lds[w]);
 }
 
 // append `value` of every lane with want == true to the queue: one atomic per wavefront
@@ -738,53 +738,50 @@ __device__ __forceinline__ void md_wave_push(bool want, uint32_t value, uint32_t
 __device__ __forceinline__ void md_commit_requeue_range(const MdArgs& a, uint32_t round, uint32_t wave0, uint32_t stride) {
   const uint32_t nq = a.counters[CTR_Q0 + round % 3];
   uint32_t* cout = &a.counters[CTR_Q0 + (round + 1) % 3];
-  const uint32_t* qin = a.queue[round & 1];
   uint32_t* qout = a.queue[(round + 1) & 1];
   for (uint32_t i0 = wave0; i0 < nq; i0 += stride) {  // wave-uniform
     const uint32_t i = i0 + lane_id();
     const bool valid = i < nq;
-    // everything that depends on the cell alone is requested together: its records and its sleepers' entries
-    uint32_t c = 0, np = 0, st = ST_FINISHED, old = 0, cnt_new = 0, b = 0, bq = 0, bslot = 0;
-    uint4 sl[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) sl[k] = make_uint4(NONE32, NONE32, NONE32, NONE32);
+    // first round trip: what the activation in this slot of the queue ended with (written by the sweep)
+    uint4 r0 = make_uint4(0, 0, 0, ST_FINISHED), r1 = make_uint4(0, 0, 0, 0);
     if (valid) {
-      c = qin[i];
-      old = a.cell[c].z;
-      np = a.npos[c];
-      st = a.status[c];
-      cnt_new = a.ncnt[c];
-      b = a.blk_cell[c];
-      bq = a.blk_q[c];
-      bslot = a.blk_slot[c] & 0xFFu;
+      r0 = a.result[(size_t)i * 2];
+      r1 = a.result[(size_t)i * 2 + 1];  // (only meaningful for a stalled cell; requested anyway: no second round trip)
+    }
+    const uint32_t c = r0.x, np = r0.y, st = r0.w & 0xFFu;
+    const bool fin = valid && st == ST_FINISHED;
+    const bool moved = valid && ((r0.w >> 8) & 1u);
+    const bool stalled = valid && st == ST_STALLED;
+    const uint32_t b = r1.x, bq = r1.y, bslot = r1.z;
+    // second round trip: the entries of the cells sleeping on this one (with the points they wait for), the blocker's
+    // pending frontier
+    uint4 sl[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) sl[k] = make_uint4(NONE32, 0u, NONE32, 0u);
+    if (moved) {
       const uint4* row = reinterpret_cast<const uint4*>(a.sleeper + (size_t)c * 28);
 #pragma unroll
-      for (int k = 0; k < 7; ++k) sl[k] = row[k];
+      for (int k = 0; k < 14; ++k) sl[k] = row[k];
     }
-    const bool fin = valid && st == ST_FINISHED;
-    const bool moved = valid && (np > old || fin);
-    const bool stalled = valid && st == ST_STALLED;
+    const uint32_t bpos = stalled ? a.npos[b] : 0u;
     if (valid) {
       a.cell[c].z = np;
-      a.cell[c].w = cnt_new;
+      a.cell[c].w = r0.z;
     }
     const uint64_t fm = __ballot(fin);
     if (fm && lane_id() == 0) atomicAdd(&a.counters[CTR_DONE_CELLS], (uint32_t)__popcll(fm));
-    // second round trip: the blocker's pending frontier, the blocking points of the sleepers
     uint32_t w[27];
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      const uint4 v = sl[k / 4];
-      w[k] = moved ? (k % 4 == 0 ? v.x : (k % 4 == 1 ? v.y : (k % 4 == 2 ? v.z : v.w))) : NONE32;
-    }
-    const uint32_t bpos = stalled ? a.npos[b] : 0u;
     uint32_t wake = 0;
 #pragma unroll
-    for (int k = 0; k < 27; ++k)
-      if (w[k] != NONE32 && (fin || a.blk_q[w[k]] < np)) wake |= 1u << k;
+    for (int k = 0; k < 27; ++k) {
+      const uint4 v = sl[k / 2];
+      w[k] = (k & 1) ? v.z : v.x;
+      const uint32_t wq = (k & 1) ? v.w : v.y;
+      if (w[k] != NONE32 && (fin || wq < np)) wake |= 1u << k;
+    }
     // the cell's own fate
     const bool push = (valid && st == ST_YIELD) || (stalled && bpos > bq);
-    if (stalled && !push) a.sleeper[(size_t)b * 28 + (26u - bslot)] = c;  // the direction from b to c
+    if (stalled && !push) a.sleeper[(size_t)b * 28 + (26u - bslot)] = make_uint2(c, bq);  // the direction from b to c
     // one queue reservation for the wavefront: the cells themselves, then the sleepers they wake
     const uint32_t cnt = (push ? 1u : 0u) + (uint32_t)__popc(wake);
     const uint32_t incl = wave_incl_sum(cnt);
@@ -798,7 +795,7 @@ __device__ __forceinline__ void md_commit_requeue_range(const MdArgs& a, uint32_
       for (int k = 0; k < 27; ++k)
         if ((wake >> k) & 1u) {
           qout[off++] = w[k];
-          a.sleeper[(size_t)c * 28 + k] = NONE32;
+          a.sleeper[(size_t)c * 28 + k].x = NONE32;
         }
     }
   }
@@ -863,7 +860,7 @@ __global__ __launch_bounds__(MDP_THREADS, 4) void md_persistent_kernel(MdArgs a,
     {
       const uint32_t nq = a.counters[CTR_Q0 + round % 3];
       const uint32_t* qin = a.queue[round & 1];
-      for (uint32_t i = blockIdx.x * MDP_WAVES + w; i < nq; i += nblocks * MDP_WAVES) md_sweep_cell<1, true>(a, qin[i], lds[w]);
+      for (uint32_t i = blockIdx.x * MDP_WAVES + w; i < nq; i += nblocks * MDP_WAVES) md_sweep_cell<1, true>(a, i, qin[i], lds[w]);
     }
     if (!md_grid_barrier(bar, nblocks, epoch, &s_flag)) return;
     md_commit_requeue_range(a, round, wave0, stride);
@@ -908,11 +905,9 @@ __global__ __launch_bounds__(256) void md_lazy_start_kernel(MdArgs a, uint32_t n
       push = true;
     } else {
       const uint32_t b = a.nbr_id[(size_t)c * 27];
-      a.blk_cell[c] = b;
       const uint4 o = a.cell[b];
-      a.blk_q[c] = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
-      a.status[c] = ST_STALLED;
-      a.sleeper[(size_t)b * 28 + (26u - a.nbr_slot[(size_t)c * 32])] = c;
+      const uint32_t bq = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
+      a.sleeper[(size_t)b * 28 + (26u - a.nbr_slot[(size_t)c * 32])] = make_uint2(c, bq);
     }
   }
   md_wave_push(push, c, q, counter);
@@ -1059,12 +1054,13 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   if (ncells == 0) return SWZ_OK;
 
-  uint32_t* cellbuf = nullptr;  // 9 per-cell u32 arrays + the packed {start,end,pos,cnt} records
-  SWZ_TRY(c->get("md_cells", (size_t)ncells * 9, &cellbuf));
-  uint32_t** fields[] = {&a.crel, &a.csnode, &a.npos, &a.ncnt, &a.status, &a.blk_p, &a.blk_slot, &a.blk_q, &a.blk_cell};
-  for (size_t f = 0; f < 9; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
-  SWZ_TRY(c->get("md_sleeper", (size_t)ncells * 28, &a.sleeper));  // 27 directions, rows of 7 x 16 bytes
-  SWZ_HIP(c, memset_large(a.sleeper, 0xFF, (size_t)ncells * 28 * 4, c->stream));
+  uint32_t* cellbuf = nullptr;  // 6 per-cell u32 arrays + the packed {start,end,pos,cnt} records
+  SWZ_TRY(c->get("md_cells", (size_t)ncells * 6, &cellbuf));
+  uint32_t** fields[] = {&a.crel, &a.csnode, &a.npos, &a.blk_p, &a.blk_slot, &a.blk_q};
+  for (size_t f = 0; f < 6; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
+  SWZ_TRY(c->get("md_sleeper", (size_t)ncells * 28, &a.sleeper));  // 27 directions, rows of 14 x 16 bytes
+  SWZ_HIP(c, memset_large(a.sleeper, 0xFF, (size_t)ncells * 28 * sizeof(uint2), c->stream));
+  SWZ_TRY(c->get("md_result", (size_t)ncells * 2, &a.result));  // a round's queue never holds more than all cells
   SWZ_TRY(c->get("md_cell4", (size_t)ncells, &a.cell));
   SWZ_TRY(c->get("md_nbr_id", (size_t)ncells * 27, &a.nbr_id));
   SWZ_TRY(c->get("md_nbr_slot", (size_t)ncells * 32, &a.nbr_slot));
