@@ -30,6 +30,13 @@
 namespace swz {
 
 constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
+#ifndef SWZ_SP_BATCH
+#define SWZ_SP_BATCH 4
+#endif
+// adjacent cells searched together (their table entries, then their j-th records, in flight at once).  Four: the kernel
+// then needs 62 registers and runs 8 wavefronts per SIMD; nine (all a point usually has) need 91 -> 5 per SIMD and are
+// 25 % slower at 1 B points (level 2: 110 against 88 ms), 5-6 cells 72 registers and 92 ms.
+constexpr int SP_BATCH = SWZ_SP_BATCH;
 constexpr int SP_K = 8;  // recorded neighbours per point (32 B); more -> the point re-searches every round
 enum : uint8_t { SP_U = 0, SP_A = 1, SP_R = 2 };
 
@@ -164,9 +171,9 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   // of every run, are requested together, so the search costs 1 + (longest run) memory round trips.
   const uint2* __restrict__ tab = a.table + base;
   while (need) {
-    uint32_t q[9], qe[9];
+    uint32_t q[SP_BATCH], qe[SP_BATCH];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < SP_BATCH; ++i) {
       q[i] = 0u;
       qe[i] = 0u;
       if (need) {
@@ -183,10 +190,10 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
       }
     }
     for (;;) {
-      float rx[9], ry[9], rz[9];
+      float rx[SP_BATCH], ry[SP_BATCH], rz[SP_BATCH];
       bool any = false;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
+      for (int i = 0; i < SP_BATCH; ++i) {
         if (q[i] < qe[i]) {
           const float4 r = a.rec[q[i]];
           rx[i] = r.x;
@@ -197,7 +204,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
       }
       if (!any) break;
 #pragma unroll
-      for (int i = 0; i < 9; ++i) {
+      for (int i = 0; i < SP_BATCH; ++i) {
         if (q[i] < qe[i]) {
           const float dx = me.x - rx[i], dy = me.y - ry[i], dz = me.z - rz[i];
           const float d2 = dx * dx + dy * dy + dz * dz;
