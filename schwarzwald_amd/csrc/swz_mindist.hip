@@ -490,7 +490,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
 #endif
     const uint32_t p = cur + l;
     const bool valid = p < e;
-    int sx = 0, sy = 0, sz = 0;
     double px = 0, py = 0, pz = 0;
     uint64_t key = 0;
     if (nat != cur) request(cur);
@@ -499,33 +498,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
     pz = nz;
     key = nkey;
     if (U > 1 && cur + WAVE < e) request(cur + WAVE);
-    if (valid) {
-      // slab coordinates inside the cell (culling of blocker scans)
-      const uint64_t sub = (key >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
-      sx = (int)contract_bits_by_3(sub >> 2);
-      sy = (int)contract_bits_by_3(sub >> 1);
-      sz = (int)contract_bits_by_3(sub);
-    }
-    // adjacent cells that can hold a point closer than the spacing to this lane's point: squared slab
-    // gaps per axis and direction, summed per slot (once per chunk, all lanes in parallel)
-    uint32_t needmask = 0;
-    {
-      const int smax = (1 << a.sub_levels) - 1;
-      const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
-                   lz = (double)sz, hz = (double)(smax - sz);
-      const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
-      const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
-      const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
-#pragma unroll
-      for (int k = 0; k < 27; ++k)
-        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) needmask |= 1u << k;
-    }
 #ifdef SWZ_MD_STATS
     ++dbg_chunk;
 #endif
-    uint32_t needrank = 0;  // the same in scan order, restricted to cells that may hold undecided points
-    for (uint32_t r = 0; r < nnb; ++r)
-      if ((emask_r >> r) & 1u) needrank |= ((needmask >> bcast_u32(slot_of_rank, (int)r)) & 1u) << r;
     bool rej = !valid;
     // (R) against the committed accepted points of the neighbourhood, window by window
     for (uint32_t base = 0; base < T && !(a.ablate & 2u); base += MD_EXT_CAP) {
@@ -542,6 +517,31 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
 #ifdef SWZ_MD_STATS
     dbg_tchunk += wall_clock64() - dbg_tc;
 #endif
+    // Adjacent cells that can hold a point closer than the spacing to this lane's point: squared slab gaps per axis
+    // and direction, summed per slot (all lanes in parallel) -- only for chunks that have a survivor and somebody it
+    // could wait for (most chunks of a large cell find every point rejected)
+    uint32_t needmask = 0, needrank = 0;  // needrank: the same in scan order, restricted to cells that may hold undecided points
+    if (U == 1 || (alive && emask_r)) {  // (small cells nearly always have both: no branch there)
+      int sx = 0, sy = 0, sz = 0;
+      if (valid) {
+        // slab coordinates inside the cell (culling of blocker scans)
+        const uint64_t sub = (key >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+        sx = (int)contract_bits_by_3(sub >> 2);
+        sy = (int)contract_bits_by_3(sub >> 1);
+        sz = (int)contract_bits_by_3(sub);
+      }
+      const int smax = (1 << a.sub_levels) - 1;
+      const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
+                   lz = (double)sz, hz = (double)(smax - sz);
+      const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
+      const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
+      const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
+#pragma unroll
+      for (int k = 0; k < 27; ++k)
+        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) needmask |= 1u << k;
+      for (uint32_t r = 0; r < nnb; ++r)
+        if ((emask_r >> r) & 1u) needrank |= ((needmask >> bcast_u32(slot_of_rank, (int)r)) & 1u) << r;
+    }
     // (A) for many survivors at once: one pass over the possibly-undecided points of the earlier
     // adjacent cells, every surviving lane testing its own point against the broadcast one
     bool pre = false;          // blocker flags of this chunk were precomputed for all lanes
