@@ -181,6 +181,7 @@ int swz_destroy(swz_ctx* c) {
   c->release_all();
   c->prof_collect();
   for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+  for (hipStream_t st : c->aux_streams) (void)hipStreamDestroy(st);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
   return SWZ_OK;

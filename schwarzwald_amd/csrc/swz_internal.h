@@ -47,6 +47,7 @@ struct swz_ctx {
   std::map<std::string, swz::KernelStat> kstats;
   std::vector<swz::PendingEvent> pending;
   std::vector<hipEvent_t> event_pool;
+  std::vector<hipStream_t> aux_streams;  // side streams for work that may overlap (MIN_DISTANCE node groups), made on demand
 
   // ---- error helpers
   int fail(int code, const std::string& msg) {

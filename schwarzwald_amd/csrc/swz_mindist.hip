@@ -83,6 +83,7 @@ struct MdArgs {
   uint32_t patient;          // 1 = a stalled cell sleeps until the blocking CELL is finished, not just the blocking point
   float lazy_frac;           // lazy start: sleep until this fraction of the latest earlier neighbour is decided
   uint32_t ff_min;           // cells with more remaining points than this try the fast-forward first
+  uint32_t group, groups;    // the sampled nodes are dealt to `groups` independent sets of cells (node % groups); this is set `group`
   uint32_t xcd_chunks;       // 1 = each XCD sweeps a contiguous eighth of the queue
   uint32_t ablate;           // debugging only (SWZ_MD_ABLATE): 1 = never blocked, 2 = no rejection tests
   double usq[3];
@@ -887,10 +888,9 @@ __global__ __launch_bounds__(256) void md_gather_active_kernel(const uint32_t* _
   az[i] = Z[s];
 }
 
-__global__ __launch_bounds__(256) void md_fill_queue_kernel(uint32_t* q, uint32_t n, uint32_t* counter) {
+__global__ __launch_bounds__(256) void md_fill_queue_kernel(MdArgs a, uint32_t n, uint32_t* q, uint32_t* counter) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) q[i] = i;
-  if (i == 0) *counter = n;
+  md_wave_push(i < n && a.csnode[i] % a.groups == a.group, i, q, counter);
 }
 
 // Patient levels start lazily: only the cells without an earlier adjacent cell are queued, every other cell
@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void md_fill_queue_kernel(uint32_t* q, uint32_
 __global__ __launch_bounds__(256) void md_lazy_start_kernel(MdArgs a, uint32_t ncells, uint32_t* q, uint32_t* counter) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   bool push = false;
-  if (c < ncells) {
+  if (c < ncells && a.csnode[c] % a.groups == a.group) {
     if (a.nbr_slot[(size_t)c * 32 + 31] == 0) {
       push = true;
     } else {
@@ -1101,15 +1101,45 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   bool lazy = many_small || typical <= 1024.0;
   if (const char* e = c->opt("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
   a.lazy_frac = c->opt("SWZ_MD_LAZY_FRAC") ? (float)atof(c->opt("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
-  if (lazy) {
-    SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_Q0, 0, 4, c->stream));
-    hipLaunchKernelGGL(md_lazy_start_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, a.queue[0],
-                       lb.counters + CTR_Q0);
-  } else {
-    hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, a.queue[0], ncells,
-                       lb.counters + CTR_Q0);
+  // two builds of the sweep: for cells of hundreds of points and more (four chunks per memory round trip in blocker
+  // scans and the fast-forward, 4 wavefronts per SIMD) and for levels of small cells (neither, 5 per SIMD)
+  bool big_cells = typical > 128.0;
+  if (const char* e = c->opt("SWZ_MD_BIG")) big_cells = atoi(e) != 0;
+  // Node groups.  The nodes of a level are sampled independently, so their cells can be dealt to G sets that run their
+  // rounds on G streams: while one set's second launch publishes (a few dependent round trips on a few thousand
+  // cells) or its queue is short (the ramps at the start and the end of a level), the other sets' sweeps use the GPU.
+  uint32_t groups = 1;
+  if (sample_nodes >= 2 && !big_cells) groups = 2;
+  if (const char* e = c->opt("SWZ_MD_GROUPS")) groups = (uint32_t)std::max(1, std::min(8, atoi(e)));
+  groups = std::min(groups, sample_nodes);
+  if (c->opt("SWZ_MD_PERSISTENT") && atoi(c->opt("SWZ_MD_PERSISTENT")) != 0) groups = 1;  // one launch runs all cells
+  std::vector<MdArgs> ga(groups, a);
+  std::vector<hipStream_t> gs(groups, c->stream);
+  for (uint32_t g = 0; g < groups; ++g) {
+    ga[g].group = g;
+    ga[g].groups = groups;
+    if (g > 0) {
+      const std::string tag = std::to_string(g);
+      SWZ_TRY(c->get(("md_queue0_g" + tag).c_str(), (size_t)ncells, &ga[g].queue[0]));
+      SWZ_TRY(c->get(("md_queue1_g" + tag).c_str(), (size_t)ncells, &ga[g].queue[1]));
+      SWZ_TRY(c->get(("md_result_g" + tag).c_str(), (size_t)ncells * 2, &ga[g].result));
+      SWZ_TRY(c->get(("md_counters_g" + tag).c_str(), (size_t)CTR_COUNT, &ga[g].counters));
+      SWZ_HIP(c, hipMemsetAsync(ga[g].counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
+      while (c->aux_streams.size() < g) {
+        hipStream_t st = nullptr;
+        SWZ_HIP(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->aux_streams.push_back(st);
+      }
+      gs[g] = c->aux_streams[g - 1];
+    }
+    SWZ_HIP(c, hipMemsetAsync(ga[g].counters + CTR_Q0, 0, 4, c->stream));
+    if (lazy)
+      hipLaunchKernelGGL(md_lazy_start_kernel, dim3(cb), dim3(256), 0, c->stream, ga[g], ncells, ga[g].queue[0], ga[g].counters + CTR_Q0);
+    else
+      hipLaunchKernelGGL(md_fill_queue_kernel, dim3(cb), dim3(256), 0, c->stream, ga[g], ncells, ga[g].queue[0], ga[g].counters + CTR_Q0);
+    SWZ_LAUNCH_CHECK(c);
   }
-  SWZ_LAUNCH_CHECK(c);
+  a = ga[0];
 
   // rounds; the host only looks at the done counter every `batch` rounds
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
@@ -1131,8 +1161,9 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     commit_cap = std::max(1u, sweep_cap / 2u);
     sweep_cap *= 256u / MD_THREADS;
   }
-  const uint32_t sweep_grid = std::min<uint32_t>(sweep_cap, std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
-  const uint32_t commit_grid = std::min<uint32_t>(commit_cap, std::max<uint32_t>(1u, div_up(ncells, 256)));
+  // (the sets of node groups share the GPU: each gets its part of the grid)
+  const uint32_t sweep_grid = std::min<uint32_t>(std::max(8u, sweep_cap / groups), std::max<uint32_t>(1u, div_up(ncells, MD_WAVES)));
+  const uint32_t commit_grid = std::min<uint32_t>(std::max(1u, commit_cap / groups), std::max<uint32_t>(1u, div_up(ncells, 256)));
   uint32_t round = 0, done = 0;
   // SWZ_MD_PERSISTENT=1: one resident workgroup per CU runs the rounds inside one launch (md_persistent_kernel).
   // Measured at 1 B points (round 2): root 169 ms against 117 ms with three launches per round (128 against 89 us
@@ -1166,10 +1197,6 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     }
   }
   const uint32_t batch = 32;
-  // two builds of the sweep: for cells of hundreds of points and more (four chunks per memory round trip in blocker
-  // scans and the fast-forward, 4 wavefronts per SIMD) and for levels of small cells (neither, 5 per SIMD)
-  bool big_cells = typical > 128.0;
-  if (const char* e = c->opt("SWZ_MD_BIG")) big_cells = atoi(e) != 0;
   // a level that does not finish is reported, not waited for: points that change while they are being tiled
   // (keys and positions no longer agree) can make single cells arbitrarily expensive
   const auto wall0 = std::chrono::steady_clock::now();
@@ -1177,19 +1204,34 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   if (const char* e = c->opt("SWZ_MD_TIME_LIMIT")) wall_limit = atof(e);
   uint64_t max_rounds = 4ull * m + 1024;
   if (const char* e = c->opt("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
+  // the side streams start after everything queued so far and are joined again when the level is done
+  hipEvent_t fork = nullptr;
+  if (groups > 1) {
+    fork = c->take_event();
+    SWZ_HIP(c, hipEventRecord(fork, c->stream));
+    for (uint32_t g = 1; g < groups; ++g) SWZ_HIP(c, hipStreamWaitEvent(gs[g], fork, 0));
+  }
+  std::vector<uint32_t> gdone(groups, 0);
   while (done < ncells) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
-      if (a.batch_blockers)
-        hipLaunchKernelGGL((md_sweep_kernel<1, true>), dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
-      else if (big_cells)
-        hipLaunchKernelGGL((md_sweep_kernel<4, false>), dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
-      else
-        hipLaunchKernelGGL((md_sweep_kernel<1, false>), dim3(sweep_grid), dim3(MD_THREADS), 0, c->stream, a, round);
-      hipLaunchKernelGGL(md_commit_requeue_kernel, dim3(commit_grid), dim3(256), 0, c->stream, a, round);
+      for (uint32_t g = 0; g < groups; ++g) {
+        if (a.batch_blockers)
+          hipLaunchKernelGGL((md_sweep_kernel<1, true>), dim3(sweep_grid), dim3(MD_THREADS), 0, gs[g], ga[g], round);
+        else if (big_cells)
+          hipLaunchKernelGGL((md_sweep_kernel<4, false>), dim3(sweep_grid), dim3(MD_THREADS), 0, gs[g], ga[g], round);
+        else
+          hipLaunchKernelGGL((md_sweep_kernel<1, false>), dim3(sweep_grid), dim3(MD_THREADS), 0, gs[g], ga[g], round);
+        hipLaunchKernelGGL(md_commit_requeue_kernel, dim3(commit_grid), dim3(256), 0, gs[g], ga[g], round);
+      }
     }
     SWZ_LAUNCH_CHECK(c);
-    SWZ_HIP(c, hipMemcpyAsync(&done, lb.counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
-    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    for (uint32_t g = 0; g < groups; ++g)
+      SWZ_HIP(c, hipMemcpyAsync(&gdone[g], ga[g].counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, gs[g]));
+    done = 0;
+    for (uint32_t g = 0; g < groups; ++g) {
+      SWZ_HIP(c, hipStreamSynchronize(gs[g]));
+      done += gdone[g];
+    }
     if (dbg && c->opt("SWZ_MD_TIMELINE")) {
       float t = 0.f;
       hipEvent_t e = c->take_event();
@@ -1214,6 +1256,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       return c->fail(SWZ_ERR_INTERNAL, msg);
     }
   }
+  if (fork) c->event_pool.push_back(fork);
   if (rounds_out) *rounds_out += round;
   if (dbg) {
     float ms = 0.f;

@@ -365,6 +365,8 @@ def test_min_distance_sparse_path_float_filter(ctx, eps):
     # the build for cells of hundreds of points (four chunks per round trip, fast-forward) on cells that large
     {"SWZ_MD_BIG": "1", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0", "SWZ_MD_LAZY": "0", "SWZ_MD_FF_MIN": "64"},
     {"SWZ_MD_BIG": "0", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0"},  # ... and the small-cell build on them
+    {"SWZ_MD_GROUPS": "1"},                          # all nodes of a level in one set of rounds
+    {"SWZ_MD_GROUPS": "3", "SWZ_MD_LAZY": "0"},      # ... dealt to three sets on three streams
 ], ids=lambda m: "-".join("%s%s" % (k[7:10], v) for k, v in m.items()))
 def test_min_distance_sweep_scheduling_modes(ctx, monkeypatch, mode):
     """The frontier sweep picks its scheduling per level from the cell statistics (patient stalls, lazy start, scan
