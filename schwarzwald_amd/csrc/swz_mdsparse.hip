@@ -189,7 +189,8 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
         }
       }
     }
-    for (;;) {
+    // One step over the batch's runs with all their loads in flight (runs are short: half of them end here) ...
+    for (int step = 0; step < 1; ++step) {
       float rx[SP_BATCH], ry[SP_BATCH], rz[SP_BATCH];
       bool any = false;
 #pragma unroll
@@ -215,12 +216,38 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
         }
       }
     }
+    // ... then what is left of the longer runs, one record per step: the kernel is bound by its vector ALU instructions
+    // (rocprofv3: 1950 per wavefront, 80 % of the cycles), and a step of the loop above costs all four runs' worth of
+    // them for every wavefront that has a single lane with a single long run (measured at 1 B points, level 2: the
+    // all-runs loop until everything is read 88 ms, three steps of it before the walk 88, two 85, one 80, none 82)
+    uint32_t cq = 0, ce = 0;
+    for (;;) {
+      if (cq >= ce) {
+        bool found = false;
+#pragma unroll
+        for (int i = 0; i < SP_BATCH; ++i)
+          if (!found && q[i] < qe[i]) {
+            cq = q[i];
+            ce = qe[i];
+            q[i] = qe[i];
+            found = true;
+          }
+        if (!found) break;
+      }
+      const float4 r = a.rec[cq];
+      const float dx = me.x - r.x, dy = me.y - r.y, dz = me.z - r.z;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      if (d2 < a.f_hi && (d2 < a.f_lo || sp_exact_near(a, p, cq))) {
+        if (!f(cq)) return;
+      }
+      ++cq;
+    }
   }
 }
 
 // phase 1: record the earlier neighbours; points without any are accepted right away
 constexpr int SP_NB_THREADS = 256;
-__global__ __launch_bounds__(SP_NB_THREADS) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ overflow, uint32_t xcd) {
+__global__ __launch_bounds__(SP_NB_THREADS, 8) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ overflow, uint32_t xcd) {
   // workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the points, so the
   // neighbourhoods a workgroup reads were mostly fetched into the same L2 by the workgroups just before it
   const uint32_t blk = xcd ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
