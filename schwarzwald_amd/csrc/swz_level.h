@@ -110,7 +110,7 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
 // qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
-                              const LevelBuffers& lb, const uint32_t* snode_of, uint32_t sample_nodes,
+                              const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes,
                               uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used);
 
 }  // namespace swz

@@ -45,6 +45,7 @@ struct SpArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* snode_of;
+  uint32_t all_sampled;      // every node of the level is sampled (the usual case): no look at nmode, snode_of is the identity
   const float4* rec;   // active order: position relative to the node's min corner, rounded to float; w unused
   const uint32_t* aidx;      // exact positions of active point i: X[aidx ? aidx[i] : i]
   const double* X;
@@ -93,7 +94,11 @@ __device__ __forceinline__ uint8_t sp_eval(const uint8_t* st, const uint32_t* mi
   return rej ? SP_R : (wait ? SP_U : SP_A);
 }
 
-__device__ __forceinline__ bool sp_sampled(const SpArgs& a, uint32_t i) { return a.nmode[a.nid[i]] == MODE_SAMPLE; }
+__device__ __forceinline__ bool sp_sampled(const SpArgs& a, uint32_t i) { return a.all_sampled || a.nmode[a.nid[i]] == MODE_SAMPLE; }
+__device__ __forceinline__ uint32_t sp_snode(const SpArgs& a, uint32_t i) {
+  const uint32_t node = a.nid[i];
+  return a.all_sampled ? node : a.snode_of[node];
+}
 
 __global__ __launch_bounds__(256) void sp_table_kernel(SpArgs a) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void sp_table_kernel(SpArgs a) {
   const bool tail = i + 1 == a.m || (a.akey[i + 1] >> a.cell_shift) != pre;
   if (!head && !tail) return;
   const uint64_t code = pre & (a.cells_per_node - 1ull);
-  uint2* e = a.table + ((uint64_t)a.snode_of[a.nid[i]] * a.cells_per_node + code);
+  uint2* e = a.table + ((uint64_t)sp_snode(a, i) * a.cells_per_node + code);
   if (head) e->x = i;
   if (tail) e->y = i + 1u;
 }
@@ -132,7 +137,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   const uint64_t mykey = a.akey[p];
   const uint64_t pre = mykey >> a.cell_shift;
   const uint32_t code = (uint32_t)(pre & (a.cells_per_node - 1ull));
-  const uint64_t base = (uint64_t)a.snode_of[a.nid[p]] * a.cells_per_node;
+  const uint64_t base = (uint64_t)sp_snode(a, p) * a.cells_per_node;
   // neighbour cell codes by arithmetic on the dilated coordinates (code = x bits | y bits | z bits, every
   // third bit): minus one = (v - 1) & mask, plus one = ((v | ~mask) + 1) & mask; out of the node when the
   // coordinate is already 0 / all ones
@@ -405,7 +410,7 @@ __global__ void sp_zero_kernel(uint32_t* p) { *p = 0; }
 // positions already in active order (X/Y/Z); snode_of already scanned.  Returns SWZ_OK and sets *used
 // to false when the level does not qualify (the caller then runs the frontier sweep).
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
-                              const LevelBuffers& lb, const uint32_t* snode_of, uint32_t sample_nodes,
+                              const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes,
                               uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used) {
   *used = false;
   int cl = plan.cell_levels_geo;
@@ -423,6 +428,7 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.nid = lb.nid;
   a.nmode = lb.nmode;
   a.snode_of = snode_of;
+  a.all_sampled = all_sampled ? 1u : 0u;
   a.m = m;
   a.cell_levels = (uint32_t)cl;
   a.cells_per_node = 1ull << (3 * cl);

@@ -83,6 +83,7 @@ struct MdArgs {
   uint32_t patient;          // 1 = a stalled cell sleeps until the blocking CELL is finished, not just the blocking point
   float lazy_frac;           // lazy start: sleep until this fraction of the latest earlier neighbour is decided
   uint32_t ff_min;           // cells with more remaining points than this try the fast-forward first
+  uint32_t all_sampled;      // every node of the level is sampled (the usual case): cell heads need no look at nid / nmode
   uint32_t group, groups;    // the sampled nodes are dealt to `groups` independent sets of cells (node % groups); this is set `group`
   uint32_t xcd_chunks;       // 1 = each XCD sweeps a contiguous eighth of the queue
   uint32_t ablate;           // debugging only (SWZ_MD_ABLATE): 1 = never blocked, 2 = no rejection tests
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void md_node_flag_kernel(const uint8_t* __rest
 }
 
 __device__ __forceinline__ bool md_is_head(const MdArgs& a, uint32_t i) {
-  if (a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
+  if (!a.all_sampled && a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
   return i == 0 || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
 }
 
@@ -999,6 +1000,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   a.cells_per_node = cells_per_node;
   a.cell_shift = (plan.node_shift == 63u ? 63u : plan.node_shift) - 3u * (uint32_t)cl;
   a.sq_spacing = plan.sq_spacing;
+  a.all_sampled = sample_nodes == nnodes ? 1u : 0u;
   {
     // absolute octree level of a cell is level + cl; up to 4 further levels of the key give the slabs
     const int cell_abs = plan.level + cl;
@@ -1027,7 +1029,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   {
     // sparse levels (about one point per spacing-sized cell or fewer): one thread per point
     bool used = false;
-    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes, sample_points, occupied, rounds_out, &used));
+    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, sample_nodes, sample_points, occupied, rounds_out, &used));
     if (used) return SWZ_OK;
   }
   if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
