@@ -116,14 +116,16 @@ __global__ __launch_bounds__(256) void node_mode_kernel(const uint32_t* __restri
 // ----------------------------------------------------------------------------- RANDOM_GRID (K4a)
 // RandomSortedGridSampling::sample_points, Sampling.h:187-308: the first point of every run of equal
 // truncate_to_level(candidate_level) is taken.  candidate_level == -1 takes the first point only.
+// (when every node of the level is sampled -- the counters of node_mode_kernel say so -- nobody looks at nid / nmode)
 __global__ __launch_bounds__(256) void random_grid_kernel(const uint64_t* __restrict__ akey, uint32_t m,
                                                           const uint32_t* __restrict__ nid,
                                                           const uint8_t* __restrict__ nmode, uint32_t csh,
-                                                          uint8_t* __restrict__ taken) {
+                                                          uint8_t* __restrict__ taken, const uint32_t* __restrict__ counters) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
+  const bool all_sampled = counters[CTR_SAMPLE_NODES] == counters[CTR_NUM_NODES];
   uint8_t t = 1;
-  if (nmode[nid[i]] == MODE_SAMPLE) t = (i == 0) || ((akey[i] >> csh) != (akey[i - 1] >> csh));
+  if (all_sampled || nmode[nid[i]] == MODE_SAMPLE) t = (i == 0) || ((akey[i] >> csh) != (akey[i - 1] >> csh));
   taken[i] = t;
 }
 
@@ -271,6 +273,7 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
   const uint32_t tile_end = (m - tile_base) < (uint32_t)GA_TILE ? m : tile_base + GA_TILE;
   const uint32_t last_valid = tile_end - 1;
   const uint32_t first = tile_base + tid * GA_IPT;
+  const bool all_sampled = counters[CTR_SAMPLE_NODES] == counters[CTR_NUM_NODES];  // then nobody looks at nid / nmode
 
   double dist[GA_IPT];
   bool head[GA_IPT];
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
     if (gi < tile_end) {
       const uint64_t key = akey[gi];
       uint32_t csh = node_shift;
-      if (nmode[nid[gi]] == MODE_SAMPLE) {
+      if (all_sampled || nmode[nid[gi]] == MODE_SAMPLE) {
         double tx, ty, tz;
         const int err = cell_target(g, key, csh, tx, ty, tz);
         if (err) {
@@ -551,7 +554,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     if (!first_only && plan.cand >= (int)MAX_LEVELS) return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, "candidate level >= 21");
     ProfScope ps(c, "sample_random_grid", (uint64_t)m * 9ull);
     hipLaunchKernelGGL(random_grid_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, lb.nid, lb.nmode, csh,
-                       lb.taken);
+                       lb.taken, lb.counters);
     SWZ_LAUNCH_CHECK(c);
   } else if (plan.sampler == SWZ_GRID_CENTER || plan.sampler == SWZ_JITTERED) {
     if (plan.sampler == SWZ_GRID_CENTER && plan.cand >= (int)MAX_LEVELS)
