@@ -262,6 +262,36 @@ __device__ __forceinline__ double bcast_f64(double v, int src) {
   hi = __builtin_amdgcn_readlane(hi, src);
   return __hiloint2double(hi, lo);
 }
+// A kernel-argument scalar as a value the optimiser cannot see through.  md_sweep_cell is inlined into a loop over the
+// cells of a wavefront; vector-register copies of its double constants are loop invariant, get hoisted in front of the
+// loop and -- there are more such values than registers -- are spilled there: 15 dwords per lane and wavefront, 126 GB
+// of scratch writes per step at 1 B points (rocprofv3 WRITE_SIZE of md_sweep_kernel; the loop runs once or twice per
+// wavefront).  Taken through this, the copies are made where they are used.
+__device__ __forceinline__ double opaque(double v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
+// Wavefront scan / maximum with DPP moves instead of ds_bpermute shuffles: a shuffle needs its source-lane address in a
+// vector register, and the six addresses of a scan are one more set of loop-invariant values that got hoisted in front
+// of the cell loop and spilled (see opaque()).
+template <typename Op>
+__device__ __forceinline__ uint32_t md_wave_scan(uint32_t v, Op op, uint32_t identity) {
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+struct MdAdd {
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; }
+};
+struct MdMax {
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+};
+
 __device__ __forceinline__ uint32_t bcast_u32(uint32_t v, int src) {
   return (uint32_t)__builtin_amdgcn_readlane((int)v, src);
 }
@@ -350,7 +380,7 @@ template <int U>
 __device__ __forceinline__ uint32_t md_first_hit(const MdArgs& a, const MdLds& lds, uint32_t wn, uint32_t qs, uint32_t qe,
                                                  double bx, double by, double bz) {
   const uint32_t l = lane_id();
-  const double t = a.sq_spacing;
+  const double t = opaque(a.sq_spacing);
   uint32_t q0 = qs;
   while (qe - q0 > (uint32_t)WAVE) {  // qe > q0 always
     double x[U], y[U], z[U];
@@ -389,7 +419,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
 #endif
   const uint4 me = a.cell[c];
   const uint32_t s0 = me.x, e = me.y;
-  const double t = a.sq_spacing;
+  const double t = opaque(a.sq_spacing);
   const uint32_t P = me.z, CNT = me.w;
 
   // Large cells (U > 1) request the next chunk before the current one is worked on (most chunks of a large cell only
@@ -434,15 +464,10 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
     n_start = s0;
   }
   const uint32_t emask_r = (uint32_t)__ballot(earlier && n_pos < n_end);  // cells that may hold undecided points
-  const uint32_t incl = wave_incl_sum(n_cnt);
+  const uint32_t incl = md_wave_scan(n_cnt, MdAdd{}, 0u);
   const uint32_t off = incl - n_cnt;
   const uint32_t T = bcast_u32(incl, WAVE - 1);  // accepted points of the neighbourhood (incl. own committed)
-  uint32_t maxcnt = n_cnt;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    const uint32_t o = __shfl_xor(maxcnt, d, WAVE);
-    maxcnt = o > maxcnt ? o : maxcnt;
-  }
+  const uint32_t maxcnt = bcast_u32(md_wave_scan(n_cnt, MdMax{}, 0u), WAVE - 1);
   const bool resume = a.blk_p[c] == P;
   const uint32_t r_packed = resume ? a.blk_slot[c] : 0u;
   const uint32_t r_group = r_packed >> 8;    // rank (scan position) of that cell: earlier ranks were scanned clean
@@ -535,12 +560,13 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
       const int smax = (1 << a.sub_levels) - 1;
       const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
                    lz = (double)sz, hz = (double)(smax - sz);
-      const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
-      const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
-      const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
+      const double ux = opaque(a.usq[0]), uy = opaque(a.usq[1]), uz = opaque(a.usq[2]), cull = opaque(a.cull_sq);
+      const double gx[3] = {lx * lx * ux, 0.0, hx * hx * ux};
+      const double gy[3] = {ly * ly * uy, 0.0, hy * hy * uy};
+      const double gz[3] = {lz * lz * uz, 0.0, hz * hz * uz};
 #pragma unroll
       for (int k = 0; k < 27; ++k)
-        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) needmask |= 1u << k;
+        if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < cull) needmask |= 1u << k;
       for (uint32_t r = 0; r < nnb; ++r)
         if ((emask_r >> r) & 1u) needrank |= ((needmask >> bcast_u32(slot_of_rank, (int)r)) & 1u) << r;
     }
