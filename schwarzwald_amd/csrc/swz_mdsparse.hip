@@ -58,8 +58,8 @@ struct SpArgs {
   uint64_t cells_per_node;
   double sq_spacing;
   uint32_t sub_levels;      // key levels below the cell level that give a point's slab inside its cell
-  double usq[3];            // squared slab width per axis
-  double cull_sq;           // squared spacing with a 2^-18 margin: adjacent cells farther than this are skipped
+  float usq_f[3];           // squared slab width per axis, rounded down
+  float cull_f;             // squared spacing with a margin: adjacent cells farther than this are skipped
   uint2* table;             // [sample node][cell code] -> {first, end} active index of the cell's run
   uint32_t* nbr;            // [point][SP_K]
   uint8_t* ncount;          // recorded neighbours, SP_K + 1 = overflow
@@ -156,14 +156,16 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
     const uint64_t sub = (mykey >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
     const int smax = (1 << a.sub_levels) - 1;
     const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1), sz = (int)contract_bits_by_3(sub);
-    const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy), lz = (double)sz,
-                 hz = (double)(smax - sz);
-    const double gx[3] = {lx * lx * a.usq[0], 0.0, hx * hx * a.usq[0]};
-    const double gy[3] = {ly * ly * a.usq[1], 0.0, hy * hy * a.usq[1]};
-    const double gz[3] = {lz * lz * a.usq[2], 0.0, hz * hz * a.usq[2]};
+    // (in float: the kernel is bound by its vector ALU work and doubles cost twice; usq_f is rounded down and cull_f
+    // carries a 1e-5 margin over the 2^-18 one, far more than the three roundings of the sum can add)
+    const float lx = (float)sx, hx = (float)(smax - sx), ly = (float)sy, hy = (float)(smax - sy), lz = (float)sz,
+                hz = (float)(smax - sz);
+    const float gx[3] = {lx * lx * a.usq_f[0], 0.f, hx * hx * a.usq_f[0]};
+    const float gy[3] = {ly * ly * a.usq_f[1], 0.f, hy * hy * a.usq_f[1]};
+    const float gz[3] = {lz * lz * a.usq_f[2], 0.f, hz * hz * a.usq_f[2]};
 #pragma unroll
     for (int k = 0; k < 27; ++k)
-      if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_sq) reach |= 1u << k;
+      if (gx[k % 3] + gy[(k / 3) % 3] + gz[k / 9] < a.cull_f) reach |= 1u << k;
   }
   // the cells this point has to look at: inside the node, not later in Morton order, within reach
   uint32_t need = 0;
@@ -440,9 +442,10 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     const double ext[3] = {plan.root.maxx - plan.root.minx, plan.root.maxy - plan.root.miny, plan.root.maxz - plan.root.minz};
     for (int ax = 0; ax < 3; ++ax) {
       const double u = std::ldexp(ext[ax], -(plan.level + 1 + cl + sub));
-      a.usq[ax] = u * u;
+      a.usq_f[ax] = std::nextafterf((float)(u * u), 0.f);
+      if ((double)a.usq_f[ax] > u * u) a.usq_f[ax] = std::nextafterf(a.usq_f[ax], 0.f);
     }
-    a.cull_sq = plan.sq_spacing * (1.0 + 0x1.0p-18);
+    a.cull_f = std::nextafterf((float)(plan.sq_spacing * (1.0 + 0x1.0p-18) * (1.0 + 1e-5)), INFINITY);
   }
   a.taken = lb.taken;
   const uint64_t entries = (uint64_t)sample_nodes * a.cells_per_node;
