@@ -126,6 +126,30 @@ def test_sort_hybrid_top_digits_then_runs(ctx, opts):
             ctx.set_option(k, None)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "clusters", "duplicates", "one_run"])
+def test_sort_large_inputs_choose_their_passes(ctx, kind):
+    """Above 2^24 keys the sort decides by itself (from a sorted sample of the keys) how many top digits to pass over
+    before the run pass, and falls back to eight passes when a run of equal top bits is too long: uniform Morton-like
+    keys (four passes), keys in a few thousand clusters (six), 30 % exact duplicates of one key and all keys equal in
+    their top 40 bits (both: long runs, eight passes after all).  Checked against NumPy's stable argsort."""
+    rng = np.random.default_rng(77)
+    n = (1 << 24) + 12345
+    if kind == "uniform":
+        keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+    elif kind == "clusters":
+        centres = rng.integers(0, 1 << 63, size=4096, dtype=np.uint64) & ~np.uint64((1 << 40) - 1)
+        keys = centres[rng.integers(0, 4096, size=n)] | rng.integers(0, 1 << 40, size=n, dtype=np.uint64)
+    elif kind == "duplicates":
+        keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
+        keys[rng.random(n) < 0.3] = keys[0]
+    else:
+        keys = (np.uint64(0x1234567) << np.uint64(36)) | rng.integers(0, 1 << 23, size=n, dtype=np.uint64)
+    perm, ks = ctx.sort_by_key(keys)
+    want = np.argsort(keys, kind="stable").astype(np.uint32)
+    assert np.array_equal(perm, want)
+    assert np.array_equal(ks, keys[want])
+
+
 # ----------------------------------------------------------------------------------------- sample_points
 def _sorted_cloud(xyz, bmin, bmax):
     keys, clamped = O.index_points(xyz, bmin, bmax)
