@@ -32,6 +32,7 @@ class _TileParams(C.Structure):
                 ("flags", C.c_uint32)]
 
 
+ABI_VERSION = 2  # SWZ_ABI_VERSION of include/swz_gpu.h
 FLAG_MIN_DISTANCE_PROPERTY = 1
 
 
@@ -274,6 +275,9 @@ def load_library():
     L = C.CDLL(path)
     vp = C.c_void_p
     L.swz_abi_version.restype = C.c_int
+    if L.swz_abi_version() != ABI_VERSION:
+        raise OSError("libswz_gpu.so has ABI version %d, this binding is written for %d (include/swz_gpu.h) -- rebuild it "
+                      "with `make -C schwarzwald_amd/csrc`" % (L.swz_abi_version(), ABI_VERSION))
     L.swz_create.argtypes = [C.POINTER(vp), C.c_int]
     L.swz_destroy.argtypes = [vp]
     L.swz_last_error.restype = C.c_char_p
