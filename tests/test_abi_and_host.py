@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol(lib):
     assert len(declared) >= 20
     for name in sorted(declared):
         assert hasattr(lib, name), "libswz_gpu.so does not export %s" % name
-    assert lib.swz_abi_version() == 2 == swz.api.ABI_VERSION
+    import schwarzwald_amd.api as api
+    assert lib.swz_abi_version() == 2 == api.ABI_VERSION
 
 
 def test_no_cpu_fallback_without_device(lib):
