@@ -56,12 +56,11 @@ struct MdArgs {
                        // committed number of accepted points -- one 16-byte load per adjacent cell
   uint32_t* crel;
   uint32_t* csnode;
-  uint32_t* npos;      // pending frontier written by the sweep kernel (what a cell that goes to sleep compares with)
+  uint4* cst;          // per cell {pending frontier written by the sweep kernel (what a cell that goes to sleep compares
+                       // with), stalled candidate, its blocker's rank << 8 | slot, where the blocker scan stopped}: one
+                       // 16-byte record (a scattered load costs a 128-byte line whatever its size: four arrays were four lines)
   uint4* result;       // [queue slot][2]: what the activation in that slot of the round's queue ended with --
                        // {cell, new frontier, new count, status | moved << 8}, {blocking cell, blocking point, its slot, -}
-  uint32_t* blk_p;     // stalled candidate and where its blocker scan stopped (read by the cell's next activation)
-  uint32_t* blk_slot;
-  uint32_t* blk_q;
   uint2* sleeper;      // [cell][28], 27 used: {the adjacent cell in direction k that sleeps on this cell (NONE32 = nobody),
                        // the point it waits for}; a cell is the only writer of its entry and the cell it sleeps on the
                        // only one who clears it
@@ -183,8 +182,7 @@ struct CellBuildG {
     a.cell[c] = make_uint4(i, 0u, i, 0u);
     a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
     a.csnode[c] = a.snode_of[a.nid[i]];
-    a.npos[c] = i;  // the frontier as the round bookkeeping sees it (a cell that never ran has not moved)
-    a.blk_p[c] = NONE32;
+    a.cst[c] = make_uint4(i, NONE32, 0u, 0u);  // the frontier as the round bookkeeping sees it: a cell that never ran has not moved
   }
 };
 
@@ -468,10 +466,11 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
   const uint32_t off = incl - n_cnt;
   const uint32_t T = bcast_u32(incl, WAVE - 1);  // accepted points of the neighbourhood (incl. own committed)
   const uint32_t maxcnt = bcast_u32(md_wave_scan(n_cnt, MdMax{}, 0u), WAVE - 1);
-  const bool resume = a.blk_p[c] == P;
-  const uint32_t r_packed = resume ? a.blk_slot[c] : 0u;
+  const uint4 cst = a.cst[c];
+  const bool resume = cst.y == P;
+  const uint32_t r_packed = resume ? cst.z : 0u;
   const uint32_t r_group = r_packed >> 8;    // rank (scan position) of that cell: earlier ranks were scanned clean
-  const uint32_t r_q = resume ? a.blk_q[c] : 0u;
+  const uint32_t r_q = resume ? cst.w : 0u;
 
   uint32_t wn0 = 0;
   if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
@@ -705,14 +704,13 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
       atomicAdd(&a.counters[CTR_DBG_HIST + 5], dbg_ranks);
     }
 #endif
-    a.npos[c] = out_pos;
     const uint32_t moved = (out_pos > P || out_status == ST_FINISHED) ? 1u : 0u;
     a.result[(size_t)slot * 2] = make_uint4(c, out_pos, CNT + fresh, out_status | (moved << 8));
     if (out_status == ST_STALLED) {
       a.result[(size_t)slot * 2 + 1] = make_uint4(b_cell, b_q, b_slot & 0xFFu, 0u);
-      a.blk_p[c] = out_pos;
-      a.blk_slot[c] = b_slot;
-      a.blk_q[c] = b_q;
+      a.cst[c] = make_uint4(out_pos, out_pos, b_slot, b_q);
+    } else {
+      a.cst[c] = make_uint4(out_pos, NONE32, 0u, 0u);
     }
   }
 }
@@ -791,7 +789,7 @@ __device__ __forceinline__ void md_commit_requeue_range(const MdArgs& a, uint32_
 #pragma unroll
       for (int k = 0; k < 14; ++k) sl[k] = row[k];
     }
-    const uint32_t bpos = stalled ? a.npos[b] : 0u;
+    const uint32_t bpos = stalled ? a.cst[b].x : 0u;
     if (valid) {
       a.cell[c].z = np;
       a.cell[c].w = r0.z;
@@ -1082,10 +1080,11 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   if (ncells == 0) return SWZ_OK;
 
-  uint32_t* cellbuf = nullptr;  // 6 per-cell u32 arrays + the packed {start,end,pos,cnt} records
-  SWZ_TRY(c->get("md_cells", (size_t)ncells * 6, &cellbuf));
-  uint32_t** fields[] = {&a.crel, &a.csnode, &a.npos, &a.blk_p, &a.blk_slot, &a.blk_q};
-  for (size_t f = 0; f < 6; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
+  uint32_t* cellbuf = nullptr;  // 2 per-cell u32 arrays + the packed records
+  SWZ_TRY(c->get("md_cells", (size_t)ncells * 2, &cellbuf));
+  uint32_t** fields[] = {&a.crel, &a.csnode};
+  for (size_t f = 0; f < 2; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
+  SWZ_TRY(c->get("md_cst", (size_t)ncells, &a.cst));
   SWZ_TRY(c->get("md_sleeper", (size_t)ncells * 28, &a.sleeper));  // 27 directions, rows of 14 x 16 bytes
   SWZ_HIP(c, memset_large(a.sleeper, 0xFF, (size_t)ncells * 28 * sizeof(uint2), c->stream));
   SWZ_TRY(c->get("md_result", (size_t)ncells * 2, &a.result));  // a round's queue never holds more than all cells
