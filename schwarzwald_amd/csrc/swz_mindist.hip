@@ -39,6 +39,19 @@ constexpr int MD_FRESH_CAP = 64;  // points a cell may accept per activation
 
 enum : uint32_t { ST_STALLED = 0, ST_FINISHED = 1, ST_YIELD = 2 };
 
+// Everything about a cell that an activation -- its own or an adjacent cell's -- looks at, in ONE 128-byte line (a
+// scattered load costs a 128-byte line of HBM traffic whatever its size, tools/fetch_calib.hip): the record the other
+// cells read, the owner's bookkeeping, and the cell's first accepted points.  A cell as wide as the spacing rarely
+// accepts more than four points, so the accepted points of the neighbourhood usually arrive with the records.
+constexpr uint32_t MD_INLINE = 4;
+struct alignas(128) MdCell {
+  uint4 rec;   // {start, end, pos, cnt}: point range, committed frontier (active index), committed number of accepted points
+  uint4 cst;   // {pending frontier written by the sweep kernel (what a cell that goes to sleep compares with), stalled
+               //  candidate, its blocker's rank << 8 | slot, where the blocker scan stopped}
+  double acc[MD_INLINE][3];  // the first accepted points; the others are in MdArgs::acc_xyz
+};
+static_assert(sizeof(MdCell) == 128, "one cache line");
+
 struct MdArgs {
   const uint64_t* akey;
   const uint32_t* aidx;
@@ -52,19 +65,15 @@ struct MdArgs {
   uint8_t* taken;
   uint32_t* counters;
   // cells
-  uint4* cell;         // per cell {start, end, pos, cnt}: point range, committed frontier (active index),
-                       // committed number of accepted points -- one 16-byte load per adjacent cell
+  MdCell* cells;
   uint32_t* crel;
   uint32_t* csnode;
-  uint4* cst;          // per cell {pending frontier written by the sweep kernel (what a cell that goes to sleep compares
-                       // with), stalled candidate, its blocker's rank << 8 | slot, where the blocker scan stopped}: one
-                       // 16-byte record (a scattered load costs a 128-byte line whatever its size: four arrays were four lines)
   uint4* result;       // [queue slot][2]: what the activation in that slot of the round's queue ended with --
                        // {cell, new frontier, new count, status | moved << 8}, {blocking cell, blocking point, its slot, -}
   uint2* sleeper;      // [cell][28], 27 used: {the adjacent cell in direction k that sleeps on this cell (NONE32 = nobody),
                        // the point it waits for}; a cell is the only writer of its entry and the cell it sleeps on the
                        // only one who clears it
-  double* acc_xyz;     // per cell: positions of its accepted points, 3 doubles each, at slots [start, start+cnt)
+  double* acc_xyz;     // per cell: positions of its accepted points from the fifth on, 3 doubles each, at slots [start, start+cnt)
   uint32_t* gridmap;   // [sample node][cell code] -> cell index (build time only)
   // per cell, built once: its earlier adjacent cells, latest (largest Morton code) first
   uint32_t* nbr_id;    // [cell][27] cell index per rank
@@ -179,20 +188,20 @@ struct CellBuildG {
   MdArgs a;
   __device__ void operator()(uint32_t i, uint32_t c, uint32_t head) const {
     if (!head) return;
-    a.cell[c] = make_uint4(i, 0u, i, 0u);
+    a.cells[c].rec = make_uint4(i, 0u, i, 0u);
     a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
     a.csnode[c] = a.snode_of[a.nid[i]];
-    a.cst[c] = make_uint4(i, NONE32, 0u, 0u);  // the frontier as the round bookkeeping sees it: a cell that never ran has not moved
+    a.cells[c].cst = make_uint4(i, NONE32, 0u, 0u);  // the frontier as the round bookkeeping sees it: a cell that never ran has not moved
   }
 };
 
 __global__ __launch_bounds__(256) void md_cell_end_kernel(MdArgs a, uint32_t ncells) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   if (c >= ncells) return;
-  const uint32_t s = a.cell[c].x;
+  const uint32_t s = a.cells[c].rec.x;
   const uint32_t node_end = a.nstart[a.nid[s] + 1];
-  const uint32_t next = (c + 1 < ncells) ? a.cell[c + 1].x : a.m;
-  a.cell[c].y = next < node_end ? next : node_end;
+  const uint32_t next = (c + 1 < ncells) ? a.cells[c + 1].rec.x : a.m;
+  a.cells[c].rec.y = next < node_end ? next : node_end;
   a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + a.crel[c]] = c;
 }
 
@@ -303,7 +312,7 @@ struct MdLds {
 // Fills the LDS window [base, base + MD_EXT_CAP) of the flattened list of accepted points of the
 // neighbourhood (lane k < 27 owns the n_cnt entries of adjacent cell k starting at list offset off).
 __device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, uint32_t base, uint32_t T,
-                                                   uint32_t maxcnt, uint32_t n_cnt, uint32_t n_start, uint32_t off) {
+                                                   uint32_t maxcnt, uint32_t n_cnt, uint32_t n_start, uint32_t off, uint32_t nb) {
   const uint32_t l = lane_id();
   const uint32_t wn = (T - base) < (uint32_t)MD_EXT_CAP ? (T - base) : (uint32_t)MD_EXT_CAP;
   // which adjacent cell owns list entry ti: lane k marks its entries, then every lane fetches whole
@@ -318,9 +327,10 @@ __device__ __forceinline__ uint32_t md_fill_window(const MdArgs& a, MdLds& lds, 
   __builtin_amdgcn_wave_barrier();
   for (uint32_t ti = l; ti < ((wn + WAVE - 1) / WAVE) * WAVE; ti += WAVE) {
     const uint32_t k = ti < wn ? lds.owner[ti] : 0u;
-    const uint32_t ks = __shfl(n_start, (int)k, WAVE), ko = __shfl(off, (int)k, WAVE);
+    const uint32_t ks = __shfl(n_start, (int)k, WAVE), ko = __shfl(off, (int)k, WAVE), kb = __shfl(nb, (int)k, WAVE);
     if (ti < wn) {
-      const double* src = a.acc_xyz + (size_t)(ks + (base + ti - ko)) * 3;
+      const uint32_t j = base + ti - ko;  // the cell's j-th accepted point: in its record, or in the overflow array
+      const double* src = j < MD_INLINE ? &a.cells[kb].acc[j][0] : a.acc_xyz + (size_t)(ks + j) * 3;
       lds.ex[ti] = src[0];
       lds.ey[ti] = src[1];
       lds.ez[ti] = src[2];
@@ -415,7 +425,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
 #ifdef SWZ_MD_STATS
   const uint64_t dbg_t0 = wall_clock64();
 #endif
-  const uint4 me = a.cell[c];
+  const uint4 me = a.cells[c].rec;
   const uint32_t s0 = me.x, e = me.y;
   const double t = opaque(a.sq_spacing);
   const uint32_t P = me.z, CNT = me.w;
@@ -451,7 +461,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
     nb = raw_nb;
     slot_of_rank = raw_slot;
     earlier = true;
-    const uint4 o = a.cell[nb];
+    const uint4 o = a.cells[nb].rec;
     n_start = o.x;
     n_end = o.y;
     n_pos = o.z;
@@ -466,14 +476,14 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
   const uint32_t off = incl - n_cnt;
   const uint32_t T = bcast_u32(incl, WAVE - 1);  // accepted points of the neighbourhood (incl. own committed)
   const uint32_t maxcnt = bcast_u32(md_wave_scan(n_cnt, MdMax{}, 0u), WAVE - 1);
-  const uint4 cst = a.cst[c];
+  const uint4 cst = a.cells[c].cst;
   const bool resume = cst.y == P;
   const uint32_t r_packed = resume ? cst.z : 0u;
   const uint32_t r_group = r_packed >> 8;    // rank (scan position) of that cell: earlier ranks were scanned clean
   const uint32_t r_q = resume ? cst.w : 0u;
 
   uint32_t wn0 = 0;
-  if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off);
+  if (T > 0) wn0 = md_fill_window(a, lds, 0, T, maxcnt, n_cnt, n_start, off, nb);
 
   // the whole list of accepted points is resident in LDS: blocker scans can tell dead points
   const uint32_t live_wn = (T <= (uint32_t)MD_EXT_CAP && !(a.ablate & 8u)) ? wn0 : 0u;
@@ -532,7 +542,7 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
     for (uint32_t base = 0; base < T && !(a.ablate & 2u); base += MD_EXT_CAP) {
       const uint32_t wn = (base == 0 && T <= (uint32_t)MD_EXT_CAP && cur == P)
                             ? wn0
-                            : ((T <= (uint32_t)MD_EXT_CAP) ? wn0 : md_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off));
+                            : ((T <= (uint32_t)MD_EXT_CAP) ? wn0 : md_fill_window(a, lds, base, T, maxcnt, n_cnt, n_start, off, nb));
       rej |= md_near_any(lds.ex, lds.ey, lds.ez, wn, px, py, pz, t);
       if (!__ballot(!rej)) break;
     }
@@ -665,7 +675,8 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
       // accepted
       if ((int)l == j) {
         a.taken[cand] = 1;
-        double* dst = a.acc_xyz + (size_t)(s0 + CNT + fresh) * 3;
+        const uint32_t ai = CNT + fresh;
+        double* dst = ai < MD_INLINE ? &a.cells[c].acc[ai][0] : a.acc_xyz + (size_t)(s0 + ai) * 3;
         dst[0] = px;
         dst[1] = py;
         dst[2] = pz;
@@ -708,9 +719,9 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
     a.result[(size_t)slot * 2] = make_uint4(c, out_pos, CNT + fresh, out_status | (moved << 8));
     if (out_status == ST_STALLED) {
       a.result[(size_t)slot * 2 + 1] = make_uint4(b_cell, b_q, b_slot & 0xFFu, 0u);
-      a.cst[c] = make_uint4(out_pos, out_pos, b_slot, b_q);
+      a.cells[c].cst = make_uint4(out_pos, out_pos, b_slot, b_q);
     } else {
-      a.cst[c] = make_uint4(out_pos, NONE32, 0u, 0u);
+      a.cells[c].cst = make_uint4(out_pos, NONE32, 0u, 0u);
     }
   }
 }
@@ -789,10 +800,10 @@ __device__ __forceinline__ void md_commit_requeue_range(const MdArgs& a, uint32_
 #pragma unroll
       for (int k = 0; k < 14; ++k) sl[k] = row[k];
     }
-    const uint32_t bpos = stalled ? a.cst[b].x : 0u;
+    const uint32_t bpos = stalled ? a.cells[b].cst.x : 0u;
     if (valid) {
-      a.cell[c].z = np;
-      a.cell[c].w = r0.z;
+      a.cells[c].rec.z = np;
+      a.cells[c].rec.w = r0.z;
     }
     const uint64_t fm = __ballot(fin);
     if (fm && lane_id() == 0) atomicAdd(&a.counters[CTR_DONE_CELLS], (uint32_t)__popcll(fm));
@@ -930,7 +941,7 @@ __global__ __launch_bounds__(256) void md_lazy_start_kernel(MdArgs a, uint32_t n
       push = true;
     } else {
       const uint32_t b = a.nbr_id[(size_t)c * 27];
-      const uint4 o = a.cell[b];
+      const uint4 o = a.cells[b].rec;
       const uint32_t bq = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
       a.sleeper[(size_t)b * 28 + (26u - a.nbr_slot[(size_t)c * 32])] = make_uint2(c, bq);
     }
@@ -1084,11 +1095,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_TRY(c->get("md_cells", (size_t)ncells * 2, &cellbuf));
   uint32_t** fields[] = {&a.crel, &a.csnode};
   for (size_t f = 0; f < 2; ++f) *fields[f] = cellbuf + f * (size_t)ncells;
-  SWZ_TRY(c->get("md_cst", (size_t)ncells, &a.cst));
   SWZ_TRY(c->get("md_sleeper", (size_t)ncells * 28, &a.sleeper));  // 27 directions, rows of 14 x 16 bytes
   SWZ_HIP(c, memset_large(a.sleeper, 0xFF, (size_t)ncells * 28 * sizeof(uint2), c->stream));
   SWZ_TRY(c->get("md_result", (size_t)ncells * 2, &a.result));  // a round's queue never holds more than all cells
-  SWZ_TRY(c->get("md_cell4", (size_t)ncells, &a.cell));
+  SWZ_TRY(c->get("md_cell128", (size_t)ncells, &a.cells));
   SWZ_TRY(c->get("md_nbr_id", (size_t)ncells * 27, &a.nbr_id));
   SWZ_TRY(c->get("md_nbr_slot", (size_t)ncells * 32, &a.nbr_slot));
   SWZ_TRY(c->get("md_acc", (size_t)m * 4, &a.acc_xyz));  // 3 doubles per point used (see md_pos above)
