@@ -39,19 +39,25 @@ else:
 # (templated kernels are listed as "void swz::md_sweep_kernel<1, false>"; the fused cell scan belongs to the class too)
 md_k, md_b = bytes_of(lambda k: "swz::md_" in k or "swz::sp_" in k or "swz::CellHeadF" in k)
 rs_k, rs_b = bytes_of(lambda k: k in ("swz::radix_scatter_kernel", "swz::radix_onesweep_kernel"))
+# launches of the scatter kernel in the profiled step: the passes over the whole input (the eight tiny passes that sort
+# the sample which picks the number of top digits do not count)
+rs_disp = sum(fetch.get(k, (0, 0))[0] for k in rs_k)
+rs_launches = rs_disp - 8 if rs_disp > 8 else max(1, rs_disp)
 md_lo = sum((fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1]) * 1024.0 for k in md_k)
 out = {
     "points": points, "sampler": "MIN_DISTANCE",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0`; "
               "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md); "
-              "check: corrected reads of the radix histogram kernel / its exact key bytes = %.4f.  The factor 2 is calibrated "
-              "for wide coalesced loads only: for the scattered 8-byte loads of the MIN_DISTANCE kernels it is an UPPER bound; "
-              "FETCH_SIZE + WRITE_SIZE uncorrected (a lower bound) is given as bytes_per_launch_lower_bound" % calib,
-    "bytes_per_launch": {"sample_min_distance": md_b / levels, "radix_scatter": rs_b / 8},
+              "check: corrected reads of the radix histogram kernel / its exact key bytes = %.4f.  The factor 2 also holds for "
+              "scattered 8-byte loads (tools/fetch_calib.hip: 268 M loads in 268 M different lines -> FETCH_SIZE 16 GiB, "
+              "TCC_EA0_RDREQ_128B one per load: the L2 reads whole 128-byte lines, also for non-temporal and agent-scope "
+              "atomic loads), so bytes_per_launch is the traffic, not an upper bound; the uncorrected sum is kept as "
+              "bytes_per_launch_lower_bound for comparison with round 1" % calib,
+    "bytes_per_launch": {"sample_min_distance": md_b / levels, "radix_scatter": rs_b / rs_launches},
     "bytes_per_launch_lower_bound": {"sample_min_distance": md_lo / levels},
     "detail": {
         "sample_min_distance": {"kernels": md_k, "launches_per_step": levels, "bytes_per_step": md_b},
-        "radix_scatter": {"kernels": rs_k, "launches_per_step": 8, "bytes_per_step": rs_b},
+        "radix_scatter": {"kernels": rs_k, "launches_per_step": rs_launches, "bytes_per_step": rs_b},
     },
 }
 json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
