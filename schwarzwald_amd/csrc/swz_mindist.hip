@@ -498,35 +498,29 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
   uint32_t b_slot = 0, b_q = 0, b_cell = 0;
   bool stop = false;
 
-  // Large cells: stretches in which every point is already rejected -- by the committed accepted points of the
-  // neighbourhood or by the ones accepted earlier in this activation -- are skipped four chunks per memory round trip.
-  // Tried at the start of a cell with many points left, and again after every chunk that had no survivor (after the
-  // first accepted points of a cell most of what follows is covered).
-  bool ff_try = U > 1 && live_wn && e - cur > a.ff_min && !(a.ablate & 16u);
+  // Very large cells (dense blobs: thousands of points per cell): skip stretches in which every point is already
+  // rejected by the committed accepted points, four chunks per memory round trip.
+  if (U > 1 && live_wn && e - cur > a.ff_min && !(a.ablate & 16u)) {
+    while (e - cur > 4u * WAVE) {
+      double x[4], y[4], z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t q = cur + (uint32_t)u * WAVE + l;
+        x[u] = a.X[q];
+        y[u] = a.Y[q];
+        z[u] = a.Z[q];
+      }
+      bool alive_l = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        alive_l |= !md_near_any(lds.ex, lds.ey, lds.ez, live_wn, x[u], y[u], z[u], t);
+      }
+      if (__ballot(alive_l)) break;
+      cur += 4u * WAVE;
+    }
+  }
 
   while (cur < e && !stop) {
-    if (U > 1 && ff_try) {
-      ff_try = false;
-      while (e - cur > 4u * WAVE) {
-        double x[4], y[4], z[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint32_t q = cur + (uint32_t)u * WAVE + l;
-          x[u] = a.X[q];
-          y[u] = a.Y[q];
-          z[u] = a.Z[q];
-        }
-        uint32_t first_alive = 4;  // first of the four chunks that has a survivor
-#pragma unroll
-        for (int u = 3; u >= 0; --u) {
-          const bool alive_l = !md_near_any(lds.ex, lds.ey, lds.ez, live_wn, x[u], y[u], z[u], t) &&
-                               !md_near_any(lds.fx, lds.fy, lds.fz, fresh, x[u], y[u], z[u], t);
-          if (__ballot(alive_l)) first_alive = (uint32_t)u;
-        }
-        cur += first_alive * WAVE;
-        if (first_alive < 4u) break;
-      }
-    }
 #ifdef SWZ_MD_STATS
     const uint64_t dbg_tc = wall_clock64();
 #endif
@@ -556,7 +550,6 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
     rej |= md_near_any(lds.fx, lds.fy, lds.fz, fresh, px, py, pz, t);
 
     uint64_t alive = __ballot(!rej);
-    if (U > 1 && !alive && live_wn && !(a.ablate & 16u)) ff_try = true;
 #ifdef SWZ_MD_STATS
     dbg_tchunk += wall_clock64() - dbg_tc;
 #endif
