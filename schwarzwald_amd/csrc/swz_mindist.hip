@@ -15,8 +15,8 @@
 //   (R) a point closer than the spacing to an already accepted earlier point is rejected;
 //   (A) a surviving point is accepted once no possibly-undecided earlier point (a point at or behind
 //       the frontier of an earlier adjacent cell) is closer than the spacing -- otherwise the cell
-//       stalls on that point and sleeps on the blocking cell's wait list until its frontier passed it.
-// Rounds read only state committed by earlier launches (pos/acc_cnt are published by a commit kernel),
+//       stalls on that point and sleeps on the blocking cell (one of its 27 sleeper slots) until its frontier passed it.
+// Rounds read only state committed by earlier launches (pos/acc_cnt are published by the second launch of a round),
 // so a stale view is merely conservative.  Decisions follow exactly the reference's distance compares,
 // hence the accepted set is bit-identical; the number of rounds is the true dependency depth of the
 // greedy sweep instead of the length of the cell adjacency chains.
