@@ -76,22 +76,33 @@ struct Box {  // AABB, core/math/AABB.h
 // get_bounds_from_morton_index(key, root, depth) -- core/tiling/OctreeAlgorithms.h:104-116 with
 // get_octant_bounds -- OctreeAlgorithms.cpp:3-18 iterated: min' = bit ? min + extent/2 : min,
 // max' = min' + extent/2, per axis, never a closed form (bit-exactness checklist item 5).
+__device__ __host__ __forceinline__ void box_descend(Box& b, uint32_t o) {
+  const double ex = b.maxx - b.minx, ey = b.maxy - b.miny, ez = b.maxz - b.minz;
+  const double nz = (o & 1u) ? (b.minz + ez / 2) : b.minz;
+  const double ny = (o & 2u) ? (b.miny + ey / 2) : b.miny;
+  const double nx = (o & 4u) ? (b.minx + ex / 2) : b.minx;
+  b.minx = nx;
+  b.miny = ny;
+  b.minz = nz;
+  b.maxx = nx + ex / 2;
+  b.maxy = ny + ey / 2;
+  b.maxz = nz + ez / 2;
+}
 __device__ __host__ __forceinline__ Box bounds_from_key(uint64_t key, const Box& root, int depth) {
   Box b = root;
-  for (int level = 0; level < depth; ++level) {
-    const uint32_t o = (uint32_t)(key >> level_shift(level)) & 7u;
-    const double ex = b.maxx - b.minx, ey = b.maxy - b.miny, ez = b.maxz - b.minz;
-    const double nz = (o & 1u) ? (b.minz + ez / 2) : b.minz;
-    const double ny = (o & 2u) ? (b.miny + ey / 2) : b.miny;
-    const double nx = (o & 4u) ? (b.minx + ex / 2) : b.minx;
-    b.minx = nx;
-    b.miny = ny;
-    b.minz = nz;
-    b.maxx = nx + ex / 2;
-    b.maxy = ny + ey / 2;
-    b.maxz = nz + ez / 2;
-  }
+  for (int level = 0; level < depth; ++level) box_descend(b, (uint32_t)(key >> level_shift(level)) & 7u);
   return b;
+}
+// The same for N keys at once: N independent chains of dependent f64 operations in one loop.
+template <int N>
+__device__ __forceinline__ void bounds_from_keys(const uint64_t (&key)[N], const Box& root, int depth, Box (&b)[N]) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) b[j] = root;
+  for (int level = 0; level < depth; ++level) {
+    const uint32_t sh = level_shift(level);
+#pragma unroll
+    for (int j = 0; j < N; ++j) box_descend(b[j], (uint32_t)(key[j] >> sh) & 7u);
+  }
 }
 
 // Vector3::squaredDistanceTo -- core/math/Vector3.h:55-62: (dx*dx + dy*dy) + dz*dz, no FMA

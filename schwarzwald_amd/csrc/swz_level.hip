@@ -47,6 +47,10 @@ struct KeepF {
   const uint8_t* taken;
   __device__ uint32_t operator()(uint32_t i) const { return taken[i] ? 0u : 1u; }
 };
+template <>
+struct FsCountsZeroBytes<KeepF> {
+  static constexpr bool value = true;
+};
 struct CompactG {
   const uint64_t* akey;
   const uint32_t* aidx;
@@ -159,25 +163,44 @@ struct Agg {
 __device__ __forceinline__ bool agg_less(double d1, uint32_t i1, double d2, uint32_t i2) {
   return d1 < d2 || (d1 == d2 && i1 < i2);
 }
-__device__ __forceinline__ Agg agg_combine(const Agg& a, const Agg& b) {  // a covers earlier points than b
-  if (b.f) return b;
+__device__ __forceinline__ Agg agg_combine(Agg a, Agg b) {  // a covers earlier points than b
+  const bool take_b = b.f != 0 || agg_less(b.d, b.i, a.d, a.i);  // selects only: no branches, nothing on the stack
   Agg r;
-  r.f = a.f;
-  if (agg_less(b.d, b.i, a.d, a.i)) {
-    r.d = b.d;
-    r.i = b.i;
-  } else {
-    r.d = a.d;
-    r.i = a.i;
-  }
+  r.d = take_b ? b.d : a.d;
+  r.i = take_b ? b.i : a.i;
+  r.f = a.f | b.f;
   return r;
 }
-__device__ __forceinline__ Agg agg_shfl_up(const Agg& a, int delta) {
+__device__ __forceinline__ Agg agg_shfl_up(Agg a, int delta) {
   Agg r;
   r.d = __shfl_up(a.d, delta, WAVE);
   r.i = __shfl_up(a.i, delta, WAVE);
   r.f = __shfl_up(a.f, delta, WAVE);
   return r;
+}
+// One step of the wave's inclusive scan over DPP: the aggregate of the lanes the control word names (the identity
+// where it names none) combined in front of the lane's own.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ Agg agg_dpp_step(Agg v) {
+  const uint64_t db = (uint64_t)__double_as_longlong(v.d);
+  const uint64_t inf = 0x7FF0000000000000ull;
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)inf, (int)(uint32_t)db, CTRL, ROW_MASK, 0xF, false);
+  const uint32_t hi =
+    (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(inf >> 32), (int)(uint32_t)(db >> 32), CTRL, ROW_MASK, 0xF, false);
+  Agg o;
+  o.d = __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+  o.i = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v.i, CTRL, ROW_MASK, 0xF, false);
+  o.f = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.f, CTRL, ROW_MASK, 0xF, false);
+  return agg_combine(o, v);
+}
+__device__ __forceinline__ Agg agg_wave_incl_scan(Agg v) {
+  v = agg_dpp_step<0x111, 0xF>(v);  // row_shr:1
+  v = agg_dpp_step<0x112, 0xF>(v);  // row_shr:2
+  v = agg_dpp_step<0x114, 0xF>(v);  // row_shr:4
+  v = agg_dpp_step<0x118, 0xF>(v);  // row_shr:8
+  v = agg_dpp_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v = agg_dpp_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
 }
 
 struct TileSummary {
@@ -208,21 +231,24 @@ __device__ __forceinline__ uint32_t prev_pow2(uint32_t x) {
   return x - (x >> 1);
 }
 
-// Cell prefix shift and sampling target of the cell that `key` falls in.  Returns an SWZ_ERR_* code
-// (JITTERED only) or 0.
-__device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, uint32_t& csh, double& tx,
+// Depth of the bounds chain cell_target starts from: the candidate cell (GRID_CENTER) or the node (JITTERED).
+__device__ __forceinline__ int cell_box_depth(const GridParams& g) {
+  return g.sampler == SWZ_GRID_CENTER ? g.cand + 1 : g.level + 1;
+}
+// Cell prefix shift and sampling target of the cell that `key` falls in; `kb` = bounds_from_key(key, g.root,
+// cell_box_depth(g)).  Returns an SWZ_ERR_* code (JITTERED only) or 0.
+__device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, const Box& kb, uint32_t& csh, double& tx,
                                            double& ty, double& tz) {
   if (g.sampler == SWZ_GRID_CENTER) {
     // GridCenterSampling, Sampling.h:387-390: centre of get_bounds_from_morton_index(key, root, cand + 1)
     csh = level_shift(g.cand);
-    const Box b = bounds_from_key(key, g.root, g.cand + 1);
-    tx = b.minx + (b.maxx - b.minx) / 2;  // AABB::getCenter, AABB.h:70
-    ty = b.miny + (b.maxy - b.miny) / 2;
-    tz = b.minz + (b.maxz - b.minz) / 2;
+    tx = kb.minx + (kb.maxx - kb.minx) / 2;  // AABB::getCenter, AABB.h:70
+    ty = kb.miny + (kb.maxy - kb.miny) / 2;
+    tz = kb.minz + (kb.maxz - kb.minz) / 2;
     return 0;
   }
   // JitteredSampling, Sampling.h:621-739
-  const Box nb = bounds_from_key(key, g.root, g.level + 1);
+  const Box& nb = kb;
   const double ext_x = nb.maxx - nb.minx;
   const double perfect = ext_x / g.spacing_node;
   const uint32_t perfect_u = perfect >= 4294967295.0 ? 4294967295u : (uint32_t)perfect;
@@ -262,7 +288,10 @@ __device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, ui
   return 0;
 }
 
-__global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
+#ifndef SWZ_GA_MINW
+#define SWZ_GA_MINW 1
+#endif
+__global__ __launch_bounds__(GA_THREADS, SWZ_GA_MINW) void grid_argmin_kernel(
   const uint64_t* __restrict__ akey, const uint32_t* __restrict__ aidx, uint32_t m, const uint32_t* __restrict__ nid,
   const uint8_t* __restrict__ nmode, const double* __restrict__ X, const double* __restrict__ Y,
   const double* __restrict__ Z, GridParams g, uint32_t node_shift, uint8_t* __restrict__ taken,
@@ -275,14 +304,63 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
   const uint32_t first = tile_base + tid * GA_IPT;
   const bool all_sampled = counters[CTR_SAMPLE_NODES] == counters[CTR_NUM_NODES];  // then nobody looks at nid / nmode
 
-  double dist[GA_IPT];
-  bool head[GA_IPT];
+  // Every load an item needs is issued before the arithmetic starts: the bounds chain below is a loop of dependent
+  // f64 operations, and the loads of the next item must not queue up behind it.
+  uint64_t key[GA_IPT];
+  uint32_t spos[GA_IPT];
+  bool sample[GA_IPT];
+  double px[GA_IPT], py[GA_IPT], pz[GA_IPT];
   uint64_t prev_key = 0;
   bool have_prev = false;
   if (first < tile_end && first > 0) {
     prev_key = akey[first - 1];
     have_prev = true;
   }
+  if (GA_IPT == 2 && first + 2 <= tile_end) {  // the usual case: two-item vector loads
+    const ulonglong2 k2 = *reinterpret_cast<const ulonglong2*>(akey + first);
+    key[0] = k2.x;
+    key[GA_IPT - 1] = k2.y;
+    if (aidx) {
+      const uint2 p2 = *reinterpret_cast<const uint2*>(aidx + first);
+      spos[0] = p2.x;
+      spos[GA_IPT - 1] = p2.y;
+    } else {
+      spos[0] = first;
+      spos[GA_IPT - 1] = first + 1;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GA_IPT; ++j) {
+      const uint32_t gc = first + j < tile_end ? first + j : last_valid;
+      key[j] = akey[gc];
+      spos[j] = spos_of(aidx, gc);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gc = first + j < tile_end ? first + j : last_valid;
+    sample[j] = all_sampled || nmode[nid[gc]] == MODE_SAMPLE;
+  }
+  if (GA_IPT == 2 && first + 2 <= tile_end && !aidx) {
+    const double2 x2 = *reinterpret_cast<const double2*>(X + first);
+    const double2 y2 = *reinterpret_cast<const double2*>(Y + first);
+    const double2 z2 = *reinterpret_cast<const double2*>(Z + first);
+    px[0] = x2.x, px[GA_IPT - 1] = x2.y;
+    py[0] = y2.x, py[GA_IPT - 1] = y2.y;
+    pz[0] = z2.x, pz[GA_IPT - 1] = z2.y;
+  } else {
+#pragma unroll
+    for (int j = 0; j < GA_IPT; ++j) {
+      px[j] = X[spos[j]];
+      py[j] = Y[spos[j]];
+      pz[j] = Z[spos[j]];
+    }
+  }
+  Box kb[GA_IPT];
+  bounds_from_keys<GA_IPT>(key, g.root, cell_box_depth(g), kb);
+
+  double dist[GA_IPT];
+  bool head[GA_IPT];
   uint32_t last_csh = node_shift;  // shift of the last valid item (for the last_open test)
   uint64_t last_key = 0;
   bool any_head = false;
@@ -292,27 +370,25 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
     dist[j] = __builtin_inf();
     head[j] = false;
     if (gi < tile_end) {
-      const uint64_t key = akey[gi];
       uint32_t csh = node_shift;
-      if (all_sampled || nmode[nid[gi]] == MODE_SAMPLE) {
+      if (sample[j]) {
         double tx, ty, tz;
-        const int err = cell_target(g, key, csh, tx, ty, tz);
+        const int err = cell_target(g, key[j], kb[j], csh, tx, ty, tz);
         if (err) {
           atomicMax(&counters[CTR_ERROR], (uint32_t)err);
           csh = node_shift;
         } else {
-          const uint32_t p = spos_of(aidx, gi);
-          dist[j] = sq_dist(X[p], Y[p], Z[p], tx, ty, tz);
+          dist[j] = sq_dist(px[j], py[j], pz[j], tx, ty, tz);
         }
       } else {
         taken[gi] = 1;  // take-all node
       }
-      head[j] = !have_prev || ((key >> csh) != (prev_key >> csh));
+      head[j] = !have_prev || ((key[j] >> csh) != (prev_key >> csh));
       any_head |= head[j];
-      prev_key = key;
+      prev_key = key[j];
       have_prev = true;
       last_csh = csh;
-      last_key = key;
+      last_key = key[j];
     }
   }
 
@@ -332,18 +408,23 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_kernel(
       }
     }
   }
-  Agg incl = a;
-#pragma unroll
-  for (int delta = 1; delta < WAVE; delta <<= 1) {
-    const Agg o = agg_shfl_up(incl, delta);
-    if (l >= (uint32_t)delta) incl = agg_combine(o, incl);
-  }
+  const Agg incl = agg_wave_incl_scan(a);
   if (l == WAVE - 1) wave_tot[w] = incl;
-  Agg excl = agg_shfl_up(incl, 1);
-  if (l == 0) excl = Agg{__builtin_inf(), NONE, 0};
+  const Agg up = agg_shfl_up(incl, 1);
+  Agg excl;
+  excl.d = l == 0 ? __builtin_inf() : up.d;
+  excl.i = l == 0 ? NONE : up.i;
+  excl.f = l == 0 ? 0u : up.f;
   const int tile_has_start = __syncthreads_or(any_head ? 1 : 0);
   Agg carry{__builtin_inf(), NONE, 0};
-  for (uint32_t i = 0; i < w; ++i) carry = agg_combine(carry, wave_tot[i]);
+#pragma unroll
+  for (uint32_t i = 0; i + 1 < (uint32_t)(GA_THREADS / WAVE); ++i) {
+    const Agg t = wave_tot[i];
+    const Agg cc = agg_combine(carry, t);
+    carry.d = i < w ? cc.d : carry.d;
+    carry.i = i < w ? cc.i : carry.i;
+    carry.f = i < w ? cc.f : carry.f;
+  }
   carry = agg_combine(carry, excl);
 
   // second pass: close runs, emit winners / partial aggregates
