@@ -95,25 +95,27 @@ __global__ __launch_bounds__(256) void node_mode_kernel(const uint32_t* __restri
                                                         uint64_t max_points, int force_sample, int terminal,
                                                         int reroot, const uint64_t* __restrict__ akey, uint32_t nsh,
                                                         const uint64_t* __restrict__ ckey, uint32_t nc) {
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= counters[CTR_NUM_NODES]) return;
-  const uint32_t cnt = nstart[j + 1] - nstart[j];
-  bool cached = false;  // previously_taken_points_count > 0 (TilingAlgorithms.cpp:272-275)
-  if (nc) {
-    const uint64_t prefix = akey[nstart[j]] >> nsh;
-    uint32_t lo = 0, hi = nc;
-    while (lo < hi) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      if ((ckey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
+  // grid-stride over the nodes: their number is only known on the device, and it is small next to the points
+  const uint32_t nnodes = counters[CTR_NUM_NODES];
+  for (uint32_t j = blockIdx.x * 256 + threadIdx.x; j < nnodes; j += gridDim.x * 256u) {
+    const uint32_t cnt = nstart[j + 1] - nstart[j];
+    bool cached = false;  // previously_taken_points_count > 0 (TilingAlgorithms.cpp:272-275)
+    if (nc) {
+      const uint64_t prefix = akey[nstart[j]] >> nsh;
+      uint32_t lo = 0, hi = nc;
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if ((ckey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
+      }
+      cached = lo < nc && (ckey[lo] >> nsh) == prefix;
     }
-    cached = lo < nc && (ckey[lo] >> nsh) == prefix;
-  }
-  const bool sample = !terminal && (force_sample || cached || (uint64_t)cnt > max_points);
-  nmode[j] = sample ? MODE_SAMPLE : MODE_TAKE_ALL;
-  if (sample) {
-    if (reroot) atomicMax(&counters[CTR_ERROR], (uint32_t)SWZ_ERR_REROOT_UNSUPPORTED);
-    atomicAdd(&counters[CTR_SAMPLE_NODES], 1u);
-    atomicAdd(&counters[CTR_SAMPLE_POINTS], cnt);
+    const bool sample = !terminal && (force_sample || cached || (uint64_t)cnt > max_points);
+    nmode[j] = sample ? MODE_SAMPLE : MODE_TAKE_ALL;
+    if (sample) {
+      if (reroot) atomicMax(&counters[CTR_ERROR], (uint32_t)SWZ_ERR_REROOT_UNSUPPORTED);
+      atomicAdd(&counters[CTR_SAMPLE_NODES], 1u);
+      atomicAdd(&counters[CTR_SAMPLE_POINTS], cnt);
+    }
   }
 }
 
@@ -622,7 +624,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     ProfScope ps(c, "level_nodes", (uint64_t)m * 8ull, 3);
     SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
                        lb.counters + CTR_NUM_NODES, "lvl"));
-    hipLaunchKernelGGL(node_mode_kernel, dim3(nb), dim3(256), 0, c->stream, lb.nstart, lb.nmode, lb.counters,
+    hipLaunchKernelGGL(node_mode_kernel, dim3(std::min(nb, 2048u)), dim3(256), 0, c->stream, lb.nstart, lb.nmode, lb.counters,
                        plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0, as.akey,
                        plan.node_shift, as.ckey, as.nc);
     SWZ_LAUNCH_CHECK(c);
