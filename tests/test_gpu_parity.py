@@ -255,6 +255,25 @@ def test_tile_accurate_matches_oracle(ctx, sampler, kind, n, max_pts, d):
     assert g.stats["max_level"] == o["stats"]["max_level"]
 
 
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("n", [70001, 131073])
+def test_tile_odd_counts_and_arbitrary_bounds(ctx, sampler, n):
+    """Odd point counts (the y and z columns of the sorted positions then start 8 bytes off a 16-byte boundary, the
+    last thread of the grid samplers holds one point) in root bounds whose halving chain rounds at every level."""
+    rng = np.random.default_rng(n)
+    bmin = [512345.678, -1234.5678901, 98.7654321]
+    side = 123.456789
+    bmax = [bmin[0] + side, bmin[1] + side, bmin[2] + side]
+    xyz = np.array(bmin) + rng.random((n, 3)) * side
+    spacing = O.spacing_from_diagonal(bmin, bmax, 100)
+    o, g = _tile_both(ctx, xyz, bmin, bmax, sampler, 700, spacing)
+    assert o["status"] == 0
+    assert np.array_equal(g.keys, o["keys"])
+    assert np.array_equal(g.perm, o["perm"])
+    assert np.array_equal(g.level, o["level"])
+    assert g.stats["num_nodes"] == o["stats"]["num_nodes"]
+
+
 def test_tile_max_depth_makes_terminal_nodes(ctx):
     rng = np.random.default_rng(8)
     xyz = rng.random((100000, 3))
