@@ -42,6 +42,11 @@ struct NodeAssignG {
     if (i == m - 1) nstart[id + 1] = m;
   }
 };
+__global__ void single_node_kernel(uint32_t* __restrict__ nstart, uint32_t* __restrict__ num_nodes, uint32_t m) {
+  nstart[0] = 0;
+  nstart[1] = m;
+  *num_nodes = 1;
+}
 // fused stable compaction: survivors move to the next level's active set, taken points get their level
 struct KeepF {
   const uint8_t* taken;
@@ -622,8 +627,15 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
   SWZ_HIP(c, hipMemsetAsync(lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
   {
     ProfScope ps(c, "level_nodes", (uint64_t)m * 8ull, 3);
-    SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
-                       lb.counters + CTR_NUM_NODES, "lvl"));
+    if (plan.node_shift >= 63u && m > 0) {
+      // the root (Morton keys have 63 bits): one node, nothing to segment -- two passes over the keys saved
+      SWZ_HIP(c, hipMemsetAsync(lb.nid, 0, (size_t)m * sizeof(uint32_t), c->stream));
+      hipLaunchKernelGGL(single_node_kernel, dim3(1), dim3(1), 0, c->stream, lb.nstart, lb.counters + CTR_NUM_NODES, m);
+      SWZ_LAUNCH_CHECK(c);
+    } else {
+      SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
+                         lb.counters + CTR_NUM_NODES, "lvl"));
+    }
     hipLaunchKernelGGL(node_mode_kernel, dim3(std::min(nb, 2048u)), dim3(256), 0, c->stream, lb.nstart, lb.nmode, lb.counters,
                        plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0, as.akey,
                        plan.node_shift, as.ckey, as.nc);

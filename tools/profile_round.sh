@@ -3,25 +3,25 @@
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile
 rm -rf $OUT; mkdir -p $OUT
-python bench.py --md-mode both > $OUT/bench_1B_min_distance.json 2> $OUT/bench.err
-python bench.py --points 100000000 --sampler GRID_CENTER --steps 5 --warmup 2 --cpu-sample 2000000 > $OUT/bench_100M_grid_center.json 2>> $OUT/bench.err
+timeout 600 python bench.py --md-mode both > $OUT/bench_1B_min_distance.json 2> $OUT/bench.err
+timeout 600 python bench.py --points 100000000 --sampler GRID_CENTER --steps 5 --warmup 2 --cpu-sample 2000000 > $OUT/bench_100M_grid_center.json 2>> $OUT/bench.err
 for s in RANDOM_GRID GRID_CENTER JITTERED; do
-  python bench.py --sampler $s --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_$s.json 2>> $OUT/bench.err
+  timeout 600 python bench.py --sampler $s --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_$s.json 2>> $OUT/bench.err
 done
-python bench.py --steps 2 --warmup 1 --cpu-sample 0 --payload rgb,intensity > $OUT/bench_1B_min_distance_payload.json 2>> $OUT/bench.err
+timeout 600 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --payload rgb,intensity > $OUT/bench_1B_min_distance_payload.json 2>> $OUT/bench.err
 # BASELINE config 5, single-GPU shape: batches from pinned host memory, attributes along, copies under the kernels
-python bench.py --points 500000000 --batches 5 --staged --payload rgb,intensity --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_500M_5batches_staged.json 2>> $OUT/bench.err
-python bench.py --points 500000000 --batches 5 --staged --payload rgb,intensity --sampler RANDOM_GRID --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_500M_5batches_staged_RANDOM_GRID.json 2>> $OUT/bench.err
-python bench.py --strategy FAST --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_min_distance_FAST.json 2>> $OUT/bench.err
-SWZ_BENCH_FORCE_SHARDED=1 python bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_min_distance_sharded_driver_1rank.json 2>> $OUT/bench.err
-python tools/clustered_probe.py 100000000 MIN_DISTANCE > $OUT/clustered_100M.txt 2>> $OUT/bench.err
-python tools/clustered_probe.py 100000000 MIN_DISTANCE property >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
-python tools/clustered_probe.py 100000000 GRID_CENTER >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
+timeout 600 python bench.py --points 500000000 --batches 5 --staged --payload rgb,intensity --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_500M_5batches_staged.json 2>> $OUT/bench.err
+timeout 600 python bench.py --points 500000000 --batches 5 --staged --payload rgb,intensity --sampler RANDOM_GRID --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_500M_5batches_staged_RANDOM_GRID.json 2>> $OUT/bench.err
+timeout 600 python bench.py --strategy FAST --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_min_distance_FAST.json 2>> $OUT/bench.err
+SWZ_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_1B_min_distance_sharded_driver_1rank.json 2>> $OUT/bench.err
+timeout 600 python tools/clustered_probe.py 100000000 MIN_DISTANCE > $OUT/clustered_100M.txt 2>> $OUT/bench.err
+timeout 600 python tools/clustered_probe.py 100000000 MIN_DISTANCE property >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
+timeout 600 python tools/clustered_probe.py 100000000 GRID_CENTER >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 > $OUT/stats_run.json 2>/dev/null
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 > $OUT/stats_run.json 2>/dev/null
 find $OUT/stats -name "*kernel_trace*" -delete
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --cpu-sample 0 > /dev/null 2>&1
 python3 - <<'PY'
 import csv, glob, collections, os
 out = os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", "profile")
