@@ -270,8 +270,10 @@ __device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, co
   const uint64_t gz = contract_bits_by_3(rel) & mask;  // OctreeNodeIndex64::to_grid_index, OctreeNodeIndex.h:357-363
   const uint64_t gy = contract_bits_by_3(rel >> 1) & mask;
   const uint64_t gx = contract_bits_by_3(rel >> 2) & mask;
-  const double cell_size = ext_x / cells;
-  const double perm_size = cell_size / cells;
+  // ext_x / cells and cell_size / cells: cells = 2^levels, so the quotients are the scaled operands (ldexp rounds a
+  // result that underflows once, like the division)
+  const double cell_size = ldexp(ext_x, -(int)levels);
+  const double perm_size = ldexp(cell_size, -(int)levels);
   const uint8_t* table;
   uint32_t width;
   if (cells <= 16) {
@@ -284,11 +286,13 @@ __device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, co
     table = PERMUTATIONS_64;
     width = 64;
   }
-  const uint32_t plen = cells < 64 ? cells : 64;
+  // length of the permutation in use: min(cells, 64), a power of two like cells -- "% plen" below is a mask (the
+  // 64-bit remainder the expression would otherwise compile to costs more than the rest of the function)
+  const uint32_t plen_mask = (cells < 64 ? cells : 64) - 1u;
   const uint32_t s0 = g.jitter_start, s1 = (g.jitter_start + 1) % 16, s2 = (g.jitter_start + 2) % 16;
-  const uint32_t px = (uint32_t)table[s0 * width + (uint32_t)((gy + gz) % plen)] - 1u;
-  const uint32_t py = (uint32_t)table[s1 * width + (uint32_t)((gx + gz) % plen)] - 1u;
-  const uint32_t pz = (uint32_t)table[s2 * width + (uint32_t)((gx + gy) % plen)] - 1u;
+  const uint32_t px = (uint32_t)table[s0 * width + ((uint32_t)(gy + gz) & plen_mask)] - 1u;
+  const uint32_t py = (uint32_t)table[s1 * width + ((uint32_t)(gx + gz) & plen_mask)] - 1u;
+  const uint32_t pz = (uint32_t)table[s2 * width + ((uint32_t)(gx + gy) & plen_mask)] - 1u;
   tx = nb.minx + ((double)gx * cell_size + (double)px * perm_size);
   ty = nb.miny + ((double)gy * cell_size + (double)py * perm_size);
   tz = nb.minz + ((double)gz * cell_size + (double)pz * perm_size);
