@@ -1,5 +1,6 @@
 // swz_api.hip -- the C-ABI entry points of include/swz_gpu.h: context, workspace, profiling,
 // host-buffer wrappers around the device-resident stages.
+#include <algorithm>
 #include <cstring>
 
 #include "swz_device.h"
@@ -20,10 +21,45 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
     size_t want = bytes + bytes / 16;
     want = (want + 255) & ~size_t(255);
     hipError_t e = hipMalloc(&b.ptr, want);
+    // SWZ_FAIL_ALLOC=<name>: treat every first attempt to allocate that buffer as out of memory (tests of the path below)
+    if (const char* fa = opt("SWZ_FAIL_ALLOC"))
+      if (e == hipSuccess && strcmp(fa, name) == 0) {
+        (void)hipFree(b.ptr);
+        b.ptr = nullptr;
+        e = hipErrorOutOfMemory;
+      }
+    if (e == hipErrorOutOfMemory) {  // give back the level scratch nobody has asked for since an earlier level
+      (void)hipGetLastError();
+      SWZ_HIP(this, hipStreamSynchronize(stream));
+      for (auto& kv : bufs) {
+        const std::string& nm = kv.first;
+        const bool level_scratch = nm.compare(0, 3, "md_") == 0 || nm.compare(0, 3, "sp_") == 0 || nm.compare(0, 3, "pm_") == 0;
+        if (level_scratch && kv.second.ptr && kv.second.epoch < scratch_epoch && &kv.second != &b) {
+          (void)hipFree(kv.second.ptr);
+          kv.second.ptr = nullptr;
+          kv.second.cap = 0;
+        }
+      }
+      e = hipMalloc(&b.ptr, want);
+    }
     if (e != hipSuccess) {
       b.ptr = nullptr;
-      return fail(SWZ_ERR_HIP, std::string("hipMalloc(") + name + ", " + std::to_string(want) +
-                                 " bytes): " + hipGetErrorString(e));
+      // the largest buffers the workspace holds, for whoever has to find the memory
+      std::vector<std::pair<size_t, std::string>> held;
+      size_t total = 0;
+      for (const auto& kv : bufs) {
+        total += kv.second.cap;
+        if (kv.second.cap) held.emplace_back(kv.second.cap, kv.first);
+      }
+      std::sort(held.rbegin(), held.rend());
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      std::string top;
+      for (size_t i = 0; i < held.size() && i < 14; ++i)
+        top += " " + held[i].second + "=" + std::to_string(held[i].first >> 20) + "M";
+      return fail(SWZ_ERR_HIP, std::string("hipMalloc(") + name + ", " + std::to_string(want) + " bytes): " + hipGetErrorString(e) +
+                                 "; workspace holds " + std::to_string(total >> 20) + " MiB, device free " +
+                                 std::to_string(free_b >> 20) + " of " + std::to_string(total_b >> 20) + " MiB; largest:" + top);
     }
     b.cap = want;
     // SWZ_POISON=<byte>: fill new workspace memory (hipMalloc does not): shakes out reads of never-written memory
@@ -32,6 +68,7 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
       if (!only || strstr(name, only)) SWZ_HIP(this, hipMemsetAsync(b.ptr, atoi(e), want, stream));
     }
   }
+  b.epoch = scratch_epoch;
   *out = b.ptr;
   return SWZ_OK;
 }

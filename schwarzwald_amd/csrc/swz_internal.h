@@ -19,6 +19,7 @@ constexpr uint32_t MAX_LEVELS = 21;  // MortonIndex64Levels, core/datastructures
 struct DevBuf {
   void* ptr = nullptr;
   size_t cap = 0;
+  uint64_t epoch = 0;  // swz_ctx::scratch_epoch at the last get()
 };
 
 struct KernelStat {
@@ -59,7 +60,12 @@ struct swz_ctx {
     return SWZ_ERR_HIP;
   }
 
-  // ---- grow-only named workspace
+  // ---- grow-only named workspace.  The MIN_DISTANCE samplers (buffers "md_*", "sp_*", "pm_*") use theirs for one level
+  // at a time and say so (next_scratch_epoch() at the start of a level): when the device is out of memory, get() frees
+  // such buffers of earlier levels or calls and tries again -- a cloud whose levels need very different per-cell and
+  // per-point arrays then needs the largest level's memory, not the sum over the levels.
+  uint64_t scratch_epoch = 1;
+  void next_scratch_epoch() { ++scratch_epoch; }
   int get(const char* name, size_t bytes, void** out);
   template <typename T>
   int get(const char* name, size_t count, T** out) {

@@ -492,6 +492,7 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   const uint32_t m = as.m;
   const uint32_t nsh = plan.node_shift;
   const auto wall0 = std::chrono::steady_clock::now();
+  c->next_scratch_epoch();  // what the level before asked for ("md_*", "sp_*", "pm_*") may go if memory runs out
   uint32_t occupied[12] = {0};
   {
     uint32_t* d_hist = nullptr;

@@ -953,6 +953,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
                        const LevelBuffers& lb, uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points,
                        uint32_t* rounds_out) {
   const uint32_t m = as.m;
+  c->next_scratch_epoch();  // what the level before asked for ("md_*", "sp_*") may go if memory runs out
 
   // occupied cells at every candidate cell level (one pass over the keys)
   uint32_t occupied[12] = {0};
@@ -1069,9 +1070,10 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   }
   if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
     double *ax = nullptr, *ay = nullptr, *az = nullptr;
-    // the two big per-point buffers are shared with the sparse path (never live at the same time):
-    // "md_pos" = 32 B per point (x[], y[], z[] here, {x,y,z,key} records there), "md_acc" = 32 B per point
-    SWZ_TRY(c->get("md_pos", (size_t)m * 4, &ax));
+    // the two big per-point buffers are shared with the sparse path (never live at the same time): "md_pos" = x[], y[],
+    // z[] here (24 B per point), {x,y,z,key} records there (32 B), "md_acc" the same sizes.  Each path asks for what it
+    // uses: at 1 B clustered points the 2 x 8 GB between the two decide whether a level with 226 M cells fits
+    SWZ_TRY(c->get("md_pos", (size_t)m * 3, &ax));
     ay = ax + m;
     az = ay + m;
     hipLaunchKernelGGL(md_gather_active_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.aidx, m, sp.X, sp.Y,
@@ -1101,7 +1103,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   SWZ_TRY(c->get("md_cell128", (size_t)ncells, &a.cells));
   SWZ_TRY(c->get("md_nbr_id", (size_t)ncells * 27, &a.nbr_id));
   SWZ_TRY(c->get("md_nbr_slot", (size_t)ncells * 32, &a.nbr_slot));
-  SWZ_TRY(c->get("md_acc", (size_t)m * 4, &a.acc_xyz));  // 3 doubles per point used (see md_pos above)
+  SWZ_TRY(c->get("md_acc", (size_t)m * 3, &a.acc_xyz));  // 3 doubles per point (see md_pos above)
   SWZ_TRY(c->get("md_queue0", (size_t)ncells, &a.queue[0]));
   SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
   const uint64_t grid_entries = (uint64_t)sample_nodes * cells_per_node;

@@ -274,6 +274,24 @@ def test_tile_odd_counts_and_arbitrary_bounds(ctx, sampler, n):
     assert g.stats["num_nodes"] == o["stats"]["num_nodes"]
 
 
+@pytest.mark.parametrize("name", ["md_gridmap", "md_cell128", "sp_table", "md_pos"])
+def test_min_distance_out_of_memory_gives_back_the_scratch_of_earlier_levels(ctx, name):
+    """When the device runs out of memory, the workspace frees the MIN_DISTANCE buffers no level has asked for since an
+    earlier level (or call) and allocates again (SWZ_FAIL_ALLOC pretends the first attempt failed): same results."""
+    rng = np.random.default_rng(77)
+    clouds = [rng.random((150000, 3)), _clustered(rng, 120000)]
+    spacing = O.spacing_from_diagonal(*UNIT, 120)
+    try:
+        ctx.set_option("SWZ_FAIL_ALLOC", name)
+        for xyz in clouds:  # the second call meets the buffers of the first
+            o, g = _tile_both(ctx, xyz, *UNIT, O.MIN_DISTANCE, 800, spacing)
+            assert o["status"] == 0
+            assert np.array_equal(g.perm, o["perm"])
+            assert np.array_equal(g.level, o["level"])
+    finally:
+        ctx.set_option("SWZ_FAIL_ALLOC", None)
+
+
 def test_tile_max_depth_makes_terminal_nodes(ctx):
     rng = np.random.default_rng(8)
     xyz = rng.random((100000, 3))
