@@ -128,16 +128,36 @@ __global__ __launch_bounds__(256) void node_mode_kernel(const uint32_t* __restri
 // RandomSortedGridSampling::sample_points, Sampling.h:187-308: the first point of every run of equal
 // truncate_to_level(candidate_level) is taken.  candidate_level == -1 takes the first point only.
 // (when every node of the level is sampled -- the counters of node_mode_kernel say so -- nobody looks at nid / nmode)
+// Four consecutive points per thread: two 16-byte key loads and ONE 4-byte store of the four flags (a wavefront's byte
+// stores fill 64 bytes of a line each).
+constexpr uint32_t RG_IPT = 4;
 __global__ __launch_bounds__(256) void random_grid_kernel(const uint64_t* __restrict__ akey, uint32_t m,
                                                           const uint32_t* __restrict__ nid,
                                                           const uint8_t* __restrict__ nmode, uint32_t csh,
                                                           uint8_t* __restrict__ taken, const uint32_t* __restrict__ counters) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
+  const uint64_t i0 = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * RG_IPT;
+  if (i0 >= m) return;
   const bool all_sampled = counters[CTR_SAMPLE_NODES] == counters[CTR_NUM_NODES];
-  uint8_t t = 1;
-  if (all_sampled || nmode[nid[i]] == MODE_SAMPLE) t = (i == 0) || ((akey[i] >> csh) != (akey[i - 1] >> csh));
-  taken[i] = t;
+  if (i0 + RG_IPT <= m) {
+    const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(akey + i0);
+    const ulonglong2 kb = *reinterpret_cast<const ulonglong2*>(akey + i0 + 2);
+    const uint64_t prev = i0 ? akey[i0 - 1] : 0ull;
+    const uint64_t k[RG_IPT + 1] = {prev >> csh, ka.x >> csh, ka.y >> csh, kb.x >> csh, kb.y >> csh};
+    uint32_t packed = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < RG_IPT; ++j) {
+      uint32_t t = 1;
+      if (all_sampled || nmode[nid[i0 + j]] == MODE_SAMPLE) t = (i0 + j == 0) || (k[j + 1] != k[j]);
+      packed |= t << (8u * j);
+    }
+    *reinterpret_cast<uint32_t*>(taken + i0) = packed;
+    return;
+  }
+  for (uint64_t i = i0; i < m; ++i) {  // the last thread's partial group
+    uint8_t t = 1;
+    if (all_sampled || nmode[nid[i]] == MODE_SAMPLE) t = (i == 0) || ((akey[i] >> csh) != (akey[i - 1] >> csh));
+    taken[i] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void take_all_kernel(uint32_t m, const uint32_t* __restrict__ nid,
@@ -652,7 +672,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     const uint32_t csh = first_only ? plan.node_shift : level_shift(plan.cand);
     if (!first_only && plan.cand >= (int)MAX_LEVELS) return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, "candidate level >= 21");
     ProfScope ps(c, "sample_random_grid", (uint64_t)m * 9ull);
-    hipLaunchKernelGGL(random_grid_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, lb.nid, lb.nmode, csh,
+    hipLaunchKernelGGL(random_grid_kernel, dim3(div_up(m, 256u * RG_IPT)), dim3(256), 0, c->stream, as.akey, m, lb.nid, lb.nmode, csh,
                        lb.taken, lb.counters);
     SWZ_LAUNCH_CHECK(c);
   } else if (plan.sampler == SWZ_GRID_CENTER || plan.sampler == SWZ_JITTERED) {
