@@ -94,11 +94,10 @@ __device__ __host__ __forceinline__ Box bounds_from_key(uint64_t key, const Box&
   return b;
 }
 // The same for N keys at once: N independent chains of dependent f64 operations in one loop.
+// b[j] holds the bounds of key[j]'s ancestor at depth `from` on entry (the root box for from = 0).
 template <int N>
-__device__ __forceinline__ void bounds_from_keys(const uint64_t (&key)[N], const Box& root, int depth, Box (&b)[N]) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) b[j] = root;
-  for (int level = 0; level < depth; ++level) {
+__device__ __forceinline__ void bounds_from_keys(const uint64_t (&key)[N], int from, int depth, Box (&b)[N]) {
+  for (int level = from; level < depth; ++level) {
     const uint32_t sh = level_shift(level);
 #pragma unroll
     for (int j = 0; j < N; ++j) box_descend(b[j], (uint32_t)(key[j] >> sh) & 7u);

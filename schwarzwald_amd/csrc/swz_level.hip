@@ -246,7 +246,18 @@ struct GridParams {
   int cand;               // GRID_CENTER candidate level (>= 0 here)
   double spacing_node;    // JITTERED
   uint32_t jitter_start;  // JITTERED
+  // bounds of every octree cell at depth table_depth, indexed by the key's first table_depth octants (0: no table).
+  // The points of a cell all walk the same halving chain; its first table_depth steps are looked up instead (the
+  // table is small enough to stay in the caches, and neighbouring lanes read the same entry).
+  const Box* box_table;
+  int table_depth;
 };
+constexpr int GRID_TABLE_MAX_DEPTH = 6;  // 8^6 boxes of 48 bytes = 12.6 MB (deeper tables were measured: no faster)
+__global__ __launch_bounds__(256) void grid_box_table_kernel(Box root, int depth, Box* __restrict__ table) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (1u << (3 * depth))) return;
+  table[t] = bounds_from_key((uint64_t)t << level_shift(depth - 1), root, depth);
+}
 
 // get_prev_power_of_two -- core/util/stuff.cpp:340-349
 __device__ __forceinline__ uint32_t prev_pow2(uint32_t x) {
@@ -388,7 +399,15 @@ __global__ __launch_bounds__(GA_THREADS, SWZ_GA_MINW) void grid_argmin_kernel(
     }
   }
   Box kb[GA_IPT];
-  bounds_from_keys<GA_IPT>(key, g.root, cell_box_depth(g), kb);
+  if (g.table_depth > 0) {
+    const uint32_t tsh = level_shift(g.table_depth - 1);
+#pragma unroll
+    for (int j = 0; j < GA_IPT; ++j) kb[j] = g.box_table[key[j] >> tsh];
+  } else {
+#pragma unroll
+    for (int j = 0; j < GA_IPT; ++j) kb[j] = g.root;
+  }
+  bounds_from_keys<GA_IPT>(key, g.table_depth, cell_box_depth(g), kb);
 
   double dist[GA_IPT];
   bool head[GA_IPT];
@@ -689,8 +708,24 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     g.cand = plan.cand;
     g.spacing_node = plan.spacing_node;
     g.jitter_start = plan.jitter_start;
+    g.box_table = nullptr;
+    g.table_depth = 0;
     ProfScope ps(c, plan.sampler == SWZ_GRID_CENTER ? "sample_grid_center" : "sample_jittered", (uint64_t)m * 33ull,
                  2);
+    {  // all but the last three steps of the bounds chain from a table (worth it from a few thousand points per entry on)
+      const int chain = plan.sampler == SWZ_GRID_CENTER ? plan.cand + 1 : plan.level + 1;
+      int td = std::min(chain - 3, GRID_TABLE_MAX_DEPTH);
+      if (const char* e = c->opt("SWZ_GRID_TABLE_DEPTH")) td = std::min(std::min(atoi(e), chain), GRID_TABLE_MAX_DEPTH);
+      while (td > 0 && ((uint64_t)1 << (3 * td)) * 64u > (uint64_t)m) --td;
+      if (td > 0) {
+        Box* d_table = nullptr;
+        SWZ_TRY(c->get("grid_boxes", (size_t)1 << (3 * td), &d_table));
+        hipLaunchKernelGGL(grid_box_table_kernel, dim3(div_up(1u << (3 * td), 256)), dim3(256), 0, c->stream, plan.root, td, d_table);
+        SWZ_LAUNCH_CHECK(c);
+        g.box_table = d_table;
+        g.table_depth = td;
+      }
+    }
     hipLaunchKernelGGL(grid_argmin_kernel, dim3(ntiles), dim3(GA_THREADS), 0, c->stream, as.akey, as.aidx, m, lb.nid,
                        lb.nmode, sp.X, sp.Y, sp.Z, g, plan.node_shift, lb.taken, d_sum, lb.counters);
     SWZ_LAUNCH_CHECK(c);

@@ -292,6 +292,27 @@ def test_min_distance_out_of_memory_gives_back_the_scratch_of_earlier_levels(ctx
         ctx.set_option("SWZ_FAIL_ALLOC", None)
 
 
+@pytest.mark.parametrize("depth", [0, 2, 6])
+@pytest.mark.parametrize("sampler", [O.GRID_CENTER, O.JITTERED])
+def test_grid_samplers_box_table_depths(ctx, sampler, depth):
+    """The first steps of the cell bounds chain come from a table of boxes (its depth normally follows the level's
+    point count): none, a shallow and the deepest table, in bounds whose chain rounds."""
+    rng = np.random.default_rng(31 + depth)
+    bmin = [-7.123456789, 100.000001, 3.3333333]
+    side = 17.71717171
+    bmax = [b + side for b in bmin]
+    xyz = np.array(bmin) + rng.random((180001, 3)) * side
+    spacing = O.spacing_from_diagonal(bmin, bmax, 180)
+    try:
+        ctx.set_option("SWZ_GRID_TABLE_DEPTH", depth)
+        o, g = _tile_both(ctx, xyz, bmin, bmax, sampler, 900, spacing)
+    finally:
+        ctx.set_option("SWZ_GRID_TABLE_DEPTH", None)
+    assert o["status"] == 0
+    assert np.array_equal(g.perm, o["perm"])
+    assert np.array_equal(g.level, o["level"])
+
+
 def test_tile_max_depth_makes_terminal_nodes(ctx):
     rng = np.random.default_rng(8)
     xyz = rng.random((100000, 3))
