@@ -69,6 +69,16 @@ __device__ __host__ __forceinline__ uint64_t contract_bits_by_3(uint64_t v) {
   return v;
 }
 
+// the same for values below 2^32 (the 64-bit masks truncated: every step only shifts right)
+__device__ __host__ __forceinline__ uint32_t contract_bits_by_3_u32(uint32_t v) {
+  v &= 0x49249249u;
+  v = (v | (v >> 2)) & 0xC30C30C3u;
+  v = (v | (v >> 4)) & 0x0F00F00Fu;
+  v = (v | (v >> 8)) & 0xFF0000FFu;
+  v = (v | (v >> 16)) & 0x0000FFFFu;
+  return v;
+}
+
 struct Box {  // AABB, core/math/AABB.h
   double minx, miny, minz, maxx, maxy, maxz;
 };

@@ -251,6 +251,15 @@ struct GridParams {
   // table is small enough to stay in the caches, and neighbouring lanes read the same entry).
   const Box* box_table;
   int table_depth;
+  const struct JitNode* jit_table;  // JITTERED: what the sampler derives from a node's bounds, per node prefix (or null)
+};
+// JitteredSampling's per-node quantities (Sampling.h:621-668): every point of a node derives the same ones
+struct alignas(16) JitNode {
+  double minx, miny, minz;  // the node's bounds_from_key minimum
+  double cell_size, perm_size;
+  uint32_t cells, levels;
+  int32_t err;  // SWZ_ERR_JITTER_* or 0
+  uint32_t pad;
 };
 constexpr int GRID_TABLE_MAX_DEPTH = 6;  // 8^6 boxes of 48 bytes = 12.6 MB (deeper tables were measured: no faster)
 __global__ __launch_bounds__(256) void grid_box_table_kernel(Box root, int depth, Box* __restrict__ table) {
@@ -273,38 +282,51 @@ __device__ __forceinline__ uint32_t prev_pow2(uint32_t x) {
 __device__ __forceinline__ int cell_box_depth(const GridParams& g) {
   return g.sampler == SWZ_GRID_CENTER ? g.cand + 1 : g.level + 1;
 }
-// Cell prefix shift and sampling target of the cell that `key` falls in; `kb` = bounds_from_key(key, g.root,
-// cell_box_depth(g)).  Returns an SWZ_ERR_* code (JITTERED only) or 0.
-__device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, const Box& kb, uint32_t& csh, double& tx,
-                                           double& ty, double& tz) {
-  if (g.sampler == SWZ_GRID_CENTER) {
-    // GridCenterSampling, Sampling.h:387-390: centre of get_bounds_from_morton_index(key, root, cand + 1)
-    csh = level_shift(g.cand);
-    tx = kb.minx + (kb.maxx - kb.minx) / 2;  // AABB::getCenter, AABB.h:70
-    ty = kb.miny + (kb.maxy - kb.miny) / 2;
-    tz = kb.minz + (kb.maxz - kb.minz) / 2;
-    return 0;
-  }
-  // JitteredSampling, Sampling.h:621-739
-  const Box& nb = kb;
+// GridCenterSampling, Sampling.h:387-390: centre of kb = get_bounds_from_morton_index(key, root, cand + 1)
+__device__ __forceinline__ void grid_center_target(const Box& kb, double& tx, double& ty, double& tz) {
+  tx = kb.minx + (kb.maxx - kb.minx) / 2;  // AABB::getCenter, AABB.h:70
+  ty = kb.miny + (kb.maxy - kb.miny) / 2;
+  tz = kb.minz + (kb.maxz - kb.minz) / 2;
+}
+// JitteredSampling, Sampling.h:621-668: the grid of a node with bounds nb = bounds_from_key(key, root, level + 1)
+__device__ __forceinline__ JitNode jitter_node(const Box& nb, double spacing_node, int level) {
+  JitNode n;
+  n.minx = nb.minx;
+  n.miny = nb.miny;
+  n.minz = nb.minz;
+  n.pad = 0;
+  n.err = 0;
   const double ext_x = nb.maxx - nb.minx;
-  const double perfect = ext_x / g.spacing_node;
+  const double perfect = ext_x / spacing_node;
   const uint32_t perfect_u = perfect >= 4294967295.0 ? 4294967295u : (uint32_t)perfect;
-  const uint32_t cells = prev_pow2(perfect_u);
-  if (cells < 16) return SWZ_ERR_JITTER_GRID_TOO_SMALL;
-  const uint32_t levels = 31u - (uint32_t)__clz((int)cells);  // (uint32_t)std::log2(power of two)
-  const uint32_t grid_level = (uint32_t)g.level + levels;
-  if (grid_level >= MAX_LEVELS) return SWZ_ERR_JITTER_NODE_TOO_DEEP;
-  csh = level_shift((int)grid_level);
-  const uint64_t rel = (key >> csh) & ((1ull << (3u * levels)) - 1ull);
-  const uint64_t mask = (1ull << levels) - 1ull;
-  const uint64_t gz = contract_bits_by_3(rel) & mask;  // OctreeNodeIndex64::to_grid_index, OctreeNodeIndex.h:357-363
-  const uint64_t gy = contract_bits_by_3(rel >> 1) & mask;
-  const uint64_t gx = contract_bits_by_3(rel >> 2) & mask;
+  n.cells = prev_pow2(perfect_u);
+  n.levels = n.cells ? 31u - (uint32_t)__clz((int)n.cells) : 0u;  // (uint32_t)std::log2(power of two)
+  if (n.cells < 16) n.err = SWZ_ERR_JITTER_GRID_TOO_SMALL;
+  else if ((uint32_t)level + n.levels >= MAX_LEVELS) n.err = SWZ_ERR_JITTER_NODE_TOO_DEEP;
   // ext_x / cells and cell_size / cells: cells = 2^levels, so the quotients are the scaled operands (ldexp rounds a
   // result that underflows once, like the division)
-  const double cell_size = ldexp(ext_x, -(int)levels);
-  const double perm_size = ldexp(cell_size, -(int)levels);
+  n.cell_size = ldexp(ext_x, -(int)n.levels);
+  n.perm_size = ldexp(n.cell_size, -(int)n.levels);
+  return n;
+}
+// Sampling.h:669-739: cell prefix shift and jittered target of the grid cell `key` falls in (n.err == 0)
+__device__ __forceinline__ void jitter_target(const GridParams& g, uint64_t key, const JitNode& n, uint32_t& csh, double& tx,
+                                              double& ty, double& tz) {
+  const uint32_t cells = n.cells, levels = n.levels;
+  csh = level_shift((int)((uint32_t)g.level + levels));
+  const uint64_t rel = (key >> csh) & ((1ull << (3u * levels)) - 1ull);
+  const uint64_t mask = (1ull << levels) - 1ull;
+  uint32_t gx, gy, gz;  // OctreeNodeIndex64::to_grid_index, OctreeNodeIndex.h:357-363 (below 2^levels <= 2^20)
+  if (levels <= 10u) {  // the usual case (grids up to 1024 cells a side): rel has at most 30 bits, half the instructions
+    const uint32_t r = (uint32_t)rel, m32 = (uint32_t)mask;
+    gz = contract_bits_by_3_u32(r) & m32;
+    gy = contract_bits_by_3_u32(r >> 1) & m32;
+    gx = contract_bits_by_3_u32(r >> 2) & m32;
+  } else {
+    gz = (uint32_t)(contract_bits_by_3(rel) & mask);
+    gy = (uint32_t)(contract_bits_by_3(rel >> 1) & mask);
+    gx = (uint32_t)(contract_bits_by_3(rel >> 2) & mask);
+  }
   const uint8_t* table;
   uint32_t width;
   if (cells <= 16) {
@@ -317,17 +339,24 @@ __device__ __forceinline__ int cell_target(const GridParams& g, uint64_t key, co
     table = PERMUTATIONS_64;
     width = 64;
   }
-  // length of the permutation in use: min(cells, 64), a power of two like cells -- "% plen" below is a mask (the
-  // 64-bit remainder the expression would otherwise compile to costs more than the rest of the function)
+  // length of the permutation in use: min(cells, 64), a power of two like cells -- "% plen" is a mask (the 64-bit
+  // remainder the expression would otherwise compile to costs more than the rest of the function).  (The three rows in
+  // use copied to LDS instead of three dependent byte loads from memory: measured, no faster.)
   const uint32_t plen_mask = (cells < 64 ? cells : 64) - 1u;
   const uint32_t s0 = g.jitter_start, s1 = (g.jitter_start + 1) % 16, s2 = (g.jitter_start + 2) % 16;
-  const uint32_t px = (uint32_t)table[s0 * width + ((uint32_t)(gy + gz) & plen_mask)] - 1u;
-  const uint32_t py = (uint32_t)table[s1 * width + ((uint32_t)(gx + gz) & plen_mask)] - 1u;
-  const uint32_t pz = (uint32_t)table[s2 * width + ((uint32_t)(gx + gy) & plen_mask)] - 1u;
-  tx = nb.minx + ((double)gx * cell_size + (double)px * perm_size);
-  ty = nb.miny + ((double)gy * cell_size + (double)py * perm_size);
-  tz = nb.minz + ((double)gz * cell_size + (double)pz * perm_size);
-  return 0;
+  const uint32_t px = (uint32_t)table[s0 * width + ((gy + gz) & plen_mask)] - 1u;
+  const uint32_t py = (uint32_t)table[s1 * width + ((gx + gz) & plen_mask)] - 1u;
+  const uint32_t pz = (uint32_t)table[s2 * width + ((gx + gy) & plen_mask)] - 1u;
+  tx = n.minx + ((double)gx * n.cell_size + (double)px * n.perm_size);
+  ty = n.miny + ((double)gy * n.cell_size + (double)py * n.perm_size);
+  tz = n.minz + ((double)gz * n.cell_size + (double)pz * n.perm_size);
+}
+__global__ __launch_bounds__(256) void jitter_node_table_kernel(Box root, int level, double spacing_node,
+                                                                JitNode* __restrict__ table) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= (1u << (3 * (level + 1)))) return;
+  const Box nb = level < 0 ? root : bounds_from_key((uint64_t)t << level_shift(level), root, level + 1);
+  table[t] = jitter_node(nb, spacing_node, level);
 }
 
 #ifndef SWZ_GA_MINW
@@ -399,15 +428,26 @@ __global__ __launch_bounds__(GA_THREADS, SWZ_GA_MINW) void grid_argmin_kernel(
     }
   }
   Box kb[GA_IPT];
-  if (g.table_depth > 0) {
-    const uint32_t tsh = level_shift(g.table_depth - 1);
+  JitNode jn[GA_IPT];
+  if (g.jit_table) {  // JITTERED with a table: nothing of the node is computed here
+    const uint32_t tsh = g.level < 0 ? 63u : level_shift(g.level);
 #pragma unroll
-    for (int j = 0; j < GA_IPT; ++j) kb[j] = g.box_table[key[j] >> tsh];
+    for (int j = 0; j < GA_IPT; ++j) jn[j] = g.jit_table[key[j] >> tsh];
   } else {
+    if (g.table_depth > 0) {
+      const uint32_t tsh = level_shift(g.table_depth - 1);
 #pragma unroll
-    for (int j = 0; j < GA_IPT; ++j) kb[j] = g.root;
+      for (int j = 0; j < GA_IPT; ++j) kb[j] = g.box_table[key[j] >> tsh];
+    } else {
+#pragma unroll
+      for (int j = 0; j < GA_IPT; ++j) kb[j] = g.root;
+    }
+    bounds_from_keys<GA_IPT>(key, g.table_depth, cell_box_depth(g), kb);
+    if (g.sampler != SWZ_GRID_CENTER) {
+#pragma unroll
+      for (int j = 0; j < GA_IPT; ++j) jn[j] = jitter_node(kb[j], g.spacing_node, g.level);
+    }
   }
-  bounds_from_keys<GA_IPT>(key, g.table_depth, cell_box_depth(g), kb);
 
   double dist[GA_IPT];
   bool head[GA_IPT];
@@ -422,8 +462,15 @@ __global__ __launch_bounds__(GA_THREADS, SWZ_GA_MINW) void grid_argmin_kernel(
     if (gi < tile_end) {
       uint32_t csh = node_shift;
       if (sample[j]) {
-        double tx, ty, tz;
-        const int err = cell_target(g, key[j], kb[j], csh, tx, ty, tz);
+        double tx = 0, ty = 0, tz = 0;
+        int err = 0;
+        if (g.sampler == SWZ_GRID_CENTER) {
+          csh = level_shift(g.cand);
+          grid_center_target(kb[j], tx, ty, tz);
+        } else {
+          err = jn[j].err;
+          if (!err) jitter_target(g, key[j], jn[j], csh, tx, ty, tz);
+        }
         if (err) {
           atomicMax(&counters[CTR_ERROR], (uint32_t)err);
           csh = node_shift;
@@ -710,6 +757,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     g.jitter_start = plan.jitter_start;
     g.box_table = nullptr;
     g.table_depth = 0;
+    g.jit_table = nullptr;
     ProfScope ps(c, plan.sampler == SWZ_GRID_CENTER ? "sample_grid_center" : "sample_jittered", (uint64_t)m * 33ull,
                  2);
     {  // all but the last three steps of the bounds chain from a table (worth it from a few thousand points per entry on)
@@ -717,6 +765,18 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
       int td = std::min(chain - 3, GRID_TABLE_MAX_DEPTH);
       if (const char* e = c->opt("SWZ_GRID_TABLE_DEPTH")) td = std::min(std::min(atoi(e), chain), GRID_TABLE_MAX_DEPTH);
       while (td > 0 && ((uint64_t)1 << (3 * td)) * 64u > (uint64_t)m) --td;
+      const char* jt = c->opt("SWZ_JITTER_TABLE");
+      if (plan.sampler == SWZ_JITTERED && chain <= GRID_TABLE_MAX_DEPTH && !(jt && atoi(jt) == 0)) {
+        // one entry per node prefix: the node's box and everything the sampler derives from it
+        JitNode* d_nodes = nullptr;
+        const uint32_t entries = 1u << (3 * chain);
+        SWZ_TRY(c->get("grid_jitter_nodes", (size_t)entries, &d_nodes));
+        hipLaunchKernelGGL(jitter_node_table_kernel, dim3(div_up(entries, 256)), dim3(256), 0, c->stream, plan.root, plan.level,
+                           plan.spacing_node, d_nodes);
+        SWZ_LAUNCH_CHECK(c);
+        g.jit_table = d_nodes;
+        td = 0;
+      }
       if (td > 0) {
         Box* d_table = nullptr;
         SWZ_TRY(c->get("grid_boxes", (size_t)1 << (3 * td), &d_table));
