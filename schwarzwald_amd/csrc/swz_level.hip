@@ -278,7 +278,7 @@ __device__ __forceinline__ uint32_t prev_pow2(uint32_t x) {
   return x - (x >> 1);
 }
 
-// Depth of the bounds chain cell_target starts from: the candidate cell (GRID_CENTER) or the node (JITTERED).
+// Depth of the bounds chain a point's target starts from: the candidate cell (GRID_CENTER) or the node (JITTERED).
 __device__ __forceinline__ int cell_box_depth(const GridParams& g) {
   return g.sampler == SWZ_GRID_CENTER ? g.cand + 1 : g.level + 1;
 }
