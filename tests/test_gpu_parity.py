@@ -315,6 +315,19 @@ def test_grid_samplers_box_table_depths(ctx, sampler, depth):
     assert np.array_equal(g.level, o["level"])
 
 
+def test_jittered_fine_grid_uses_the_wide_index_path(ctx):
+    """Spacing = diagonal / 4000: the root's jitter grid has 2048 cells a side (11 levels, 33 bits of cell index: the
+    64-bit bit tricks); a tight blob puts thousands of points into single cells so that the targets decide."""
+    rng = np.random.default_rng(2048)
+    xyz = np.vstack([rng.random((50000, 3)), 0.4321 + 0.0004 * rng.standard_normal((100001, 3))])
+    spacing = O.spacing_from_diagonal(*UNIT, 4000)
+    o, g = _tile_both(ctx, xyz, *UNIT, O.JITTERED, 1000, spacing)
+    assert o["status"] == 0
+    assert o["stats"]["max_level"] >= 1
+    assert np.array_equal(g.perm, o["perm"])
+    assert np.array_equal(g.level, o["level"])
+
+
 def test_tile_max_depth_makes_terminal_nodes(ctx):
     rng = np.random.default_rng(8)
     xyz = rng.random((100000, 3))
