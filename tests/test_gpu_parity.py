@@ -328,6 +328,20 @@ def test_jittered_fine_grid_uses_the_wide_index_path(ctx):
     assert np.array_equal(g.level, o["level"])
 
 
+def test_tile_more_nodes_than_the_node_kernels_have_threads(ctx):
+    """A spacing of half the diagonal lets every node keep one point only: 1.5 M points make a full octree whose level 6
+    has more than 2048 x 256 nodes (the per-node kernels stride over them)."""
+    rng = np.random.default_rng(99)
+    xyz = rng.random((1500000, 3))
+    spacing = O.spacing_from_diagonal(*UNIT, 2)
+    o, g = _tile_both(ctx, xyz, *UNIT, O.RANDOM_GRID, 1, spacing)
+    assert o["status"] == 0
+    assert o["stats"]["num_nodes"] > 2 * 2048 * 256
+    assert np.array_equal(g.perm, o["perm"])
+    assert np.array_equal(g.level, o["level"])
+    assert g.stats["num_nodes"] == o["stats"]["num_nodes"]
+
+
 def test_tile_max_depth_makes_terminal_nodes(ctx):
     rng = np.random.default_rng(8)
     xyz = rng.random((100000, 3))
