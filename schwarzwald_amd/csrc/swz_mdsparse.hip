@@ -153,9 +153,10 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   // (conservative: a slab never overstates the gap).
   uint32_t reach = 0;  // bit k: adjacent cell k (x fastest) can hold a point closer than the spacing
   {
-    const uint64_t sub = (mykey >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
+    // (at most 4 sub levels: 12 bits -- the 32-bit form of the bit trick, a third of the instructions of the 64-bit one)
+    const uint32_t sub = (uint32_t)(mykey >> (a.cell_shift - 3u * a.sub_levels)) & ((1u << (3u * a.sub_levels)) - 1u);
     const int smax = (1 << a.sub_levels) - 1;
-    const int sx = (int)contract_bits_by_3(sub >> 2), sy = (int)contract_bits_by_3(sub >> 1), sz = (int)contract_bits_by_3(sub);
+    const int sx = (int)contract_bits_by_3_u32(sub >> 2), sy = (int)contract_bits_by_3_u32(sub >> 1), sz = (int)contract_bits_by_3_u32(sub);
     // (in float: the kernel is bound by its vector ALU work and doubles cost twice; usq_f is rounded down and cull_f
     // carries a 1e-5 margin over the 2^-18 one, far more than the three roundings of the sum can add)
     const float lx = (float)sx, hx = (float)(smax - sx), ly = (float)sy, hy = (float)(smax - sy), lz = (float)sz,

@@ -561,10 +561,11 @@ __device__ void md_sweep_cell(const MdArgs& a, uint32_t slot, uint32_t c, MdLds&
       int sx = 0, sy = 0, sz = 0;
       if (valid) {
         // slab coordinates inside the cell (culling of blocker scans)
-        const uint64_t sub = (key >> (a.cell_shift - 3u * a.sub_levels)) & ((1ull << (3u * a.sub_levels)) - 1ull);
-        sx = (int)contract_bits_by_3(sub >> 2);
-        sy = (int)contract_bits_by_3(sub >> 1);
-        sz = (int)contract_bits_by_3(sub);
+        // (at most 4 sub levels = 12 bits: the 32-bit form of the bit trick)
+        const uint32_t sub = (uint32_t)(key >> (a.cell_shift - 3u * a.sub_levels)) & ((1u << (3u * a.sub_levels)) - 1u);
+        sx = (int)contract_bits_by_3_u32(sub >> 2);
+        sy = (int)contract_bits_by_3_u32(sub >> 1);
+        sz = (int)contract_bits_by_3_u32(sub);
       }
       const int smax = (1 << a.sub_levels) - 1;
       const double lx = (double)sx, hx = (double)(smax - sx), ly = (double)sy, hy = (double)(smax - sy),
