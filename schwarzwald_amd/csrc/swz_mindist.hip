@@ -1236,7 +1236,12 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       if (round > 4ull * m + 1024) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE frontier sweep did not terminate");
     }
   }
-  const uint32_t batch = 32;
+  // rounds queued between two looks at the level's progress (the streams drain for the look: 30-50 us): 32 at first,
+  // 128 once a level has shown that it takes hundreds of rounds (a level that is done keeps running the queued rounds,
+  // empty, 15 us each); SWZ_MD_BATCH fixes the number
+  uint32_t batch = 32, batches_done = 0;
+  const bool fixed_batch = c->opt("SWZ_MD_BATCH") != nullptr;
+  if (fixed_batch) batch = std::max(1u, (uint32_t)atoi(c->opt("SWZ_MD_BATCH")));
   // a level that does not finish is reported, not waited for: points that change while they are being tiled
   // (keys and positions no longer agree) can make single cells arbitrarily expensive
   const auto wall0 = std::chrono::steady_clock::now();
@@ -1265,6 +1270,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
       }
     }
     SWZ_LAUNCH_CHECK(c);
+    if (!fixed_batch && ++batches_done % 4u == 0u && batch < 128u) batch *= 2u;
     for (uint32_t g = 0; g < groups; ++g)
       SWZ_HIP(c, hipMemcpyAsync(&gdone[g], ga[g].counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, gs[g]));
     done = 0;
