@@ -40,9 +40,14 @@ struct ActiveSet {
 };
 
 struct SortedPoints {
-  const double* X = nullptr;  // positions in Morton order, SoA
+  const double* X = nullptr;  // positions in Morton order, SoA (null when the sampler decides on the keys: see xyz / perm)
   const double* Y = nullptr;
   const double* Z = nullptr;
+  // The clamped input positions (AoS, caller's order) and the sort's permutation: sorted position s is point perm[s].
+  // MIN_DISTANCE decides almost every pair on the coordinates its keys already hold (swz_mdkeys.hip) and looks up the
+  // few pairs inside the quantisation band here, so the positions are never brought into Morton order.
+  const double* xyz = nullptr;
+  const uint32_t* perm = nullptr;
 };
 
 // What the host decides once per level (all float/libm corner cases of the reference live here,
@@ -106,6 +111,27 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
 int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                                 const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes,
                                 uint32_t sample_points, uint32_t* phases_out);
+
+// ---- MIN_DISTANCE on key coordinates (swz_mdkeys.hip) ----------------------------------------------------------
+// The key of a point is its position quantised to 2^-21 of the (cubic) bounds: the integer coordinates of two points
+// bound their distance to +-sqrt(3) key cells, so a compare against the spacing is decided on the keys alone unless the
+// integer distance lies within that band around it; those pairs -- a few in ten thousand at the root, a few per cent of
+// the near pairs at level 3 -- are evaluated on the exact positions with the reference's arithmetic.  The result is
+// therefore the exact one.  KeyMetric holds the thresholds in key cells.
+struct KeyMetric {
+  bool ok = false;     // the level can be decided on keys (cubic bounds, spacing of at least key_min_cells key cells)
+  double T = 0.0;      // spacing in key cells
+  float f_lo = 0.f;    // float squared integer distance <  f_lo: closer than the spacing for sure
+  float f_hi = 0.f;    //                                >= f_hi: at least the spacing apart for sure
+};
+KeyMetric key_metric(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp);
+// true when min_distance_level will not need sp.X / sp.Y / sp.Z for this level
+bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp);
+// Frontier sweep on key coordinates for a dense level; *used = false when the level does not qualify.
+// cl: cell levels below the node chosen by the caller; typical_pop: points-weighted mean cell population.
+int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
+                            const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes, uint32_t sample_points,
+                            const uint32_t* snode_of, int cl, double typical_pop, uint32_t* rounds_out, bool* used);
 
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
 // qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.

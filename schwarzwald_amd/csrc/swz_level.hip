@@ -911,7 +911,7 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   }
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(out.level, 0x80, (size_t)n, c->stream));  // -128 = not persisted yet
-  t.sp = SortedPoints{X, Y, Z};
+  t.sp = SortedPoints{X, Y, Z, d_xyz, out.perm};
   SWZ_TRY(alloc_level_buffers(c, n + front, &t.lb));
   // survivors ping-pong between the sort's secondary buffers and one extra pair
   t.key_buf[0] = keys_b;
@@ -1363,7 +1363,7 @@ int sample_points_device(swz_ctx* c, int sampler, uint64_t max_points, const uin
                              behaviour == SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, false);
   if (!uses_node_key) plan.node_shift = 63;  // one node: the range
   ActiveSet as{d_keys, nullptr, n};
-  SortedPoints sp{X, Y, Z};
+  SortedPoints sp{X, Y, Z, d_xyz, d_idx};
   LevelResult r;
   SWZ_TRY(level_step(c, plan, as, sp, lb, nullptr, nullptr, nullptr, &r));
   SWZ_HIP(c, hipMemcpyAsync(d_taken, lb.taken, n, hipMemcpyDeviceToDevice, c->stream));

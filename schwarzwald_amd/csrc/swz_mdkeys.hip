@@ -1,0 +1,907 @@
+// swz_mdkeys.hip -- MIN_DISTANCE frontier sweep on KEY COORDINATES: the exact greedy set without moving positions.
+//
+// Reference: PoissonDiskSampling::sample_points (core/tiling/Sampling.h:421-471) + SparseGrid::add
+// (core/datastructures/SparseGrid.cpp:116-146) + GridCell::isDistant (GridCell.cpp:43-58); the result is the
+// lexicographically-first maximal independent set in Morton order (see swz_mindist.hip for the derivation and the
+// frontier rules (R) / (A), which are the same here).
+//
+// What is different from swz_mindist.hip:
+//  * A Morton key IS the position, quantised to 2^-21 of the (cubic) bounds.  For two points with integer key
+//    coordinates i, j the true distance in key cells lies within sqrt(3) of |i - j| (each coordinate is somewhere in its
+//    cell), so "closer than the spacing?" is decided on the keys unless |i - j| falls into a band of +-1.75 cells around
+//    the spacing (14 530 cells at the root for spacing = diagonal / 250).  Only those pairs are evaluated on the exact
+//    positions, with the reference's arithmetic, through the sort's permutation.  Blocker scans need no exact answer at
+//    all: "possibly closer" keeps a cell waiting, which is always allowed.  Nothing is gathered: a cell's points are a
+//    run of the level's sorted keys (8 coalesced bytes per point instead of 24 gathered ones).
+//  * A point that is known to be rejected (closer than the spacing to an accepted earlier point) gets a state byte, so a
+//    cell tests each of its points against the accepted points of its neighbourhood once -- not again on every
+//    activation -- and blocker scans skip dead points without testing them.
+//  * ONE launch per round.  A cell's record (frontier, accepted points) is double buffered and stamped with the round
+//    that wrote it: an activation reads, of every adjacent cell, the newer record written BEFORE this round (stable: its
+//    owner writes the other one) and writes its own new record itself -- no second launch that publishes.  Sleeping and
+//    waking without that launch: a cell that stalls writes {point it waits for, round} into the blocking cell's slot for
+//    its direction and queues itself once more ("confirm": one round later the blocker's record of THIS round is stable
+//    and says whether the point has been passed meanwhile).  A cell whose frontier moves claims the slots it has passed
+//    with a compare-and-swap and queues their owners -- except slots stamped with the current round, whose owners
+//    confirm themselves.  Whoever wins the compare-and-swap activates the sleeper, so a cell is never queued twice.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "swz_level.h"
+#include "swz_scan.h"
+
+namespace swz {
+
+constexpr uint32_t QNONE = 0xFFFFFFFFu;
+constexpr unsigned long long QEMPTY = ~0ull;
+constexpr uint32_t MQ_WOKEN = 0x80000000u;  // queue entry: activated by a claimed slot (or never slept): no confirm step
+constexpr int MQ_LIST_CAP = 128;            // accepted points of the neighbourhood in LDS (window)
+constexpr int MQ_FRESH_CAP = 32;            // points a cell may accept per activation
+constexpr int MQ_RG_MAX = 8;                // 16-byte granules per record buffer: header + up to 7 accepted points
+constexpr uint32_t MQ_FIRST_ROUND = 2;      // record buffers start with stamps 0 and 1
+
+enum : uint8_t { QS_OPEN = 0, QS_TAKEN = 1, QS_DEAD = 2 };
+
+// ----------------------------------------------------------------------------- thresholds in key cells
+KeyMetric key_metric(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp) {
+  KeyMetric k;
+  if (!sp.xyz || !sp.perm) return k;
+  if (const char* e = c->opt("SWZ_MD_KEYS"))
+    if (atoi(e) == 0) return k;
+  const double ex = plan.root.maxx - plan.root.minx, ey = plan.root.maxy - plan.root.miny, ez = plan.root.maxz - plan.root.minz;
+  if (!(ex > 0.0) || ex != ey || ey != ez) return k;  // one key cell must be a cube (the Tiler's bounds are)
+  const double cell = ex / 2097152.0;
+  const double T = std::sqrt(plan.sq_spacing) / cell;
+  double tmin = 64.0;  // below that most near pairs fall into the band (levels >= 7 at spacing = diagonal / 250)
+  if (const char* e = c->opt("SWZ_MD_KEYS_MIN_CELLS")) tmin = atof(e);
+  if (!(T >= tmin) || !(T < 4.0e6)) return k;
+  // A coordinate u = (p - min) * scale (calculate_morton_index, OctreeAlgorithms.h:64-87) has key coordinate
+  // i = min(trunc(fl(u)), 2^21 - 1): u is within [i, i + 1] up to the rounding of fl (1e-9 cells).  Per axis
+  // |du - di| <= 1 + 2e-9, so | |du| - |di| | <= sqrt(3) (1 + 2e-9) < 1.7321.  The squared integer distance is evaluated
+  // in float (exact differences, three roundings: relative 3 * 2^-24, i.e. T * 2^-23 cells of distance near the
+  // spacing).  Band: 1.75 + T * 2^-20 cells -- the reference's own rounding (1e-16 relative) disappears in the slack.
+  double band = 1.75 + T * 0x1.0p-20;
+  if (const char* e = c->opt("SWZ_MD_KEYS_BAND")) band += atof(e);  // tests: a wide band sends many / all pairs to the exact path
+  const double lo = T - band, hi = T + band;
+  float f_lo = 0.f;
+  if (lo > 0.0) {
+    f_lo = (float)(lo * lo);
+    while ((double)f_lo > lo * lo) f_lo = std::nextafterf(f_lo, 0.f);
+    f_lo = std::nextafterf(f_lo, 0.f);
+  }
+  float f_hi = (float)(hi * hi);
+  while ((double)f_hi < hi * hi) f_hi = std::nextafterf(f_hi, INFINITY);
+  f_hi = std::nextafterf(f_hi, INFINITY);
+  k.T = T;
+  k.f_lo = f_lo;
+  k.f_hi = f_hi;
+  k.ok = true;
+  return k;
+}
+
+// ----------------------------------------------------------------------------- device helpers
+struct MqArgs {
+  const uint64_t* akey;
+  const uint32_t* aidx;
+  uint32_t m;
+  const uint32_t* nid;
+  const uint8_t* nmode;
+  const uint32_t* nstart;
+  const double* xyz;      // exact positions: point perm[aidx ? aidx[i] : i]
+  const uint32_t* perm;
+  uint8_t* taken;
+  uint32_t* counters;
+  uint64_t* qpos;         // [m] key coordinates x | y << 21 | z << 42 of the active points
+  uint8_t* state;         // [m] QS_*
+  uint2* cinfo;           // [cell] {start, end}
+  uint32_t* crel;         // [cell] cell code inside its node (build time)
+  uint32_t* csnode;       // [cell] index of its node among the sampled nodes
+  uint32_t* gridmap;      // [sample node][cell code] -> cell (build time)
+  uint32_t* qnbr;         // [cell][32]: adjacent cell in direction k = (dx+1)*9 + (dy+1)*3 + (dz+1), 13 = the cell itself
+  uint4* rec;             // [cell][2][rg]: header {frontier, accepted, stamp, end} + the first rg-1 accepted points
+  float4* ovf;            // accepted point j >= rg-1 of the cell ending at `end`: ovf[end - 1 - (j - (rg-1))]
+  unsigned long long* slot;  // [cell][32]: {round written << 32 | point waited for} of the sleeper in direction k
+  uint4* qst;             // [cell]: {stalled candidate or NONE, blocker direction, point waited for, round of the stall}
+  uint32_t* queue[2];
+  const uint32_t* snode_of;
+  uint32_t cell_shift;    // key >> cell_shift = node prefix + cell code
+  uint64_t cells_per_node;
+  uint32_t cell_bits;     // cell_shift / 3: a cell is 2^cell_bits key cells wide
+  uint32_t rg, rg2_shift; // granules per record buffer (4 or 8); log2(2 * rg)
+  float f_lo, f_hi;
+  double sq_spacing;
+  uint32_t patient;
+  float lazy_frac;
+  uint32_t all_sampled;
+  uint32_t group, groups;
+  uint32_t no_dead_test;  // debugging / tests: blocker scans do not test for dead points
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t qb_u32(uint32_t v, int src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, src); }
+__device__ __forceinline__ float qb_f32(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ unsigned long long qb_u64(unsigned long long v, int src) {
+  const uint32_t lo = qb_u32((uint32_t)v, src), hi = qb_u32((uint32_t)(v >> 32), src);
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <typename Op>
+__device__ __forceinline__ uint32_t mq_wave_scan(uint32_t v, Op op, uint32_t identity) {
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x111, 0xF, 0xF, false));  // row_shr:1
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x112, 0xF, 0xF, false));  // row_shr:2
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x114, 0xF, 0xF, false));  // row_shr:4
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x118, 0xF, 0xF, false));  // row_shr:8
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x142, 0xA, 0xF, false));  // row_bcast:15
+  v = op(v, (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, 0x143, 0xC, 0xF, false));  // row_bcast:31
+  return v;
+}
+struct MqAdd {
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a + b; }
+};
+struct MqMax {
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
+};
+
+__device__ __forceinline__ uint64_t mq_pack(uint64_t key) {
+  // octant = x << 2 | y << 1 | z (MortonIndex.h:62-79): bit 3j+2 of the key is bit j of x
+  return contract_bits_by_3(key >> 2) | (contract_bits_by_3(key >> 1) << 21) | (contract_bits_by_3(key) << 42);
+}
+__device__ __forceinline__ void mq_unpack(uint64_t v, float& x, float& y, float& z) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  x = (float)(lo & 0x1FFFFFu);
+  y = (float)(((lo >> 21) | (hi << 11)) & 0x1FFFFFu);
+  z = (float)(hi >> 10);
+}
+// squared distance of two points in key cells: the differences of integers below 2^21 are exact in float, the three
+// roundings of the sum are part of the band (key_metric)
+__device__ __forceinline__ float mq_d2(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+// the reference's compare on the exact positions (GridCell.cpp:52) for active points i and j
+__device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint32_t j) {
+  const uint32_t si = a.aidx ? a.aidx[i] : i, sj = a.aidx ? a.aidx[j] : j;
+  const double* p = a.xyz + (size_t)a.perm[si] * 3;
+  const double* q = a.xyz + (size_t)a.perm[sj] * 3;
+  return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
+}
+
+struct MqLds {
+  uint4 stage[27 * 2 * MQ_RG_MAX];  // both record buffers of the 27 cells of the neighbourhood
+  float4 list[MQ_LIST_CAP];         // accepted points of the earlier adjacent cells and of this cell (window)
+  float4 fresh[MQ_FRESH_CAP];       // accepted in this activation
+};
+
+__device__ __forceinline__ bool mq_is_head(const MqArgs& a, uint32_t i) {
+  if (!a.all_sampled && a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
+  return i == 0 || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
+}
+
+// ----------------------------------------------------------------------------- build
+__global__ __launch_bounds__(256) void mq_pack_kernel(const uint64_t* __restrict__ akey, uint32_t m, uint64_t* __restrict__ qpos,
+                                                      uint8_t* __restrict__ state) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  qpos[i] = mq_pack(akey[i]);
+  state[i] = QS_OPEN;
+}
+
+struct MqHeadF {
+  MqArgs a;
+  __device__ uint32_t operator()(uint32_t i) const { return mq_is_head(a, i) ? 1u : 0u; }
+};
+struct MqCellBuildG {
+  MqArgs a;
+  __device__ void operator()(uint32_t i, uint32_t c, uint32_t head) const {
+    if (!head) return;
+    a.cinfo[c].x = i;
+    a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
+    a.csnode[c] = a.all_sampled ? a.nid[i] : a.snode_of[a.nid[i]];
+  }
+};
+
+__global__ __launch_bounds__(256) void mq_cell_end_kernel(MqArgs a, uint32_t ncells) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const uint32_t s = a.cinfo[c].x;
+  const uint32_t node_end = a.nstart[a.nid[s] + 1];
+  const uint32_t next = (c + 1 < ncells) ? a.cinfo[c + 1].x : a.m;
+  const uint32_t e = next < node_end ? next : node_end;
+  a.cinfo[c].y = e;
+  a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + a.crel[c]] = c;
+  uint4* r = a.rec + ((size_t)c << a.rg2_shift);
+  r[0] = make_uint4(s, 0u, 0u, e);
+  r[a.rg] = make_uint4(s, 0u, 1u, e);
+  a.qst[c] = make_uint4(QNONE, 0u, 0u, 0u);
+}
+
+// the 26 adjacent cells by direction (codes by arithmetic on the dilated coordinates, as md_nbr_build_kernel does)
+__global__ __launch_bounds__(256) void mq_nbr_build_kernel(MqArgs a, uint32_t ncells) {
+  for (uint64_t cbase = (uint64_t)blockIdx.x * 8u; cbase < ncells; cbase += (uint64_t)gridDim.x * 8u) {
+    const uint32_t c = (uint32_t)cbase + threadIdx.x / 32u;
+    const uint32_t k = threadIdx.x & 31u;
+    if (c >= ncells) continue;
+    uint32_t nb = QNONE;
+    if (k == 13u) {
+      nb = c;
+    } else if (k < 27u) {
+      const uint32_t rel = a.crel[c];
+      const uint32_t all = (uint32_t)(a.cells_per_node - 1ull);
+      const uint32_t mz = all & 0x09249249u, my = mz << 1, mx = mz << 2;
+      const uint32_t v[3] = {rel & mx, rel & my, rel & mz};
+      const uint32_t mk[3] = {mx, my, mz};
+      const uint32_t d[3] = {k / 9u, (k / 3u) % 3u, k % 3u};  // 0: minus one, 1: same, 2: plus one
+      bool inside = true;
+      uint32_t nrel = 0;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        uint32_t w = v[ax];
+        if (d[ax] == 0u) {
+          inside &= w != 0u;
+          w = (w - 1u) & mk[ax];
+        } else if (d[ax] == 2u) {
+          inside &= w != mk[ax];
+          w = ((w | ~mk[ax]) + 1u) & mk[ax];
+        }
+        nrel |= w;
+      }
+      if (inside) nb = a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + nrel];
+    }
+    a.qnbr[(size_t)c * 32 + k] = nb;
+  }
+}
+
+// append `value` of every lane with want == true to the queue: one atomic per wavefront
+__device__ __forceinline__ void mq_wave_push(bool want, uint32_t value, uint32_t* qout, uint32_t* cout) {
+  const uint64_t m = __ballot(want);
+  if (!m) return;
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane_id() == leader) base = atomicAdd(cout, (uint32_t)__popcll(m));
+  base = __shfl(base, leader, WAVE);
+  if (want) qout[base + (uint32_t)__popcll(m & lanemask_lt())] = value;
+}
+
+// Start of a level.  lazy: only the cells without an earlier adjacent cell are queued; every other cell sleeps on its
+// latest earlier neighbour until that one has decided the given fraction of its points (sleeping on a cell that is not
+// the real blocker is always safe: the cell looks again when it wakes up).  Otherwise every cell is queued.
+__global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells, int lazy, uint32_t* q, uint32_t* counter) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  bool push = false;
+  if (c < ncells && a.csnode[c] % a.groups == a.group) {
+    push = true;
+    if (lazy) {
+      uint32_t best = QNONE, bk = 0;
+      for (uint32_t k = 0; k < 27u; ++k) {
+        const uint32_t nb = a.qnbr[(size_t)c * 32 + k];
+        if (nb != QNONE && nb < c && (best == QNONE || nb > best)) {
+          best = nb;
+          bk = k;
+        }
+      }
+      if (best != QNONE) {
+        push = false;
+        const uint2 o = a.cinfo[best];
+        const uint32_t bq = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
+        a.slot[(size_t)best * 32 + (26u - bk)] = (unsigned long long)bq;  // stamp 0: written before the first round
+        a.qst[c] = make_uint4(a.cinfo[c].x, bk, bq, 0u);
+      }
+    }
+  }
+  mq_wave_push(push, c | MQ_WOKEN, q, counter);
+}
+
+// ----------------------------------------------------------------------------- the sweep
+// First point of [qs, qe) that may keep a candidate at (cx, cy, cz) waiting: not known dead and possibly closer than the
+// spacing (inside the band counts: waiting is always allowed), or NONE.  A point that is closer than the spacing for sure
+// to one of the live_wn accepted points in LDS is dead as well (its cell has not looked at it since).
+template <int SU>
+__device__ __forceinline__ uint32_t mq_scan(const MqArgs& a, const MqLds& lds, uint32_t live_wn, uint32_t qs, uint32_t qe, float cx,
+                                            float cy, float cz) {
+  const uint32_t l = lane_id();
+  for (uint32_t q0 = qs; q0 < qe; q0 += (uint32_t)SU * WAVE) {
+    uint64_t v[SU];
+    uint8_t s[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const uint32_t q = q0 + (uint32_t)u * WAVE + l;
+      const bool inb = q < qe;
+      v[u] = inb ? a.qpos[q] : 0ull;
+      s[u] = inb ? a.state[q] : (uint8_t)QS_DEAD;
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      float x, y, z;
+      mq_unpack(v[u], x, y, z);
+      bool hit = s[u] != QS_DEAD && mq_d2(x, y, z, cx, cy, cz) < a.f_hi;
+      uint64_t hb = __ballot(hit);
+      if (hb && live_wn) {
+        if (hit) {
+          for (uint32_t i = 0; i < live_wn; ++i) {
+            const float4 e = lds.list[i];
+            if (mq_d2(x, y, z, e.x, e.y, e.z) < a.f_lo) {
+              hit = false;
+              break;
+            }
+          }
+        }
+        hb = __ballot(hit);
+      }
+      if (hb) return q0 + (uint32_t)u * WAVE + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
+    }
+  }
+  return QNONE;
+}
+
+enum : uint32_t { QO_FINISHED = 0, QO_STALLED = 1, QO_YIELD = 2 };
+
+// One wavefront advances one cell as far as it can.  U: chunks of 64 points held in registers at a time.
+template <int U>
+__device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, MqLds& lds, uint32_t* qout, uint32_t* cout) {
+  const uint32_t l = lane_id();
+  const bool woken = (qentry & MQ_WOKEN) != 0u;
+  const uint32_t c = qentry & ~MQ_WOKEN;
+  const uint32_t rg = a.rg, rg2s = a.rg2_shift, cap = rg - 1u;
+  const float f_lo = a.f_lo, f_hi = a.f_hi;
+
+  // ---- first round trip: everything that hangs on the cell index alone
+  const uint32_t nbv = a.qnbr[(size_t)c * 32 + (l & 31u)];
+  const unsigned long long myslot = a.slot[(size_t)c * 32 + (l & 31u)];
+  const uint2 ci = a.cinfo[c];
+  const uint4 st = a.qst[c];
+  uint4* myrec = a.rec + ((size_t)c << rg2s);
+  const uint4 h0 = myrec[0], h1 = myrec[rg];
+  const uint32_t sbuf = h1.z > h0.z ? 1u : 0u;  // the newer of this cell's own records (both are from earlier rounds)
+  const uint32_t e = ci.y, P = sbuf ? h1.x : h0.x, CNT = sbuf ? h1.y : h0.y;
+  if (P >= e) return;  // (a finished cell is never queued)
+
+  // ---- confirm: this cell stalled last time it ran and nobody has claimed its slot since
+  if (st.x != QNONE && !woken) {
+    const uint32_t bk = uni(st.y);
+    const uint32_t B = qb_u32(nbv, (int)bk);
+    const uint4* brec = a.rec + ((size_t)B << rg2s);
+    const uint4 b0 = brec[0], b1 = brec[rg];
+    const bool use1 = b1.z < round && (b0.z >= round || b1.z > b0.z);
+    const uint4 hb = use1 ? b1 : b0;
+    const bool passed = hb.x > st.z || hb.x >= hb.w;
+    if (!passed) return;  // still asleep: the blocker wakes this cell when it gets there
+    const unsigned long long expect = ((unsigned long long)st.w << 32) | st.z;
+    unsigned long long old = expect;
+    if (l == 0) old = atomicCAS(&a.slot[(size_t)B * 32 + (26u - bk)], expect, QEMPTY);
+    old = qb_u64(old, 0);
+    if (old != expect) return;  // the blocker got there first and has queued this cell for the next round
+  }
+
+  // ---- second round trip: the records of the neighbourhood (staged in LDS), the window of own points at the frontier
+  uint64_t pv[U];
+  uint8_t ps[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const uint32_t p = P + (uint32_t)u * WAVE + l;
+    const bool inb = p < e;
+    pv[u] = inb ? a.qpos[p] : 0ull;
+    ps[u] = inb ? a.state[p] : (uint8_t)QS_DEAD;
+  }
+  {
+    const uint32_t ngran = 27u << rg2s;
+    uint4 tmp[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const uint32_t g = (uint32_t)j * WAVE + l;
+      const uint32_t n = g >> rg2s, part = g & ((1u << rg2s) - 1u);
+      const uint32_t nb = (uint32_t)__shfl((int)nbv, (int)(n < 27u ? n : 0u), WAVE);
+      tmp[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (g < ngran && nb != QNONE && nb <= c) tmp[j] = a.rec[((size_t)nb << rg2s) + part];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      const uint32_t g = (uint32_t)j * WAVE + l;
+      const uint32_t n = g >> rg2s, part = g & ((1u << rg2s) - 1u);
+      if (g < ngran) lds.stage[n * 16u + (part < rg ? part : 8u + part - rg)] = tmp[j];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // lane k < 27: adjacent cell k (13: this cell).  Of its two records the newer one written before this round.
+  const bool valid = l < 27u && nbv != QNONE && nbv <= c;
+  const bool earlier = valid && l != 13u;
+  uint32_t n_pos = 0, n_cnt = 0, n_end = 0, pick = 0;
+  if (valid) {
+    const uint4 a0 = lds.stage[l * 16u], a1 = lds.stage[l * 16u + 8u];
+    pick = (a1.z < round && (a0.z >= round || a1.z > a0.z)) ? 1u : 0u;
+    const uint4 hd = pick ? a1 : a0;
+    n_pos = hd.x;
+    n_cnt = hd.y;
+    n_end = hd.w;
+  }
+  const uint32_t incl = mq_wave_scan(n_cnt, MqAdd{}, 0u);
+  const uint32_t off = incl - n_cnt;
+  const uint32_t T = qb_u32(incl, WAVE - 1);  // accepted points of the neighbourhood, own committed ones included
+  const uint32_t maxcnt = qb_u32(mq_wave_scan(n_cnt, MqMax{}, 0u), WAVE - 1);
+  // entries [base, base + MQ_LIST_CAP) of the flattened list -> LDS (lane k copies what adjacent cell k contributes)
+  auto fill = [&](uint32_t base) -> uint32_t {
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = 0; j < maxcnt; ++j) {
+      const uint32_t ti = off + j;
+      if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP) {
+        uint4 src;
+        if (j < cap) src = lds.stage[l * 16u + pick * 8u + 1u + j];
+        else src = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (j - cap)));
+        *reinterpret_cast<uint4*>(&lds.list[ti - base]) = src;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    return (T - base) < (uint32_t)MQ_LIST_CAP ? (T - base) : (uint32_t)MQ_LIST_CAP;
+  };
+  const uint32_t wn0 = T ? fill(0u) : 0u;
+  uint32_t resident = 0;  // first entry of the list window LDS holds
+  const uint32_t live_wn = (T <= (uint32_t)MQ_LIST_CAP && !a.no_dead_test) ? wn0 : 0u;  // the whole list is resident: scans can tell dead points
+
+  uint32_t fresh = 0;
+  uint32_t out_pos = e, out_status = QO_FINISHED, b_k = 0, b_q = 0;
+  const uint32_t S = 1u << a.cell_bits;
+
+  for (uint32_t W0 = P; W0 < e; W0 += (uint32_t)U * WAVE) {
+    float fx[U], fy[U], fz[U];
+    uint32_t alive = 0;  // bit u: this lane's point of chunk u is open (neither decided nor known dead)
+    if (W0 != P) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t p = W0 + (uint32_t)u * WAVE + l;
+        const bool inb = p < e;
+        pv[u] = inb ? a.qpos[p] : 0ull;
+        ps[u] = inb ? a.state[p] : (uint8_t)QS_DEAD;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      mq_unpack(pv[u], fx[u], fy[u], fz[u]);
+      alive |= (ps[u] == QS_OPEN ? 1u : 0u) << u;
+    }
+    if (!__ballot(alive != 0u)) continue;  // a window of dead points
+
+    // (R) against the committed accepted points of the neighbourhood, window by window, then against the points
+    // accepted earlier in this activation (they matter for the windows after the first).  Per chunk the smallest squared
+    // key distance to a list entry decides: below f_lo some accepted point is closer than the spacing for sure; below
+    // f_hi (and not below f_lo) at least one pair lies inside the band and goes to the exact compare.
+    {
+      uint32_t nearb = 0;
+      for (uint32_t base = 0;; base += (uint32_t)MQ_LIST_CAP) {
+        const bool last = base >= T;  // the extra pass: the points accepted earlier in this activation
+        uint32_t wn = fresh;
+        if (!last) {
+          if (resident != base) {
+            (void)fill(base);
+            resident = base;
+          }
+          wn = (T - base) < (uint32_t)MQ_LIST_CAP ? (T - base) : (uint32_t)MQ_LIST_CAP;
+        }
+        const float4* lst = last ? lds.fresh : lds.list;
+        float dmin[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dmin[u] = __builtin_inff();
+        for (uint32_t i = 0; i < wn; ++i) {
+          const float4 en = lst[i];
+#pragma unroll
+          for (int u = 0; u < U; ++u) dmin[u] = fminf(dmin[u], mq_d2(fx[u], fy[u], fz[u], en.x, en.y, en.z));
+        }
+        uint32_t pend = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          nearb |= (dmin[u] < f_lo ? 1u : 0u) << u;
+          pend |= (dmin[u] >= f_lo && dmin[u] < f_hi ? 1u : 0u) << u;
+        }
+        pend &= alive & ~nearb;
+        if (__ballot(pend != 0u)) {  // pairs inside the band: the exact compare on the original positions
+          for (uint32_t i = 0; i < wn; ++i) {
+            const float4 en = lst[i];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+              if ((pend >> u) & 1u) {
+                const float d2 = mq_d2(fx[u], fy[u], fz[u], en.x, en.y, en.z);
+                if (d2 >= f_lo && d2 < f_hi && mq_exact_near(a, W0 + (uint32_t)u * WAVE + l, __float_as_uint(en.w))) {
+                  nearb |= 1u << u;
+                  pend &= ~(1u << u);
+                }
+              }
+            }
+          }
+        }
+        if (last) break;
+      }
+      const uint32_t died = alive & nearb;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if ((died >> u) & 1u) a.state[W0 + (uint32_t)u * WAVE + l] = QS_DEAD;
+      alive &= ~nearb;
+    }
+
+    // (A) surviving points in order: accept, or stall on a possibly undecided earlier point
+    bool stop = false;
+    for (;;) {
+      int cu = -1;
+      uint64_t bm = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint64_t b = __ballot((alive >> u) & 1u);
+        if (cu < 0 && b) {
+          cu = u;
+          bm = b;
+        }
+      }
+      if (cu < 0) break;
+      const int j = __ffsll((unsigned long long)bm) - 1;
+      const uint32_t cand = W0 + (uint32_t)cu * WAVE + (uint32_t)j;
+      float cx = 0.f, cy = 0.f, cz = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (u == cu) {
+          cx = qb_f32(fx[u], j);
+          cy = qb_f32(fy[u], j);
+          cz = qb_f32(fz[u], j);
+        }
+      }
+      // earlier adjacent cells that still hold undecided points and lie within reach of the candidate (gap between its
+      // key cell and the adjacent cell, per axis: a point over there differs by more than that many cells)
+      uint32_t need;
+      {
+        const uint32_t lx = (uint32_t)cx & (S - 1u), ly = (uint32_t)cy & (S - 1u), lz = (uint32_t)cz & (S - 1u);
+        const uint32_t dxk = l / 9u, dyk = (l / 3u) % 3u, dzk = l % 3u;
+        const float gx = dxk == 0u ? (float)lx : (dxk == 2u ? (float)(S - 1u - lx) : 0.f);
+        const float gy = dyk == 0u ? (float)ly : (dyk == 2u ? (float)(S - 1u - ly) : 0.f);
+        const float gz = dzk == 0u ? (float)lz : (dzk == 2u ? (float)(S - 1u - lz) : 0.f);
+        const float gap2 = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx));
+        need = (uint32_t)__ballot(earlier && n_pos < n_end && gap2 < f_hi);
+      }
+      bool blocked = false;
+      while (need && !blocked) {
+        const int k = __ffs((int)need) - 1;
+        need &= need - 1u;
+        const uint32_t qs = qb_u32(n_pos, k), qe = qb_u32(n_end, k);
+        const uint32_t hq = mq_scan<(U > 1 ? 4 : 1)>(a, lds, live_wn, qs, qe, cx, cy, cz);
+        if (hq != QNONE) {
+          blocked = true;
+          b_k = (uint32_t)k;
+          b_q = a.patient ? qe - 1u : hq;
+        }
+      }
+      if (blocked) {
+        out_pos = cand;
+        out_status = QO_STALLED;
+        stop = true;
+        break;
+      }
+      // accepted
+      if ((int)l == j) {
+        a.taken[cand] = 1;
+        a.state[cand] = QS_TAKEN;
+        alive &= ~(1u << cu);
+      }
+      if (l == 0) lds.fresh[fresh] = make_float4(cx, cy, cz, __uint_as_float(cand));
+      ++fresh;
+      // the points it rejects (all open points of the window are later ones)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if ((alive >> u) & 1u) {
+          const float d2 = mq_d2(fx[u], fy[u], fz[u], cx, cy, cz);
+          bool nr = d2 < f_lo;
+          if (!nr && d2 < f_hi) nr = mq_exact_near(a, W0 + (uint32_t)u * WAVE + l, cand);
+          if (nr) {
+            a.state[W0 + (uint32_t)u * WAVE + l] = QS_DEAD;
+            alive &= ~(1u << u);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (fresh == (uint32_t)MQ_FRESH_CAP) {  // LDS list full: publish and go on in the next round
+        uint32_t next = W0 + (uint32_t)U * WAVE;
+#pragma unroll
+        for (int u = U - 1; u >= 0; --u) {
+          const uint64_t b = __ballot((alive >> u) & 1u);
+          if (b) next = W0 + (uint32_t)u * WAVE + (uint32_t)__ffsll((unsigned long long)b) - 1u;
+        }
+        if (next < e) {
+          out_pos = next;
+          out_status = QO_YIELD;
+          stop = true;
+        }
+        break;
+      }
+    }
+    if (stop) break;
+    if (fresh == (uint32_t)MQ_FRESH_CAP && W0 + (uint32_t)U * WAVE < e) {  // (full exactly at the end of a window)
+      out_pos = W0 + (uint32_t)U * WAVE;
+      out_status = QO_YIELD;
+      break;
+    }
+  }
+
+  // ---- publish: the new record goes into the buffer that does NOT hold the newest one
+  const uint32_t wb = sbuf ^ 1u;
+  const uint32_t ncnt = CNT + fresh;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t j = l; j < ncnt && j < cap; j += WAVE) {
+    uint4 src;
+    if (j < CNT) src = lds.stage[13u * 16u + sbuf * 8u + 1u + j];
+    else src = *reinterpret_cast<const uint4*>(&lds.fresh[j - CNT]);
+    myrec[wb * rg + 1u + j] = src;
+  }
+  for (uint32_t jj = l; jj < fresh; jj += WAVE) {
+    const uint32_t j = CNT + jj;
+    if (j >= cap) a.ovf[e - 1u - (j - cap)] = lds.fresh[jj];
+  }
+  const bool fin = out_pos >= e;
+  if (l == 0) {
+    myrec[wb * rg] = make_uint4(fin ? e : out_pos, ncnt, round, e);
+    a.qst[c] = out_status == QO_STALLED ? make_uint4(out_pos, b_k, b_q, round) : make_uint4(QNONE, 0u, 0u, 0u);
+    if (fin) atomicAdd(&a.counters[CTR_DONE_CELLS], 1u);
+  }
+  // ---- wake the later adjacent cells that sleep on a point the frontier has passed (slots written in THIS round belong
+  // to cells that confirm themselves next round); go to sleep / come back next round
+  bool won = false;
+  if (l < 27u && nbv != QNONE && nbv > c && myslot != QEMPTY && (uint32_t)(myslot >> 32) != round &&
+      (fin || (uint32_t)myslot < out_pos)) {
+    won = atomicCAS(&a.slot[(size_t)c * 32 + l], myslot, QEMPTY) == myslot;
+  }
+  if (out_status == QO_STALLED && l == 0) {
+    const uint32_t B = qb_u32(nbv, (int)uni(b_k));
+    a.slot[(size_t)B * 32 + (26u - b_k)] = ((unsigned long long)round << 32) | b_q;
+  }
+  const uint64_t wm = __ballot(won);
+  const uint32_t self = fin ? 0u : 1u;
+  const uint32_t total = (uint32_t)__popcll(wm) + self;
+  if (total) {
+    uint32_t base = 0;
+    if (l == 0) base = atomicAdd(cout, total);
+    base = qb_u32(base, 0);
+    if (won) qout[base + (uint32_t)__popcll(wm & lanemask_lt())] = nbv | MQ_WOKEN;
+    if (self && l == 0) qout[base + (uint32_t)__popcll(wm)] = out_status == QO_YIELD ? (c | MQ_WOKEN) : c;
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t round) {
+  __shared__ MqLds lds;
+  const uint32_t r0 = round - MQ_FIRST_ROUND;
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (r0 + 2u) % 3u] = 0;
+  const uint32_t nq = a.counters[CTR_Q0 + r0 % 3u];
+  const uint32_t* qin = a.queue[r0 & 1u];
+  uint32_t* qout = a.queue[(r0 + 1u) & 1u];
+  uint32_t* cout = &a.counters[CTR_Q0 + (r0 + 1u) % 3u];
+  for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) mq_activate<U>(a, round, uni(qin[i]), lds, qout, cout);
+}
+
+// ----------------------------------------------------------------------------- host
+bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp) {
+  return !plan.md_property && key_metric(c, plan, sp).ok;
+}
+
+int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+                            uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points, const uint32_t* snode_of, int cl,
+                            double typical_pop, uint32_t* rounds_out, bool* used) {
+  *used = false;
+  const KeyMetric km = key_metric(c, plan, sp);
+  if (!km.ok) return SWZ_OK;
+  const uint32_t m = as.m;
+  MqArgs a{};
+  a.akey = as.akey;
+  a.aidx = as.aidx;
+  a.m = m;
+  a.nid = lb.nid;
+  a.nmode = lb.nmode;
+  a.nstart = lb.nstart;
+  a.xyz = sp.xyz;
+  a.perm = sp.perm;
+  a.taken = lb.taken;
+  a.counters = lb.counters;
+  a.snode_of = snode_of;
+  a.cells_per_node = 1ull << (3 * cl);
+  a.cell_shift = (plan.node_shift == 63u ? 63u : plan.node_shift) - 3u * (uint32_t)cl;
+  a.cell_bits = a.cell_shift / 3u;
+  a.f_lo = km.f_lo;
+  a.f_hi = km.f_hi;
+  a.sq_spacing = plan.sq_spacing;
+  a.all_sampled = sample_nodes == nnodes ? 1u : 0u;
+  a.no_dead_test = (c->opt("SWZ_MD_ABLATE") && (atoi(c->opt("SWZ_MD_ABLATE")) & 8)) ? 1u : 0u;
+  if (a.cell_bits > 21u) return SWZ_OK;
+
+  ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
+  // cells = runs of the cell prefix inside sampled nodes
+  uint32_t* d_cell_sums = nullptr;
+  SWZ_TRY(fused_scan_sums(c, MqHeadF{a}, m, lb.counters + CTR_NUM_CELLS, "mqc", &d_cell_sums));
+  uint32_t ncells = 0;
+  SWZ_HIP(c, hipMemcpyAsync(&ncells, lb.counters + CTR_NUM_CELLS, 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  *used = true;
+  if (ncells == 0) return SWZ_OK;
+  if (ncells >= 0x7FFFFFFFu) {
+    *used = false;
+    return SWZ_OK;
+  }
+  // a cell r spacings wide ends with about 0.75 r^3 accepted points: records of 3 or 7 inline ones
+  const double r_cell = std::ldexp(1.0, (int)a.cell_bits) / km.T;
+  a.rg = (0.75 * r_cell * r_cell * r_cell <= 2.5) ? 4u : 8u;
+  if (const char* e = c->opt("SWZ_MD_KEYS_RG")) a.rg = atoi(e) >= 8 ? 8u : 4u;
+  a.rg2_shift = a.rg == 4u ? 3u : 4u;
+
+  SWZ_TRY(c->get("md_qpos", (size_t)m, &a.qpos));
+  SWZ_TRY(c->get("md_qstate", (size_t)m, &a.state));
+  SWZ_TRY(c->get("md_qovf", (size_t)m, &a.ovf));
+  SWZ_TRY(c->get("md_qcinfo", (size_t)ncells, &a.cinfo));
+  uint32_t* cellbuf = nullptr;
+  SWZ_TRY(c->get("md_qcells", (size_t)ncells * 2, &cellbuf));
+  a.crel = cellbuf;
+  a.csnode = cellbuf + ncells;
+  SWZ_TRY(c->get("md_qnbr", (size_t)ncells * 32, &a.qnbr));
+  SWZ_TRY(c->get("md_qrec", (size_t)ncells * 2 * a.rg, &a.rec));
+  SWZ_TRY(c->get("md_qslot", (size_t)ncells * 32, &a.slot));
+  SWZ_TRY(c->get("md_qst", (size_t)ncells, &a.qst));
+  SWZ_TRY(c->get("md_queue0", (size_t)ncells, &a.queue[0]));
+  SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
+  const uint64_t grid_entries = (uint64_t)sample_nodes * a.cells_per_node;
+  SWZ_TRY(c->get("md_gridmap", (size_t)grid_entries, &a.gridmap));
+  SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
+  SWZ_HIP(c, memset_large(a.slot, 0xFF, (size_t)ncells * 32 * sizeof(unsigned long long), c->stream));
+
+  hipLaunchKernelGGL(mq_pack_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.akey, m, a.qpos, a.state);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_TRY(fused_scan_apply(c, MqHeadF{a}, MqCellBuildG{a}, m, d_cell_sums));
+  const uint32_t cb = div_up(ncells, 256);
+  hipLaunchKernelGGL(mq_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
+  SWZ_LAUNCH_CHECK(c);
+  hipLaunchKernelGGL(mq_nbr_build_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_STAGE(c, "mq tables");
+
+  // scheduling: the same rules as the sweep on positions (swz_mindist.hip)
+  const bool many_small = ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0;
+  a.patient = many_small ? 1u : 0u;
+  if (const char* e = c->opt("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
+  bool lazy = many_small || typical_pop <= 1024.0;
+  if (const char* e = c->opt("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
+  a.lazy_frac = c->opt("SWZ_MD_LAZY_FRAC") ? (float)atof(c->opt("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
+  bool big_cells = typical_pop > 64.0;
+  if (const char* e = c->opt("SWZ_MD_BIG")) big_cells = atoi(e) != 0;
+  uint32_t groups = 1;
+  if (sample_nodes >= 2 && !big_cells) groups = 2;
+  if (const char* e = c->opt("SWZ_MD_GROUPS")) groups = (uint32_t)std::max(1, std::min(8, atoi(e)));
+  groups = std::min(groups, sample_nodes);
+  std::vector<MqArgs> ga(groups, a);
+  std::vector<hipStream_t> gs(groups, c->stream);
+  for (uint32_t g = 0; g < groups; ++g) {
+    ga[g].group = g;
+    ga[g].groups = groups;
+    if (g > 0) {
+      const std::string tag = std::to_string(g);
+      SWZ_TRY(c->get(("md_queue0_g" + tag).c_str(), (size_t)ncells, &ga[g].queue[0]));
+      SWZ_TRY(c->get(("md_queue1_g" + tag).c_str(), (size_t)ncells, &ga[g].queue[1]));
+      SWZ_TRY(c->get(("md_counters_g" + tag).c_str(), (size_t)CTR_COUNT, &ga[g].counters));
+      SWZ_HIP(c, hipMemsetAsync(ga[g].counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
+      while (c->aux_streams.size() < g) {
+        hipStream_t stn = nullptr;
+        SWZ_HIP(c, hipStreamCreateWithFlags(&stn, hipStreamNonBlocking));
+        c->aux_streams.push_back(stn);
+      }
+      gs[g] = c->aux_streams[g - 1];
+    }
+    SWZ_HIP(c, hipMemsetAsync(ga[g].counters + CTR_Q0, 0, 12, c->stream));
+    hipLaunchKernelGGL(mq_start_kernel, dim3(cb), dim3(256), 0, c->stream, ga[g], ncells, lazy ? 1 : 0, ga[g].queue[0],
+                       ga[g].counters + CTR_Q0);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
+  if (dbg)
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d on keys: %u pts in %u nodes, %u cells (cell levels %d), spacing %.1f key cells, band "
+                    "[%.0f, %.0f), records of %u, typical cell %.0f pts, lazy %d (%.2f) patient %u groups %u big %d\n",
+            plan.level, sample_points, sample_nodes, ncells, cl, km.T, (double)km.f_lo, (double)km.f_hi, a.rg - 1u, typical_pop, (int)lazy,
+            (double)a.lazy_frac, a.patient, groups, (int)big_cells);
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (dbg) {
+    ev0 = c->take_event();
+    ev1 = c->take_event();
+    (void)hipEventRecord(ev0, c->stream);
+  }
+  uint32_t sweep_cap = 256u * 16u;  // one wavefront per workgroup; 16 per CU fit by LDS
+  if (const char* e = c->opt("SWZ_MD_GRID")) sweep_cap = std::max(1, atoi(e)) * 4u;
+  const uint32_t sweep_grid = std::min<uint32_t>(std::max(8u, sweep_cap / groups), std::max<uint32_t>(1u, ncells));
+  uint32_t batch = 32, batches_done = 0;
+  const bool fixed_batch = c->opt("SWZ_MD_BATCH") != nullptr;
+  if (fixed_batch) batch = std::max(1u, (uint32_t)atoi(c->opt("SWZ_MD_BATCH")));
+  const auto wall0 = std::chrono::steady_clock::now();
+  double wall_limit = 900.0;
+  if (const char* e = c->opt("SWZ_MD_TIME_LIMIT")) wall_limit = atof(e);
+  uint64_t max_rounds = 8ull * m + 1024;
+  if (const char* e = c->opt("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
+  hipEvent_t fork = nullptr;
+  if (groups > 1) {
+    fork = c->take_event();
+    SWZ_HIP(c, hipEventRecord(fork, c->stream));
+    for (uint32_t g = 1; g < groups; ++g) SWZ_HIP(c, hipStreamWaitEvent(gs[g], fork, 0));
+  }
+  std::vector<uint32_t> gdone(groups, 0);
+  uint32_t round = MQ_FIRST_ROUND, done = 0;
+  while (done < ncells) {
+    for (uint32_t b = 0; b < batch; ++b, ++round) {
+      for (uint32_t g = 0; g < groups; ++g) {
+        if (big_cells)
+          hipLaunchKernelGGL((mq_sweep_kernel<4>), dim3(sweep_grid), dim3(WAVE), 0, gs[g], ga[g], round);
+        else
+          hipLaunchKernelGGL((mq_sweep_kernel<1>), dim3(sweep_grid), dim3(WAVE), 0, gs[g], ga[g], round);
+      }
+    }
+    SWZ_LAUNCH_CHECK(c);
+    if (!fixed_batch && ++batches_done % 4u == 0u && batch < 128u) batch *= 2u;
+    for (uint32_t g = 0; g < groups; ++g)
+      SWZ_HIP(c, hipMemcpyAsync(&gdone[g], ga[g].counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, gs[g]));
+    done = 0;
+    for (uint32_t g = 0; g < groups; ++g) {
+      SWZ_HIP(c, hipStreamSynchronize(gs[g]));
+      done += gdone[g];
+    }
+    if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > wall_limit) {
+      char msg[200];
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys exceeded %.0f s: level %d, %u of %u cells done after %u rounds", wall_limit,
+               plan.level, done, ncells, round);
+      return c->fail(SWZ_ERR_INTERNAL, msg);
+    }
+    if (round > max_rounds) {
+      char msg[160];
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys did not terminate: level %d, %u of %u cells done after %u rounds", plan.level,
+               done, ncells, round);
+      return c->fail(SWZ_ERR_INTERNAL, msg);
+    }
+  }
+  if (fork) c->event_pool.push_back(fork);
+  if (const char* dc = c->opt("SWZ_MD_DUMP_CELL")) {  // debugging: the final state of one cell
+    const uint32_t cell = (uint32_t)atoll(dc);
+    if (cell < ncells) {
+      uint2 ci;
+      SWZ_HIP(c, hipMemcpy(&ci, a.cinfo + cell, sizeof(ci), hipMemcpyDeviceToHost));
+      std::vector<uint8_t> st(ci.y - ci.x), tk(ci.y - ci.x);
+      SWZ_HIP(c, hipMemcpy(st.data(), a.state + ci.x, st.size(), hipMemcpyDeviceToHost));
+      SWZ_HIP(c, hipMemcpy(tk.data(), a.taken + ci.x, tk.size(), hipMemcpyDeviceToHost));
+      std::vector<uint4> r(2 * a.rg);
+      SWZ_HIP(c, hipMemcpy(r.data(), a.rec + ((size_t)cell << a.rg2_shift), r.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+      uint32_t nbr[32];
+      SWZ_HIP(c, hipMemcpy(nbr, a.qnbr + (size_t)cell * 32, sizeof(nbr), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[swz] cell %u: [%u, %u)\n  state:", cell, ci.x, ci.y);
+      for (size_t i = 0; i < st.size(); ++i) fprintf(stderr, "%s%u", i % 64 == 0 ? "\n   " : "", (unsigned)st[i]);
+      fprintf(stderr, "\n  taken:");
+      for (size_t i = 0; i < tk.size(); ++i) fprintf(stderr, "%s%u", i % 64 == 0 ? "\n   " : "", (unsigned)tk[i]);
+      for (uint32_t b = 0; b < 2; ++b) {
+        const uint4 h = r[b * a.rg];
+        fprintf(stderr, "\n  record %u: pos %u cnt %u stamp %u end %u:", b, h.x, h.y, h.z, h.w);
+        for (uint32_t j = 0; j + 1 < a.rg; ++j) {
+          float4 en;
+          memcpy(&en, &r[b * a.rg + 1 + j], 16);
+          uint32_t id;
+          memcpy(&id, &en.w, 4);
+          fprintf(stderr, " (%.0f %.0f %.0f #%u)", en.x, en.y, en.z, id);
+        }
+      }
+      fprintf(stderr, "\n  neighbours:");
+      for (int k = 0; k < 27; ++k) fprintf(stderr, " %d", (int)nbr[k]);
+      fprintf(stderr, "\n");
+    }
+  }
+  if (rounds_out) *rounds_out += round - MQ_FIRST_ROUND;
+  if (dbg) {
+    float ms = 0.f;
+    (void)hipEventRecord(ev1, c->stream);
+    (void)hipEventSynchronize(ev1);
+    (void)hipEventElapsedTime(&ms, ev0, ev1);
+    c->event_pool.push_back(ev0);
+    c->event_pool.push_back(ev1);
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d on keys: sweep %.2f ms, %u rounds\n", plan.level, ms, round - MQ_FIRST_ROUND);
+  }
+  return SWZ_OK;
+}
+
+}  // namespace swz

@@ -1069,6 +1069,14 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
     SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, sample_nodes, sample_points, occupied, rounds_out, &used));
     if (used) return SWZ_OK;
   }
+  {
+    // dense levels whose spacing spans enough key cells: the frontier sweep on key coordinates (swz_mdkeys.hip)
+    bool used = false;
+    SWZ_TRY(min_distance_keys_level(c, plan, as, sp, lb, nnodes, sample_nodes, sample_points, snode, cl,
+                                    pop[std::min(3, plan.cell_levels_geo - cl)], rounds_out, &used));
+    if (used) return SWZ_OK;
+  }
+  if (!sp.X) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE: this level needs the positions in Morton order and they were not gathered");
   if (as.aidx) {  // below the root the survivors are a subsequence: bring their positions into active order
     double *ax = nullptr, *ay = nullptr, *az = nullptr;
     // the two big per-point buffers are shared with the sparse path (never live at the same time): "md_pos" = x[], y[],
