@@ -43,7 +43,6 @@ constexpr unsigned long long QEMPTY = ~0ull;
 constexpr uint32_t MQ_WOKEN = 0x80000000u;  // queue entry: activated by a claimed slot (or never slept): no confirm step
 constexpr int MQ_LIST_CAP = 128;            // accepted points of the neighbourhood in LDS (window)
 constexpr int MQ_FRESH_CAP = 32;            // points a cell may accept per activation
-constexpr int MQ_RG_MAX = 8;                // 16-byte granules per record buffer: header + up to 7 accepted points
 constexpr uint32_t MQ_FIRST_ROUND = 2;      // record buffers start with stamps 0 and 1
 
 enum : uint8_t { QS_OPEN = 0, QS_TAKEN = 1, QS_DEAD = 2 };
@@ -108,7 +107,10 @@ struct MqArgs {
   float4* ovf;            // accepted point j >= rg-1 of the cell ending at `end`: ovf[end - 1 - (j - (rg-1))]
   unsigned long long* slot;  // [cell][32]: {round written << 32 | point waited for} of the sleeper in direction k
   uint4* qst;             // [cell]: {stalled candidate or NONE, blocker direction, point waited for, round of the stall}
-  uint32_t* queue[2];
+  uint32_t* queue[2];     // [nseg][segcap]: the round's cells, in nseg segments so that no single counter takes every push
+  uint32_t* qctr;         // [3 rotating rounds][nseg] segment fill counters, one per 128-byte line
+  uint32_t* qtotal;       // [3]: entries the round started with (what the host polls: 0 = the level is done)
+  uint32_t nseg, nseg_shift, segcap;
   const uint32_t* snode_of;
   uint32_t cell_shift;    // key >> cell_shift = node prefix + cell code
   uint64_t cells_per_node;
@@ -121,6 +123,7 @@ struct MqArgs {
   uint32_t all_sampled;
   uint32_t group, groups;
   uint32_t no_dead_test;  // debugging / tests: blocker scans do not test for dead points
+  uint32_t stats;         // SWZ_DEBUG: count activations by kind in counters[CTR_DBG_HIST ...]
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -173,11 +176,14 @@ __device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint3
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 
+#define MQ_STAT(idx) do { if (a.stats && l == 0) atomicAdd(&a.counters[CTR_DBG_HIST + (idx)], 1u); } while (0)
+
 struct MqLds {
-  uint4 stage[27 * 2 * MQ_RG_MAX];  // both record buffers of the 27 cells of the neighbourhood
-  float4 list[MQ_LIST_CAP];         // accepted points of the earlier adjacent cells and of this cell (window)
-  float4 fresh[MQ_FRESH_CAP];       // accepted in this activation
+  uint4* stage;   // [27][2][rg]: both record buffers of the 27 cells of the neighbourhood
+  float4* list;   // [MQ_LIST_CAP]: accepted points of the earlier adjacent cells and of this cell (window)
+  float4* fresh;  // [MQ_FRESH_CAP]: accepted in this activation
 };
+static inline size_t mq_lds_bytes(uint32_t rg) { return (size_t)(27u * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u; }
 
 __device__ __forceinline__ bool mq_is_head(const MqArgs& a, uint32_t i) {
   if (!a.all_sampled && a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
@@ -272,7 +278,7 @@ __device__ __forceinline__ void mq_wave_push(bool want, uint32_t value, uint32_t
 // Start of a level.  lazy: only the cells without an earlier adjacent cell are queued; every other cell sleeps on its
 // latest earlier neighbour until that one has decided the given fraction of its points (sleeping on a cell that is not
 // the real blocker is always safe: the cell looks again when it wakes up).  Otherwise every cell is queued.
-__global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells, int lazy, uint32_t* q, uint32_t* counter) {
+__global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells, int lazy) {
   const uint32_t c = blockIdx.x * 256 + threadIdx.x;
   bool push = false;
   if (c < ncells && a.csnode[c] % a.groups == a.group) {
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells
       }
     }
   }
-  mq_wave_push(push, c | MQ_WOKEN, q, counter);
+  const uint32_t seg = blockIdx.x & (a.nseg - 1u);  // (at most 256 entries per block: a segment cannot overflow here)
+  mq_wave_push(push, c | MQ_WOKEN, a.queue[0] + (size_t)seg * a.segcap, a.qctr + (size_t)seg * 32u);
 }
 
 // ----------------------------------------------------------------------------- the sweep
@@ -344,7 +351,7 @@ enum : uint32_t { QO_FINISHED = 0, QO_STALLED = 1, QO_YIELD = 2 };
 
 // One wavefront advances one cell as far as it can.  U: chunks of 64 points held in registers at a time.
 template <int U>
-__device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, MqLds& lds, uint32_t* qout, uint32_t* cout) {
+__device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, const MqLds& lds, uint32_t* qout, uint32_t* cout, uint32_t seg0) {
   const uint32_t l = lane_id();
   const bool woken = (qentry & MQ_WOKEN) != 0u;
   const uint32_t c = qentry & ~MQ_WOKEN;
@@ -371,14 +378,21 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
     const bool use1 = b1.z < round && (b0.z >= round || b1.z > b0.z);
     const uint4 hb = use1 ? b1 : b0;
     const bool passed = hb.x > st.z || hb.x >= hb.w;
-    if (!passed) return;  // still asleep: the blocker wakes this cell when it gets there
+    if (!passed) {
+      MQ_STAT(1);
+      return;  // still asleep: the blocker wakes this cell when it gets there
+    }
     const unsigned long long expect = ((unsigned long long)st.w << 32) | st.z;
     unsigned long long old = expect;
     if (l == 0) old = atomicCAS(&a.slot[(size_t)B * 32 + (26u - bk)], expect, QEMPTY);
     old = qb_u64(old, 0);
-    if (old != expect) return;  // the blocker got there first and has queued this cell for the next round
+    if (old != expect) {
+      MQ_STAT(2);
+      return;  // the blocker got there first and has queued this cell for the next round
+    }
   }
 
+  MQ_STAT(0);
   // ---- second round trip: the records of the neighbourhood (staged in LDS), the window of own points at the frontier
   uint64_t pv[U];
   uint8_t ps[U];
@@ -403,8 +417,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
       const uint32_t g = (uint32_t)j * WAVE + l;
-      const uint32_t n = g >> rg2s, part = g & ((1u << rg2s) - 1u);
-      if (g < ngran) lds.stage[n * 16u + (part < rg ? part : 8u + part - rg)] = tmp[j];
+      if (g < ngran) lds.stage[g] = tmp[j];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -414,7 +427,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
   const bool earlier = valid && l != 13u;
   uint32_t n_pos = 0, n_cnt = 0, n_end = 0, pick = 0;
   if (valid) {
-    const uint4 a0 = lds.stage[l * 16u], a1 = lds.stage[l * 16u + 8u];
+    const uint4 a0 = lds.stage[l << rg2s], a1 = lds.stage[(l << rg2s) + rg];
     pick = (a1.z < round && (a0.z >= round || a1.z > a0.z)) ? 1u : 0u;
     const uint4 hd = pick ? a1 : a0;
     n_pos = hd.x;
@@ -432,7 +445,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
       const uint32_t ti = off + j;
       if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP) {
         uint4 src;
-        if (j < cap) src = lds.stage[l * 16u + pick * 8u + 1u + j];
+        if (j < cap) src = lds.stage[(l << rg2s) + pick * rg + 1u + j];
         else src = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (j - cap)));
         *reinterpret_cast<uint4*>(&lds.list[ti - base]) = src;
       }
@@ -565,6 +578,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
         const int k = __ffs((int)need) - 1;
         need &= need - 1u;
         const uint32_t qs = qb_u32(n_pos, k), qe = qb_u32(n_end, k);
+        MQ_STAT(4);
         const uint32_t hq = mq_scan<(U > 1 ? 4 : 1)>(a, lds, live_wn, qs, qe, cx, cy, cz);
         if (hq != QNONE) {
           blocked = true;
@@ -573,6 +587,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
         }
       }
       if (blocked) {
+        MQ_STAT(3);
         out_pos = cand;
         out_status = QO_STALLED;
         stop = true;
@@ -629,7 +644,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
   __builtin_amdgcn_wave_barrier();
   for (uint32_t j = l; j < ncnt && j < cap; j += WAVE) {
     uint4 src;
-    if (j < CNT) src = lds.stage[13u * 16u + sbuf * 8u + 1u + j];
+    if (j < CNT) src = lds.stage[(13u << rg2s) + sbuf * rg + 1u + j];
     else src = *reinterpret_cast<const uint4*>(&lds.fresh[j - CNT]);
     myrec[wb * rg + 1u + j] = src;
   }
@@ -641,7 +656,6 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
   if (l == 0) {
     myrec[wb * rg] = make_uint4(fin ? e : out_pos, ncnt, round, e);
     a.qst[c] = out_status == QO_STALLED ? make_uint4(out_pos, b_k, b_q, round) : make_uint4(QNONE, 0u, 0u, 0u);
-    if (fin) atomicAdd(&a.counters[CTR_DONE_CELLS], 1u);
   }
   // ---- wake the later adjacent cells that sleep on a point the frontier has passed (slots written in THIS round belong
   // to cells that confirm themselves next round); go to sleep / come back next round
@@ -658,24 +672,74 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, Mq
   const uint32_t self = fin ? 0u : 1u;
   const uint32_t total = (uint32_t)__popcll(wm) + self;
   if (total) {
-    uint32_t base = 0;
-    if (l == 0) base = atomicAdd(cout, total);
+    // into one segment of the next round's queue -- chosen by the cell so that the work spreads over all workgroups
+    // whatever this one read -- or, that one full, into the next that has room (the segments hold twice the cells
+    // between them and a round never has more entries than cells)
+    uint32_t base = 0, seg = (seg0 + c * 0x9E3779B1u + (c >> 7)) & (a.nseg - 1u);
+    if (l == 0) {
+      uint32_t tries = 0;
+      for (; tries < a.nseg; ++tries) {
+        base = atomicAdd(cout + (size_t)seg * 32u, total);
+        if (base + total <= a.segcap) break;
+        seg = (seg + 1u) & (a.nseg - 1u);
+      }
+      if (tries == a.nseg) {
+        atomicMax(&a.counters[CTR_ERROR], (uint32_t)SWZ_ERR_INTERNAL);
+        base = QNONE;
+      }
+    }
     base = qb_u32(base, 0);
-    if (won) qout[base + (uint32_t)__popcll(wm & lanemask_lt())] = nbv | MQ_WOKEN;
-    if (self && l == 0) qout[base + (uint32_t)__popcll(wm)] = out_status == QO_YIELD ? (c | MQ_WOKEN) : c;
+    seg = qb_u32(seg, 0);
+    if (base != QNONE) {
+      uint32_t* q = qout + (size_t)seg * a.segcap + base;
+      if (won) q[(uint32_t)__popcll(wm & lanemask_lt())] = nbv | MQ_WOKEN;
+      if (self && l == 0) q[(uint32_t)__popcll(wm)] = out_status == QO_YIELD ? (c | MQ_WOKEN) : c;
+    }
   }
 }
 
 template <int U>
 __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t round) {
-  __shared__ MqLds lds;
+  extern __shared__ uint4 mq_smem[];
+  MqLds lds;
+  lds.stage = mq_smem;
+  lds.list = reinterpret_cast<float4*>(mq_smem + 27u * 2u * a.rg);
+  lds.fresh = lds.list + MQ_LIST_CAP;
   const uint32_t r0 = round - MQ_FIRST_ROUND;
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.counters[CTR_Q0 + (r0 + 2u) % 3u] = 0;
-  const uint32_t nq = a.counters[CTR_Q0 + r0 % 3u];
-  const uint32_t* qin = a.queue[r0 & 1u];
+  const uint32_t ci = r0 % 3u, co = (r0 + 1u) % 3u, cz = (r0 + 2u) % 3u;
+  if (blockIdx.x == 0) {  // the counters the round after the next will fill; this round's total for the host
+    const uint32_t l = lane_id();
+    uint32_t mine = 0;
+    for (uint32_t sg = l; sg < a.nseg; sg += WAVE) {
+      a.qctr[((size_t)cz * a.nseg + sg) * 32u] = 0;
+      const uint32_t n = a.qctr[((size_t)ci * a.nseg + sg) * 32u];
+      mine += n < a.segcap ? n : a.segcap;
+    }
+    const uint32_t tot = qb_u32(mq_wave_scan(mine, MqAdd{}, 0u), WAVE - 1);
+    if (l == 0) a.qtotal[ci] = tot;
+  }
+  const uint32_t seg = blockIdx.x & (a.nseg - 1u);
+  uint32_t nq = a.qctr[((size_t)ci * a.nseg + seg) * 32u];
+  nq = nq < a.segcap ? nq : a.segcap;  // (a counter overshoots when a push found the segment full and went elsewhere)
+  const uint32_t* qin = a.queue[r0 & 1u] + (size_t)seg * a.segcap;
   uint32_t* qout = a.queue[(r0 + 1u) & 1u];
-  uint32_t* cout = &a.counters[CTR_Q0 + (r0 + 1u) % 3u];
-  for (uint32_t i = blockIdx.x; i < nq; i += gridDim.x) mq_activate<U>(a, round, uni(qin[i]), lds, qout, cout);
+  uint32_t* cout = a.qctr + (size_t)co * a.nseg * 32u;
+  for (uint32_t i = blockIdx.x >> a.nseg_shift; i < nq; i += gridDim.x >> a.nseg_shift)
+    mq_activate<U>(a, round, uni(qin[i]), lds, qout, cout, seg);
+}
+
+// after the last round: every cell must have reached its end (a protocol error would otherwise go unnoticed)
+__global__ __launch_bounds__(256) void mq_verify_kernel(MqArgs a, uint32_t ncells, uint32_t* __restrict__ open_cells) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  bool open = false;
+  if (c < ncells) {
+    const uint4* r = a.rec + ((size_t)c << a.rg2_shift);
+    const uint4 h0 = r[0], h1 = r[a.rg];
+    const uint4 h = h1.z > h0.z ? h1 : h0;
+    open = h.x < h.w;
+  }
+  const uint64_t bm = __ballot(open);
+  if (bm && lane_id() == 0) atomicAdd(open_cells, (uint32_t)__popcll(bm));
 }
 
 // ----------------------------------------------------------------------------- host
@@ -710,6 +774,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   a.sq_spacing = plan.sq_spacing;
   a.all_sampled = sample_nodes == nnodes ? 1u : 0u;
   a.no_dead_test = (c->opt("SWZ_MD_ABLATE") && (atoi(c->opt("SWZ_MD_ABLATE")) & 8)) ? 1u : 0u;
+  a.stats = c->opt("SWZ_MD_STATS") ? 1u : 0u;
   if (a.cell_bits > 21u) return SWZ_OK;
 
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
@@ -743,8 +808,6 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   SWZ_TRY(c->get("md_qrec", (size_t)ncells * 2 * a.rg, &a.rec));
   SWZ_TRY(c->get("md_qslot", (size_t)ncells * 32, &a.slot));
   SWZ_TRY(c->get("md_qst", (size_t)ncells, &a.qst));
-  SWZ_TRY(c->get("md_queue0", (size_t)ncells, &a.queue[0]));
-  SWZ_TRY(c->get("md_queue1", (size_t)ncells, &a.queue[1]));
   const uint64_t grid_entries = (uint64_t)sample_nodes * a.cells_per_node;
   SWZ_TRY(c->get("md_gridmap", (size_t)grid_entries, &a.gridmap));
   SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
@@ -773,15 +836,24 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   if (sample_nodes >= 2 && !big_cells) groups = 2;
   if (const char* e = c->opt("SWZ_MD_GROUPS")) groups = (uint32_t)std::max(1, std::min(8, atoi(e)));
   groups = std::min(groups, sample_nodes);
+  // the round's queue in segments with a counter each (a single counter word takes ~90 atomics per microsecond, and
+  // every activation pushes): workgroup b reads segment b % nseg and pushes into it
+  a.nseg_shift = 5;
+  if (const char* e = c->opt("SWZ_MD_KEYS_SEGS")) a.nseg_shift = (uint32_t)std::max(0, std::min(8, atoi(e)));
+  a.nseg = 1u << a.nseg_shift;
+  a.segcap = (uint32_t)std::min<uint64_t>(0x7FFFFFF0ull, 2ull * ncells / a.nseg + 4096ull);
   std::vector<MqArgs> ga(groups, a);
   std::vector<hipStream_t> gs(groups, c->stream);
   for (uint32_t g = 0; g < groups; ++g) {
     ga[g].group = g;
     ga[g].groups = groups;
+    const std::string tag = std::to_string(g);
+    SWZ_TRY(c->get(("md_qqueue0_g" + tag).c_str(), (size_t)a.nseg * a.segcap, &ga[g].queue[0]));
+    SWZ_TRY(c->get(("md_qqueue1_g" + tag).c_str(), (size_t)a.nseg * a.segcap, &ga[g].queue[1]));
+    SWZ_TRY(c->get(("md_qctr_g" + tag).c_str(), (size_t)3 * a.nseg * 32 + 32, &ga[g].qctr));
+    ga[g].qtotal = ga[g].qctr + (size_t)3 * a.nseg * 32;
+    SWZ_HIP(c, hipMemsetAsync(ga[g].qctr, 0, ((size_t)3 * a.nseg * 32 + 32) * sizeof(uint32_t), c->stream));
     if (g > 0) {
-      const std::string tag = std::to_string(g);
-      SWZ_TRY(c->get(("md_queue0_g" + tag).c_str(), (size_t)ncells, &ga[g].queue[0]));
-      SWZ_TRY(c->get(("md_queue1_g" + tag).c_str(), (size_t)ncells, &ga[g].queue[1]));
       SWZ_TRY(c->get(("md_counters_g" + tag).c_str(), (size_t)CTR_COUNT, &ga[g].counters));
       SWZ_HIP(c, hipMemsetAsync(ga[g].counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
       while (c->aux_streams.size() < g) {
@@ -791,9 +863,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
       }
       gs[g] = c->aux_streams[g - 1];
     }
-    SWZ_HIP(c, hipMemsetAsync(ga[g].counters + CTR_Q0, 0, 12, c->stream));
-    hipLaunchKernelGGL(mq_start_kernel, dim3(cb), dim3(256), 0, c->stream, ga[g], ncells, lazy ? 1 : 0, ga[g].queue[0],
-                       ga[g].counters + CTR_Q0);
+    hipLaunchKernelGGL(mq_start_kernel, dim3(cb), dim3(256), 0, c->stream, ga[g], ncells, lazy ? 1 : 0);
     SWZ_LAUNCH_CHECK(c);
   }
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
@@ -808,9 +878,21 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     ev1 = c->take_event();
     (void)hipEventRecord(ev0, c->stream);
   }
-  uint32_t sweep_cap = 256u * 16u;  // one wavefront per workgroup; 16 per CU fit by LDS
-  if (const char* e = c->opt("SWZ_MD_GRID")) sweep_cap = std::max(1, atoi(e)) * 4u;
-  const uint32_t sweep_grid = std::min<uint32_t>(std::max(8u, sweep_cap / groups), std::max<uint32_t>(1u, ncells));
+  // one wavefront per workgroup, as many as are resident at once (registers and LDS decide), a multiple of the segments
+  const size_t lds_bytes = mq_lds_bytes(a.rg);
+  uint32_t sweep_grid = 0;
+  {
+    int dev = 0, cus = 0, per_cu = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const hipError_t oe = big_cells ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mq_sweep_kernel<4>, WAVE, lds_bytes)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mq_sweep_kernel<1>, WAVE, lds_bytes);
+    if (oe != hipSuccess || per_cu < 1) per_cu = 8;
+    if (cus < 1) cus = 256;
+    uint32_t cap = (uint32_t)cus * (uint32_t)per_cu;
+    if (const char* e = c->opt("SWZ_MD_GRID")) cap = (uint32_t)std::max(1, atoi(e)) * 4u;
+    sweep_grid = std::max(a.nseg, (std::min<uint32_t>(cap / groups, ncells) + a.nseg - 1u) / a.nseg * a.nseg);
+  }
   uint32_t batch = 32, batches_done = 0;
   const bool fixed_batch = c->opt("SWZ_MD_BATCH") != nullptr;
   if (fixed_batch) batch = std::max(1u, (uint32_t)atoi(c->opt("SWZ_MD_BATCH")));
@@ -825,40 +907,62 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     SWZ_HIP(c, hipEventRecord(fork, c->stream));
     for (uint32_t g = 1; g < groups; ++g) SWZ_HIP(c, hipStreamWaitEvent(gs[g], fork, 0));
   }
-  std::vector<uint32_t> gdone(groups, 0);
-  uint32_t round = MQ_FIRST_ROUND, done = 0;
-  while (done < ncells) {
+  // a level is done when a round starts with an empty queue: only running cells wake sleeping ones
+  std::vector<uint32_t> gleft(groups, 1);
+  uint32_t round = MQ_FIRST_ROUND;
+  bool running = true;
+  while (running) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
       for (uint32_t g = 0; g < groups; ++g) {
         if (big_cells)
-          hipLaunchKernelGGL((mq_sweep_kernel<4>), dim3(sweep_grid), dim3(WAVE), 0, gs[g], ga[g], round);
+          hipLaunchKernelGGL((mq_sweep_kernel<4>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
         else
-          hipLaunchKernelGGL((mq_sweep_kernel<1>), dim3(sweep_grid), dim3(WAVE), 0, gs[g], ga[g], round);
+          hipLaunchKernelGGL((mq_sweep_kernel<1>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
       }
     }
     SWZ_LAUNCH_CHECK(c);
     if (!fixed_batch && ++batches_done % 4u == 0u && batch < 128u) batch *= 2u;
-    for (uint32_t g = 0; g < groups; ++g)
-      SWZ_HIP(c, hipMemcpyAsync(&gdone[g], ga[g].counters + CTR_DONE_CELLS, 4, hipMemcpyDeviceToHost, gs[g]));
-    done = 0;
+    for (uint32_t g = 0; g < groups; ++g)  // what the last launched round started with
+      SWZ_HIP(c, hipMemcpyAsync(&gleft[g], ga[g].qtotal + (round - 1u - MQ_FIRST_ROUND) % 3u, 4, hipMemcpyDeviceToHost, gs[g]));
+    running = false;
     for (uint32_t g = 0; g < groups; ++g) {
       SWZ_HIP(c, hipStreamSynchronize(gs[g]));
-      done += gdone[g];
+      running |= gleft[g] != 0u;
     }
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > wall_limit) {
       char msg[200];
-      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys exceeded %.0f s: level %d, %u of %u cells done after %u rounds", wall_limit,
-               plan.level, done, ncells, round);
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys exceeded %.0f s: level %d, %u cells, %u rounds", wall_limit, plan.level,
+               ncells, round);
       return c->fail(SWZ_ERR_INTERNAL, msg);
     }
     if (round > max_rounds) {
       char msg[160];
-      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys did not terminate: level %d, %u of %u cells done after %u rounds", plan.level,
-               done, ncells, round);
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys did not terminate: level %d, %u cells, %u rounds", plan.level, ncells, round);
       return c->fail(SWZ_ERR_INTERNAL, msg);
     }
   }
   if (fork) c->event_pool.push_back(fork);
+  {  // every cell at its end, no queue segment ever full everywhere
+    uint32_t* d_open = nullptr;
+    SWZ_TRY(c->get("md_qopen", (size_t)4, &d_open));
+    SWZ_HIP(c, hipMemsetAsync(d_open, 0, 4, c->stream));
+    hipLaunchKernelGGL(mq_verify_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, d_open);
+    SWZ_LAUNCH_CHECK(c);
+    uint32_t open_cells = 0, err = 0;
+    SWZ_HIP(c, hipMemcpyAsync(&open_cells, d_open, 4, hipMemcpyDeviceToHost, c->stream));
+    for (uint32_t g = 0; g < groups; ++g) {
+      uint32_t eg = 0;
+      SWZ_HIP(c, hipMemcpyAsync(&eg, ga[g].counters + CTR_ERROR, 4, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      err |= eg;
+    }
+    if (open_cells || err) {
+      char msg[200];
+      snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys ended with %u of %u cells undecided at level %d after %u rounds (queue overflow: %s)",
+               open_cells, ncells, plan.level, round - MQ_FIRST_ROUND, err ? "yes" : "no");
+      return c->fail(SWZ_ERR_INTERNAL, msg);
+    }
+  }
   if (const char* dc = c->opt("SWZ_MD_DUMP_CELL")) {  // debugging: the final state of one cell
     const uint32_t cell = (uint32_t)atoll(dc);
     if (cell < ncells) {
@@ -900,6 +1004,12 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     c->event_pool.push_back(ev0);
     c->event_pool.push_back(ev1);
     fprintf(stderr, "[swz] MIN_DISTANCE level %d on keys: sweep %.2f ms, %u rounds\n", plan.level, ms, round - MQ_FIRST_ROUND);
+    for (uint32_t g = 0; g < groups; ++g) {
+      uint32_t h[CTR_COUNT];
+      SWZ_HIP(c, hipMemcpy(h, ga[g].counters, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "[swz]   group %u: %u full activations, %u confirms still asleep, %u confirms that lost the claim, %u stalls, %u scans\n", g,
+              h[CTR_DBG_HIST], h[CTR_DBG_HIST + 1], h[CTR_DBG_HIST + 2], h[CTR_DBG_HIST + 3], h[CTR_DBG_HIST + 4]);
+    }
   }
   return SWZ_OK;
 }
