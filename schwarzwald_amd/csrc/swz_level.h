@@ -125,6 +125,9 @@ struct KeyMetric {
   float f_hi = 0.f;    //                                >= f_hi: at least the spacing apart for sure
 };
 KeyMetric key_metric(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp);
+// The caller's index of every active point: perm[aidx[i]] in one array (a streaming pass: aidx ascends), so that the exact
+// compare of a pair costs two dependent loads per point instead of three.  At the root this is perm itself.
+int key_point_ids(swz_ctx* c, const ActiveSet& as, const SortedPoints& sp, const uint32_t** ids);
 // true when min_distance_level will not need sp.X / sp.Y / sp.Z for this level
 bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp);
 // Frontier sweep on key coordinates for a dense level; *used = false when the level does not qualify.

@@ -855,6 +855,7 @@ struct TileSession {
   uint32_t* perm = nullptr;  // original index per sorted position
   int8_t* level = nullptr;
   uint32_t* dup = nullptr;
+  const double* xyz_in = nullptr;  // the caller's positions (clamped by the encode)
   SortedPoints sp;
   LevelBuffers lb;
   uint64_t* key_buf[2] = {nullptr, nullptr};
@@ -867,7 +868,33 @@ struct TileSession {
   int max_level = -1;
   int fast_start = -1;
   uint32_t ghosts = 0;  // leading points that belong to other shards (sharded batches only)
+  uint32_t front = 0;   // entries kept free in front of the per-position arrays (sharded batches)
 };
+
+// positions of the session's points into Morton order (once)
+static int session_gather_positions(swz_ctx* c, TileSession& t) {
+  if (t.sp.X) return SWZ_OK;
+  double *X = nullptr, *Y = nullptr, *Z = nullptr;
+  SWZ_TRY(c->get("sorted_x", (size_t)t.n + t.front, &X));
+  SWZ_TRY(c->get("sorted_y", (size_t)t.n + t.front, &Y));
+  SWZ_TRY(c->get("sorted_z", (size_t)t.n + t.front, &Z));
+  X += t.front;
+  Y += t.front;
+  Z += t.front;
+  SWZ_STAGE(c, "sort");
+  SWZ_TRY(gather_positions(c, t.xyz_in, t.perm, t.n, X, Y, Z));
+  SWZ_STAGE(c, "gather");
+  t.sp.X = X;
+  t.sp.Y = Y;
+  t.sp.Z = Z;
+  return SWZ_OK;
+}
+// a level that cannot be decided on keys needs them
+static int session_need_positions(swz_ctx* c, TileSession& t, const LevelPlan& plan) {
+  if (t.sp.X || plan.sampler != SWZ_MIN_DISTANCE) return SWZ_OK;
+  if (min_distance_level_uses_keys(c, plan, t.sp)) return SWZ_OK;
+  return session_gather_positions(c, t);
+}
 
 // K1 + K2 + gather: index, sort, positions into Morton order
 // `front`: entries kept free in FRONT of every per-sorted-position array (sharded batches prepend ghosts).
@@ -885,6 +912,7 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   t.perm = out.perm;
   t.level = out.level;
   t.dup = out.dup;
+  t.xyz_in = d_xyz;
   uint64_t* keys_b = nullptr;
   uint32_t* vals_b = nullptr;
   SWZ_TRY(c->get("sort_keys_b", (size_t)n, &keys_b));
@@ -897,21 +925,20 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
     SWZ_TRY(encode_device(c, d_xyz, n, bmin, bmax, out.keys));
     SWZ_TRY(radix_sort_pairs(c, out.keys, out.perm, keys_b, vals_b, n, true));
   }
-  double *X = nullptr, *Y = nullptr, *Z = nullptr;
-  if (p.sampler != SWZ_RANDOM_GRID) {  // RANDOM_GRID decides on the keys alone
-    SWZ_TRY(c->get("sorted_x", (size_t)n + front, &X));
-    SWZ_TRY(c->get("sorted_y", (size_t)n + front, &Y));
-    SWZ_TRY(c->get("sorted_z", (size_t)n + front, &Z));
-    X += front;
-    Y += front;
-    Z += front;
-    SWZ_STAGE(c, "sort");
-    SWZ_TRY(gather_positions(c, d_xyz, out.perm, n, X, Y, Z));
-    SWZ_STAGE(c, "gather");
+  // The positions in Morton order (SoA).  RANDOM_GRID decides on the keys alone.  MIN_DISTANCE decides on the key
+  // coordinates and looks up the pairs inside the quantisation band through the permutation (swz_mdkeys.hip): there
+  // the gather is put off until a level asks for it (session_need_positions) -- for cubic bounds and exact mode that is
+  // a level so deep that its spacing spans fewer than 64 key cells, which few clouds reach.  Sharded batches that
+  // prepend ghosts (front > 0) index two position arrays and always gather.
+  t.sp = SortedPoints{nullptr, nullptr, nullptr, front ? nullptr : d_xyz, out.perm};
+  t.front = front;
+  if (p.sampler != SWZ_RANDOM_GRID) {
+    const LevelPlan top = make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
+    const bool on_keys = p.sampler == SWZ_MIN_DISTANCE && !(p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && key_metric(c, top, t.sp).ok;
+    if (!on_keys) SWZ_TRY(session_gather_positions(c, t));
   }
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(out.level, 0x80, (size_t)n, c->stream));  // -128 = not persisted yet
-  t.sp = SortedPoints{X, Y, Z, d_xyz, out.perm};
   SWZ_TRY(alloc_level_buffers(c, n + front, &t.lb));
   // survivors ping-pong between the sort's secondary buffers and one extra pair
   t.key_buf[0] = keys_b;
@@ -940,6 +967,7 @@ static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int fi
         plan.max_points = ~0ull;
       }
     }
+    SWZ_TRY(session_need_positions(c, t, plan));
     LevelResult r;
     SWZ_TRY(level_step(c, plan, t.as, t.sp, t.lb, t.level, t.key_buf[t.which], t.idx_buf[t.which], &r));
     t.visited += t.as.m;
@@ -1092,6 +1120,7 @@ int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], con
                                bmax, true, false);
     plan.md_property = (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
     ActiveSet as{rkey, ridx, m};
+    SWZ_TRY(session_need_positions(c, t, plan));
     LevelResult r;
     SWZ_TRY(level_step(c, plan, as, t.sp, t.lb, nullptr, nullptr, nullptr, &r));
     hipLaunchKernelGGL(recon_mark_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, ridx, m, t.lb.taken,
@@ -1258,6 +1287,7 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   SWZ_TRY(c->get("shard_perm", (size_t)total, &out.perm));
   SWZ_TRY(c->get("shard_level", (size_t)total, &out.level));
   SWZ_TRY(session_prepare(c, s->t, xyz, total, bmin, bmax, p, out));
+  SWZ_TRY(session_gather_positions(c, s->t));  // swz_shard_root_taken hands out positions in Morton order
   s->t.ghosts = ghosts;
   s->n_local = n;
   }

@@ -84,6 +84,24 @@ KeyMetric key_metric(const swz_ctx* c, const LevelPlan& plan, const SortedPoints
   return k;
 }
 
+__global__ __launch_bounds__(256) void mq_point_ids_kernel(const uint32_t* __restrict__ aidx, const uint32_t* __restrict__ perm, uint32_t m,
+                                                           uint32_t* __restrict__ ids) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) ids[i] = perm[aidx[i]];
+}
+int key_point_ids(swz_ctx* c, const ActiveSet& as, const SortedPoints& sp, const uint32_t** ids) {
+  if (!as.aidx) {
+    *ids = sp.perm;
+    return SWZ_OK;
+  }
+  uint32_t* d = nullptr;
+  SWZ_TRY(c->get("md_qids", (size_t)as.m, &d));
+  hipLaunchKernelGGL(mq_point_ids_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, as.aidx, sp.perm, as.m, d);
+  SWZ_LAUNCH_CHECK(c);
+  *ids = d;
+  return SWZ_OK;
+}
+
 // ----------------------------------------------------------------------------- device helpers
 struct MqArgs {
   const uint64_t* akey;
@@ -92,8 +110,8 @@ struct MqArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* nstart;
-  const double* xyz;      // exact positions: point perm[aidx ? aidx[i] : i]
-  const uint32_t* perm;
+  const double* xyz;      // exact positions: point ids[i] of the caller's array
+  const uint32_t* ids;
   uint8_t* taken;
   uint32_t* counters;
   uint64_t* qpos;         // [m] key coordinates x | y << 21 | z << 42 of the active points
@@ -170,9 +188,8 @@ __device__ __forceinline__ float mq_d2(float ax, float ay, float az, float bx, f
 }
 // the reference's compare on the exact positions (GridCell.cpp:52) for active points i and j
 __device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint32_t j) {
-  const uint32_t si = a.aidx ? a.aidx[i] : i, sj = a.aidx ? a.aidx[j] : j;
-  const double* p = a.xyz + (size_t)a.perm[si] * 3;
-  const double* q = a.xyz + (size_t)a.perm[sj] * 3;
+  const double* p = a.xyz + (size_t)a.ids[i] * 3;
+  const double* q = a.xyz + (size_t)a.ids[j] * 3;
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 
@@ -762,7 +779,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   a.nmode = lb.nmode;
   a.nstart = lb.nstart;
   a.xyz = sp.xyz;
-  a.perm = sp.perm;
+  SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
   a.taken = lb.taken;
   a.counters = lb.counters;
   a.snode_of = snode_of;

@@ -46,11 +46,14 @@ struct SpArgs {
   const uint8_t* nmode;
   const uint32_t* snode_of;
   uint32_t all_sampled;      // every node of the level is sampled (the usual case): no look at nmode, snode_of is the identity
-  const float4* rec;   // active order: position relative to the node's min corner, rounded to float; w unused
+  const float4* rec;   // active order: position relative to the node's min corner, rounded to float; w unused --
+                       // or, when the level is decided on keys (xyz != null), the point's integer key coordinates
   const uint32_t* aidx;      // exact positions of active point i: X[aidx ? aidx[i] : i]
   const double* X;
   const double* Y;
   const double* Z;
+  const double* xyz;         // on keys: exact position of active point i = xyz[3 * ids[i]]
+  const uint32_t* ids;
   float f_lo, f_hi;          // float squared distance < f_lo: closer than the spacing for sure, >= f_hi: farther for sure
   uint32_t m;
   uint32_t cell_shift;      // key >> cell_shift = node prefix + cell code
@@ -124,8 +127,22 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t* __restri
   rec[i] = make_float4((float)(X[s] - nb.minx), (float)(Y[s] - nb.miny), (float)(Z[s] - nb.minz), 0.f);
 }
 
+// Key coordinates as records (swz_level.h, KeyMetric): the differences of integers below 2^21 are exact in float, and
+// the band [f_lo, f_hi) around the spacing holds every pair the quantisation cannot decide.
+__global__ __launch_bounds__(256) void sp_key_records_kernel(const uint64_t* __restrict__ akey, uint32_t m, float4* __restrict__ rec) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= m) return;
+  const uint64_t k = akey[i];
+  rec[i] = make_float4((float)contract_bits_by_3(k >> 2), (float)contract_bits_by_3(k >> 1), (float)contract_bits_by_3(k), 0.f);
+}
+
 // the exact compare of the reference on the original positions (GridCell.cpp:52)
 __device__ __forceinline__ bool sp_exact_near(const SpArgs& a, uint32_t p, uint32_t q) {
+  if (a.xyz) {
+    const double* u = a.xyz + (size_t)a.ids[p] * 3;
+    const double* v = a.xyz + (size_t)a.ids[q] * 3;
+    return sq_dist(u[0], u[1], u[2], v[0], v[1], v[2]) < a.sq_spacing;
+  }
   const uint32_t sp = a.aidx ? a.aidx[p] : p, sq = a.aidx ? a.aidx[q] : q;
   return sq_dist(a.X[sp], a.Y[sp], a.Z[sp], a.X[sq], a.Y[sq], a.Z[sq]) < a.sq_spacing;
 }
@@ -177,6 +194,10 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   }
   // Up to nine of them at a time (usually all: about eight remain): their table entries, then the j-th record
   // of every run, are requested together, so the search costs 1 + (longest run) memory round trips.
+  // Pairs inside the band of the float compare need the exact positions: a chain of dependent scattered loads that the
+  // whole wavefront waits for.  The first one of a point is put aside and evaluated after the search, all lanes together
+  // (a second one is rare and evaluated on the spot).
+  uint32_t pend0 = SP_NONE;
   const uint2* __restrict__ tab = a.table + base;
   while (need) {
     uint32_t q[SP_BATCH], qe[SP_BATCH];
@@ -217,8 +238,14 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
         if (q[i] < qe[i]) {
           const float dx = me.x - rx[i], dy = me.y - ry[i], dz = me.z - rz[i];
           const float d2 = dx * dx + dy * dy + dz * dz;
-          if (d2 < a.f_hi && (d2 < a.f_lo || sp_exact_near(a, p, q[i]))) {
-            if (!f(q[i])) return;
+          if (d2 < a.f_hi) {
+            if (d2 < a.f_lo) {
+              if (!f(q[i])) return;
+            } else if (pend0 == SP_NONE) {
+              pend0 = q[i];
+            } else if (sp_exact_near(a, p, q[i])) {
+              if (!f(q[i])) return;
+            }
           }
           ++q[i];
         }
@@ -245,11 +272,20 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
       const float4 r = a.rec[cq];
       const float dx = me.x - r.x, dy = me.y - r.y, dz = me.z - r.z;
       const float d2 = dx * dx + dy * dy + dz * dz;
-      if (d2 < a.f_hi && (d2 < a.f_lo || sp_exact_near(a, p, cq))) {
-        if (!f(cq)) return;
+      if (d2 < a.f_hi) {
+        if (d2 < a.f_lo) {
+          if (!f(cq)) return;
+        } else if (pend0 == SP_NONE) {
+          pend0 = cq;
+        } else if (sp_exact_near(a, p, cq)) {
+          if (!f(cq)) return;
+        }
       }
       ++cq;
     }
+  }
+  if (pend0 != SP_NONE && sp_exact_near(a, p, pend0)) {
+    if (!f(pend0)) return;
   }
 }
 
@@ -458,7 +494,19 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.X = sp.X;
   a.Y = sp.Y;
   a.Z = sp.Z;
-  {
+  const KeyMetric km = key_metric(c, plan, sp);
+  if (!km.ok && !sp.X) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE: this level needs the positions in Morton order and they were not gathered");
+  if (km.ok) {
+    a.xyz = sp.xyz;
+    SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
+    a.f_lo = km.f_lo;
+    a.f_hi = km.f_hi;
+    if (const char* e = c->opt("SWZ_SP_FILTER_EPS"))  // tests: 1e30 sends every compare within reach to the exact path
+      if (atof(e) >= 0.5) {
+        a.f_lo = 0.f;
+        a.f_hi = INFINITY;
+      }
+  } else {
     // Float filter.  A record coordinate is fl(x - corner) with |x - corner| <= E (the node's extent; twice that is
     // assumed): error <= 2^-24 * 2E; the float difference of two of them adds 2^-24 * 2E: |dxf - dx| <= delta =
     // 2^-22 * E.  |sum dxf^2 - d^2| <= 2 sqrt(3) d delta + 3 delta^2, plus 3 roundings of the sum (2^-22 relative, generous).
@@ -489,8 +537,11 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
   SWZ_HIP(c, memset_large(a.state, SP_U, (size_t)m, c->stream));
   const uint32_t nb = div_up(m, 256);
-  hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, plan.root,
-                     plan.level + 1, rec);
+  if (km.ok)
+    hipLaunchKernelGGL(sp_key_records_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, rec);
+  else
+    hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, plan.root,
+                       plan.level + 1, rec);
   SWZ_LAUNCH_CHECK(c);
   hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
   SWZ_LAUNCH_CHECK(c);

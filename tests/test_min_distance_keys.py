@@ -154,3 +154,41 @@ def test_key_sweep_fast_strategy(ctx):
     finally:
         ctx.set_option("SWZ_MD_SPARSE_LIMIT", None)
     assert np.array_equal(g.level, o["level"]) and np.array_equal(g.dup, o["dup"])
+
+
+@pytest.mark.parametrize("band", ["0", "25", "1e9"])
+def test_sparse_levels_on_keys(ctx, band):
+    """The thread-per-point path of the sparse levels takes its records from the keys as well; forced onto every level
+    here, with the band widened so that a large share of its compares goes to the exact positions."""
+    rng = np.random.default_rng(815)
+    side = 2.5
+    bmin = np.array([100.0, -7.75, 0.3])
+    bmax = bmin + side
+    xyz = bmin + rng.random((400000, 3)) * side * np.array([1.0, 0.7, 0.3])
+    opts = {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_MD_KEYS_BAND": band}
+    for d in (250, 90):
+        _check(ctx, xyz, bmin.tolist(), bmax.tolist(), d, 2000, opts)
+
+
+def test_no_position_gather_on_keys(ctx):
+    """With cubic bounds exact MIN_DISTANCE never brings the positions into Morton order: the profile of a call has no
+    gather_positions entry (and has one when the key path is switched off)."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(1)
+    xyz = rng.random((200000, 3))
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    p = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=2000, spacing_at_root=spacing)
+    ctx.profile_enable(True)
+    try:
+        ctx.profile_reset()
+        ctx.tile(xyz, *UNIT, p)
+        on_keys = ctx.profile_get()
+        ctx.set_option("SWZ_MD_KEYS", "0")
+        ctx.profile_reset()
+        ctx.tile(xyz, *UNIT, p)
+        on_positions = ctx.profile_get()
+    finally:
+        ctx.set_option("SWZ_MD_KEYS", None)
+        ctx.profile_enable(False)
+    assert "gather_positions" not in on_keys
+    assert "gather_positions" in on_positions
