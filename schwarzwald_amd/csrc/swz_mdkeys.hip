@@ -169,6 +169,9 @@ struct MqAdd {
 struct MqMax {
   __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; }
 };
+struct MqMin {
+  __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a < b ? a : b; }
+};
 
 __device__ __forceinline__ uint64_t mq_pack(uint64_t key) {
   // octant = x << 2 | y << 1 | z (MortonIndex.h:62-79): bit 3j+2 of the key is bit j of x
@@ -193,6 +196,13 @@ __device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint3
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 
+#ifdef SWZ_MQ_STATS
+#define MQ_T(var) const uint64_t var = wall_clock64()
+#define MQ_TACC(idx, t0, t1) do { if (l == 0 && (c & 31u) == 0u) atomicAdd(&a.counters[CTR_DBG_HIST + 8 + (idx)], (uint32_t)((t1) - (t0))); } while (0)
+#else
+#define MQ_T(var) do { } while (0)
+#define MQ_TACC(idx, t0, t1) do { } while (0)
+#endif
 #define MQ_STAT(idx) do { if (a.stats && l == 0) atomicAdd(&a.counters[CTR_DBG_HIST + (idx)], 1u); } while (0)
 
 struct MqLds {
@@ -375,6 +385,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   const uint32_t rg = a.rg, rg2s = a.rg2_shift, cap = rg - 1u;
   const float f_lo = a.f_lo, f_hi = a.f_hi;
 
+  MQ_T(t_begin);
   // ---- first round trip: everything that hangs on the cell index alone
   const uint32_t nbv = a.qnbr[(size_t)c * 32 + (l & 31u)];
   const unsigned long long myslot = a.slot[(size_t)c * 32 + (l & 31u)];
@@ -410,6 +421,8 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   }
 
   MQ_STAT(0);
+  MQ_T(t_rt1);
+  MQ_TACC(0, t_begin, t_rt1);
   // ---- second round trip: the records of the neighbourhood (staged in LDS), the window of own points at the frontier
   uint64_t pv[U];
   uint8_t ps[U];
@@ -439,6 +452,8 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   }
   __builtin_amdgcn_wave_barrier();
 
+  MQ_T(t_rt2);
+  MQ_TACC(1, t_rt1, t_rt2);
   // lane k < 27: adjacent cell k (13: this cell).  Of its two records the newer one written before this round.
   const bool valid = l < 27u && nbv != QNONE && nbv <= c;
   const bool earlier = valid && l != 13u;
@@ -451,21 +466,36 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     n_cnt = hd.y;
     n_end = hd.w;
   }
-  const uint32_t incl = mq_wave_scan(n_cnt, MqAdd{}, 0u);
-  const uint32_t off = incl - n_cnt;
-  const uint32_t T = qb_u32(incl, WAVE - 1);  // accepted points of the neighbourhood, own committed ones included
+  // The flattened list of accepted points holds first what is NEW to this cell: the entries of adjacent cells whose record
+  // was written in or after the round this cell last ran in (its own newest record carries that round) -- it could not
+  // see that record then.  The points this cell tested last time (those below `tested`) only meet the new entries.
+  const uint32_t my_last = sbuf ? h1.z : h0.z;
+  const bool k_new = valid && l != 13u && (pick ? lds.stage[(l << rg2s) + rg].z : lds.stage[l << rg2s].z) >= my_last;
+  const uint32_t incl_new = mq_wave_scan(k_new ? n_cnt : 0u, MqAdd{}, 0u);
+  const uint32_t incl_old = mq_wave_scan(k_new ? 0u : n_cnt, MqAdd{}, 0u);
+  const uint32_t Tnew = qb_u32(incl_new, WAVE - 1);
+  const uint32_t T = Tnew + qb_u32(incl_old, WAVE - 1);  // accepted points of the neighbourhood, own committed ones included
+  const uint32_t off = k_new ? incl_new - n_cnt : Tnew + incl_old - n_cnt;
   const uint32_t maxcnt = qb_u32(mq_wave_scan(n_cnt, MqMax{}, 0u), WAVE - 1);
-  // entries [base, base + MQ_LIST_CAP) of the flattened list -> LDS (lane k copies what adjacent cell k contributes)
+  const uint32_t tested = (st.x != QNONE && my_last >= MQ_FIRST_ROUND) ? st.x : P;
+  // entries [base, base + MQ_LIST_CAP) of the flattened list -> LDS (lane k copies what adjacent cell k contributes;
+  // the ones beyond the record's inline capacity are fetched four at a time)
   auto fill = [&](uint32_t base) -> uint32_t {
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = 0; j < maxcnt; ++j) {
+    for (uint32_t j = 0; j < maxcnt && j < cap; ++j) {
       const uint32_t ti = off + j;
-      if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP) {
-        uint4 src;
-        if (j < cap) src = lds.stage[(l << rg2s) + pick * rg + 1u + j];
-        else src = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (j - cap)));
-        *reinterpret_cast<uint4*>(&lds.list[ti - base]) = src;
-      }
+      if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP)
+        *reinterpret_cast<uint4*>(&lds.list[ti - base]) = lds.stage[(l << rg2s) + pick * rg + 1u + j];
+    }
+    for (uint32_t j0 = cap; j0 < maxcnt; j0 += 2u) {  // (two loads in flight; no arrays: they would live in scratch)
+      const uint32_t ja = j0, jb = j0 + 1u, ta = off + ja, tb = off + jb;
+      const bool ma = ja < n_cnt && ta >= base && ta < base + (uint32_t)MQ_LIST_CAP;
+      const bool mb = jb < n_cnt && tb >= base && tb < base + (uint32_t)MQ_LIST_CAP;
+      uint4 sa = make_uint4(0u, 0u, 0u, 0u), sb = sa;
+      if (ma) sa = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (ja - cap)));
+      if (mb) sb = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (jb - cap)));
+      if (ma) *reinterpret_cast<uint4*>(&lds.list[ta - base]) = sa;
+      if (mb) *reinterpret_cast<uint4*>(&lds.list[tb - base]) = sb;
     }
     __builtin_amdgcn_wave_barrier();
     return (T - base) < (uint32_t)MQ_LIST_CAP ? (T - base) : (uint32_t)MQ_LIST_CAP;
@@ -474,8 +504,11 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   uint32_t resident = 0;  // first entry of the list window LDS holds
   const uint32_t live_wn = (T <= (uint32_t)MQ_LIST_CAP && !a.no_dead_test) ? wn0 : 0u;  // the whole list is resident: scans can tell dead points
 
+  MQ_T(t_fill);
+  MQ_TACC(2, t_rt2, t_fill);
   uint32_t fresh = 0;
   uint32_t out_pos = e, out_status = QO_FINISHED, b_k = 0, b_q = 0;
+  uint32_t tested_now = P;  // the end of the last window whose points have met the whole list
   const uint32_t S = 1u << a.cell_bits;
 
   for (uint32_t W0 = P; W0 < e; W0 += (uint32_t)U * WAVE) {
@@ -495,18 +528,48 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       mq_unpack(pv[u], fx[u], fy[u], fz[u]);
       alive |= (ps[u] == QS_OPEN ? 1u : 0u) << u;
     }
+    tested_now = W0 + (uint32_t)U * WAVE;
     if (!__ballot(alive != 0u)) continue;  // a window of dead points
 
     // (R) against the committed accepted points of the neighbourhood, window by window, then against the points
-    // accepted earlier in this activation (they matter for the windows after the first).  Per chunk the smallest squared
-    // key distance to a list entry decides: below f_lo some accepted point is closer than the spacing for sure; below
-    // f_hi (and not below f_lo) at least one pair lies inside the band and goes to the exact compare.
+    // accepted earlier in this activation (they matter for the windows after the first).  The kernel is bound by its
+    // vector ALU work here (a root cell's first activation: 478 points x 40 accepted points), so every chunk first
+    // finds the list entries that can matter to it at all -- one lane per ENTRY: is it within reach of the bounding
+    // box of the chunk's open points? -- and tests only those.  64 consecutive points in Morton order fill a small
+    // block, and on later activations the few open points of a cell a tiny one: most entries drop out.
+    // Per chunk the smallest squared key distance to a tested entry decides: below f_lo some accepted point is closer
+    // than the spacing for sure; below f_hi at least one pair lies inside the band and goes to the exact compare.
     {
+      // Levels of small cells (one chunk per window) first find the entries that can matter at all -- one lane per
+      // ENTRY: is it within reach of the bounding box of the open points? -- and test only those: a coarsened cell of
+      // level 1 sees ~120 accepted points around it, and a point can be close to a handful.  Cells of hundreds of
+      // points (several chunks per window) gain nothing from that on their first activation; they save on the later
+      // ones by testing the points they have tested before against the new entries only.
+      float bx0 = 0.f, bx1 = 0.f, by0 = 0.f, by1 = 0.f, bz0 = 0.f, bz1 = 0.f;
+      if (U == 1) {
+        const bool al = alive & 1u;
+        const uint32_t hi_id = 0xFFFFFFFFu;  // coordinates are non-negative floats: their bit patterns order like they do
+        bx0 = __uint_as_float(qb_u32(mq_wave_scan(al ? __float_as_uint(fx[0]) : hi_id, MqMin{}, hi_id), WAVE - 1));
+        by0 = __uint_as_float(qb_u32(mq_wave_scan(al ? __float_as_uint(fy[0]) : hi_id, MqMin{}, hi_id), WAVE - 1));
+        bz0 = __uint_as_float(qb_u32(mq_wave_scan(al ? __float_as_uint(fz[0]) : hi_id, MqMin{}, hi_id), WAVE - 1));
+        bx1 = __uint_as_float(qb_u32(mq_wave_scan(al ? __float_as_uint(fx[0]) : 0u, MqMax{}, 0u), WAVE - 1));
+        by1 = __uint_as_float(qb_u32(mq_wave_scan(al ? __float_as_uint(fy[0]) : 0u, MqMax{}, 0u), WAVE - 1));
+        bz1 = __uint_as_float(qb_u32(mq_wave_scan(al ? __float_as_uint(fz[0]) : 0u, MqMax{}, 0u), WAVE - 1));
+      }
+      // chunks whose points were all tested by the last activation (uniform)
+      uint32_t oldc = 0;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (W0 + (uint32_t)(u + 1) * WAVE <= tested) oldc |= 1u << u;
       uint32_t nearb = 0;
       for (uint32_t base = 0;; base += (uint32_t)MQ_LIST_CAP) {
         const bool last = base >= T;  // the extra pass: the points accepted earlier in this activation
         uint32_t wn = fresh;
         if (!last) {
+          if (oldc == (1u << U) - 1u && base >= Tnew) {  // nothing in this window of the list is new to any chunk
+            base = T;  // (on to the pass over the points accepted in this activation)
+            continue;
+          }
           if (resident != base) {
             (void)fill(base);
             resident = base;
@@ -517,10 +580,34 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
         float dmin[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) dmin[u] = __builtin_inff();
-        for (uint32_t i = 0; i < wn; ++i) {
-          const float4 en = lst[i];
+        if (U == 1) {
+          const uint32_t lim = (last || !(oldc & 1u)) ? wn : (Tnew > base ? ((Tnew - base) < wn ? (Tnew - base) : wn) : 0u);
+          for (uint32_t b0 = 0; b0 < lim; b0 += WAVE) {
+            bool rel = false;  // lane i: is entry b0 + i within reach of the box?
+            if (b0 + l < lim) {
+              const float4 en = lst[b0 + l];
+              const float gx = fmaxf(fmaxf(bx0 - en.x, en.x - bx1), 0.f);
+              const float gy = fmaxf(fmaxf(by0 - en.y, en.y - by1), 0.f);
+              const float gz = fmaxf(fmaxf(bz0 - en.z, en.z - bz1), 0.f);
+              rel = __builtin_fmaf(gz, gz, __builtin_fmaf(gy, gy, gx * gx)) < f_hi;
+            }
+            uint64_t rm = __ballot(rel);
+            while (rm) {
+              const int bit = __ffsll((unsigned long long)rm) - 1;
+              rm &= rm - 1ull;
+              const float4 en = lst[b0 + (uint32_t)bit];
+              dmin[0] = fminf(dmin[0], mq_d2(fx[0], fy[0], fz[0], en.x, en.y, en.z));
+            }
+          }
+        } else {
+          // every entry against every chunk -- only the new ones when all chunks met the others last time
+          const uint32_t nnew = last ? wn : (Tnew > base ? ((Tnew - base) < wn ? (Tnew - base) : wn) : 0u);
+          const uint32_t lim = oldc == (1u << U) - 1u ? nnew : wn;
+          for (uint32_t i = 0; i < lim; ++i) {
+            const float4 en = lst[i];
 #pragma unroll
-          for (int u = 0; u < U; ++u) dmin[u] = fminf(dmin[u], mq_d2(fx[u], fy[u], fz[u], en.x, en.y, en.z));
+            for (int u = 0; u < U; ++u) dmin[u] = fminf(dmin[u], mq_d2(fx[u], fy[u], fz[u], en.x, en.y, en.z));
+          }
         }
         uint32_t pend = 0;
 #pragma unroll
@@ -553,6 +640,8 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       alive &= ~nearb;
     }
 
+    MQ_T(t_r);
+    MQ_TACC(3, t_fill, t_r);
     // (A) surviving points in order: accept, or stall on a possibly undecided earlier point
     bool stop = false;
     for (;;) {
@@ -655,6 +744,8 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     }
   }
 
+  MQ_T(t_cand);
+  MQ_TACC(4, t_fill, t_cand);
   // ---- publish: the new record goes into the buffer that does NOT hold the newest one
   const uint32_t wb = sbuf ^ 1u;
   const uint32_t ncnt = CNT + fresh;
@@ -672,7 +763,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   const bool fin = out_pos >= e;
   if (l == 0) {
     myrec[wb * rg] = make_uint4(fin ? e : out_pos, ncnt, round, e);
-    a.qst[c] = out_status == QO_STALLED ? make_uint4(out_pos, b_k, b_q, round) : make_uint4(QNONE, 0u, 0u, 0u);
+    a.qst[c] = out_status == QO_STALLED ? make_uint4(tested_now, b_k, b_q, round) : make_uint4(QNONE, 0u, 0u, 0u);
   }
   // ---- wake the later adjacent cells that sleep on a point the frontier has passed (slots written in THIS round belong
   // to cells that confirm themselves next round); go to sleep / come back next round
@@ -713,6 +804,12 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       if (self && l == 0) q[(uint32_t)__popcll(wm)] = out_status == QO_YIELD ? (c | MQ_WOKEN) : c;
     }
   }
+  MQ_T(t_end);
+  MQ_TACC(5, t_cand, t_end);
+  MQ_TACC(6, t_begin, t_end);
+#ifdef SWZ_MQ_STATS
+  if (l == 0 && (c & 31u) == 0u) atomicAdd(&a.counters[CTR_DBG_HIST + 8 + 7], 1u);
+#endif
 }
 
 template <int U>
@@ -1026,6 +1123,15 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
       SWZ_HIP(c, hipMemcpy(h, ga[g].counters, sizeof(h), hipMemcpyDeviceToHost));
       fprintf(stderr, "[swz]   group %u: %u full activations, %u confirms still asleep, %u confirms that lost the claim, %u stalls, %u scans\n", g,
               h[CTR_DBG_HIST], h[CTR_DBG_HIST + 1], h[CTR_DBG_HIST + 2], h[CTR_DBG_HIST + 3], h[CTR_DBG_HIST + 4]);
+#ifdef SWZ_MQ_STATS
+      {
+        const double ns = std::max(1u, h[CTR_DBG_HIST + 15]) * 100.0;  // 100 MHz ticks -> us
+        fprintf(stderr, "[swz]   timed %u full activations (us): first loads %.2f, records + window %.2f, list %.2f, first window (R) %.2f, "
+                        "windows + candidates + scans %.2f, publish + wake %.2f, total %.2f\n", h[CTR_DBG_HIST + 15], h[CTR_DBG_HIST + 8] / ns,
+                h[CTR_DBG_HIST + 9] / ns, h[CTR_DBG_HIST + 10] / ns, h[CTR_DBG_HIST + 11] / ns, h[CTR_DBG_HIST + 12] / ns, h[CTR_DBG_HIST + 13] / ns,
+                h[CTR_DBG_HIST + 14] / ns);
+      }
+#endif
     }
   }
   return SWZ_OK;
