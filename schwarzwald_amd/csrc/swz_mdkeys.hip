@@ -110,8 +110,9 @@ struct MqArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* nstart;
-  const double* xyz;      // exact positions: point ids[i] of the caller's array
-  const uint32_t* ids;
+  const double* xyz;      // exact positions: point perm[aidx ? aidx[i] : i] of the caller's array (pairs inside the band are
+                          // rare enough on dense levels that the three dependent loads do not matter)
+  const uint32_t* perm;
   uint8_t* taken;
   uint32_t* counters;
   uint64_t* qpos;         // [m] key coordinates x | y << 21 | z << 42 of the active points
@@ -128,6 +129,7 @@ struct MqArgs {
   uint32_t* queue[2];     // [nseg][segcap]: the round's cells, in nseg segments so that no single counter takes every push
   uint32_t* qctr;         // [3 rotating rounds][nseg] segment fill counters, one per 128-byte line
   uint32_t* qtotal;       // [3]: entries the round started with (what the host polls: 0 = the level is done)
+  uint32_t* qhead;        // [3 rotating rounds][nseg] tickets: the next entry of the segment nobody has taken yet
   uint32_t nseg, nseg_shift, segcap;
   const uint32_t* snode_of;
   uint32_t cell_shift;    // key >> cell_shift = node prefix + cell code
@@ -191,8 +193,8 @@ __device__ __forceinline__ float mq_d2(float ax, float ay, float az, float bx, f
 }
 // the reference's compare on the exact positions (GridCell.cpp:52) for active points i and j
 __device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint32_t j) {
-  const double* p = a.xyz + (size_t)a.ids[i] * 3;
-  const double* q = a.xyz + (size_t)a.ids[j] * 3;
+  const double* p = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[i] : i] * 3;
+  const double* q = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[j] : j] * 3;
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 
@@ -233,9 +235,12 @@ struct MqHeadF {
 struct MqCellBuildG {
   MqArgs a;
   __device__ void operator()(uint32_t i, uint32_t c, uint32_t head) const {
+    const uint64_t key = a.akey[i];  // (the scan's head functor has just read it: a cache hit)
+    a.qpos[i] = mq_pack(key);
+    a.state[i] = QS_OPEN;
     if (!head) return;
     a.cinfo[c].x = i;
-    a.crel[c] = (uint32_t)((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
+    a.crel[c] = (uint32_t)((key >> a.cell_shift) & (a.cells_per_node - 1ull));
     a.csnode[c] = a.all_sampled ? a.nid[i] : a.snode_of[a.nid[i]];
   }
 };
@@ -826,6 +831,7 @@ __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t ro
     uint32_t mine = 0;
     for (uint32_t sg = l; sg < a.nseg; sg += WAVE) {
       a.qctr[((size_t)cz * a.nseg + sg) * 32u] = 0;
+      a.qhead[((size_t)cz * a.nseg + sg) * 32u] = 0;
       const uint32_t n = a.qctr[((size_t)ci * a.nseg + sg) * 32u];
       mine += n < a.segcap ? n : a.segcap;
     }
@@ -838,8 +844,20 @@ __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t ro
   const uint32_t* qin = a.queue[r0 & 1u] + (size_t)seg * a.segcap;
   uint32_t* qout = a.queue[(r0 + 1u) & 1u];
   uint32_t* cout = a.qctr + (size_t)co * a.nseg * 32u;
-  for (uint32_t i = blockIdx.x >> a.nseg_shift; i < nq; i += gridDim.x >> a.nseg_shift)
-    mq_activate<U>(a, round, uni(qin[i]), lds, qout, cout, seg);
+  // The workgroups of a segment draw its entries by ticket: activations differ in cost by an order of magnitude (a
+  // confirm that finds its cell still asleep, a first activation of 500 points), and with a fixed stride the launch
+  // lasts as long as its unluckiest workgroup.  The next ticket is requested before the current entry is worked on.
+  uint32_t* head = a.qhead + ((size_t)ci * a.nseg + seg) * 32u;
+  uint32_t i = blockIdx.x >> a.nseg_shift;  // the first entries go by position: no ticket needed
+  const uint32_t wgs = gridDim.x >> a.nseg_shift;
+  uint32_t entry = qin[i < a.segcap ? i : 0u];  // (requested together with the segment's count, not after it)
+  while (i < nq) {
+    uint32_t next = 0;
+    if (lane_id() == 0) next = atomicAdd(head, 1u);  // (the result is first looked at after the activation)
+    mq_activate<U>(a, round, uni(entry), lds, qout, cout, seg);
+    i = wgs + qb_u32(next, 0);
+    if (i < nq) entry = qin[i];
+  }
 }
 
 // after the last round: every cell must have reached its end (a protocol error would otherwise go unnoticed)
@@ -876,7 +894,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   a.nmode = lb.nmode;
   a.nstart = lb.nstart;
   a.xyz = sp.xyz;
-  SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
+  a.perm = sp.perm;
   a.taken = lb.taken;
   a.counters = lb.counters;
   a.snode_of = snode_of;
@@ -927,8 +945,6 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
   SWZ_HIP(c, memset_large(a.slot, 0xFF, (size_t)ncells * 32 * sizeof(unsigned long long), c->stream));
 
-  hipLaunchKernelGGL(mq_pack_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, as.akey, m, a.qpos, a.state);
-  SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(fused_scan_apply(c, MqHeadF{a}, MqCellBuildG{a}, m, d_cell_sums));
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(mq_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
@@ -964,9 +980,10 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     const std::string tag = std::to_string(g);
     SWZ_TRY(c->get(("md_qqueue0_g" + tag).c_str(), (size_t)a.nseg * a.segcap, &ga[g].queue[0]));
     SWZ_TRY(c->get(("md_qqueue1_g" + tag).c_str(), (size_t)a.nseg * a.segcap, &ga[g].queue[1]));
-    SWZ_TRY(c->get(("md_qctr_g" + tag).c_str(), (size_t)3 * a.nseg * 32 + 32, &ga[g].qctr));
-    ga[g].qtotal = ga[g].qctr + (size_t)3 * a.nseg * 32;
-    SWZ_HIP(c, hipMemsetAsync(ga[g].qctr, 0, ((size_t)3 * a.nseg * 32 + 32) * sizeof(uint32_t), c->stream));
+    SWZ_TRY(c->get(("md_qctr_g" + tag).c_str(), (size_t)6 * a.nseg * 32 + 32, &ga[g].qctr));
+    ga[g].qhead = ga[g].qctr + (size_t)3 * a.nseg * 32;
+    ga[g].qtotal = ga[g].qctr + (size_t)6 * a.nseg * 32;
+    SWZ_HIP(c, hipMemsetAsync(ga[g].qctr, 0, ((size_t)6 * a.nseg * 32 + 32) * sizeof(uint32_t), c->stream));
     if (g > 0) {
       SWZ_TRY(c->get(("md_counters_g" + tag).c_str(), (size_t)CTR_COUNT, &ga[g].counters));
       SWZ_HIP(c, hipMemsetAsync(ga[g].counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
