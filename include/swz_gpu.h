@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SWZ_ABI_VERSION 2
+#define SWZ_ABI_VERSION 3
 
 /* status codes */
 enum {
@@ -37,7 +37,8 @@ enum {
   SWZ_ERR_JITTER_NODE_TOO_DEEP = 4,  /* JitteredSampling throws: Sampling.h:642-653 */
   SWZ_ERR_REROOT_UNSUPPORTED = 5,    /* node needs Morton re-rooting, TilingAlgorithms.cpp:444-483 */
   SWZ_ERR_TOO_MANY_POINTS = 6,       /* more than 2^32-65536 points in one batch */
-  SWZ_ERR_INTERNAL = 7
+  SWZ_ERR_INTERNAL = 7,
+  SWZ_ERR_TILER_FAILED = 8           /* swz_tiler: an earlier batch failed part-way; the node store is incomplete */
 };
 
 /* --sampling values, TilerProcess::make_sampling_strategy (core/process/TilerProcess.cpp:491-516)
@@ -408,6 +409,11 @@ typedef struct {
 int swz_tiler_shard_begin_device(swz_tiler* tiler, double* d_xyz, uint64_t n, const swz_attribute_columns* d_attrs,
                                  const swz_tiler_shard_info* info, uint64_t* root_file_count_out);
 int swz_tiler_shard_finish(swz_tiler* tiler, swz_tile_stats* stats);
+/* A batch that fails part-way (workspace out of memory, a MIN_DISTANCE level that does not terminate, a HIP error)
+ * leaves the node store half updated: the tiler is then POISONED -- every later swz_tiler_* call except
+ * swz_tiler_destroy / swz_tiler_get_info returns SWZ_ERR_TILER_FAILED and names the original failure.  A driver that
+ * keeps several tilers in step (one per GPU) poisons the others itself when one of them fails. */
+int swz_tiler_poison(swz_tiler* tiler, const char* why);
 /* points stored in the files of one octree level (-1 = root) and their positions in file order */
 int swz_tiler_level_count(swz_tiler* tiler, int level, uint64_t* count_out);
 int swz_tiler_level_positions_device(swz_tiler* tiler, int level, double* d_xyz_out);
@@ -444,6 +450,30 @@ swz_ctx* swz_group_ctx(swz_group* group, int shard);
 int swz_group_tile(swz_group* group, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n,
                    const double bounds_min[3], const double bounds_max[3], const swz_tile_params* params,
                    swz_group_result* results);
+
+/* A data set that arrives in several batches, sharded over the group's GPUs from ONE C++ process (BASELINE config 5;
+ * the reference is one process too: core/process/Tiler.cpp:189-198, 499-527).  One swz_tiler per shard owns the subtrees
+ * of the shard's level-0 octants and ITS part of the root's file.  Per batch: encode, group by destination, ONE
+ * exchange step of the point rows and of every attribute column, then the root node -- its take-all / sample decision
+ * uses the counts of the whole root, and for MIN_DISTANCE the shards take turns with the lower shards' root files as
+ * ghosts -- and, without communication, the levels below.
+ *   swz_group_tiler_open / _close: creates / destroys the shards' tilers (ACCURATE strategy, exact samplers).
+ *   swz_group_add_batch: d_xyz[s] / n[s] / d_attrs[s] as in swz_group_tile; stats (may be NULL) receives one entry per shard.
+ *   swz_group_stage_batch / swz_group_tile_staged: the same from PINNED host memory -- the copies of batch k + 1 run on a
+ *     copy stream per shard (hipMemcpyAsync) beside the kernels of batch k; at most two batches are staged.
+ *   swz_group_finalize: ends the data set (FAST would reconstruct here; ACCURATE has nothing left to do).
+ *   swz_group_tiler: shard s's tiler, for swz_tiler_node_table / _export_device / _pools_device / _get_info.  The
+ *     root's file is the concatenation of the shards' parts in shard order.
+ * A batch that fails on one shard poisons every shard's tiler (swz_tiler_poison). */
+int swz_group_tiler_open(swz_group* group, const double bounds_min[3], const double bounds_max[3], const swz_tile_params* params,
+                         uint64_t capacity_hint_per_shard);
+int swz_group_tiler_close(swz_group* group);
+swz_tiler* swz_group_tiler(swz_group* group, int shard);
+int swz_group_add_batch(swz_group* group, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n,
+                        swz_tile_stats* stats_per_shard);
+int swz_group_stage_batch(swz_group* group, const double* const* xyz_host, const swz_attribute_columns* attrs_host, const uint64_t* n);
+int swz_group_tile_staged(swz_group* group, swz_tile_stats* stats_per_shard);
+int swz_group_finalize(swz_group* group, swz_tile_stats* stats_per_shard);
 
 /* page-locked host memory for the staging entry points (hipHostMalloc / hipHostFree) */
 int swz_host_alloc_pinned(uint64_t bytes, void** out);

@@ -15,6 +15,8 @@ SAMPLERS = {"RANDOM_GRID": RANDOM_GRID, "GRID_CENTER": GRID_CENTER, "MIN_DISTANC
             "JITTERED": JITTERED}
 TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS, ALWAYS_ADHERE_TO_MIN_SPACING = 0, 1
 ACCURATE, FAST = 0, 1
+ERR_INTERNAL = 7
+ERR_TILER_FAILED = 8
 ERR_PEER_FAILED = 100  # raised by the multi-GPU driver on the ranks that did not fail themselves
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -32,7 +34,7 @@ class _TileParams(C.Structure):
                 ("flags", C.c_uint32)]
 
 
-ABI_VERSION = 2  # SWZ_ABI_VERSION of include/swz_gpu.h
+ABI_VERSION = 3  # SWZ_ABI_VERSION of include/swz_gpu.h
 FLAG_MIN_DISTANCE_PROPERTY = 1
 
 
@@ -338,6 +340,7 @@ def load_library():
     L.swz_tiler_shard_begin_device.argtypes = [vp, vp, C.c_uint64, cols, C.POINTER(_TilerShardInfo), _u64p]
     L.swz_tiler_shard_finish.argtypes = [vp, C.POINTER(_TileStats)]
     L.swz_tiler_level_count.argtypes = [vp, C.c_int, _u64p]
+    L.swz_tiler_poison.argtypes = [vp, C.c_char_p]
     L.swz_tiler_level_positions_device.argtypes = [vp, C.c_int, vp]
     L.swz_host_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(vp)]
     L.swz_host_free_pinned.argtypes = [vp]
@@ -357,7 +360,7 @@ def load_library():
                  "swz_tiler_finalize", "swz_tiler_get_info", "swz_tiler_export_device", "swz_tiler_node_table",
                  "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned",
                  "swz_tiler_shard_begin_device", "swz_tiler_shard_finish", "swz_tiler_level_count",
-                 "swz_tiler_level_positions_device"):
+                 "swz_tiler_level_positions_device", "swz_tiler_poison"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -635,6 +638,10 @@ class Tiler:
         ctx._check(self._lib.swz_tiler_create(ctx._ctx, _vec3(bmin), _vec3(bmax), C.byref(p), int(capacity_hint),
                                               C.byref(self._t)))
         self._keep = []
+
+    def poison(self, why="poisoned by the caller"):
+        """Marks the tiler failed (what a failing batch does by itself): every later call raises ERR_TILER_FAILED."""
+        self._ctx._check(self._lib.swz_tiler_poison(self._t, why.encode()))
 
     def close(self):
         if getattr(self, "_t", None):

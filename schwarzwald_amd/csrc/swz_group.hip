@@ -102,6 +102,24 @@ struct swz_group {
   int turn = 0;  // MIN_DISTANCE root: the shard whose turn it is
   std::mutex turn_m;
   std::condition_variable turn_cv;
+  // a data set in several batches: one swz_tiler per shard (swz_group_tiler_open)
+  std::vector<swz_tiler*> tiler;
+  std::vector<uint64_t> root_stored;  // points in the root's file on every shard (before / after the batch's root step)
+  double tbmin[3] = {0, 0, 0}, tbmax[3] = {0, 0, 0};
+  swz_tile_params tparams{};
+  // batches staged from pinned host memory: two device buffers per shard, filled on a copy stream of their own
+  struct Staged {
+    std::vector<uint64_t> n;  // per shard
+    int slot = 0;
+  };
+  std::vector<Staged> staged;  // at most two, oldest first
+  std::vector<hipStream_t> copy_stream;
+  std::vector<hipEvent_t> copy_done[2];
+  std::vector<double*> stage_xyz[2];
+  std::vector<swz_attribute_columns> stage_attr[2];
+  std::vector<uint64_t> stage_cap[2];
+  uint32_t stage_mask = 0;  // attribute columns of the staged batches (the same for every batch)
+  int next_slot = 0;
 };
 
 namespace {
@@ -118,7 +136,17 @@ struct ShardCall {
   const swz_tile_params* params;
   const swz_attribute_columns* attrs;  // may be NULL
   swz_group_result* result;
+  bool batch = false;            // true: one batch of the group's tilers (swz_group_add_batch), result unused
+  swz_tile_stats* stats = nullptr;
 };
+
+// true when no shard has reported a failure (looked at by every shard thread right after a barrier, so all of them see
+// the same answer and leave the collective steps together)
+bool all_ok(const swz_group* g) {
+  for (int s : g->status)
+    if (s != SWZ_OK) return false;
+  return true;
+}
 
 bool fail(swz_group* g, int r, int code, const std::string& msg) {
   g->status[r] = code;
@@ -210,9 +238,19 @@ void shard_thread(ShardCall a) {
   for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
     if (row_bytes[t]) columns.push_back({(const char*)send_attr.column[t], (char*)recv_attr.column[t], row_bytes[t], t});
   g->barrier.wait();  // ---- every receive buffer exists
-  if (g->transport == 1 && N > 1) {
+  // A shard that has failed so far posts no sends or receives, and its peers would wait for them for ever (RCCL) or
+  // copy into buffers that do not exist: every shard looks at every status HERE -- nobody changes one between the
+  // barrier above and the one after the exchange -- and they skip the collective steps together.
+  const bool go = all_ok(g);
+  if (!go) {
+    ok = false;  // (this shard's own status stays as it is: the group reports the shard that failed first)
+  } else if (g->transport == 1 && N > 1) {
     // grouped RCCL point-to-point = the all-to-all(v): bounded messages, both sides cut their block the same way
-    if (ok && g->rccl.GroupStart() != 0) ok = fail(g, r, SWZ_ERR_HIP, "ncclGroupStart failed");
+    bool started = false;
+    if (ok) {
+      started = g->rccl.GroupStart() == 0;
+      if (!started) ok = fail(g, r, SWZ_ERR_HIP, "ncclGroupStart failed");
+    }
     for (const Column& col : columns)
       for (int p = 0; p < N && ok; ++p) {
         if (p == r) continue;
@@ -224,7 +262,7 @@ void shard_thread(ShardCall a) {
           if (g->rccl.Recv(col.dst_here + recv_off[p] * col.bytes + at, std::min(kChunkBytes, rb - at), Rccl::kUint8, p, g->comms[r], c->stream) != 0)
             ok = fail(g, r, SWZ_ERR_HIP, "ncclRecv failed");
       }
-    if (g->rccl.GroupEnd() != 0 && ok) ok = fail(g, r, SWZ_ERR_HIP, "ncclGroupEnd failed");
+    if (started && g->rccl.GroupEnd() != 0 && ok) ok = fail(g, r, SWZ_ERR_HIP, "ncclGroupEnd failed");
     for (const Column& col : columns)
       if (ok && g->send_counts[r][r])
         GRP_HIP(hipMemcpyAsync(col.dst_here + recv_off[r] * col.bytes, col.src + send_off[r] * col.bytes,
@@ -247,6 +285,11 @@ void shard_thread(ShardCall a) {
   GRP_HIP(hipStreamSynchronize(c->stream));
   g->barrier.wait();  // ---- all rows have arrived everywhere
 
+  // (the same vote again: a shard whose exchange failed must not keep the others waiting at the root)
+  if (!all_ok(g)) ok = false;
+  const bool proceed = ok || a.batch;  // a batch keeps every shard's tiler in step with the collective decisions below
+
+  if (!a.batch) {
   // 3. the root node
   const bool sequential_root = a.params->sampler == SWZ_MIN_DISTANCE && global_points > a.params->max_points_per_node;
   uint64_t taken = 0;
@@ -303,6 +346,57 @@ void shard_thread(ShardCall a) {
     a.result->attrs = recv_attr;
     a.result->num_points = ok ? m : 0;
     a.result->stats = stats;
+  }
+  } else if (proceed) {
+    // 3'. one batch of the shard's tiler (swz_tiler_shard_*): the root's take-all / sample decision uses the counts of
+    // the WHOLE root (cached points anywhere force sampling, TilingAlgorithms.cpp:272-275); for MIN_DISTANCE the greedy
+    // order visits the shards in turn, each with the root files of the lower ones -- as they are after this batch --
+    // as ghosts.  4'. the levels below are local.
+    swz_tiler* t = g->tiler[r];
+    uint64_t root_before = 0;
+    for (int s = 0; s < N; ++s) root_before += g->root_stored[s];
+    const bool sample = root_before > 0 || global_points + root_before > g->tparams.max_points_per_node;
+    const bool sequential_root = g->tparams.sampler == SWZ_MIN_DISTANCE && sample && global_points > 0;
+    swz_tiler_shard_info info{global_points, root_before, nullptr, 0};
+    uint64_t have = 0;
+    auto tiler_try = [&](int st) {
+      if (ok && st != SWZ_OK) ok = fail(g, r, st, swz_last_error(c));
+    };
+    if (!sequential_root) {
+      if (ok) tiler_try(swz_tiler_shard_begin_device(t, recv, m, &recv_attr, &info, &have));
+    } else {
+      {
+        std::unique_lock<std::mutex> lk(g->turn_m);
+        g->turn_cv.wait(lk, [&] { return g->turn == r; });
+      }
+      uint64_t gh = 0;
+      for (int s = 0; s < r; ++s) gh += g->root_taken_count[s];
+      double* gp = nullptr;
+      if (ok && c->get("grp_ghosts", (size_t)std::max<uint64_t>(gh, 1) * 3, &gp) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+      uint64_t at = 0;
+      for (int s = 0; s < r && ok; ++s) {
+        if (!g->root_taken_count[s]) continue;
+        GRP_HIP(hipMemcpyPeerAsync(gp + at * 3, g->devices[r], g->root_taken[s], g->devices[s], (size_t)g->root_taken_count[s] * 24, c->stream));
+        at += g->root_taken_count[s];
+      }
+      GRP_HIP(hipStreamSynchronize(c->stream));
+      info.d_ghost_xyz = gh ? gp : nullptr;
+      info.num_ghosts = gh;
+      if (ok) tiler_try(swz_tiler_shard_begin_device(t, recv, m, &recv_attr, &info, &have));
+      double* mine = nullptr;
+      if (ok && c->get("grp_root_taken", (size_t)std::max<uint64_t>(have, 1) * 3, &mine) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+      if (ok && have) tiler_try(swz_tiler_level_positions_device(t, -1, mine));
+      g->root_taken[r] = mine;
+      g->root_taken_count[r] = ok ? have : 0;
+      {
+        std::lock_guard<std::mutex> lk(g->turn_m);
+        g->turn = r + 1;
+      }
+      g->turn_cv.notify_all();
+    }
+    swz_tile_stats stats{};
+    if (ok) tiler_try(swz_tiler_shard_finish(t, &stats));
+    if (a.stats) *a.stats = stats;
   }
   g->barrier.wait();  // ---- nobody reads a neighbour's buffers any more
 }
@@ -362,8 +456,39 @@ int swz_group_create(int num_shards, const int* devices, int transport, swz_grou
   return SWZ_OK;
 }
 
+static void group_free_tilers(swz_group* g) {
+  for (size_t r = 0; r < g->tiler.size(); ++r)
+    if (g->tiler[r]) (void)swz_tiler_destroy(g->tiler[r]);
+  g->tiler.clear();
+  for (size_t r = 0; r < g->copy_stream.size(); ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    if (g->copy_stream[r]) {
+      (void)hipStreamSynchronize(g->copy_stream[r]);
+      (void)hipStreamDestroy(g->copy_stream[r]);
+    }
+    for (int k = 0; k < 2; ++k) {
+      if (r < g->copy_done[k].size() && g->copy_done[k][r]) (void)hipEventDestroy(g->copy_done[k][r]);
+      if (r < g->stage_xyz[k].size() && g->stage_xyz[k][r]) (void)hipFree(g->stage_xyz[k][r]);
+      if (r < g->stage_attr[k].size())
+        for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+          if (g->stage_attr[k][r].column[t]) (void)hipFree(g->stage_attr[k][r].column[t]);
+    }
+  }
+  g->copy_stream.clear();
+  for (int k = 0; k < 2; ++k) {
+    g->copy_done[k].clear();
+    g->stage_xyz[k].clear();
+    g->stage_attr[k].clear();
+    g->stage_cap[k].clear();
+  }
+  g->staged.clear();
+  g->stage_mask = 0;
+  g->next_slot = 0;
+}
+
 int swz_group_destroy(swz_group* g) {
   if (!g) return SWZ_OK;
+  group_free_tilers(g);
   for (void* comm : g->comms)
     if (comm && g->rccl.CommDestroy) (void)g->rccl.CommDestroy(comm);
   for (swz_ctx* c : g->ctx) swz_destroy(c);
@@ -400,6 +525,205 @@ int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_colum
       g->err = "shard " + std::to_string(r) + ": " + g->status_msg[r];
       return g->status[r];
     }
+  return SWZ_OK;
+}
+
+// ---- a data set in several batches (BASELINE config 5 from the C++ host): one swz_tiler per shard -------------------
+static int group_first_failure(swz_group* g) {
+  for (int r = 0; r < g->n; ++r)
+    if (g->status[r] != SWZ_OK) {
+      g->err = "shard " + std::to_string(r) + ": " + g->status_msg[r];
+      return g->status[r];
+    }
+  return SWZ_OK;
+}
+
+int swz_group_tiler_open(swz_group* g, const double bmin[3], const double bmax[3], const swz_tile_params* params,
+                         uint64_t capacity_hint_per_shard) {
+  if (!g || !bmin || !bmax || !params) return SWZ_ERR_BAD_ARG;
+  if (!g->tiler.empty()) {
+    g->err = "swz_group_tiler_open: a data set is open already (swz_group_tiler_close)";
+    return SWZ_ERR_BAD_ARG;
+  }
+  if (params->strategy != SWZ_ACCURATE || (params->flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY)) {
+    g->err = "sharded batches support the ACCURATE strategy and exact MIN_DISTANCE";
+    return SWZ_ERR_BAD_ARG;
+  }
+  for (int a = 0; a < 3; ++a) {
+    g->tbmin[a] = bmin[a];
+    g->tbmax[a] = bmax[a];
+  }
+  g->tparams = *params;
+  g->tiler.assign(g->n, nullptr);
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    const int st = swz_tiler_create(g->ctx[r], bmin, bmax, params, capacity_hint_per_shard, &g->tiler[r]);
+    if (st != SWZ_OK) {
+      g->err = "shard " + std::to_string(r) + ": " + swz_last_error(g->ctx[r]);
+      group_free_tilers(g);
+      return st;
+    }
+  }
+  g->root_stored.assign(g->n, 0);
+  g->copy_stream.assign(g->n, nullptr);
+  for (int k = 0; k < 2; ++k) {
+    g->copy_done[k].assign(g->n, nullptr);
+    g->stage_xyz[k].assign(g->n, nullptr);
+    g->stage_attr[k].assign(g->n, swz_attribute_columns{});
+    g->stage_cap[k].assign(g->n, 0);
+  }
+  return SWZ_OK;
+}
+
+int swz_group_tiler_close(swz_group* g) {
+  if (!g) return SWZ_ERR_BAD_ARG;
+  group_free_tilers(g);
+  return SWZ_OK;
+}
+
+swz_tiler* swz_group_tiler(swz_group* g, int shard) {
+  return (g && shard >= 0 && shard < (int)g->tiler.size()) ? g->tiler[shard] : nullptr;
+}
+
+int swz_group_add_batch(swz_group* g, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n,
+                        swz_tile_stats* stats) {
+  if (!g || !d_xyz || !n) return SWZ_ERR_BAD_ARG;
+  if (g->tiler.empty()) {
+    g->err = "swz_group_add_batch: no data set is open (swz_group_tiler_open)";
+    return SWZ_ERR_BAD_ARG;
+  }
+  if (d_attrs)
+    for (int r = 1; r < g->n; ++r)
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+        if ((d_attrs[r].column[t] != nullptr) != (d_attrs[0].column[t] != nullptr)) {
+          g->err = "every shard must hand over the same attribute columns";
+          return SWZ_ERR_BAD_ARG;
+        }
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    const int st = swz_tiler_level_count(g->tiler[r], -1, &g->root_stored[r]);
+    if (st != SWZ_OK) {
+      g->err = "shard " + std::to_string(r) + ": " + swz_last_error(g->ctx[r]);
+      return st;
+    }
+  }
+  g->turn = 0;
+  std::fill(g->status.begin(), g->status.end(), SWZ_OK);
+  std::fill(g->root_taken_count.begin(), g->root_taken_count.end(), 0);
+  std::vector<std::thread> threads;
+  for (int r = 0; r < g->n; ++r) {
+    ShardCall call{g, r, d_xyz[r], n[r], g->tbmin, g->tbmax, &g->tparams, d_attrs ? &d_attrs[r] : nullptr, nullptr};
+    call.batch = true;
+    call.stats = stats ? &stats[r] : nullptr;
+    threads.emplace_back(shard_thread, call);
+  }
+  for (auto& t : threads) t.join();
+  const int st = group_first_failure(g);
+  if (st != SWZ_OK)  // the shards that did not fail have committed the batch and the failing one has not: nobody goes on
+    for (int r = 0; r < g->n; ++r) (void)swz_tiler_poison(g->tiler[r], ("a shard of the group failed to tile a batch: " + g->err).c_str());
+  return st;
+}
+
+// Staging: the batch is copied from pinned host memory into one of two device buffers per shard on the shard's copy
+// stream, beside whatever its tiling stream is doing (the batch before).  At most two batches are staged.
+int swz_group_stage_batch(swz_group* g, const double* const* xyz_host, const swz_attribute_columns* attrs_host, const uint64_t* n) {
+  if (!g || !xyz_host || !n) return SWZ_ERR_BAD_ARG;
+  if (g->tiler.empty() || g->staged.size() >= 2) {
+    g->err = g->tiler.empty() ? "swz_group_stage_batch: no data set is open" : "swz_group_stage_batch: two batches are staged already";
+    return SWZ_ERR_BAD_ARG;
+  }
+  uint32_t mask = 0;
+  for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+    if (attrs_host && attrs_host[0].column[t]) mask |= 1u << t;
+  const int slot = g->next_slot;
+  swz_group::Staged sb;
+  sb.slot = slot;
+  sb.n.assign(n, n + g->n);
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    auto hip = [&](hipError_t e, const char* what) {
+      if (e == hipSuccess) return true;
+      g->err = "shard " + std::to_string(r) + ": " + what + ": " + hipGetErrorString(e);
+      return false;
+    };
+    if (!g->copy_stream[r] && !hip(hipStreamCreateWithFlags(&g->copy_stream[r], hipStreamNonBlocking), "hipStreamCreate")) return SWZ_ERR_HIP;
+    if (!g->copy_done[slot][r] && !hip(hipEventCreateWithFlags(&g->copy_done[slot][r], hipEventDisableTiming), "hipEventCreate")) return SWZ_ERR_HIP;
+    uint32_t mine = 0;
+    for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+      if (attrs_host && attrs_host[r].column[t]) mine |= 1u << t;
+    if (mine != mask) {
+      g->err = "every shard must hand over the same attribute columns";
+      return SWZ_ERR_BAD_ARG;
+    }
+    if (g->stage_cap[slot][r] < std::max<uint64_t>(n[r], 1) || (mask & ~g->stage_mask)) {
+      // (the buffer is free: the batch it held has been tiled -- swz_group_tile_staged returns after the shard's stream is idle)
+      const uint64_t cap = std::max<uint64_t>(n[r] + n[r] / 8, 1);
+      if (g->stage_xyz[slot][r]) (void)hipFree(g->stage_xyz[slot][r]);
+      g->stage_xyz[slot][r] = nullptr;
+      if (!hip(hipMalloc(&g->stage_xyz[slot][r], cap * 24), "hipMalloc(stage)")) return SWZ_ERR_HIP;
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t) {
+        if (g->stage_attr[slot][r].column[t]) (void)hipFree(g->stage_attr[slot][r].column[t]);
+        g->stage_attr[slot][r].column[t] = nullptr;
+        if ((mask >> t) & 1u)
+          if (!hip(hipMalloc(&g->stage_attr[slot][r].column[t], cap * swz_attribute_row_bytes(t)), "hipMalloc(stage column)")) return SWZ_ERR_HIP;
+      }
+      g->stage_cap[slot][r] = cap;
+    }
+    if (n[r]) {
+      if (!hip(hipMemcpyAsync(g->stage_xyz[slot][r], xyz_host[r], n[r] * 24, hipMemcpyHostToDevice, g->copy_stream[r]), "hipMemcpyAsync")) return SWZ_ERR_HIP;
+      for (int t = 0; t < SWZ_ATTR_COUNT; ++t)
+        if ((mask >> t) & 1u)
+          if (!hip(hipMemcpyAsync(g->stage_attr[slot][r].column[t], attrs_host[r].column[t], n[r] * swz_attribute_row_bytes(t),
+                                  hipMemcpyHostToDevice, g->copy_stream[r]), "hipMemcpyAsync")) return SWZ_ERR_HIP;
+    }
+    if (!hip(hipEventRecord(g->copy_done[slot][r], g->copy_stream[r]), "hipEventRecord")) return SWZ_ERR_HIP;
+  }
+  g->stage_mask |= mask;
+  g->staged.push_back(sb);
+  g->next_slot ^= 1;
+  return SWZ_OK;
+}
+
+int swz_group_tile_staged(swz_group* g, swz_tile_stats* stats) {
+  if (!g) return SWZ_ERR_BAD_ARG;
+  if (g->staged.empty()) {
+    g->err = "swz_group_tile_staged: nothing is staged";
+    return SWZ_ERR_BAD_ARG;
+  }
+  const swz_group::Staged sb = g->staged.front();
+  g->staged.erase(g->staged.begin());
+  std::vector<double*> xyz(g->n);
+  std::vector<swz_attribute_columns> attrs(g->n);
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    // the shard's kernels wait for its copy on the device; the host goes on
+    const hipError_t e = hipStreamWaitEvent(g->ctx[r]->stream, g->copy_done[sb.slot][r], 0);
+    if (e != hipSuccess) {
+      g->err = "shard " + std::to_string(r) + ": hipStreamWaitEvent: " + hipGetErrorString(e);
+      return SWZ_ERR_HIP;
+    }
+    xyz[r] = g->stage_xyz[sb.slot][r];
+    attrs[r] = g->stage_attr[sb.slot][r];
+  }
+  return swz_group_add_batch(g, xyz.data(), g->stage_mask ? attrs.data() : nullptr, sb.n.data(), stats);
+}
+
+int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
+  if (!g) return SWZ_ERR_BAD_ARG;
+  if (g->tiler.empty() || !g->staged.empty()) {
+    g->err = g->tiler.empty() ? "swz_group_finalize: no data set is open" : "swz_group_finalize: staged batches have not been tiled";
+    return SWZ_ERR_BAD_ARG;
+  }
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    swz_tile_stats st{};
+    const int rc = swz_tiler_finalize(g->tiler[r], &st);
+    if (rc != SWZ_OK) {
+      g->err = "shard " + std::to_string(r) + ": " + swz_last_error(g->ctx[r]);
+      return rc;
+    }
+    if (stats) stats[r] = st;
+  }
   return SWZ_OK;
 }
 

@@ -85,6 +85,10 @@ struct swz_tiler {
   double staged_wait_ms = 0.0;  // time swz_tiler_tile_staged had to WAIT for its copy (0 when fully overlapped)
   // a batch between swz_tiler_shard_begin_device and swz_tiler_shard_finish
   bool batch_open = false;
+  // A batch that fails part-way leaves levels of the node store merged and its survivors lost: the tiler is poisoned
+  // and every later call reports SWZ_ERR_TILER_FAILED (the store must not be read or extended any more).
+  bool failed = false;
+  std::string failed_why;
   swz::BatchWork bw;
   swz::ActiveSet as;
   int next_level = -1;
@@ -92,6 +96,21 @@ struct swz_tiler {
   uint32_t acc_rounds = 0, acc_levels = 0;
   int acc_max_level = -1;
 };
+
+static int tiler_guard(swz_tiler* t) {
+  if (!t->failed) return SWZ_OK;
+  return t->c->fail(SWZ_ERR_TILER_FAILED, "swz_tiler: an earlier batch failed part-way (" + t->failed_why +
+                                            "); the node store is incomplete -- destroy the tiler");
+}
+// st != SWZ_OK after the tiler started to change its state: remember it
+static int tiler_poison(swz_tiler* t, int st) {
+  if (st != SWZ_OK && !t->failed) {
+    t->failed = true;
+    t->failed_why = t->c->err;
+    t->batch_open = false;
+  }
+  return st;
+}
 
 namespace swz {
 
@@ -1117,6 +1136,7 @@ int swz_tiler_add_batch_device(swz_tiler* t, double* d_xyz, uint64_t n, swz_tile
   if (!t) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_add_batch_device: staged batches are pending");
   if (n && !d_xyz) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_add_batch_device: NULL buffer");
   if ((uint64_t)t->total + n > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
@@ -1125,8 +1145,8 @@ int swz_tiler_add_batch_device(swz_tiler* t, double* d_xyz, uint64_t n, swz_tile
   const int st = tiler_add_batch(t, d_xyz, (uint32_t)n, stats);
   const hipError_t e = hipStreamSynchronize(c->stream);
   c->prof_collect();
-  if (st != SWZ_OK) return st;
-  SWZ_HIP(c, e);
+  if (st != SWZ_OK) return tiler_poison(t, st);
+  if (e != hipSuccess) return tiler_poison(t, c->hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
   return SWZ_OK;
 }
 
@@ -1137,6 +1157,7 @@ int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const 
   if (!t) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   if (!info) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL shard info");
   if (t->p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
   if ((t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && t->p.sampler == SWZ_MIN_DISTANCE)
@@ -1178,11 +1199,8 @@ int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const 
   }
   const hipError_t e = hipStreamSynchronize(c->stream);
   c->prof_collect();
-  if (st != SWZ_OK) {
-    t->batch_open = false;
-    return st;
-  }
-  SWZ_HIP(c, e);
+  if (st != SWZ_OK) return tiler_poison(t, st);
+  if (e != hipSuccess) return tiler_poison(t, c->hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
   if (root_file_count_out) *root_file_count_out = t->lv[0].cnt;
   return SWZ_OK;
 }
@@ -1191,23 +1209,32 @@ int swz_tiler_shard_finish(swz_tiler* t, swz_tile_stats* stats) {
   if (!t) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   zero_stats(stats);
   if (!t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_finish: no batch is open");
   if (t->next_level < 0) t->next_level = 0;  // the root was skipped (an empty batch)
   const int st = tiler_batch_run(t, 20, nullptr);
   const hipError_t e = hipStreamSynchronize(c->stream);
   c->prof_collect();
-  if (st != SWZ_OK) {
-    t->batch_open = false;
-    return st;
-  }
-  SWZ_HIP(c, e);
+  if (st != SWZ_OK) return tiler_poison(t, st);
+  if (e != hipSuccess) return tiler_poison(t, c->hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
   tiler_batch_close(t, stats);
+  return SWZ_OK;
+}
+
+int swz_tiler_poison(swz_tiler* t, const char* why) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  if (!t->failed) {
+    t->failed = true;
+    t->failed_why = why ? why : "poisoned by the caller";
+    t->batch_open = false;
+  }
   return SWZ_OK;
 }
 
 int swz_tiler_level_count(swz_tiler* t, int level, uint64_t* count_out) {
   if (!t || !count_out || level < -1 || level > 20) return SWZ_ERR_BAD_ARG;
+  SWZ_TRY(tiler_guard(t));
   *count_out = t->lv[level + 1].cnt;
   return SWZ_OK;
 }
@@ -1216,6 +1243,7 @@ int swz_tiler_level_positions_device(swz_tiler* t, int level, double* d_xyz_out)
   if (!t || level < -1 || level > 20) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   const StoreLevel& s = t->lv[level + 1];
   if (!s.cnt) return SWZ_OK;
   if (!d_xyz_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_level_positions_device: NULL buffer");
@@ -1229,6 +1257,7 @@ int swz_tiler_stage_batch(swz_tiler* t, const double* xyz_host, uint64_t n, cons
   if (!t) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   if (t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
   if (t->staged_sizes.size() >= 2) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_stage_batch: two batches are already staged");
   if (n && !xyz_host) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_stage_batch: NULL buffer");
@@ -1273,6 +1302,7 @@ int swz_tiler_tile_staged(swz_tiler* t, swz_tile_stats* stats) {
   if (!t) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   if (t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_tile_staged: nothing is staged");
   const uint32_t n = t->staged_sizes.front();
   hipEvent_t ev = t->staged_events.front();
@@ -1286,8 +1316,9 @@ int swz_tiler_tile_staged(swz_tiler* t, swz_tile_stats* stats) {
   const hipError_t e = hipStreamSynchronize(c->stream);
   (void)hipEventDestroy(ev);
   c->prof_collect();
-  if (st != SWZ_OK) return st;
-  SWZ_HIP(c, e);
+  // (a failure also leaves the pools one staged batch ahead of the ids the next batch would use)
+  if (st != SWZ_OK) return tiler_poison(t, st);
+  if (e != hipSuccess) return tiler_poison(t, c->hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
   return SWZ_OK;
 }
 
@@ -1302,9 +1333,10 @@ int swz_tiler_add_batch(swz_tiler* t, const double* xyz_host, uint64_t n, const 
 int swz_tiler_finalize(swz_tiler* t, swz_tile_stats* stats) {
   if (!t) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(t->c, hipSetDevice(t->c->device));
+  SWZ_TRY(tiler_guard(t));
   const int st = tiler_finalize(t, stats);
   t->c->prof_collect();
-  return st;
+  return tiler_poison(t, st);
 }
 
 int swz_tiler_get_info(swz_tiler* t, swz_tiler_info* info) {
@@ -1329,6 +1361,7 @@ int swz_tiler_node_table(swz_tiler* t, uint64_t max_nodes, int8_t* node_level_ou
   if (!t || !num_nodes_out) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   std::vector<int8_t> nl;
   std::vector<uint64_t> nk, no, nc;
   uint64_t nn = 0;
@@ -1348,6 +1381,7 @@ int swz_tiler_export_device(swz_tiler* t, uint64_t* d_keys_out, uint32_t* d_ids_
   if (!t) return SWZ_ERR_BAD_ARG;
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
   size_t off = 0;
   for (int l = 0; l < 22; ++l) {
     const StoreLevel& s = t->lv[l];

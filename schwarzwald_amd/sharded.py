@@ -382,6 +382,11 @@ class ShardedBatchTiler:
         zero = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
         stats = guarded(lambda: self.tiler.shard_finish(), zero)
         if self._all_sum(1 if failure else 0):
+            # the ranks that did not fail have committed this batch and the failing one has not: no rank may go on
+            try:
+                self.tiler.poison("a rank of the sharded run failed to tile this batch")
+            except api.SwzError:
+                pass
             if failure:
                 raise failure[0]
             raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")

@@ -177,6 +177,163 @@ int main(int argc, char** argv) {
         swz_device_free(d_attrs[s].column[SWZ_ATTR_RGB]);
       }
     }
+
+    // ---- the same group, a data set in several batches (swz_group_add_batch / _stage_batch, one swz_tiler per shard):
+    // the union of the shards' node files = the multi-batch oracle's, file by file and in file order; the root's file
+    // is the concatenation of the shards' parts in shard order.  k = 1 from device buffers, k = 3 staged from pinned memory.
+    if (transport == 0 || shards == 1)
+      for (int sampler = 0; sampler < 4; ++sampler)
+        for (int k : {1, 3}) {
+          swz_tile_params p{};
+          p.sampler = sampler;
+          p.max_points_per_node = 2000;
+          p.spacing_at_root = spacing;
+          p.max_depth = 100;
+          p.strategy = SWZ_ACCURATE;
+          p.fast_concurrency = 8;
+          if (swz_group_tiler_open(g, mn, mx, &p, 0) != SWZ_OK) return fail("swz_group_tiler_open", swz_group_last_error(g));
+          orc_tile_params op{sampler, 2000, spacing, 100, ORC_ACCURATE, 8};
+          orc_tiler* oracle = orc_tiler_create(mn, mx, &op);
+          std::vector<std::vector<void*>> pinned;  // freed after the data set
+          for (int b = 0; b < k; ++b) {
+            const size_t b0 = n * b / k, b1 = n * (b + 1) / k, bn = b1 - b0;
+            std::vector<double> copy(xyz.begin() + 3 * b0, xyz.begin() + 3 * b1);
+            if (orc_tiler_add_batch(oracle, copy.data(), bn) != 0) return fail("oracle tiler batch");
+            // the batch's points lie on the shards in uneven pieces (the last shard takes the rest, the second is empty)
+            std::vector<size_t> bc(shards + 1, 0);
+            for (int s = 1; s <= shards; ++s) bc[s] = (s == 2 && shards > 2) ? bc[1] : std::min(bn, (size_t)((double)bn * s * s / ((double)shards * shards)));
+            bc[shards] = bn;
+            std::vector<uint64_t> cnt(shards);
+            std::vector<swz_tile_stats> st(shards);
+            if (k == 1) {
+              std::vector<double*> d_xyz(shards, nullptr);
+              std::vector<swz_attribute_columns> d_attrs(shards);
+              for (int s = 0; s < shards; ++s) {
+                cnt[s] = bc[s + 1] - bc[s];
+                d_attrs[s] = swz_attribute_columns{};
+                const uint64_t rows = std::max<uint64_t>(cnt[s], 1);
+                swz_ctx* c = swz_group_ctx(g, s);
+                if (swz_device_alloc_on(c, rows * 24, (void**)&d_xyz[s]) != SWZ_OK || swz_device_alloc_on(c, rows * 8, &d_attrs[s].column[SWZ_ATTR_GPS_TIME]) != SWZ_OK)
+                  return fail("device alloc");
+                if (cnt[s] && (swz_copy_to_device(c, d_xyz[s], xyz.data() + 3 * (b0 + bc[s]), cnt[s] * 24) != SWZ_OK ||
+                               swz_copy_to_device(c, d_attrs[s].column[SWZ_ATTR_GPS_TIME], gps.data() + b0 + bc[s], cnt[s] * 8) != SWZ_OK))
+                  return fail("upload");
+              }
+              if (swz_group_add_batch(g, d_xyz.data(), d_attrs.data(), cnt.data(), st.data()) != SWZ_OK) return fail("swz_group_add_batch", swz_group_last_error(g));
+              for (int s = 0; s < shards; ++s) {
+                swz_device_free(d_xyz[s]);
+                swz_device_free(d_attrs[s].column[SWZ_ATTR_GPS_TIME]);
+              }
+            } else {
+              std::vector<const double*> h_xyz(shards, nullptr);
+              std::vector<swz_attribute_columns> h_attrs(shards);
+              pinned.emplace_back();
+              for (int s = 0; s < shards; ++s) {
+                cnt[s] = bc[s + 1] - bc[s];
+                h_attrs[s] = swz_attribute_columns{};
+                void *px = nullptr, *pg = nullptr;
+                if (swz_host_alloc_pinned(std::max<uint64_t>(cnt[s], 1) * 24, &px) != SWZ_OK || swz_host_alloc_pinned(std::max<uint64_t>(cnt[s], 1) * 8, &pg) != SWZ_OK)
+                  return fail("pinned alloc");
+                pinned.back().push_back(px);
+                pinned.back().push_back(pg);
+                std::copy(xyz.begin() + 3 * (b0 + bc[s]), xyz.begin() + 3 * (b0 + bc[s + 1]), (double*)px);
+                std::copy(gps.begin() + b0 + bc[s], gps.begin() + b0 + bc[s + 1], (double*)pg);
+                h_xyz[s] = (const double*)px;
+                h_attrs[s].column[SWZ_ATTR_GPS_TIME] = pg;
+              }
+              // batch b + 1 is staged before batch b is tiled whenever there is one: its copy runs beside the kernels
+              if (b == 0 && swz_group_stage_batch(g, h_xyz.data(), h_attrs.data(), cnt.data()) != SWZ_OK) return fail("swz_group_stage_batch", swz_group_last_error(g));
+              if (b + 1 < k) {
+                const size_t c0 = n * (b + 1) / k, c1 = n * (b + 2) / k, cn = c1 - c0;
+                std::vector<size_t> cc(shards + 1, 0);
+                for (int s = 1; s <= shards; ++s) cc[s] = (s == 2 && shards > 2) ? cc[1] : std::min(cn, (size_t)((double)cn * s * s / ((double)shards * shards)));
+                cc[shards] = cn;
+                std::vector<const double*> n_xyz(shards, nullptr);
+                std::vector<swz_attribute_columns> n_attrs(shards);
+                std::vector<uint64_t> ncnt(shards);
+                pinned.emplace_back();
+                for (int s = 0; s < shards; ++s) {
+                  ncnt[s] = cc[s + 1] - cc[s];
+                  n_attrs[s] = swz_attribute_columns{};
+                  void *px = nullptr, *pg = nullptr;
+                  if (swz_host_alloc_pinned(std::max<uint64_t>(ncnt[s], 1) * 24, &px) != SWZ_OK || swz_host_alloc_pinned(std::max<uint64_t>(ncnt[s], 1) * 8, &pg) != SWZ_OK)
+                    return fail("pinned alloc");
+                  pinned.back().push_back(px);
+                  pinned.back().push_back(pg);
+                  std::copy(xyz.begin() + 3 * (c0 + cc[s]), xyz.begin() + 3 * (c0 + cc[s + 1]), (double*)px);
+                  std::copy(gps.begin() + c0 + cc[s], gps.begin() + c0 + cc[s + 1], (double*)pg);
+                  n_xyz[s] = (const double*)px;
+                  n_attrs[s].column[SWZ_ATTR_GPS_TIME] = pg;
+                }
+                if (swz_group_stage_batch(g, n_xyz.data(), n_attrs.data(), ncnt.data()) != SWZ_OK) return fail("swz_group_stage_batch (next)", swz_group_last_error(g));
+              }
+              if (swz_group_tile_staged(g, st.data()) != SWZ_OK) return fail("swz_group_tile_staged", swz_group_last_error(g));
+            }
+          }
+          if (swz_group_finalize(g, nullptr) != SWZ_OK) return fail("swz_group_finalize", swz_group_last_error(g));
+          if (orc_tiler_finalize(oracle) != 0) return fail("oracle tiler finalize");
+          // the shards' node files, ids translated to input indices through the GPS-time column of the shard's pools
+          std::map<std::string, std::vector<uint32_t>> got_files;
+          uint64_t total_points = 0;
+          for (int s = 0; s < shards; ++s) {
+            swz_tiler* t = swz_group_tiler(g, s);
+            swz_ctx* c = swz_group_ctx(g, s);
+            swz_tiler_info info{};
+            if (swz_tiler_get_info(t, &info) != SWZ_OK) return fail("swz_tiler_get_info");
+            total_points += info.num_points;
+            if (!info.num_stored) continue;
+            std::vector<int8_t> nl(info.num_nodes);
+            std::vector<uint64_t> nk(info.num_nodes), no(info.num_nodes), nc(info.num_nodes);
+            uint64_t nn = 0;
+            if (swz_tiler_node_table(t, info.num_nodes, nl.data(), nk.data(), no.data(), nc.data(), &nn) != SWZ_OK) return fail("swz_tiler_node_table");
+            uint32_t* d_ids = nullptr;
+            if (swz_device_alloc_on(c, info.num_stored * 4, (void**)&d_ids) != SWZ_OK) return fail("device alloc");
+            if (swz_tiler_export_device(t, nullptr, d_ids, nullptr) != SWZ_OK) return fail("swz_tiler_export_device");
+            std::vector<uint32_t> ids(info.num_stored);
+            if (swz_copy_to_host(c, ids.data(), d_ids, info.num_stored * 4) != SWZ_OK) return fail("download ids");
+            swz_device_free(d_ids);
+            const double* d_pool = nullptr;
+            swz_attribute_columns pool_cols{};
+            if (swz_tiler_pools_device(t, &d_pool, &pool_cols) != SWZ_OK || !pool_cols.column[SWZ_ATTR_GPS_TIME]) return fail("swz_tiler_pools_device");
+            std::vector<double> pool_gps(info.num_points);
+            if (swz_copy_to_host(c, pool_gps.data(), pool_cols.column[SWZ_ATTR_GPS_TIME], info.num_points * 8) != SWZ_OK) return fail("download pool column");
+            for (uint64_t j = 0; j < nn; ++j) {
+              std::string name = "r";
+              for (int l = 0; l <= nl[j]; ++l) name.push_back((char)('0' + swz_host::get_octant_at_level(nk[j], (uint32_t)l)));
+              if (nl[j] >= 0 && got_files.count(name)) return fail("a node below the root on two shards", name.c_str());
+              std::vector<uint32_t>& f = got_files[name];  // (the root: appended in shard order)
+              for (uint64_t i = no[j]; i < no[j] + nc[j]; ++i) {
+                if (ids[i] >= info.num_points) return fail("point id out of range");
+                f.push_back((uint32_t)pool_gps[ids[i]]);
+              }
+            }
+          }
+          if (total_points != n) return fail("points lost or duplicated over the batches");
+          uint64_t onn = 0, ons = 0;
+          orc_tiler_counts(oracle, &onn, &ons, nullptr, nullptr);
+          std::vector<int8_t> onl(onn);
+          std::vector<uint64_t> onk(onn), ono(onn), onc(onn);
+          std::vector<uint32_t> oids(ons);
+          orc_tiler_export(oracle, onl.data(), onk.data(), ono.data(), onc.data(), oids.data(), nullptr);
+          orc_tiler_destroy(oracle);
+          std::map<std::string, std::vector<uint32_t>> expect;
+          for (uint64_t j = 0; j < onn; ++j) {
+            std::string name = "r";
+            for (int l = 0; l <= onl[j]; ++l) name.push_back((char)('0' + swz_host::get_octant_at_level(onk[j], (uint32_t)l)));
+            expect[name].assign(oids.begin() + ono[j], oids.begin() + ono[j] + onc[j]);
+          }
+          if (got_files != expect) {
+            size_t bad = 0;
+            for (const auto& kv : expect) bad += !got_files.count(kv.first) || got_files[kv.first] != kv.second;
+            std::fprintf(stderr, "%s, %d shards, %d batches: %zu of %zu node files differ (%zu files here)\n", names[sampler], shards, k, bad,
+                         expect.size(), got_files.size());
+            return fail("node files of the sharded multi-batch tilers differ from the oracle");
+          }
+          if (swz_group_tiler_close(g) != SWZ_OK) return fail("swz_group_tiler_close");
+          for (auto& v : pinned)
+            for (void* q : v) swz_host_free_pinned(q);
+          std::printf("%-12s %d shard(s) %d batch(es) files ok: %zu nodes\n", names[sampler], shards, k, expect.size());
+        }
     swz_group_destroy(g);
 
     // the reference-shaped C++ class on top: node files (names, contents, order) equal the oracle's

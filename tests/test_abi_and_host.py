@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), "libswz_gpu.so does not export %s" % name
     import schwarzwald_amd.api as api
-    assert lib.swz_abi_version() == 2 == api.ABI_VERSION
+    assert lib.swz_abi_version() == 3 == api.ABI_VERSION
 
 
 def test_no_cpu_fallback_without_device(lib):

@@ -234,3 +234,38 @@ def test_single_batch_entry_point_reports_reroot(ctx):
     with pytest.raises(swz.SwzError) as e:
         ctx.tile(xyz, *DEEP, swz.TileParams(sampler=swz.RANDOM_GRID, max_points_per_node=200, spacing_at_root=sp))
     assert e.value.code == 5
+
+
+@pytest.mark.gpu
+def test_gpu_tiler_is_poisoned_by_a_batch_that_fails_part_way(ctx):
+    """A batch that fails after the first levels have been merged into the node store leaves the tiler unusable: every
+    later call must say so (SWZ_ERR_TILER_FAILED) instead of reusing point ids on a half-updated store."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(31)
+    parts = [rng.random((60000, 3)) for _ in range(3)]
+    spacing = O.spacing_from_diagonal(*UNIT, 250)
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=500, spacing_at_root=spacing)
+    with swz.Tiler(ctx, UNIT[0], UNIT[1], params) as t:
+        t.add_batch(parts[0])
+        try:
+            ctx.set_option("SWZ_MD_SPARSE_LIMIT", "0")
+            ctx.set_option("SWZ_MD_ROUND_LIMIT", "1")  # the first MIN_DISTANCE level of the batch gives up
+            with pytest.raises(swz.SwzError) as e1:
+                t.add_batch(parts[1])
+            assert e1.value.code == swz.api.ERR_INTERNAL
+        finally:
+            ctx.set_option("SWZ_MD_SPARSE_LIMIT", None)
+            ctx.set_option("SWZ_MD_ROUND_LIMIT", None)
+        for call in (lambda: t.add_batch(parts[2]), t.finalize, lambda: t.level_count(-1), t.node_table):
+            with pytest.raises(swz.SwzError) as e2:
+                call()
+            assert e2.value.code == swz.api.ERR_TILER_FAILED
+            assert "earlier batch failed" in str(e2.value)
+        assert t.info()["num_points"] == 60000  # still answers, so that a caller can report what was lost
+    # a tiler poisoned from outside (what the multi-GPU driver does on the ranks that did not fail)
+    with swz.Tiler(ctx, UNIT[0], UNIT[1], params) as t:
+        t.add_batch(parts[0])
+        t.poison("peer failed")
+        with pytest.raises(swz.SwzError) as e3:
+            t.add_batch(parts[1])
+        assert e3.value.code == swz.api.ERR_TILER_FAILED and "peer failed" in str(e3.value)
