@@ -409,6 +409,17 @@ typedef struct {
 int swz_tiler_shard_begin_device(swz_tiler* tiler, double* d_xyz, uint64_t n, const swz_attribute_columns* d_attrs,
                                  const swz_tiler_shard_info* info, uint64_t* root_file_count_out);
 int swz_tiler_shard_finish(swz_tiler* tiler, swz_tile_stats* stats);
+/* FAST (TilingAlgorithmV3) on a sharded data set: swz_tiler_shard_begin_device indexes and sorts only (FAST has no root
+ * step per batch); after the FIRST batch's begin every shard reports its points per 6-octant prefix (2^18 counts, host),
+ * the driver sums them over the shards, derives the start level (TilingAlgorithms.cpp:1473-1535) and tells every shard
+ * before swz_tiler_shard_finish.  At the end of the data set: swz_tiler_shard_fast_finalize_local rebuilds the skipped
+ * levels of the shard's octants down to level 0; the driver samples the root from the level-0 files of ALL shards (in
+ * shard order, swz_tiler_level_positions_device(0)) and hands every shard the flags of its entries. */
+int swz_tiler_shard_fast_histogram(swz_tiler* tiler, uint32_t* counts_out /* 262144, host */);
+int swz_fast_start_level_from_counts(const uint64_t* counts /* 262144, host */, uint32_t fast_concurrency, int32_t* start_level_out);
+int swz_tiler_shard_set_start_level(swz_tiler* tiler, int32_t start_level);
+int swz_tiler_shard_fast_finalize_local(swz_tiler* tiler, swz_tile_stats* stats);
+int swz_tiler_shard_fast_set_root(swz_tiler* tiler, const uint8_t* d_taken);
 /* A batch that fails part-way (workspace out of memory, a MIN_DISTANCE level that does not terminate, a HIP error)
  * leaves the node store half updated: the tiler is then POISONED -- every later swz_tiler_* call except
  * swz_tiler_destroy / swz_tiler_get_info returns SWZ_ERR_TILER_FAILED and names the original failure.  A driver that

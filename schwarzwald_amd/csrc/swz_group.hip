@@ -107,6 +107,8 @@ struct swz_group {
   std::vector<uint64_t> root_stored;  // points in the root's file on every shard (before / after the batch's root step)
   double tbmin[3] = {0, 0, 0}, tbmax[3] = {0, 0, 0};
   swz_tile_params tparams{};
+  int fast_start = -1;                       // FAST: the start level, known after the first batch
+  std::vector<std::vector<uint32_t>> hist;   // FAST, first batch: every shard's points per 6-octant prefix
   // batches staged from pinned host memory: two device buffers per shard, filled on a copy stream of their own
   struct Staged {
     std::vector<uint64_t> n;  // per shard
@@ -353,15 +355,42 @@ void shard_thread(ShardCall a) {
     // order visits the shards in turn, each with the root files of the lower ones -- as they are after this batch --
     // as ghosts.  4'. the levels below are local.
     swz_tiler* t = g->tiler[r];
+    auto tiler_try = [&](int st) {
+      if (ok && st != SWZ_OK) ok = fail(g, r, st, swz_last_error(c));
+    };
+    if (g->tparams.strategy == SWZ_FAST) {
+      // TilingAlgorithmV3: no root step per batch.  The start level comes from the FIRST batch's distribution over all
+      // shards (TilingAlgorithms.cpp:1473-1535) and is kept (:1230-1236).
+      const bool first = g->fast_start < 0;  // (read before the first barrier below; shard 0 writes it after that barrier)
+      swz_tiler_shard_info info{global_points, 0, nullptr, 0};
+      uint64_t have = 0;
+      if (ok && global_points < g->tparams.fast_concurrency) ok = fail(g, r, SWZ_ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points");
+      if (ok) tiler_try(swz_tiler_shard_begin_device(t, recv, m, &recv_attr, &info, &have));
+      if (first) {
+        g->hist[r].assign(1u << 18, 0u);
+        if (ok) tiler_try(swz_tiler_shard_fast_histogram(t, g->hist[r].data()));
+        g->barrier.wait();
+        if (r == 0) {
+          std::vector<uint64_t> sum(1u << 18, 0);
+          for (int s = 0; s < N; ++s)
+            for (uint32_t b = 0; b < (1u << 18); ++b) sum[b] += g->hist[s][b];
+          int32_t S = -1;
+          (void)swz_fast_start_level_from_counts(sum.data(), g->tparams.fast_concurrency, &S);
+          g->fast_start = S;
+        }
+        g->barrier.wait();
+      }
+      if (ok) tiler_try(swz_tiler_shard_set_start_level(t, g->fast_start));
+      swz_tile_stats stats{};
+      if (ok) tiler_try(swz_tiler_shard_finish(t, &stats));
+      if (a.stats) *a.stats = stats;
+    } else {
     uint64_t root_before = 0;
     for (int s = 0; s < N; ++s) root_before += g->root_stored[s];
     const bool sample = root_before > 0 || global_points + root_before > g->tparams.max_points_per_node;
     const bool sequential_root = g->tparams.sampler == SWZ_MIN_DISTANCE && sample && global_points > 0;
     swz_tiler_shard_info info{global_points, root_before, nullptr, 0};
     uint64_t have = 0;
-    auto tiler_try = [&](int st) {
-      if (ok && st != SWZ_OK) ok = fail(g, r, st, swz_last_error(c));
-    };
     if (!sequential_root) {
       if (ok) tiler_try(swz_tiler_shard_begin_device(t, recv, m, &recv_attr, &info, &have));
     } else {
@@ -397,8 +426,16 @@ void shard_thread(ShardCall a) {
     swz_tile_stats stats{};
     if (ok) tiler_try(swz_tiler_shard_finish(t, &stats));
     if (a.stats) *a.stats = stats;
+    }
   }
   g->barrier.wait();  // ---- nobody reads a neighbour's buffers any more
+}
+
+// flag of the i-th sorted element back to the position its element had before the sort
+__global__ __launch_bounds__(256) void grp_unsort_flags_kernel(const uint32_t* __restrict__ perm, const uint8_t* __restrict__ taken, uint32_t n,
+                                                               uint8_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) flags[perm[i]] = taken[i];
 }
 
 }  // namespace
@@ -545,10 +582,12 @@ int swz_group_tiler_open(swz_group* g, const double bmin[3], const double bmax[3
     g->err = "swz_group_tiler_open: a data set is open already (swz_group_tiler_close)";
     return SWZ_ERR_BAD_ARG;
   }
-  if (params->strategy != SWZ_ACCURATE || (params->flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY)) {
-    g->err = "sharded batches support the ACCURATE strategy and exact MIN_DISTANCE";
+  if (params->flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) {
+    g->err = "sharded batches support exact MIN_DISTANCE only";
     return SWZ_ERR_BAD_ARG;
   }
+  g->fast_start = -1;
+  g->hist.assign(g->n, std::vector<uint32_t>());
   for (int a = 0; a < 3; ++a) {
     g->tbmin[a] = bmin[a];
     g->tbmax[a] = bmax[a];
@@ -714,15 +753,92 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
     g->err = g->tiler.empty() ? "swz_group_finalize: no data set is open" : "swz_group_finalize: staged batches have not been tiled";
     return SWZ_ERR_BAD_ARG;
   }
+  const bool fast = g->tparams.strategy == SWZ_FAST && g->fast_start > 0;
+  auto shard_fail = [&](int r, int rc) {
+    g->err = "shard " + std::to_string(r) + ": " + swz_last_error(g->ctx[r]);
+    for (int s = 0; s < g->n; ++s) (void)swz_tiler_poison(g->tiler[s], ("the group failed to finalize: " + g->err).c_str());
+    return rc;
+  };
   for (int r = 0; r < g->n; ++r) {
     (void)hipSetDevice(g->devices[r]);
     swz_tile_stats st{};
-    const int rc = swz_tiler_finalize(g->tiler[r], &st);
-    if (rc != SWZ_OK) {
-      g->err = "shard " + std::to_string(r) + ": " + swz_last_error(g->ctx[r]);
-      return rc;
-    }
+    const int rc = fast ? swz_tiler_shard_fast_finalize_local(g->tiler[r], &st) : swz_tiler_finalize(g->tiler[r], &st);
+    if (rc != SWZ_OK) return shard_fail(r, rc);
     if (stats) stats[r] = st;
+  }
+  if (!fast) return SWZ_OK;
+  // The root of TilingAlgorithmV3::finalize (reconstruct_single_node, :1661-1715) samples what its eight children hold,
+  // and they lie on different shards: their files come together on shard 0 in shard order (= octant order: the order
+  // the reference appends them in), are indexed against the root bounds and sampled with AlwaysAdhereToMinSpacing there;
+  // every shard keeps the part of the root's file that comes from its own points.
+  std::vector<uint64_t> cnt(g->n, 0), off(g->n + 1, 0);
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    const int rc = swz_tiler_level_count(g->tiler[r], 0, &cnt[r]);
+    if (rc != SWZ_OK) return shard_fail(r, rc);
+    off[r + 1] = off[r] + cnt[r];
+  }
+  const uint64_t total = off[g->n];
+  swz_ctx* c0 = g->ctx[0];
+  uint8_t* d_flags0 = nullptr;
+  if (total) {
+    if (total > 0xFFFF0000ull) {
+      g->err = "more than 2^32-65536 points in the level-0 files";
+      return SWZ_ERR_TOO_MANY_POINTS;
+    }
+    (void)hipSetDevice(g->devices[0]);
+    double* all = nullptr;
+    uint64_t *keys = nullptr, *skeys = nullptr;
+    uint32_t* perm = nullptr;
+    uint8_t* taken = nullptr;
+    if (c0->get("grp_root_xyz", (size_t)total * 3, &all) != SWZ_OK || c0->get("grp_root_keys", (size_t)total, &keys) != SWZ_OK ||
+        c0->get("grp_root_skeys", (size_t)total, &skeys) != SWZ_OK || c0->get("grp_root_perm", (size_t)total, &perm) != SWZ_OK ||
+        c0->get("grp_root_taken", (size_t)total, &taken) != SWZ_OK || c0->get("grp_root_flags", (size_t)total, &d_flags0) != SWZ_OK)
+      return shard_fail(0, SWZ_ERR_HIP);
+    for (int r = 0; r < g->n; ++r) {
+      if (!cnt[r]) continue;
+      (void)hipSetDevice(g->devices[r]);
+      swz_ctx* c = g->ctx[r];
+      double* mine = nullptr;
+      if (c->get("grp_l0_xyz", (size_t)cnt[r] * 3, &mine) != SWZ_OK) return shard_fail(r, SWZ_ERR_HIP);
+      const int rc = swz_tiler_level_positions_device(g->tiler[r], 0, mine);
+      if (rc != SWZ_OK) return shard_fail(r, rc);
+      if (hipStreamSynchronize(c->stream) != hipSuccess ||
+          hipMemcpyPeer(all + off[r] * 3, g->devices[0], mine, g->devices[r], (size_t)cnt[r] * 24) != hipSuccess) {
+        c->err = "copy of the level-0 file to shard 0 failed";
+        return shard_fail(r, SWZ_ERR_HIP);
+      }
+    }
+    (void)hipSetDevice(g->devices[0]);
+    int rc = swz_morton_encode_device(c0, all, total, g->tbmin, g->tbmax, keys);
+    if (rc == SWZ_OK) rc = swz_sort_by_key_device(c0, keys, total, perm, skeys);
+    if (rc == SWZ_OK)
+      rc = swz::sample_points_device(c0, g->tparams.sampler, g->tparams.max_points_per_node, skeys, perm, (uint32_t)total, all, 0, -1, g->tbmin,
+                                     g->tbmax, g->tparams.spacing_at_root, SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, taken, nullptr);
+    if (rc != SWZ_OK) return shard_fail(0, rc);
+    hipLaunchKernelGGL(grp_unsort_flags_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, c0->stream, perm, taken, (uint32_t)total, d_flags0);
+    if (hipStreamSynchronize(c0->stream) != hipSuccess) {
+      c0->err = "root reconstruction failed on the device";
+      return shard_fail(0, SWZ_ERR_HIP);
+    }
+  }
+  for (int r = 0; r < g->n; ++r) {
+    (void)hipSetDevice(g->devices[r]);
+    swz_ctx* c = g->ctx[r];
+    uint8_t* mine = nullptr;
+    if (cnt[r]) {
+      if (r == 0) {
+        mine = d_flags0;
+      } else {
+        if (c->get("grp_l0_flags", (size_t)cnt[r], &mine) != SWZ_OK) return shard_fail(r, SWZ_ERR_HIP);
+        if (hipMemcpyPeer(mine, g->devices[r], d_flags0 + off[r], g->devices[0], (size_t)cnt[r]) != hipSuccess) {
+          c->err = "copy of the root flags failed";
+          return shard_fail(r, SWZ_ERR_HIP);
+        }
+      }
+    }
+    const int rc = swz_tiler_shard_fast_set_root(g->tiler[r], mine);
+    if (rc != SWZ_OK) return shard_fail(r, rc);
   }
   return SWZ_OK;
 }

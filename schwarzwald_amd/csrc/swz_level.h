@@ -100,6 +100,10 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
                int8_t* level_out, uint64_t* okey, uint32_t* oidx, LevelResult* res);
 // estimate_start_node_level_in_octree (TilingAlgorithms.cpp:1473-1535) of a sorted batch
 int fast_start_level(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint32_t concurrency, int* start_level);
+// the same in two steps for a batch that is spread over several GPUs: counts per 6-octant prefix (2^18, host), summed by
+// the driver, then the estimate
+int fast_prefix_counts(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint32_t* counts_host);
+int fast_start_level_from_counts(const uint64_t* counts, uint32_t concurrency);
 
 // MIN_DISTANCE for one level; fills lb.taken for the points of MODE_SAMPLE nodes (take-all points
 // are flagged by the caller).  rounds_out accumulates the dependency rounds executed.

@@ -1063,6 +1063,33 @@ __global__ __launch_bounds__(256) void recon_mark_kernel(const uint32_t* __restr
   if (i < m && taken[i]) dup[aidx[i]] |= bit;
 }
 
+// points per 6-octant prefix of a sorted batch (what the start-level estimate looks at), host array of 2^18 counts
+int fast_prefix_counts(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint32_t* counts_host) {
+  const uint32_t nbins = 1u << 18;
+  uint32_t* d_starts = nullptr;
+  SWZ_TRY(c->get("fast_starts", (size_t)nbins + 1, &d_starts));
+  std::vector<uint32_t> starts(nbins + 1, 0);
+  if (n) {
+    hipLaunchKernelGGL(prefix_bounds_kernel, dim3(div_up(nbins + 1, 256)), dim3(256), 0, c->stream, d_keys_sorted, n, d_starts, nbins);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_HIP(c, hipMemcpyAsync(starts.data(), d_starts, (nbins + 1) * 4, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  for (uint32_t b = 0; b < nbins; ++b) counts_host[b] = starts[b + 1] - starts[b];
+  return SWZ_OK;
+}
+// the estimate from counts that may be the sum over the shards of a batch (each below 2^32 in total)
+int fast_start_level_from_counts(const uint64_t* counts, uint32_t concurrency) {
+  std::vector<uint32_t> starts((1u << 18) + 1, 0);
+  uint64_t run = 0;
+  for (uint32_t b = 0; b < (1u << 18); ++b) {
+    starts[b] = (uint32_t)std::min<uint64_t>(run, 0xFFFFFFFFull);
+    run += counts[b];
+  }
+  starts[1u << 18] = (uint32_t)std::min<uint64_t>(run, 0xFFFFFFFFull);
+  return (int)estimate_start_level_host(starts, concurrency);
+}
+
 int fast_start_level(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint32_t concurrency, int* start_level) {
   const uint32_t nbins = 1u << 18;
   uint32_t* d_starts = nullptr;

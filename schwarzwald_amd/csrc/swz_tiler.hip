@@ -89,6 +89,7 @@ struct swz_tiler {
   // and every later call reports SWZ_ERR_TILER_FAILED (the store must not be read or extended any more).
   bool failed = false;
   std::string failed_why;
+  bool shard_fast = false;  // a FAST batch of a sharded data set is open: the start level comes from the driver
   swz::BatchWork bw;
   swz::ActiveSet as;
   int next_level = -1;
@@ -831,7 +832,7 @@ static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t
   if (t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
   if (t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: the previous batch is still open (swz_tiler_shard_finish)");
   // parallel::scatter throws for a batch with fewer points than indexing threads (util/threading/Parallel.h:181-186)
-  if (t->p.strategy == SWZ_FAST && n < t->p.fast_concurrency)
+  if (t->p.strategy == SWZ_FAST && n < t->p.fast_concurrency && !t->shard_fast)  // (a sharded batch: its driver checks the whole batch)
     return c->fail(SWZ_ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points");
   const uint32_t base = t->total;
   uint64_t* keys = nullptr;
@@ -875,8 +876,8 @@ static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t
   w.wused = n;
   t->next_level = -1;
   if (t->p.strategy == SWZ_FAST) {
-    if (t->fast_start < 0) SWZ_TRY(fast_start_level(c, keys, n, t->p.fast_concurrency, &t->fast_start));
-    t->next_level = t->fast_start - 1;
+    if (t->fast_start < 0 && !t->shard_fast) SWZ_TRY(fast_start_level(c, keys, n, t->p.fast_concurrency, &t->fast_start));
+    t->next_level = t->fast_start - 1;  // (a sharded batch: set again once the driver has told the start level)
   }
   t->as = ActiveSet{keys, nullptr, n};
   t->acc_visited = t->acc_nodes = 0;
@@ -957,19 +958,19 @@ static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_sta
 // TilingAlgorithmV3::finalize -> reconstruct_left_out_nodes (:1717-1784): every ancestor of a start node samples the
 // points its children hold (children in octant order = the store order of the level below), re-indexed against the
 // root bounds, with AlwaysAdhereToMinSpacing (reconstruct_single_node :1661-1715).
-static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats) {
+static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats, int lowest_children = 0) {
   swz_ctx* c = t->c;
   zero_stats(stats);
   if (t->finalized) return SWZ_OK;
   if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_finalize: staged batches have not been tiled");
-  t->finalized = true;
+  t->finalized = lowest_children == 0;  // (a shard stops below the root: swz_tiler_shard_fast_set_root ends the data set)
   if (t->p.strategy != SWZ_FAST || t->fast_start <= 0) return SWZ_OK;
   const int S = t->fast_start;
   uint64_t nodes = 0;
   uint32_t rounds = 0;
   uint32_t* counters = nullptr;
   SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
-  for (int lv = S - 1; lv >= 0; --lv) {  // children at node level lv, parents at lv - 1
+  for (int lv = S - 1; lv >= lowest_children; --lv) {  // children at node level lv, parents at lv - 1
     StoreLevel& src = t->lv[lv + 1];
     StoreLevel& dst = t->lv[lv];
     const uint32_t m = src.cnt;
@@ -1159,9 +1160,9 @@ int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const 
   SWZ_HIP(c, hipSetDevice(c->device));
   SWZ_TRY(tiler_guard(t));
   if (!info) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL shard info");
-  if (t->p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
   if ((t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && t->p.sampler == SWZ_MIN_DISTANCE)
     return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
+  const bool fast = t->p.strategy == SWZ_FAST;
   if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: staged batches are pending");
   if ((n && !d_xyz) || (info->num_ghosts && !info->d_ghost_xyz)) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL buffer");
   if ((uint64_t)t->total + n > 0xFFFF0000ull || info->num_ghosts > 0x7FFFFFFFull)
@@ -1187,8 +1188,11 @@ int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const 
     SWZ_HIP(c, hipMemcpyAsync((char*)t->pool_attr[a] + (size_t)t->total * rb, d_attrs->column[a], (size_t)n * rb,
                               hipMemcpyDeviceToDevice, c->stream));
   }
+  t->shard_fast = fast;
   int st = tiler_batch_prepare(t, d_xyz, (uint32_t)n, (uint32_t)info->num_ghosts);
-  if (st == SWZ_OK && info->global_new_points > 0) {
+  t->shard_fast = false;
+  // FAST (TilingAlgorithmV3) skips the levels above its start nodes until the data set ends: no root step per batch
+  if (st == SWZ_OK && info->global_new_points > 0 && !fast) {
     ShardRoot sr;
     sr.active = true;
     // tile_internal_node :272-275 with the counts of the WHOLE root: cached points force sampling, else count <= max takes all
@@ -1212,7 +1216,12 @@ int swz_tiler_shard_finish(swz_tiler* t, swz_tile_stats* stats) {
   SWZ_TRY(tiler_guard(t));
   zero_stats(stats);
   if (!t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_finish: no batch is open");
-  if (t->next_level < 0) t->next_level = 0;  // the root was skipped (an empty batch)
+  if (t->p.strategy == SWZ_FAST) {
+    if (t->fast_start < 1) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_finish: FAST needs swz_tiler_shard_set_start_level first");
+    t->next_level = t->fast_start - 1;
+  } else if (t->next_level < 0) {
+    t->next_level = 0;  // the root was skipped (an empty batch)
+  }
   const int st = tiler_batch_run(t, 20, nullptr);
   const hipError_t e = hipStreamSynchronize(c->stream);
   c->prof_collect();
@@ -1220,6 +1229,80 @@ int swz_tiler_shard_finish(swz_tiler* t, swz_tile_stats* stats) {
   if (e != hipSuccess) return tiler_poison(t, c->hip_fail(e, "hipStreamSynchronize", __FILE__, __LINE__));
   tiler_batch_close(t, stats);
   return SWZ_OK;
+}
+
+// ---- FAST on a sharded data set.  The start level of TilingAlgorithmV3 comes from the distribution of the FIRST batch
+// (TilingAlgorithms.cpp:1473-1535, kept afterwards :1230-1236): every shard reports the counts of its part per 6-octant
+// prefix, the driver sums them and tells every shard the level.  Start nodes lie at level >= 2, inside one shard's
+// octants, so batches need no root step; when the data set ends every shard rebuilds the skipped levels of its own
+// octants down to level 0 and the root is rebuilt from the level-0 files of all shards by the driver.
+int swz_tiler_shard_fast_histogram(swz_tiler* t, uint32_t* counts_out) {
+  if (!t || !counts_out) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
+  if (!t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_fast_histogram: no batch is open");
+  return tiler_poison(t, fast_prefix_counts(c, t->as.akey, t->as.m, counts_out));
+}
+int swz_fast_start_level_from_counts(const uint64_t* counts, uint32_t fast_concurrency, int32_t* start_level_out) {
+  if (!counts || !start_level_out || !fast_concurrency) return SWZ_ERR_BAD_ARG;
+  *start_level_out = fast_start_level_from_counts(counts, fast_concurrency);
+  return SWZ_OK;
+}
+int swz_tiler_shard_set_start_level(swz_tiler* t, int32_t start_level) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_TRY(tiler_guard(t));
+  if (t->p.strategy != SWZ_FAST || start_level < 1 || start_level > 6) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_set_start_level: FAST tilers, levels 1..6");
+  if (t->fast_start >= 0 && t->fast_start != start_level) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_set_start_level: the start level is fixed by the first batch");
+  t->fast_start = start_level;
+  return SWZ_OK;
+}
+int swz_tiler_shard_fast_finalize_local(swz_tiler* t, swz_tile_stats* stats) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
+  if (t->p.strategy != SWZ_FAST) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_fast_finalize_local: not a FAST tiler");
+  const int st = tiler_finalize(t, stats, 1);  // parents down to level 0; the root spans the shards
+  c->prof_collect();
+  return tiler_poison(t, st);
+}
+// d_taken: one flag per entry of this shard's level-0 files, in file order: the entry belongs to the rebuilt root
+int swz_tiler_shard_fast_set_root(swz_tiler* t, const uint8_t* d_taken) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
+  if (t->p.strategy != SWZ_FAST || t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_fast_set_root: an open FAST tiler is needed");
+  StoreLevel& src = t->lv[1];
+  StoreLevel& dst = t->lv[0];
+  const uint32_t m = src.cnt;
+  t->finalized = true;
+  if (m == 0) return SWZ_OK;
+  if (!d_taken) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_fast_set_root: NULL flags");
+  auto body = [&]() -> int {
+    uint64_t *keys = nullptr, *tkey = nullptr;
+    uint32_t *tgid = nullptr, *counters = nullptr;
+    SWZ_TRY(c->get("tl_keys", (size_t)m, &keys));
+    SWZ_TRY(c->get("tl_tkey", (size_t)m, &tkey));
+    SWZ_TRY(c->get("tl_tgid", (size_t)m, &tgid));
+    SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+    hipLaunchKernelGGL(tl_reencode_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, src.gid[src.cur], m, t->pool_xyz, root_box(t), keys);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(fused_scan(c, TakenF{d_taken}, TakeG{keys, nullptr, src.gid[src.cur], tkey, tgid}, m, counters + 2, "tl"));
+    uint32_t nt = 0;
+    SWZ_TRY(read_u32(c, counters + 2, &nt));
+    const int w = dst.cur ^ 1;
+    SWZ_TRY(store_reserve(c, dst, 0, w, nt));
+    SWZ_HIP(c, hipMemcpyAsync(dst.key[w], tkey, (size_t)nt * 8, hipMemcpyDeviceToDevice, c->stream));
+    SWZ_HIP(c, hipMemcpyAsync(dst.gid[w], tgid, (size_t)nt * 4, hipMemcpyDeviceToDevice, c->stream));
+    dst.cur = w;
+    dst.cnt = nt;
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    return SWZ_OK;
+  };
+  return tiler_poison(t, body());
 }
 
 int swz_tiler_poison(swz_tiler* t, const char* why) {

@@ -44,6 +44,9 @@ struct RowSink : swz_host::PointsSink {
 
 using Row = std::tuple<uint64_t, double, double, double, int>;  // key, x, y, z, level
 
+// what the multi-batch oracle stores, by (sampler, strategy, batches): it does not depend on the number of shards
+static std::map<std::tuple<int, int, int>, std::map<std::string, std::vector<uint32_t>>> g_expect;
+
 int main(int argc, char** argv) {
   const int transport = argc > 1 ? std::atoi(argv[1]) : 0;
   const size_t n = 300000;
@@ -183,22 +186,24 @@ int main(int argc, char** argv) {
     // is the concatenation of the shards' parts in shard order.  k = 1 from device buffers, k = 3 staged from pinned memory.
     if (transport == 0 || shards == 1)
       for (int sampler = 0; sampler < 4; ++sampler)
+       for (int strategy : {SWZ_ACCURATE, SWZ_FAST})  // FAST: start level from the summed histograms, root rebuilt on shard 0
         for (int k : {1, 3}) {
           swz_tile_params p{};
           p.sampler = sampler;
           p.max_points_per_node = 2000;
           p.spacing_at_root = spacing;
           p.max_depth = 100;
-          p.strategy = SWZ_ACCURATE;
+          p.strategy = strategy;
           p.fast_concurrency = 8;
           if (swz_group_tiler_open(g, mn, mx, &p, 0) != SWZ_OK) return fail("swz_group_tiler_open", swz_group_last_error(g));
-          orc_tile_params op{sampler, 2000, spacing, 100, ORC_ACCURATE, 8};
-          orc_tiler* oracle = orc_tiler_create(mn, mx, &op);
+          orc_tile_params op{sampler, 2000, spacing, 100, strategy == SWZ_FAST ? ORC_FAST : ORC_ACCURATE, 8};
+          const bool have_expect = g_expect.count(std::make_tuple(sampler, strategy, k)) != 0;
+          orc_tiler* oracle = have_expect ? nullptr : orc_tiler_create(mn, mx, &op);
           std::vector<std::vector<void*>> pinned;  // freed after the data set
           for (int b = 0; b < k; ++b) {
             const size_t b0 = n * b / k, b1 = n * (b + 1) / k, bn = b1 - b0;
             std::vector<double> copy(xyz.begin() + 3 * b0, xyz.begin() + 3 * b1);
-            if (orc_tiler_add_batch(oracle, copy.data(), bn) != 0) return fail("oracle tiler batch");
+            if (oracle && orc_tiler_add_batch(oracle, copy.data(), bn) != 0) return fail("oracle tiler batch");
             // the batch's points lie on the shards in uneven pieces (the last shard takes the rest, the second is empty)
             std::vector<size_t> bc(shards + 1, 0);
             for (int s = 1; s <= shards; ++s) bc[s] = (s == 2 && shards > 2) ? bc[1] : std::min(bn, (size_t)((double)bn * s * s / ((double)shards * shards)));
@@ -271,7 +276,7 @@ int main(int argc, char** argv) {
             }
           }
           if (swz_group_finalize(g, nullptr) != SWZ_OK) return fail("swz_group_finalize", swz_group_last_error(g));
-          if (orc_tiler_finalize(oracle) != 0) return fail("oracle tiler finalize");
+          if (oracle && orc_tiler_finalize(oracle) != 0) return fail("oracle tiler finalize");
           // the shards' node files, ids translated to input indices through the GPS-time column of the shard's pools
           std::map<std::string, std::vector<uint32_t>> got_files;
           uint64_t total_points = 0;
@@ -309,30 +314,34 @@ int main(int argc, char** argv) {
             }
           }
           if (total_points != n) return fail("points lost or duplicated over the batches");
-          uint64_t onn = 0, ons = 0;
-          orc_tiler_counts(oracle, &onn, &ons, nullptr, nullptr);
-          std::vector<int8_t> onl(onn);
-          std::vector<uint64_t> onk(onn), ono(onn), onc(onn);
-          std::vector<uint32_t> oids(ons);
-          orc_tiler_export(oracle, onl.data(), onk.data(), ono.data(), onc.data(), oids.data(), nullptr);
-          orc_tiler_destroy(oracle);
-          std::map<std::string, std::vector<uint32_t>> expect;
-          for (uint64_t j = 0; j < onn; ++j) {
-            std::string name = "r";
-            for (int l = 0; l <= onl[j]; ++l) name.push_back((char)('0' + swz_host::get_octant_at_level(onk[j], (uint32_t)l)));
-            expect[name].assign(oids.begin() + ono[j], oids.begin() + ono[j] + onc[j]);
+          if (oracle) {
+            uint64_t onn = 0, ons = 0;
+            orc_tiler_counts(oracle, &onn, &ons, nullptr, nullptr);
+            std::vector<int8_t> onl(onn);
+            std::vector<uint64_t> onk(onn), ono(onn), onc(onn);
+            std::vector<uint32_t> oids(ons);
+            orc_tiler_export(oracle, onl.data(), onk.data(), ono.data(), onc.data(), oids.data(), nullptr);
+            orc_tiler_destroy(oracle);
+            std::map<std::string, std::vector<uint32_t>>& e = g_expect[std::make_tuple(sampler, strategy, k)];
+            for (uint64_t j = 0; j < onn; ++j) {
+              std::string name = "r";
+              for (int l = 0; l <= onl[j]; ++l) name.push_back((char)('0' + swz_host::get_octant_at_level(onk[j], (uint32_t)l)));
+              e[name].assign(oids.begin() + ono[j], oids.begin() + ono[j] + onc[j]);
+            }
           }
+          const std::map<std::string, std::vector<uint32_t>>& expect = g_expect[std::make_tuple(sampler, strategy, k)];
           if (got_files != expect) {
             size_t bad = 0;
-            for (const auto& kv : expect) bad += !got_files.count(kv.first) || got_files[kv.first] != kv.second;
-            std::fprintf(stderr, "%s, %d shards, %d batches: %zu of %zu node files differ (%zu files here)\n", names[sampler], shards, k, bad,
-                         expect.size(), got_files.size());
+            for (const auto& kv : expect) bad += !got_files.count(kv.first) || got_files.at(kv.first) != kv.second;
+            std::fprintf(stderr, "%s %s, %d shards, %d batches: %zu of %zu node files differ (%zu files here)\n", names[sampler],
+                         strategy == SWZ_FAST ? "FAST" : "ACCURATE", shards, k, bad, expect.size(), got_files.size());
             return fail("node files of the sharded multi-batch tilers differ from the oracle");
           }
           if (swz_group_tiler_close(g) != SWZ_OK) return fail("swz_group_tiler_close");
           for (auto& v : pinned)
             for (void* q : v) swz_host_free_pinned(q);
-          std::printf("%-12s %d shard(s) %d batch(es) files ok: %zu nodes\n", names[sampler], shards, k, expect.size());
+          std::printf("%-12s %-8s %d shard(s) %d batch(es) files ok: %zu nodes\n", names[sampler], strategy == SWZ_FAST ? "FAST" : "ACCURATE", shards, k,
+                      expect.size());
         }
     swz_group_destroy(g);
 

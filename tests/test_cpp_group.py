@@ -30,7 +30,8 @@ def test_group_peer_copies_match_the_oracle(tmp_path):
     exe = _build(str(tmp_path))
     r = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(" ok") == 64  # per shard count: 4 samplers x (one batch + class) and x {1, 3} batches through swz_group_add_batch
+    # per shard count: 4 samplers x (one batch + class) and x {ACCURATE, FAST} x {1, 3} batches through swz_group_add_batch
+    assert r.stdout.count(" ok") == 96
 
 
 @pytest.mark.gpu
