@@ -458,6 +458,9 @@ int swz_group_destroy(swz_group* group);
 const char* swz_group_last_error(const swz_group* group);
 int swz_group_num_shards(const swz_group* group);
 swz_ctx* swz_group_ctx(swz_group* group, int shard);
+/* host wall clock of shard `shard` in the last swz_group_tile, ms since the call began: exchange done, root begun, root
+ * done, levels done (the MIN_DISTANCE root: all shards at once when the level can be decided on keys, else in turns) */
+int swz_group_shard_timing(const swz_group* group, int shard, double ms_out[4]);
 int swz_group_tile(swz_group* group, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n,
                    const double bounds_min[3], const double bounds_max[3], const swz_tile_params* params,
                    swz_group_result* results);

@@ -12,6 +12,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <array>
+#include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -20,6 +22,7 @@
 #include <vector>
 
 #include "swz_internal.h"
+#include "swz_level.h"
 
 namespace {
 
@@ -107,6 +110,9 @@ struct swz_group {
   std::vector<uint64_t> root_stored;  // points in the root's file on every shard (before / after the batch's root step)
   double tbmin[3] = {0, 0, 0}, tbmax[3] = {0, 0, 0};
   swz_tile_params tparams{};
+  std::vector<std::array<double, 4>> timing;  // per shard, ms since the call began: exchange done, root begun, root done, levels done
+  std::chrono::steady_clock::time_point t_call;
+  std::vector<swz::MdPeerView> views;        // MIN_DISTANCE root swept by all shards at once: what every shard publishes
   int fast_start = -1;                       // FAST: the start level, known after the first batch
   std::vector<std::vector<uint32_t>> hist;   // FAST, first batch: every shard's points per 6-octant prefix
   // batches staged from pinned host memory: two device buffers per shard, filled on a copy stream of their own
@@ -127,6 +133,23 @@ struct swz_group {
 namespace {
 
 int owner_of_octant(int octant, int shards) { return octant * shards / 8; }
+
+void group_barrier(void* p) { static_cast<swz_group*>(p)->barrier.wait(); }
+
+// Can the shards sweep the MIN_DISTANCE root together (swz_mdkeys.hip, MdShardRoot)?  The same answer on every shard: it
+// hangs on the bounds, the spacing and the options only.
+bool joint_root_possible(const swz_ctx* c, const swz_tile_params& p, const double bmin[3], const double bmax[3]) {
+  if (p.sampler != SWZ_MIN_DISTANCE || (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY)) return false;
+  if (const char* e = c->opt("SWZ_GROUP_JOINT_ROOT"))
+    if (atoi(e) == 0) return false;
+  const swz::LevelPlan plan = swz::make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, true, true);
+  static const double dummy_xyz = 0.0;
+  static const uint32_t dummy_perm = 0;
+  swz::SortedPoints sp;
+  sp.xyz = &dummy_xyz;
+  sp.perm = &dummy_perm;
+  return swz::key_metric(c, plan, sp).ok && plan.cell_levels_geo >= 1 && !plan.terminal && !plan.reroot;
+}
 
 struct ShardCall {
   swz_group* g;
@@ -287,18 +310,41 @@ void shard_thread(ShardCall a) {
   GRP_HIP(hipStreamSynchronize(c->stream));
   g->barrier.wait();  // ---- all rows have arrived everywhere
 
+  auto stamp = [&](int k) { g->timing[r][k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g->t_call).count(); };
+  stamp(0);
   // (the same vote again: a shard whose exchange failed must not keep the others waiting at the root)
   if (!all_ok(g)) ok = false;
   const bool proceed = ok || a.batch;  // a batch keeps every shard's tiler in step with the collective decisions below
 
   if (!a.batch) {
   // 3. the root node
+  stamp(1);
   const bool sequential_root = a.params->sampler == SWZ_MIN_DISTANCE && global_points > a.params->max_points_per_node;
   uint64_t taken = 0;
   g->root_taken_count[r] = 0;
   if (!sequential_root) {
     swz_shard_info info{global_points, nullptr, 0};
     GRP_TRY(swz_shard_begin_device(c, recv, m, a.bmin, a.bmax, a.params, &info, &taken));
+  } else if (N > 1 && joint_root_possible(c, *a.params, a.bmin, a.bmax)) {
+    // All shards sweep the root cells of their own octants at the same time; a cell at the face of a lower octant reads
+    // that shard's records through peer access (swz_mdkeys.hip).  No ghosts, no turns.
+    swz::MdShardRoot sr;
+    sr.shard = r;
+    sr.shards = N;
+    sr.views = g->views.data();
+    sr.barrier = group_barrier;
+    sr.barrier_arg = g;
+    g->views[r] = swz::MdPeerView{};
+    c->md_shard_root = &sr;
+    swz_shard_info info{global_points, nullptr, 0};
+    if (m) GRP_TRY(swz_shard_begin_device(c, recv, m, a.bmin, a.bmax, a.params, &info, &taken));
+    c->md_shard_root = nullptr;
+    if (!g->views[r].entered) {  // no points here, or the call failed before its sweep met the others: meet them for it
+      g->views[r].ncells = 0;
+      g->views[r].status = ok ? SWZ_OK : SWZ_ERR_INTERNAL;
+      g->views[r].entered = 1;
+      g->barrier.wait();
+    }
   } else {
     if (m) GRP_TRY(swz_shard_presort_device(c, recv, m, a.bmin, a.bmax, a.params, kGhostHeadroom));
     {
@@ -332,6 +378,8 @@ void shard_thread(ShardCall a) {
   }
 
   // 4. everything below the root is local
+  GRP_HIP(hipStreamSynchronize(c->stream));
+  stamp(2);
   uint64_t* okeys = nullptr;
   uint32_t* operm = nullptr;
   int8_t* olevel = nullptr;
@@ -340,6 +388,8 @@ void shard_thread(ShardCall a) {
   if (ok && c->get("grp_out_level", (size_t)m, &olevel) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
   swz_tile_stats stats{};
   GRP_TRY(swz_shard_finish_device(c, okeys, operm, olevel, &stats));
+  GRP_HIP(hipStreamSynchronize(c->stream));
+  stamp(3);
   if (a.result) {
     a.result->d_xyz = recv;
     a.result->d_keys = okeys;
@@ -487,6 +537,8 @@ int swz_group_create(int num_shards, const int* devices, int transport, swz_grou
   g->recv_total.assign(num_shards, 0);
   g->root_taken.assign(num_shards, nullptr);
   g->root_taken_count.assign(num_shards, 0);
+  g->views.assign(num_shards, swz::MdPeerView{});
+  g->timing.assign(num_shards, std::array<double, 4>{{0, 0, 0, 0}});
   g->status.assign(num_shards, SWZ_OK);
   g->status_msg.assign(num_shards, "");
   *out = g;
@@ -535,6 +587,11 @@ int swz_group_destroy(swz_group* g) {
 
 const char* swz_group_last_error(const swz_group* g) { return g ? g->err.c_str() : "swz_group_create failed"; }
 int swz_group_num_shards(const swz_group* g) { return g ? g->n : 0; }
+int swz_group_shard_timing(const swz_group* g, int shard, double ms_out[4]) {
+  if (!g || !ms_out || shard < 0 || shard >= g->n) return SWZ_ERR_BAD_ARG;
+  for (int k = 0; k < 4; ++k) ms_out[k] = g->timing[shard][k];
+  return SWZ_OK;
+}
 swz_ctx* swz_group_ctx(swz_group* g, int shard) { return (g && shard >= 0 && shard < g->n) ? g->ctx[shard] : nullptr; }
 
 int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n, const double bmin[3],
@@ -552,6 +609,7 @@ int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_colum
           return SWZ_ERR_BAD_ARG;
         }
   g->turn = 0;
+  g->t_call = std::chrono::steady_clock::now();
   std::fill(g->status.begin(), g->status.end(), SWZ_OK);
   std::vector<std::thread> threads;
   for (int r = 0; r < g->n; ++r)

@@ -81,6 +81,7 @@ struct swz_ctx {
   void prof_collect();  // after a stream sync: fold pending events into kstats
   hipEvent_t cur_e0_ = nullptr;
   void* shard = nullptr;  // swz::ShardState of an open sharded batch (swz_level.hip)
+  const void* md_shard_root = nullptr;  // swz::MdShardRoot while swz_group runs the MIN_DISTANCE root of a sharded batch on all shards at once
   bool tiler_active = false;  // a swz_tiler lives on this context: its node store is part of the workspace
   // Debug / tuning switches ("SWZ_DEBUG", "SWZ_MD_*", ...): read from the environment ONCE, when the context is
   // created, and changed afterwards only through swz_set_option -- no entry point looks at the environment.

@@ -116,6 +116,32 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
                                 const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes,
                                 uint32_t sample_points, uint32_t* phases_out);
 
+// ---- the MIN_DISTANCE root of a batch sharded over several GPUs of ONE process (swz_group)
+// Every shard sweeps the root cells of its own octants at the same time.  Cells only depend on EARLIER adjacent cells,
+// i.e. on cells of the same or of a lower shard: a cell at the face of a lower octant reads the records, key coordinates
+// and state bytes of that shard's adjacent cells through peer access (the halo), as far as that shard's completed rounds
+// have published them, and polls when it has to wait.  Nothing else is exchanged and no shard waits for another's whole
+// root.  What a shard publishes about its root level:
+struct MdPeerView {
+  const uint4* rec = nullptr;        // cell records, [cell][2][rg]
+  const uint64_t* qpos = nullptr;    // key coordinates of its active points
+  const uint8_t* state = nullptr;
+  const float4* ovf = nullptr;
+  const uint32_t* gridmap = nullptr; // [cell code of the root node] -> cell
+  const uint32_t* round_word = nullptr;  // the round its sweep is in: records stamped with an earlier round are complete
+  const uint32_t* perm = nullptr;    // exact positions of its points: xyz[3 * perm[i]]
+  const double* xyz = nullptr;
+  uint32_t ncells = 0, rg = 0, cell_shift = 0;
+  int status = 0;                    // SWZ_OK, or why this shard cannot take part
+  int entered = 0;                   // the shard's sweep has met the others at the barrier (else its driver does so for it)
+};
+struct MdShardRoot {
+  int shard = 0, shards = 1;
+  MdPeerView* views = nullptr;       // [shards], shared by the group's shards
+  void (*barrier)(void*) = nullptr;  // all shards of the group meet
+  void* barrier_arg = nullptr;
+};
+
 // ---- MIN_DISTANCE on key coordinates (swz_mdkeys.hip) ----------------------------------------------------------
 // The key of a point is its position quantised to 2^-21 of the (cubic) bounds: the integer coordinates of two points
 // bound their distance to +-sqrt(3) key cells, so a compare against the spacing is decided on the keys alone unless the
@@ -138,7 +164,8 @@ bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const
 // cl: cell levels below the node chosen by the caller; typical_pop: points-weighted mean cell population.
 int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
                             const LevelBuffers& lb, uint32_t num_nodes, uint32_t sample_nodes, uint32_t sample_points,
-                            const uint32_t* snode_of, int cl, double typical_pop, uint32_t* rounds_out, bool* used);
+                            const uint32_t* snode_of, int cl, double typical_pop, uint32_t* rounds_out, bool* used,
+                            const MdShardRoot* shard_root = nullptr);
 
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
 // qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.

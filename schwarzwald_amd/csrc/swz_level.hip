@@ -1314,7 +1314,7 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   SWZ_TRY(c->get("shard_perm", (size_t)total, &out.perm));
   SWZ_TRY(c->get("shard_level", (size_t)total, &out.level));
   SWZ_TRY(session_prepare(c, s->t, xyz, total, bmin, bmax, p, out));
-  SWZ_TRY(session_gather_positions(c, s->t));  // swz_shard_root_taken hands out positions in Morton order
+  if (!c->md_shard_root) SWZ_TRY(session_gather_positions(c, s->t));  // swz_shard_root_taken hands out positions in Morton order
   s->t.ghosts = ghosts;
   s->n_local = n;
   }

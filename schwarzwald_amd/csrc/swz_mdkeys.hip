@@ -103,6 +103,21 @@ int key_point_ids(swz_ctx* c, const ActiveSet& as, const SortedPoints& sp, const
 }
 
 // ----------------------------------------------------------------------------- device helpers
+// the root of a batch sharded over the GPUs of one process: what the lower shards publish (swz_level.h, MdPeerView)
+constexpr uint32_t MQ_PEER_SHIFT = 28;          // neighbour id = (shard + 1) << 28 | cell for a cell of another shard
+constexpr uint32_t MQ_ID_MASK = (1u << MQ_PEER_SHIFT) - 1u;
+struct MqPeers {
+  const uint4* rec[8];
+  const uint64_t* qpos[8];
+  const uint8_t* state[8];
+  const float4* ovf[8];
+  const uint32_t* gridmap[8];
+  const uint32_t* round_word[8];
+  const uint32_t* perm[8];
+  const double* xyz[8];
+  uint32_t shard, shards;
+};
+
 struct MqArgs {
   const uint64_t* akey;
   const uint32_t* aidx;
@@ -135,6 +150,7 @@ struct MqArgs {
   uint32_t cell_shift;    // key >> cell_shift = node prefix + cell code
   uint64_t cells_per_node;
   uint32_t cell_bits;     // cell_shift / 3: a cell is 2^cell_bits key cells wide
+  uint32_t cell_levels;   // octree levels between node and cell
   uint32_t rg, rg2_shift; // granules per record buffer (4 or 8); log2(2 * rg)
   float f_lo, f_hi;
   double sq_spacing;
@@ -144,6 +160,8 @@ struct MqArgs {
   uint32_t group, groups;
   uint32_t no_dead_test;  // debugging / tests: blocker scans do not test for dead points
   uint32_t stats;         // SWZ_DEBUG: count activations by kind in counters[CTR_DBG_HIST ...]
+  uint32_t* round_word;   // sharded root: the round this shard's sweep is in, for the shards that read its records
+  MqPeers peers;
 };
 
 __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -207,12 +225,31 @@ __device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint3
 #endif
 #define MQ_STAT(idx) do { if (a.stats && l == 0) atomicAdd(&a.counters[CTR_DBG_HIST + (idx)], 1u); } while (0)
 
+// Loads that see what another GPU's kernel has written back by now (nothing cached on this side): records and overflow
+// entries of a lower shard's cells.  Two 8-byte halves; tearing is caught by bracketing the reads with that shard's
+// round word (see mq_activate).
+__device__ __forceinline__ uint4 mq_ld_sys(const uint4* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+__device__ __forceinline__ uint32_t mq_ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
+// ... for a local point i and an accepted point j of shard `tag - 1` (0: this shard)
+__device__ __forceinline__ bool mq_exact_near_peer(const MqArgs& a, uint32_t i, uint32_t j, uint32_t tag) {
+  const double* p = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[i] : i] * 3;
+  const double* q = tag ? a.peers.xyz[tag - 1u] + (size_t)a.peers.perm[tag - 1u][j] * 3 : a.xyz + (size_t)a.perm[a.aidx ? a.aidx[j] : j] * 3;
+  return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
+}
+
 struct MqLds {
   uint4* stage;   // [27][2][rg]: both record buffers of the 27 cells of the neighbourhood
   float4* list;   // [MQ_LIST_CAP]: accepted points of the earlier adjacent cells and of this cell (window)
   float4* fresh;  // [MQ_FRESH_CAP]: accepted in this activation
+  uint8_t* tag;   // [MQ_LIST_CAP]: sharded root: which shard a list entry comes from (0 = this one)
 };
-static inline size_t mq_lds_bytes(uint32_t rg) { return (size_t)(27u * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u; }
+static inline size_t mq_lds_bytes(uint32_t rg) { return (size_t)(27u * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u + MQ_LIST_CAP; }
 
 __device__ __forceinline__ bool mq_is_head(const MqArgs& a, uint32_t i) {
   if (!a.all_sampled && a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
@@ -290,7 +327,21 @@ __global__ __launch_bounds__(256) void mq_nbr_build_kernel(MqArgs a, uint32_t nc
         }
         nrel |= w;
       }
-      if (inside) nb = a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + nrel];
+      if (inside) {
+        if (a.peers.shards > 1u) {
+          // the root of a sharded batch: the cell code's first octant names the owner; cells of higher shards are later
+          // ones, nobody here looks at them
+          const uint32_t owner = (nrel >> (3u * (a.cell_levels - 1u))) * a.peers.shards / 8u;
+          if (owner == a.peers.shard) {
+            nb = a.gridmap[nrel];
+          } else if (owner < a.peers.shard && a.peers.gridmap[owner]) {
+            const uint32_t id = a.peers.gridmap[owner][nrel];
+            if (id != QNONE) nb = ((owner + 1u) << MQ_PEER_SHIFT) | id;
+          }
+        } else {
+          nb = a.gridmap[(uint64_t)a.csnode[c] * a.cells_per_node + nrel];
+        }
+      }
     }
     a.qnbr[(size_t)c * 32 + k] = nb;
   }
@@ -319,7 +370,7 @@ __global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells
       uint32_t best = QNONE, bk = 0;
       for (uint32_t k = 0; k < 27u; ++k) {
         const uint32_t nb = a.qnbr[(size_t)c * 32 + k];
-        if (nb != QNONE && nb < c && (best == QNONE || nb > best)) {
+        if (nb != QNONE && (a.peers.shards <= 1u || (nb >> MQ_PEER_SHIFT) == 0u) && nb < c && (best == QNONE || nb > best)) {  // (cells of this shard only)
           best = nb;
           bk = k;
         }
@@ -342,8 +393,8 @@ __global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells
 // spacing (inside the band counts: waiting is always allowed), or NONE.  A point that is closer than the spacing for sure
 // to one of the live_wn accepted points in LDS is dead as well (its cell has not looked at it since).
 template <int SU>
-__device__ __forceinline__ uint32_t mq_scan(const MqArgs& a, const MqLds& lds, uint32_t live_wn, uint32_t qs, uint32_t qe, float cx,
-                                            float cy, float cz) {
+__device__ __forceinline__ uint32_t mq_scan(const MqArgs& a, const uint64_t* __restrict__ qpos, const uint8_t* __restrict__ state,
+                                            const MqLds& lds, uint32_t live_wn, uint32_t qs, uint32_t qe, float cx, float cy, float cz) {
   const uint32_t l = lane_id();
   for (uint32_t q0 = qs; q0 < qe; q0 += (uint32_t)SU * WAVE) {
     uint64_t v[SU];
@@ -352,8 +403,8 @@ __device__ __forceinline__ uint32_t mq_scan(const MqArgs& a, const MqLds& lds, u
     for (int u = 0; u < SU; ++u) {
       const uint32_t q = q0 + (uint32_t)u * WAVE + l;
       const bool inb = q < qe;
-      v[u] = inb ? a.qpos[q] : 0ull;
-      s[u] = inb ? a.state[q] : (uint8_t)QS_DEAD;
+      v[u] = inb ? qpos[q] : 0ull;
+      s[u] = inb ? state[q] : (uint8_t)QS_DEAD;
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
@@ -382,7 +433,7 @@ __device__ __forceinline__ uint32_t mq_scan(const MqArgs& a, const MqLds& lds, u
 enum : uint32_t { QO_FINISHED = 0, QO_STALLED = 1, QO_YIELD = 2 };
 
 // One wavefront advances one cell as far as it can.  U: chunks of 64 points held in registers at a time.
-template <int U>
+template <int U, bool PEERS>
 __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, const MqLds& lds, uint32_t* qout, uint32_t* cout, uint32_t seg0) {
   const uint32_t l = lane_id();
   const bool woken = (qentry & MQ_WOKEN) != 0u;
@@ -401,11 +452,46 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   const uint32_t sbuf = h1.z > h0.z ? 1u : 0u;  // the newer of this cell's own records (both are from earlier rounds)
   const uint32_t e = ci.y, P = sbuf ? h1.x : h0.x, CNT = sbuf ? h1.y : h0.y;
   if (P >= e) return;  // (a finished cell is never queued)
+  // adjacent cell of lane k: on this shard, or -- the root of a sharded batch -- on a lower one
+  const bool nb_have = nbv != QNONE;
+  const uint32_t nb_peer = (PEERS && nb_have) ? (nbv >> MQ_PEER_SHIFT) : 0u;  // 0: this shard, p + 1: shard p
+  const uint32_t nb_id = PEERS ? (nbv & MQ_ID_MASK) : nbv;
+  // this cell once more into the next round's queue, unchanged (a look at another shard that came too early or too late)
+  auto push_again = [&](uint32_t entry) {
+    uint32_t base = 0, seg = (seg0 + c * 0x9E3779B1u + (c >> 7)) & (a.nseg - 1u);
+    if (l == 0) {
+      uint32_t tries = 0;
+      for (; tries < a.nseg; ++tries) {
+        base = atomicAdd(cout + (size_t)seg * 32u, 1u);
+        if (base + 1u <= a.segcap) break;
+        seg = (seg + 1u) & (a.nseg - 1u);
+      }
+      if (tries == a.nseg) atomicMax(&a.counters[CTR_ERROR], (uint32_t)SWZ_ERR_INTERNAL);
+      else qout[(size_t)seg * a.segcap + base] = entry;
+    }
+  };
+  bool claimed = woken;  // the next activation must not go through the confirm step again
 
   // ---- confirm: this cell stalled last time it ran and nobody has claimed its slot since
   if (st.x != QNONE && !woken) {
     const uint32_t bk = uni(st.y);
-    const uint32_t B = qb_u32(nbv, (int)bk);
+    const uint32_t Bv = qb_u32(nbv, (int)bk);
+    const uint32_t Bp = PEERS ? (Bv >> MQ_PEER_SHIFT) : 0u, B = PEERS ? (Bv & MQ_ID_MASK) : Bv;
+    if (PEERS && Bp) {
+      // a cell of a lower shard: nobody wakes this one, it looks again every round
+      const uint32_t rb = mq_ld_sys(a.peers.round_word[Bp - 1u]);
+      const uint4* brec = a.peers.rec[Bp - 1u] + ((size_t)B << rg2s);
+      const uint4 b0 = mq_ld_sys(brec), b1 = mq_ld_sys(brec + rg);
+      const uint32_t ra = mq_ld_sys(a.peers.round_word[Bp - 1u]);
+      const bool use1 = b1.z < rb && (b0.z >= rb || b1.z > b0.z);
+      const uint4 hb = use1 ? b1 : b0;
+      const bool seen = ra == rb && (use1 || b0.z < rb);
+      if (!seen || !(hb.x > st.z || hb.x >= hb.w)) {
+        push_again(c);
+        return;
+      }
+      claimed = true;
+    } else {
     const uint4* brec = a.rec + ((size_t)B << rg2s);
     const uint4 b0 = brec[0], b1 = brec[rg];
     const bool use1 = b1.z < round && (b0.z >= round || b1.z > b0.z);
@@ -423,6 +509,8 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       MQ_STAT(2);
       return;  // the blocker got there first and has queued this cell for the next round
     }
+    claimed = true;
+    }
   }
 
   MQ_STAT(0);
@@ -438,6 +526,10 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     pv[u] = inb ? a.qpos[p] : 0ull;
     ps[u] = inb ? a.state[p] : (uint8_t)QS_DEAD;
   }
+  // (records of another shard: bracketed by that shard's round word -- a record stamped before the round it is in NOW is
+  // complete, and it stays untouched while that round lasts; when the round has moved on meanwhile the look is repeated)
+  uint32_t r_before = round;
+  if (PEERS && nb_peer && l < 27u) r_before = mq_ld_sys(a.peers.round_word[nb_peer - 1u]);
   {
     const uint32_t ngran = 27u << rg2s;
     uint4 tmp[7];
@@ -447,7 +539,15 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       const uint32_t n = g >> rg2s, part = g & ((1u << rg2s) - 1u);
       const uint32_t nb = (uint32_t)__shfl((int)nbv, (int)(n < 27u ? n : 0u), WAVE);
       tmp[j] = make_uint4(0u, 0u, 0u, 0u);
-      if (g < ngran && nb != QNONE && nb <= c) tmp[j] = a.rec[((size_t)nb << rg2s) + part];
+      if (PEERS) {
+        const uint32_t np = nb != QNONE ? (nb >> MQ_PEER_SHIFT) : 0u, ni = nb & MQ_ID_MASK;
+        if (g < ngran && nb != QNONE) {
+          if (np) tmp[j] = mq_ld_sys(a.peers.rec[np - 1u] + ((size_t)ni << rg2s) + part);
+          else if (ni <= c) tmp[j] = a.rec[((size_t)ni << rg2s) + part];
+        }
+      } else if (g < ngran && nb != QNONE && nb <= c) {
+        tmp[j] = a.rec[((size_t)nb << rg2s) + part];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
@@ -456,16 +556,25 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     }
   }
   __builtin_amdgcn_wave_barrier();
+  if (PEERS) {
+    bool late = false;
+    if (nb_peer && l < 27u) late = mq_ld_sys(a.peers.round_word[nb_peer - 1u]) != r_before;
+    if (__ballot(late)) {
+      push_again(claimed ? (c | MQ_WOKEN) : c);
+      return;
+    }
+  }
 
   MQ_T(t_rt2);
   MQ_TACC(1, t_rt1, t_rt2);
   // lane k < 27: adjacent cell k (13: this cell).  Of its two records the newer one written before this round.
-  const bool valid = l < 27u && nbv != QNONE && nbv <= c;
+  const bool valid = l < 27u && nb_have && (nb_peer != 0u || nb_id <= c);
   const bool earlier = valid && l != 13u;
   uint32_t n_pos = 0, n_cnt = 0, n_end = 0, pick = 0;
   if (valid) {
     const uint4 a0 = lds.stage[l << rg2s], a1 = lds.stage[(l << rg2s) + rg];
-    pick = (a1.z < round && (a0.z >= round || a1.z > a0.z)) ? 1u : 0u;
+    const uint32_t rr = (PEERS && nb_peer) ? r_before : round;  // stamps count in the owner's rounds
+    pick = (a1.z < rr && (a0.z >= rr || a1.z > a0.z)) ? 1u : 0u;
     const uint4 hd = pick ? a1 : a0;
     n_pos = hd.x;
     n_cnt = hd.y;
@@ -475,7 +584,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   // was written in or after the round this cell last ran in (its own newest record carries that round) -- it could not
   // see that record then.  The points this cell tested last time (those below `tested`) only meet the new entries.
   const uint32_t my_last = sbuf ? h1.z : h0.z;
-  const bool k_new = valid && l != 13u && (pick ? lds.stage[(l << rg2s) + rg].z : lds.stage[l << rg2s].z) >= my_last;
+  const bool k_new = valid && l != 13u && (nb_peer != 0u || (pick ? lds.stage[(l << rg2s) + rg].z : lds.stage[l << rg2s].z) >= my_last);
   const uint32_t incl_new = mq_wave_scan(k_new ? n_cnt : 0u, MqAdd{}, 0u);
   const uint32_t incl_old = mq_wave_scan(k_new ? 0u : n_cnt, MqAdd{}, 0u);
   const uint32_t Tnew = qb_u32(incl_new, WAVE - 1);
@@ -489,18 +598,33 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     __builtin_amdgcn_wave_barrier();
     for (uint32_t j = 0; j < maxcnt && j < cap; ++j) {
       const uint32_t ti = off + j;
-      if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP)
+      if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP) {
         *reinterpret_cast<uint4*>(&lds.list[ti - base]) = lds.stage[(l << rg2s) + pick * rg + 1u + j];
+        if (PEERS) lds.tag[ti - base] = (uint8_t)nb_peer;
+      }
+    }
+    const float4* ovf = a.ovf;
+    if (PEERS) {
+      if (nb_peer) ovf = a.peers.ovf[(nb_peer - 1u) & 7u];
     }
     for (uint32_t j0 = cap; j0 < maxcnt; j0 += 2u) {  // (two loads in flight; no arrays: they would live in scratch)
       const uint32_t ja = j0, jb = j0 + 1u, ta = off + ja, tb = off + jb;
       const bool ma = ja < n_cnt && ta >= base && ta < base + (uint32_t)MQ_LIST_CAP;
       const bool mb = jb < n_cnt && tb >= base && tb < base + (uint32_t)MQ_LIST_CAP;
       uint4 sa = make_uint4(0u, 0u, 0u, 0u), sb = sa;
-      if (ma) sa = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (ja - cap)));
-      if (mb) sb = *reinterpret_cast<const uint4*>(a.ovf + (n_end - 1u - (jb - cap)));
+      if (PEERS && nb_peer) {
+        if (ma) sa = mq_ld_sys(reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (ja - cap))));
+        if (mb) sb = mq_ld_sys(reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (jb - cap))));
+      } else {
+        if (ma) sa = *reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (ja - cap)));
+        if (mb) sb = *reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (jb - cap)));
+      }
       if (ma) *reinterpret_cast<uint4*>(&lds.list[ta - base]) = sa;
       if (mb) *reinterpret_cast<uint4*>(&lds.list[tb - base]) = sb;
+      if (PEERS) {
+        if (ma) lds.tag[ta - base] = (uint8_t)nb_peer;
+        if (mb) lds.tag[tb - base] = (uint8_t)nb_peer;
+      }
     }
     __builtin_amdgcn_wave_barrier();
     return (T - base) < (uint32_t)MQ_LIST_CAP ? (T - base) : (uint32_t)MQ_LIST_CAP;
@@ -628,7 +752,9 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
             for (int u = 0; u < U; ++u) {
               if ((pend >> u) & 1u) {
                 const float d2 = mq_d2(fx[u], fy[u], fz[u], en.x, en.y, en.z);
-                if (d2 >= f_lo && d2 < f_hi && mq_exact_near(a, W0 + (uint32_t)u * WAVE + l, __float_as_uint(en.w))) {
+                if (d2 >= f_lo && d2 < f_hi &&
+                    ((PEERS && !last) ? mq_exact_near_peer(a, W0 + (uint32_t)u * WAVE + l, __float_as_uint(en.w), lds.tag[i])
+                                      : mq_exact_near(a, W0 + (uint32_t)u * WAVE + l, __float_as_uint(en.w)))) {
                   nearb |= 1u << u;
                   pend &= ~(1u << u);
                 }
@@ -690,7 +816,9 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
         need &= need - 1u;
         const uint32_t qs = qb_u32(n_pos, k), qe = qb_u32(n_end, k);
         MQ_STAT(4);
-        const uint32_t hq = mq_scan<(U > 1 ? 4 : 1)>(a, lds, live_wn, qs, qe, cx, cy, cz);
+        const uint32_t kp = PEERS ? qb_u32(nb_peer, k) : 0u;
+        const uint32_t hq = mq_scan<(U > 1 ? 4 : 1)>(a, kp ? a.peers.qpos[kp - 1u] : a.qpos, kp ? a.peers.state[kp - 1u] : a.state, lds, live_wn, qs,
+                                                     qe, cx, cy, cz);
         if (hq != QNONE) {
           blocked = true;
           b_k = (uint32_t)k;
@@ -773,13 +901,14 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   // ---- wake the later adjacent cells that sleep on a point the frontier has passed (slots written in THIS round belong
   // to cells that confirm themselves next round); go to sleep / come back next round
   bool won = false;
-  if (l < 27u && nbv != QNONE && nbv > c && myslot != QEMPTY && (uint32_t)(myslot >> 32) != round &&
+  if (l < 27u && nb_have && nb_peer == 0u && nb_id > c && myslot != QEMPTY && (uint32_t)(myslot >> 32) != round &&
       (fin || (uint32_t)myslot < out_pos)) {
     won = atomicCAS(&a.slot[(size_t)c * 32 + l], myslot, QEMPTY) == myslot;
   }
   if (out_status == QO_STALLED && l == 0) {
-    const uint32_t B = qb_u32(nbv, (int)uni(b_k));
-    a.slot[(size_t)B * 32 + (26u - b_k)] = ((unsigned long long)round << 32) | b_q;
+    const uint32_t Bv = qb_u32(nbv, (int)uni(b_k));
+    // (a blocker on a lower shard has no slot for this cell: it confirms itself every round until the point is passed)
+    if (!(PEERS && (Bv >> MQ_PEER_SHIFT))) a.slot[(size_t)(PEERS ? (Bv & MQ_ID_MASK) : Bv) * 32 + (26u - b_k)] = ((unsigned long long)round << 32) | b_q;
   }
   const uint64_t wm = __ballot(won);
   const uint32_t self = fin ? 0u : 1u;
@@ -805,7 +934,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     seg = qb_u32(seg, 0);
     if (base != QNONE) {
       uint32_t* q = qout + (size_t)seg * a.segcap + base;
-      if (won) q[(uint32_t)__popcll(wm & lanemask_lt())] = nbv | MQ_WOKEN;
+      if (won) q[(uint32_t)__popcll(wm & lanemask_lt())] = nb_id | MQ_WOKEN;
       if (self && l == 0) q[(uint32_t)__popcll(wm)] = out_status == QO_YIELD ? (c | MQ_WOKEN) : c;
     }
   }
@@ -817,13 +946,14 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
 #endif
 }
 
-template <int U>
+template <int U, bool PEERS>
 __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t round) {
   extern __shared__ uint4 mq_smem[];
   MqLds lds;
   lds.stage = mq_smem;
   lds.list = reinterpret_cast<float4*>(mq_smem + 27u * 2u * a.rg);
   lds.fresh = lds.list + MQ_LIST_CAP;
+  lds.tag = reinterpret_cast<uint8_t*>(lds.fresh + MQ_FRESH_CAP);
   const uint32_t r0 = round - MQ_FIRST_ROUND;
   const uint32_t ci = r0 % 3u, co = (r0 + 1u) % 3u, cz = (r0 + 2u) % 3u;
   if (blockIdx.x == 0) {  // the counters the round after the next will fill; this round's total for the host
@@ -854,10 +984,18 @@ __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t ro
   while (i < nq) {
     uint32_t next = 0;
     if (lane_id() == 0) next = atomicAdd(head, 1u);  // (the result is first looked at after the activation)
-    mq_activate<U>(a, round, uni(entry), lds, qout, cout, seg);
+    mq_activate<U, PEERS>(a, round, uni(entry), lds, qout, cout, seg);
     i = wgs + qb_u32(next, 0);
     if (i < nq) entry = qin[i];
   }
+}
+
+// Sharded root: the round this shard's sweep is in, for the shards that read its records.  A launch of its own BETWEEN
+// two rounds: when a reader sees round R here, every record stamped before R is complete (round R - 1 has finished and
+// written back) and round R only ever writes the OLDER buffer of a cell -- a store from inside the sweep would become
+// visible some time into the round, when that is no longer true.
+__global__ void mq_round_word_kernel(uint32_t* word, uint32_t value) {
+  __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // after the last round: every cell must have reached its end (a protocol error would otherwise go unnoticed)
@@ -881,10 +1019,12 @@ bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const
 
 int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
                             uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points, const uint32_t* snode_of, int cl,
-                            double typical_pop, uint32_t* rounds_out, bool* used) {
+                            double typical_pop, uint32_t* rounds_out, bool* used, const MdShardRoot* shard_root) {
   *used = false;
   const KeyMetric km = key_metric(c, plan, sp);
   if (!km.ok) return SWZ_OK;
+  const bool sharded = shard_root != nullptr && shard_root->shards > 1;
+  const std::string sfx = sharded ? "_sr" : "";  // the sharded root's arrays are read by other shards until the batch ends
   const uint32_t m = as.m;
   MqArgs a{};
   a.akey = as.akey;
@@ -899,6 +1039,9 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   a.counters = lb.counters;
   a.snode_of = snode_of;
   a.cells_per_node = 1ull << (3 * cl);
+  a.cell_levels = (uint32_t)cl;
+  a.peers.shards = sharded ? (uint32_t)shard_root->shards : 1u;
+  a.peers.shard = sharded ? (uint32_t)shard_root->shard : 0u;
   a.cell_shift = (plan.node_shift == 63u ? 63u : plan.node_shift) - 3u * (uint32_t)cl;
   a.cell_bits = a.cell_shift / 3u;
   a.f_lo = km.f_lo;
@@ -928,20 +1071,20 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   if (const char* e = c->opt("SWZ_MD_KEYS_RG")) a.rg = atoi(e) >= 8 ? 8u : 4u;
   a.rg2_shift = a.rg == 4u ? 3u : 4u;
 
-  SWZ_TRY(c->get("md_qpos", (size_t)m, &a.qpos));
-  SWZ_TRY(c->get("md_qstate", (size_t)m, &a.state));
-  SWZ_TRY(c->get("md_qovf", (size_t)m, &a.ovf));
-  SWZ_TRY(c->get("md_qcinfo", (size_t)ncells, &a.cinfo));
+  SWZ_TRY(c->get(("md_qpos" + sfx).c_str(), (size_t)m, &a.qpos));
+  SWZ_TRY(c->get(("md_qstate" + sfx).c_str(), (size_t)m, &a.state));
+  SWZ_TRY(c->get(("md_qovf" + sfx).c_str(), (size_t)m, &a.ovf));
+  SWZ_TRY(c->get(("md_qcinfo" + sfx).c_str(), (size_t)ncells, &a.cinfo));
   uint32_t* cellbuf = nullptr;
-  SWZ_TRY(c->get("md_qcells", (size_t)ncells * 2, &cellbuf));
+  SWZ_TRY(c->get(("md_qcells" + sfx).c_str(), (size_t)ncells * 2, &cellbuf));
   a.crel = cellbuf;
   a.csnode = cellbuf + ncells;
-  SWZ_TRY(c->get("md_qnbr", (size_t)ncells * 32, &a.qnbr));
-  SWZ_TRY(c->get("md_qrec", (size_t)ncells * 2 * a.rg, &a.rec));
-  SWZ_TRY(c->get("md_qslot", (size_t)ncells * 32, &a.slot));
-  SWZ_TRY(c->get("md_qst", (size_t)ncells, &a.qst));
+  SWZ_TRY(c->get(("md_qnbr" + sfx).c_str(), (size_t)ncells * 32, &a.qnbr));
+  SWZ_TRY(c->get(("md_qrec" + sfx).c_str(), (size_t)ncells * 2 * a.rg, &a.rec));
+  SWZ_TRY(c->get(("md_qslot" + sfx).c_str(), (size_t)ncells * 32, &a.slot));
+  SWZ_TRY(c->get(("md_qst" + sfx).c_str(), (size_t)ncells, &a.qst));
   const uint64_t grid_entries = (uint64_t)sample_nodes * a.cells_per_node;
-  SWZ_TRY(c->get("md_gridmap", (size_t)grid_entries, &a.gridmap));
+  SWZ_TRY(c->get(("md_gridmap" + sfx).c_str(), (size_t)grid_entries, &a.gridmap));
   SWZ_HIP(c, memset_large(a.gridmap, 0xFF, (size_t)grid_entries * 4, c->stream));
   SWZ_HIP(c, memset_large(a.slot, 0xFF, (size_t)ncells * 32 * sizeof(unsigned long long), c->stream));
 
@@ -949,6 +1092,46 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(mq_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
+  if (sharded) {
+    // publish this shard's root level, meet the others, take the lower shards' views
+    MdPeerView& mine = shard_root->views[shard_root->shard];
+    int my_status = SWZ_OK;
+    if (cl < 1 || ncells >= (1u << MQ_PEER_SHIFT) || sample_nodes != 1 || as.aidx) my_status = SWZ_ERR_INTERNAL;
+    SWZ_TRY(c->get("md_qround_sr", (size_t)32, &a.round_word));
+    hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, c->stream, a.round_word, MQ_FIRST_ROUND);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    mine.rec = a.rec;
+    mine.qpos = a.qpos;
+    mine.state = a.state;
+    mine.ovf = a.ovf;
+    mine.gridmap = a.gridmap;
+    mine.round_word = a.round_word;
+    mine.perm = a.perm;
+    mine.xyz = a.xyz;
+    mine.ncells = ncells;
+    mine.rg = a.rg;
+    mine.cell_shift = a.cell_shift;
+    mine.status = my_status;
+    mine.entered = 1;
+    shard_root->barrier(shard_root->barrier_arg);
+    for (int p = 0; p < shard_root->shards; ++p) {
+      const MdPeerView& v = shard_root->views[p];
+      if (v.status != SWZ_OK || (v.ncells && (v.rg != a.rg || v.cell_shift != a.cell_shift)))
+        return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE root of a sharded batch: shard " + std::to_string(p) +
+                                           " cannot take part in the joint sweep (cell levels, cell count or record size differ)");
+      if (p < shard_root->shard && v.ncells) {
+        a.peers.rec[p] = v.rec;
+        a.peers.qpos[p] = v.qpos;
+        a.peers.state[p] = v.state;
+        a.peers.ovf[p] = v.ovf;
+        a.peers.gridmap[p] = v.gridmap;
+        a.peers.round_word[p] = v.round_word;
+        a.peers.perm[p] = v.perm;
+        a.peers.xyz[p] = v.xyz;
+      }
+    }
+  }
   hipLaunchKernelGGL(mq_nbr_build_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
   SWZ_STAGE(c, "mq tables");
@@ -966,6 +1149,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   if (sample_nodes >= 2 && !big_cells) groups = 2;
   if (const char* e = c->opt("SWZ_MD_GROUPS")) groups = (uint32_t)std::max(1, std::min(8, atoi(e)));
   groups = std::min(groups, sample_nodes);
+  if (sharded) groups = 1;
   // the round's queue in segments with a counter each (a single counter word takes ~90 atomics per microsecond, and
   // every activation pushes): workgroup b reads segment b % nseg and pushes into it
   a.nseg_shift = 5;
@@ -1016,8 +1200,8 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     int dev = 0, cus = 0, per_cu = 0;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const hipError_t oe = big_cells ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mq_sweep_kernel<4>, WAVE, lds_bytes)
-                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mq_sweep_kernel<1>, WAVE, lds_bytes);
+    const hipError_t oe = big_cells ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mq_sweep_kernel<4, false>, WAVE, lds_bytes)
+                                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mq_sweep_kernel<1, false>, WAVE, lds_bytes);
     if (oe != hipSuccess || per_cu < 1) per_cu = 8;
     if (cus < 1) cus = 256;
     uint32_t cap = (uint32_t)cus * (uint32_t)per_cu;
@@ -1045,10 +1229,17 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   while (running) {
     for (uint32_t b = 0; b < batch; ++b, ++round) {
       for (uint32_t g = 0; g < groups; ++g) {
-        if (big_cells)
-          hipLaunchKernelGGL((mq_sweep_kernel<4>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
-        else
-          hipLaunchKernelGGL((mq_sweep_kernel<1>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+        if (sharded) {
+          hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, gs[g], a.round_word, round);
+          if (big_cells)
+            hipLaunchKernelGGL((mq_sweep_kernel<4, true>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+          else
+            hipLaunchKernelGGL((mq_sweep_kernel<1, true>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+        } else if (big_cells) {
+          hipLaunchKernelGGL((mq_sweep_kernel<4, false>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+        } else {
+          hipLaunchKernelGGL((mq_sweep_kernel<1, false>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+        }
       }
     }
     SWZ_LAUNCH_CHECK(c);
@@ -1073,6 +1264,10 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     }
   }
   if (fork) c->event_pool.push_back(fork);
+  if (sharded) {  // everything this shard has written is complete now
+    hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, c->stream, a.round_word, 0xFFFFFFF0u);
+    SWZ_LAUNCH_CHECK(c);
+  }
   {  // every cell at its end, no queue segment ever full everywhere
     uint32_t* d_open = nullptr;
     SWZ_TRY(c->get("md_qopen", (size_t)4, &d_open));

@@ -1063,6 +1063,15 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   hipLaunchKernelGGL(md_node_flag_kernel, dim3(div_up(nnodes, 256)), dim3(256), 0, c->stream, lb.nmode, nnodes, snode);
   SWZ_LAUNCH_CHECK(c);
   SWZ_TRY(scan_exclusive_u32(c, snode, snode, nnodes, nullptr, "mdn"));
+  if (c->md_shard_root && plan.level == -1) {
+    // The root of a batch sharded over the GPUs of one process (swz_group): every shard sweeps the cells of its own
+    // octants, on keys, with the same cells everywhere (the finest ones: what a shard sees of the cloud must not decide).
+    bool used = false;
+    SWZ_TRY(min_distance_keys_level(c, plan, as, sp, lb, nnodes, sample_nodes, sample_points, snode, plan.cell_levels_geo, pop[0], rounds_out, &used,
+                                    static_cast<const MdShardRoot*>(c->md_shard_root)));
+    if (!used) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE root of a sharded batch: the joint sweep needs a level that can be decided on keys");
+    return SWZ_OK;
+  }
   {
     // sparse levels (about one point per spacing-sized cell or fewer): one thread per point
     bool used = false;

@@ -1,0 +1,64 @@
+// Times one sharded batch through swz_group_tile (C++ host, one process): N shards -- on N devices, or all on device 0
+// when the box has fewer -- each starting with P uniform points of the unit cube, exact MIN_DISTANCE, d = 250.
+// Prints the wall time of the call and every shard's root interval, with the root swept by all shards at once
+// (SWZ_GROUP_JOINT_ROOT unset) and in turns (SWZ_GROUP_JOINT_ROOT=0).
+//   g++ -std=c++17 -O2 tools/group_bench.cpp -o /tmp/group_bench -Lschwarzwald_amd/lib -lswz_gpu -Wl,-rpath,$PWD/schwarzwald_amd/lib
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../include/swz_gpu.h"
+
+int main(int argc, char** argv) {
+  const int shards = argc > 1 ? std::atoi(argv[1]) : 8;
+  const uint64_t per = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 25000000ull;
+  const int reps = argc > 3 ? std::atoi(argv[3]) : 3;
+  const int ndev = argc > 4 ? std::atoi(argv[4]) : 1;
+  const double mn[3] = {0, 0, 0}, mx[3] = {1, 1, 1};
+  std::vector<int> dev(shards);
+  for (int s = 0; s < shards; ++s) dev[s] = s % ndev;
+  swz_group* g = nullptr;
+  if (swz_group_create(shards, dev.data(), 0, &g) != SWZ_OK) {
+    std::fprintf(stderr, "swz_group_create: %s\n", swz_group_last_error(nullptr));
+    return 1;
+  }
+  std::vector<double*> d_xyz(shards);
+  std::vector<uint64_t> n(shards, per);
+  for (int s = 0; s < shards; ++s) {
+    swz_ctx* c = swz_group_ctx(g, s);
+    if (swz_device_alloc_on(c, per * 24, (void**)&d_xyz[s]) != SWZ_OK) return 2;
+  }
+  swz_tile_params p{};
+  p.sampler = SWZ_MIN_DISTANCE;
+  p.max_points_per_node = 20000;
+  p.spacing_at_root = (float)(std::sqrt(3.0) / 250.0);
+  p.max_depth = 100;
+  p.strategy = SWZ_ACCURATE;
+  p.fast_concurrency = 8;
+  std::vector<swz_group_result> res(shards);
+  for (int rep = 0; rep < reps; ++rep) {
+    for (int s = 0; s < shards; ++s)
+      if (swz_generate_uniform_device(swz_group_ctx(g, s), 0x5C4A72A1Dull + 3, (uint64_t)s * per, per, d_xyz[s]) != SWZ_OK) return 3;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (swz_group_tile(g, d_xyz.data(), nullptr, n.data(), mn, mx, &p, res.data()) != SWZ_OK) {
+      std::fprintf(stderr, "swz_group_tile: %s\n", swz_group_last_error(g));
+      return 4;
+    }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("rep %d: %d shards x %llu points: %.1f ms = %.0f Mpoints/s;", rep, shards, (unsigned long long)per, ms, shards * per / ms / 1e3);
+    double first_root = 1e30, last_root = 0, last_all = 0;
+    for (int s = 0; s < shards; ++s) {
+      double t[4];
+      swz_group_shard_timing(g, s, t);
+      std::printf(" s%d root %.0f-%.0f levels %.0f;", s, t[1], t[2], t[3]);
+      first_root = std::min(first_root, t[1]);
+      last_root = std::max(last_root, t[2]);
+      last_all = std::max(last_all, t[3]);
+    }
+    std::printf(" root phase %.1f ms, all done at %.1f ms\n", last_root - first_root, last_all);
+  }
+  swz_group_destroy(g);
+  return 0;
+}
