@@ -21,9 +21,37 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
-N = int(os.environ.get("SWZ_FULLSIZE_POINTS", "100000000"))
 MAX_POINTS = 20000
 SEED = 0x5C4A72A1D + 3
+_N = None
+
+
+def _points():
+    """The number of points: SWZ_FULLSIZE_POINTS, else what the GPU has room for -- BASELINE's 1 B points (configs[2],
+    the bench size) on a 288 GB part: 24 GB of positions, 13 GB of outputs and the library's workspace beside them."""
+    global _N
+    if _N is None:
+        env = int(os.environ.get("SWZ_FULLSIZE_POINTS", "0"))
+        if env:
+            _N = env
+        else:
+            import torch
+            free, _ = torch.cuda.mem_get_info(0)
+            _N = 1_000_000_000 if free >= 230e9 else (500_000_000 if free >= 120e9 else 100_000_000)
+    return _N
+
+
+def _log(msg):
+    """stdout (pytest shows it with -s or on failure) and a log file that travels back with gpurun_out/: what was verified
+    at which size is kept whether or not the run was watched (copied to profiles/rNN/ by tools/profile_round.sh)"""
+    print(msg)
+    root = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "fullsize_verification.log"), "a") as f:
+            f.write(msg + "\n")
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="module", params=["uniform", "clustered"])
@@ -32,6 +60,8 @@ def tiled(request):
     import schwarzwald_amd as swz
     dev = torch.device("cuda:0")
     torch.cuda.empty_cache()  # the library allocates with hipMalloc: hand back what earlier tests left in torch's cache
+    # the surface-like cloud makes levels of hundreds of millions of cells (per-cell tables): half the points there
+    N = _points() if request.param == "uniform" else max(_points() // 2, min(_points(), 100_000_000))
     ctx = swz.Context(0)
     # the context has its own non-blocking stream: run it on torch's, or the tile could start while the torch
     # kernels below are still writing the points (that race once made this fixture look like a hang)
@@ -59,14 +89,18 @@ def tiled(request):
                                 level.data_ptr())
         torch.cuda.synchronize()
         out[sampler] = (keys, perm, level, stats)
+        _log("%s cloud, %d points, %s: %d nodes, deepest level %d, %d levels, visit factor %.3f, %d MIN_DISTANCE rounds" % (
+            request.param, N, "MIN_DISTANCE" if sampler == swz.MIN_DISTANCE else "RANDOM_GRID", stats["num_nodes"], stats["max_level"],
+            stats["num_levels"], stats["points_visited"] / N, stats["min_distance_rounds"]))
     ctx.release_workspace()
-    yield {"xyz": xyz, "spacing": spacing, "out": out, "torch": torch, "swz": swz}
+    yield {"xyz": xyz, "spacing": spacing, "out": out, "torch": torch, "swz": swz, "n": N, "cloud": request.param}
     ctx.close()
 
 
 def test_output_is_a_sorted_permutation_with_matching_keys(tiled):
     torch, swz = tiled["torch"], tiled["swz"]
     keys, perm, level, stats = tiled["out"][swz.MIN_DISTANCE]
+    N = tiled["n"]
     assert bool((keys[1:] >= keys[:-1]).all())
     ties = keys[1:] == keys[:-1]
     assert bool((perm[1:][ties] > perm[:-1][ties]).all())  # canonical order: (key, original index)
@@ -83,6 +117,8 @@ def test_output_is_a_sorted_permutation_with_matching_keys(tiled):
     # every point was stored exactly once, on a level the statistics know about
     assert int(level.min()) >= -1 and int(level.max()) == stats["max_level"]
     assert stats["points_visited"] >= N
+    _log("%s cloud, %d points: output sorted with the canonical tie order, perm is a permutation, %d sampled keys equal the "
+         "oracle's encoder" % (tiled["cloud"], N, pick.numel()))
 
 
 def _check_level(tiled, L, rng, target_points=1_500_000):
@@ -154,7 +190,8 @@ def test_min_distance_levels_obey_the_greedy_rule(tiled):
     for L in range(-1, stats["max_level"] + 1):
         for _ in range(2):
             n, t = _check_level(tiled, L, rng)
-            print("level %d: %d points verified, %d of them taken" % (L, n, t))
+            _log("%s cloud, %d points, MIN_DISTANCE level %d: %d points of a random box verified against the greedy rule, "
+                 "%d of them taken" % (tiled["cloud"], tiled["n"], L, n, t))
             checked += n
     assert checked > 1_000_000
 
@@ -180,6 +217,8 @@ def test_random_grid_takes_the_first_point_of_every_cell(tiled):
         head[1:] = cell[1:] != cell[:-1]
         want_taken = torch.where(sampling, head, torch.ones_like(head))
         assert bool(((lv == L) == want_taken).all()), "level %d" % L
+        _log("%s cloud, %d points, RANDOM_GRID level %d: %d active points, %d taken = the heads of the cell runs (every point checked)" % (
+            tiled["cloud"], tiled["n"], L, int(active.sum()), int((lv == L).sum())))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -220,7 +259,7 @@ def test_grid_samplers_take_the_first_argmin_of_every_cell(sampler_name):
     torch.cuda.empty_cache()
     ctx = swz.Context(0)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    n = min(N, 100_000_000)
+    n = min(_points(), 100_000_000)
     xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
     ctx.generate_uniform_device(SEED, 0, n, xyz.data_ptr())
     spacing = O.spacing_from_diagonal(*UNIT, 250)
@@ -290,5 +329,5 @@ def test_grid_samplers_take_the_first_argmin_of_every_cell(sampler_name):
         assert not bool(bad.any()), "level %d: %d points decided differently" % (L, int(bad.sum()))
         checked += int(sampling.sum())
         del k, node, cell, d2, cinv, dmin, cand_idx, first, want, bad
-    print("%s, %d points: %d point decisions verified" % (sampler_name, n, checked))
+    _log("%s, %d uniform points: %d point decisions verified against the torch evaluation (first arg-min per cell)" % (sampler_name, n, checked))
     assert checked >= n

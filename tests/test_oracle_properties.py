@@ -226,3 +226,106 @@ def test_grid_center_and_jittered_against_an_independent_characterisation(sample
         assert cnt == int(want.sum())
         assert np.array_equal(i2[:cnt], order[sel][want])          # taken points, in Morton order
         assert np.array_equal(i2[cnt:], order[sel][~want])         # the rest keeps its order (stable partition)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The same characterisation in bounds whose halving chain ROUNDS (the unit cube's box edges are dyadic: any evaluation
+# order gives the same targets there).  The cell / node boxes are evaluated here in NumPy in the reference's operation
+# order -- get_octant_bounds, OctreeAlgorithms.cpp:3-18, iterated by get_bounds_from_morton_index, OctreeAlgorithms.h:104-116:
+# per level and axis  half = (max - min) / 2;  min' = bit ? min + half : min;  max' = min' + half  -- one chain per
+# point, vectorised over the points, independent of oracle/oracle.cpp.
+def _chain_bounds(keys, bmin, bmax, depth):
+    n = len(keys)
+    lo = np.tile(np.asarray(bmin, dtype=np.float64), (n, 1))
+    hi = np.tile(np.asarray(bmax, dtype=np.float64), (n, 1))
+    for level in range(depth):
+        octant = (keys >> np.uint64(3 * (20 - level))) & np.uint64(7)
+        half = (hi - lo) / 2.0
+        for axis, bit in ((0, 4), (1, 2), (2, 1)):                       # octant = x << 2 | y << 1 | z
+            up = (octant & np.uint64(bit)) != 0
+            lo[:, axis] = np.where(up, lo[:, axis] + half[:, axis], lo[:, axis])
+        hi = lo + half
+    return lo, hi
+
+
+def _prev_pow2(x):
+    x = int(x)
+    for s in (1, 2, 4, 8, 16):
+        x |= x >> s
+    return x - (x >> 1)
+
+
+def _expected_grid_sample_in_bounds(keys, pos, sampler, node_level, spacing_at_root, bmin, bmax):
+    """taken flags of a sampled node (all keys share its prefix) -- Sampling.h:314-416 (GRID_CENTER), :598-759 (JITTERED)"""
+    s_node = float(np.float32(spacing_at_root)) / 2.0 ** (node_level + 1)              # float / pow(2, L + 1) in double
+    ext_x_root = float(bmax[0]) - float(bmin[0])
+    if sampler == O.GRID_CENTER:
+        grid_level = max(-1, int(np.floor(np.log2(np.float32(ext_x_root / s_node)))) - 1)   # log2f of the narrowed ratio
+        lo, hi = _chain_bounds(keys, bmin, bmax, grid_level + 1)
+        t = lo + (hi - lo) / 2.0                                                            # AABB::getCenter
+    else:
+        nlo, nhi = _chain_bounds(keys[:1], bmin, bmax, node_level + 1)                     # the node's box
+        ext_x = float(nhi[0, 0] - nlo[0, 0])
+        cells = _prev_pow2(np.uint32(ext_x / s_node))
+        assert cells >= 16
+        levels = int(np.log2(cells))
+        grid_level = node_level + levels
+        rel = (keys >> np.uint64(3 * (20 - grid_level))) & np.uint64((1 << (3 * levels)) - 1)
+        gx, gy, gz = (_compact3(rel >> np.uint64(2)).astype(np.int64), _compact3(rel >> np.uint64(1)).astype(np.int64),
+                      _compact3(rel).astype(np.int64))
+        tab = _jitter_tables()[16 if cells <= 16 else (32 if cells <= 32 else 64)]
+        plen = min(cells, 64)
+        start = (3 * (node_level + 1)) % 16
+        px = tab[start][(gy + gz) % plen] - 1
+        py = tab[(start + 1) % 16][(gx + gz) % plen] - 1
+        pz = tab[(start + 2) % 16][(gx + gy) % plen] - 1
+        cell_size = ext_x / cells                        # the x extent serves every axis (Sampling.h:655-668)
+        perm_size = cell_size / cells
+        g = np.stack([gx, gy, gz], axis=1).astype(np.float64)
+        p = np.stack([px, py, pz], axis=1).astype(np.float64)
+        t = nlo[0] + (g * cell_size + p * perm_size)
+    cell = keys >> np.uint64(3 * (20 - grid_level)) if grid_level >= 0 else np.zeros_like(keys)
+    d = pos - t
+    d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    taken = np.zeros(len(keys), dtype=bool)
+    starts = np.nonzero(np.r_[True, cell[1:] != cell[:-1]])[0]
+    ends = np.r_[starts[1:], len(keys)]
+    for a, b in zip(starts, ends):
+        taken[a + int(np.argmin(d2[a:b]))] = True
+    return taken
+
+
+ROUNDING_BOUNDS = [
+    ([-512.25, 1000.5, -3.125], [-512.25 + 777.7, 1000.5 + 777.7, -3.125 + 777.7]),      # cubic, chain rounds
+    ([0.1, -7.3, 1e-3], [0.1 + 3.3, -7.3 + 2.9, 1e-3 + 3.7]),                            # three different extents
+]
+
+
+@pytest.mark.parametrize("sampler", [O.GRID_CENTER, O.JITTERED])
+@pytest.mark.parametrize("bounds", ROUNDING_BOUNDS, ids=["cubic", "box"])
+def test_grid_samplers_against_the_characterisation_in_bounds_whose_chain_rounds(sampler, bounds):
+    bmin, bmax = bounds
+    lo, hi = np.array(bmin), np.array(bmax)
+    rng = np.random.default_rng(77)
+    n = 50000
+    u = np.vstack([rng.random((n - 4000, 3)), 0.37 + 0.01 * rng.standard_normal((4000, 3))]).clip(0.0, 1.0)
+    xyz = lo + u * (hi - lo)
+    xyz[::19] = xyz[7]
+    sp = O.spacing_from_diagonal(bmin, bmax, 250)
+    keys, clamped = O.index_points(xyz, bmin, bmax)
+    order = O.sort_by_key(keys)
+    ks, pos = keys[order], clamped[order]
+    cases = [(-1, np.arange(n))]
+    for octant in (2, 5):
+        cases.append((0, np.nonzero((ks >> np.uint64(60)) == np.uint64(octant))[0]))
+    deep = np.nonzero((ks >> np.uint64(57)) == (ks[n // 3] >> np.uint64(57)))[0]         # one level-1 node
+    cases.append((1, deep))
+    for level, sel in cases:
+        if len(sel) == 0:
+            continue
+        node_key = int(ks[sel[0]]) >> (3 * (20 - level)) << (3 * (20 - level)) if level >= 0 else 0
+        cnt, k2, i2 = O.sample_points(sampler, 10, ks[sel], order[sel], clamped, node_key, level, bmin, bmax, sp, O.ALWAYS_ADHERE)
+        want = _expected_grid_sample_in_bounds(ks[sel], pos[sel], sampler, level, sp, bmin, bmax)
+        assert cnt == int(want.sum())
+        assert np.array_equal(i2[:cnt], order[sel][want])
+        assert np.array_equal(i2[cnt:], order[sel][~want])
