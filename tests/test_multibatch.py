@@ -269,3 +269,97 @@ def test_gpu_tiler_is_poisoned_by_a_batch_that_fails_part_way(ctx):
         with pytest.raises(swz.SwzError) as e3:
             t.add_batch(parts[1])
         assert e3.value.code == swz.api.ERR_TILER_FAILED and "peer failed" in str(e3.value)
+
+
+def _constructed_inversion(bounds):
+    """Two points a, b of one level-0 node whose order flips when their node re-reads them (read_pnts_from_disk,
+    TilingAlgorithms.cpp:80-99: the lower key levels come from an index computed against the NODE's bounds).  a sits a
+    few ulps from a key-cell boundary in x, where (x - root_min) * (2^21 / root_extent) and the same expression on the
+    node's box round to different cells; b sits in the cell between the two places a can have (same x cell as a's
+    lower one, next y cell), so a < b in one order and b < a in the other.  The boundary is a boundary of the level-0
+    sampling grid (and not of the root's), so that the root leaves both to level 0 and level 0 takes both."""
+    mn, ext = bounds[0][0], bounds[1][0] - bounds[0][0]
+    two21 = 2097152.0
+    mx = mn + ext
+    half = (mx - mn) / 2.0
+    nmin = mn + half
+    nmax = nmin + half
+
+    def root_cell(x):
+        return min(int((x - mn) * (two21 / ext)), 2 ** 21 - 1)
+
+    def node_cell(x):
+        return 2 ** 20 + (min(int((x - nmin) * (two21 / (nmax - nmin))), 2 ** 21 - 1) >> 1)
+
+    for i in range(2 ** 20 + 8192, 2 ** 21, 16384):        # boundaries of level-7 cells that are not level-6 boundaries
+        x = mn + i * (ext / two21)
+        for _ in range(64):
+            x = float(np.nextafter(x, -np.inf))
+            if root_cell(x) != node_cell(x) and {root_cell(x), node_cell(x)} == {i, i - 1}:
+                return i, x
+    raise AssertionError("no such point found")
+
+
+@pytest.mark.gpu
+def test_gpu_rekey_inversion_is_counted_and_confined(ctx):
+    """swz_tiler sorts the cached points of a node when their re-keyed order is no longer ascending; the reference
+    merges them as they are (a lossless store is read without a sort, TilingAlgorithms.cpp:103-106).  The library counts
+    such nodes' inversions (swz_tiler_info.rekey_inversions) and documents that results may differ from the reference
+    only then.  Here an inversion is constructed: the counter must see it (the oracle's own counter too), every point
+    must still be stored exactly once, and whatever differs from the oracle must be confined to the node in question."""
+    import schwarzwald_amd as swz
+    bounds = ODD
+    lo, side = np.array(bounds[0]), bounds[1][0] - bounds[0][0]
+    i, xa = _constructed_inversion(bounds)
+    cell = side / 2097152.0
+    jy, kz = 2 ** 20 + 40000, 2 ** 20 + 50000               # even y cell, any z cell, both in the upper halves (octant 7)
+    a = np.array([xa, lo[1] + (jy + 0.5) * cell, lo[2] + (kz + 0.5) * cell])
+    b = np.array([lo[0] + (i - 1 + 0.5) * cell, lo[1] + (jy + 1 + 0.5) * cell, lo[2] + (kz + 0.5) * cell])
+    # a decoy at the start of the root's grid cell (level 6: 16384 key cells wide) so that the root takes neither a nor b
+    decoy = np.array([lo[0] + ((i - 1) // 16384 * 16384 + 0.5) * cell, lo[1] + (jy // 16384 * 16384 + 0.5) * cell,
+                      lo[2] + (kz // 16384 * 16384 + 0.5) * cell])
+    rng = np.random.default_rng(2)
+    fill1 = lo + rng.random((4000, 3)) * side
+    fill2 = lo + (0.5 + 0.5 * rng.random((3000, 3))) * side   # the second batch touches octant 7, whose file holds a and b
+    batches = [np.vstack([fill1, decoy[None], b[None], a[None]]), fill2]
+    ia, ib = 4002, 4001
+    sp = O.spacing_from_diagonal(*bounds, 250)
+    t = O.Tiler(bounds[0], bounds[1], O.RANDOM_GRID, 100, sp)
+    for part in batches:
+        assert t.add_batch(part.copy()) == 0
+    assert t.finalize() == 0
+    ex, oc = t.export(), t.counts()
+    t.close()
+    params = swz.TileParams(sampler=swz.RANDOM_GRID, max_points_per_node=100, spacing_at_root=sp)
+    with swz.Tiler(ctx, bounds[0], bounds[1], params) as g:
+        for part in batches:
+            g.add_batch(part)
+        g.finalize()
+        info = g.info()
+        table = g.node_table()
+        import torch
+        ns = int(info["num_stored"])
+        d_ids = torch.empty(ns, dtype=torch.int32, device="cuda")
+        g.export_device(None, d_ids.data_ptr(), None)
+        ids = d_ids.cpu().numpy().view(np.uint32)
+    assert info["rekey_inversions"] >= 1          # the library saw the inversion ...
+    assert oc["unsorted_cached_nodes"] >= 1       # ... and so did the restatement of the reference
+    n = sum(len(p) for p in batches)
+    assert ns == n and np.array_equal(np.sort(ids), np.arange(n, dtype=np.uint32))      # every point stored exactly once
+    # node files: identical to the oracle's except in the subtree of the level-0 node that holds a and b, where the
+    # two orders take different points of the sampling cell the re-keyed a falls into
+    def files(level, key, offset, count, idlist):
+        out = {}
+        for l, k, o, c in zip(level, key, offset, count):
+            out[(int(l), int(k))] = idlist[int(o):int(o + c)].tolist()
+        return out
+    gf = files(table["level"], table["key"], table["offset"], table["count"], ids)
+    of = files(ex["level"], ex["key"], ex["offset"], ex["count"], ex["ids"])
+    octant7 = 7 << 60
+    differing = [k for k in set(gf) | set(of) if gf.get(k) != of.get(k)]
+    for (l, k) in differing:
+        assert l >= 0 and (k >> 60) == 7, "a file outside octant 7 differs: level %d key %x" % (l, k)
+    moved = set()
+    for k in differing:
+        moved |= set(gf.get(k, [])) ^ set(of.get(k, []))
+    assert moved <= {ia, ib}, moved     # only a and b change files (one of them is displaced a level down in either order)
