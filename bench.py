@@ -65,14 +65,37 @@ def parse_args():
     return ap.parse_args()
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT touching HIP (the ranks are started as children before anything in this
+    process initialises a GPU): HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set, else the KFD topology's GPU nodes.
+    None when neither tells."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    try:
+        n = 0
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for node in os.listdir(base):
+            try:
+                props = open(os.path.join(base, node, "properties")).read()
+            except OSError:
+                continue
+            for line in props.splitlines():
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        return n or None  # (no GPU node listed: rather let the ranks find out than refuse wrongly)
+    except OSError:
+        return None
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` outside torchrun: start N ranks as CHILD processes (one per GPU, RCCL) before this
     process touches a GPU, relay their output, exit with their code."""
     import socket
     import subprocess
-    import torch
-    have = torch.cuda.device_count()  # does not initialise the GPU
-    if have < args.gpus:
+    have = visible_gpus()
+    if have is not None and have < args.gpus:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
         return 2
     s = socket.socket()
@@ -90,22 +113,38 @@ def algorithmic_bytes_per_point(sampler, visit_factor):
     return 32.0 + 200.0 + per_level * visit_factor
 
 
+def library_source_sha16():
+    """What the committed traffic numbers are stamped with: a hash of the kernel sources the library is built from."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "schwarzwald_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(ROOT, "schwarzwald_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "schwarzwald_amd", "csrc", "*.inc"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(kernel_class, n, sampler):
     """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
     (profiles/rNN/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
-    command, corrected as MI355X_MICROARCH.md prescribes).  None when no matching profile is committed."""
-    t = None
-    for rnd in ("r02", "r01"):  # the newest committed profile of this configuration
+    command, corrected as MI355X_MICROARCH.md prescribes) -- only when that profile was taken on the kernel sources this
+    run uses (traffic.json carries their hash).  Returns (bytes or None, where the number comes from / why there is none)."""
+    sha = library_source_sha16()
+    for rnd in ("r03", "r02", "r01"):  # the newest committed profile of this configuration
+        path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         try:
-            t = json.load(open(os.path.join(ROOT, "profiles", rnd, "traffic.json")))
-            break
+            t = json.load(open(path))
         except Exception:
             continue
-    if t is None:
-        return None
-    if t.get("points") != n or t.get("sampler") != sampler:
-        return None
-    return t.get("bytes_per_launch", {}).get(kernel_class)
+        if t.get("points") != n or t.get("sampler") != sampler:
+            return None, "profiles/%s/traffic.json is for another workload" % rnd
+        if t.get("source_sha16") != sha:
+            return None, "stale: profiles/%s/traffic.json was measured on kernel sources %s, this run uses %s" % (
+                rnd, t.get("source_sha16", "(unstamped)"), sha)
+        return t.get("bytes_per_launch", {}).get(kernel_class), "profiles/%s/traffic.json (rocprofv3 --pmc, kernel sources %s)" % (rnd, sha)
+    return None, "no committed profile"
 
 
 def cpu_baseline(args, spacing):
@@ -232,7 +271,12 @@ def main():
     if distributed and "RANK" not in os.environ:  # SWZ_BENCH_FORCE_SHARDED=1 outside torchrun: a group of one
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29541")
+        if "MASTER_PORT" not in os.environ:  # a free port: two such benches on one box must not collide
+            import socket
+            sock = socket.socket()
+            sock.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
+            sock.close()
     if distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -373,7 +417,8 @@ def main():
             achieved = alg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                        "traffic": measured_traffic(name, n, args.sampler),
+                        "traffic": measured_traffic(name, n, args.sampler)[0],
+                        "traffic_source": measured_traffic(name, n, args.sampler)[1],
                         "launches": k["launches"], "avg_launch_ms": round(avg_ms, 4)}
         alg = algorithmic_bytes_per_point(args.sampler, visit)
         out = {

@@ -6,6 +6,8 @@ bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- FETCH_SIZE counts half the bytes
 8 passes x 8 B x points and nothing else."""
 import csv, json, sys, os
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
 d = sys.argv[1] if len(sys.argv) > 1 else "profiles/r01"
 points = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000_000
 levels = int(sys.argv[3]) if len(sys.argv) > 3 else 5  # sampled levels per step (root .. 3)
@@ -37,15 +39,16 @@ if "swz::radix_ghist_kernel" in fetch:
 else:
     calib = 2.0 * fetch["swz::radix_hist_kernel"][1] * 1024.0 / (8 * 8.0 * points)
 # (templated kernels are listed as "void swz::md_sweep_kernel<1, false>"; the fused cell scan belongs to the class too)
-md_k, md_b = bytes_of(lambda k: "swz::md_" in k or "swz::sp_" in k or "swz::CellHeadF" in k)
+md_k, md_b = bytes_of(lambda k: "swz::md_" in k or "swz::sp_" in k or "swz::mq_" in k or "swz::CellHeadF" in k or "swz::MqHeadF" in k)
 rs_k, rs_b = bytes_of(lambda k: k in ("swz::radix_scatter_kernel", "swz::radix_onesweep_kernel"))
 # launches of the scatter kernel in the profiled step: the passes over the whole input (the eight tiny passes that sort
 # the sample which picks the number of top digits do not count)
 rs_disp = sum(fetch.get(k, (0, 0))[0] for k in rs_k)
 rs_launches = rs_disp - 8 if rs_disp > 8 else max(1, rs_disp)
 md_lo = sum((fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1]) * 1024.0 for k in md_k)
+import bench  # library_source_sha16(): bench.py only quotes these numbers for the kernel sources they were measured on
 out = {
-    "points": points, "sampler": "MIN_DISTANCE",
+    "points": points, "sampler": "MIN_DISTANCE", "source_sha16": bench.library_source_sha16(),
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0`; "
               "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md); "
               "check: corrected reads of the radix histogram kernel / its exact key bytes = %.4f.  The factor 2 also holds for "
