@@ -160,6 +160,7 @@ struct MqArgs {
   uint32_t group, groups;
   uint32_t no_dead_test;  // debugging / tests: blocker scans do not test for dead points
   uint32_t stats;         // SWZ_DEBUG: count activations by kind in counters[CTR_DBG_HIST ...]
+  uint32_t chain;         // cells a wavefront may run one after the other in a launch, each woken by the one before (1: none)
   uint32_t* round_word;   // sharded root: the round this shard's sweep is in, for the shards that read its records
   MqPeers peers;
 };
@@ -234,6 +235,13 @@ __device__ __forceinline__ uint4 mq_ld_sys(const uint4* p) {
   const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
+// ... and what another wavefront of THIS GPU -- or this one, earlier in the launch -- has written: past the CU's L1
+__device__ __forceinline__ uint4 mq_ld_agent(const uint4* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
 __device__ __forceinline__ uint32_t mq_ld_sys(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 // ... for a local point i and an accepted point j of shard `tag - 1` (0: this shard)
@@ -248,8 +256,10 @@ struct MqLds {
   float4* list;   // [MQ_LIST_CAP]: accepted points of the earlier adjacent cells and of this cell (window)
   float4* fresh;  // [MQ_FRESH_CAP]: accepted in this activation
   uint8_t* tag;   // [MQ_LIST_CAP]: sharded root: which shard a list entry comes from (0 = this one)
+  uint32_t* trust;  // [MQ_CHAIN]: the cells this wavefront has run earlier in the launch, one after the other (see mq_sweep_kernel)
 };
-static inline size_t mq_lds_bytes(uint32_t rg) { return (size_t)(27u * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u + MQ_LIST_CAP; }
+constexpr uint32_t MQ_CHAIN = 8;
+static inline size_t mq_lds_bytes(uint32_t rg) { return (size_t)(27u * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u + MQ_LIST_CAP + MQ_CHAIN * 4u; }
 
 __device__ __forceinline__ bool mq_is_head(const MqArgs& a, uint32_t i) {
   if (!a.all_sampled && a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
@@ -434,7 +444,9 @@ enum : uint32_t { QO_FINISHED = 0, QO_STALLED = 1, QO_YIELD = 2 };
 
 // One wavefront advances one cell as far as it can.  U: chunks of 64 points held in registers at a time.
 template <int U, bool PEERS>
-__device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, const MqLds& lds, uint32_t* qout, uint32_t* cout, uint32_t seg0) {
+__device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, const MqLds& lds, uint32_t* qout, uint32_t* cout, uint32_t seg0,
+                            uint32_t ntrust, bool may_chain, uint32_t& chain_next) {
+  chain_next = QNONE;
   const uint32_t l = lane_id();
   const bool woken = (qentry & MQ_WOKEN) != 0u;
   const uint32_t c = qentry & ~MQ_WOKEN;
@@ -473,7 +485,11 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   bool claimed = woken;  // the next activation must not go through the confirm step again
 
   // ---- confirm: this cell stalled last time it ran and nobody has claimed its slot since
-  if (st.x != QNONE && !woken) {
+  if (!woken) {
+    // (An entry without the WOKEN flag was queued by a cell that stalled and is good for THAT stall only.  When the cell
+    // has been woken and run since by the wavefront that passed its blocking point -- in this very launch, see
+    // mq_sweep_kernel --, there is no stall on record any more, or one of this round: the entry is void.)
+    if (st.x == QNONE || st.w == round) return;
     const uint32_t bk = uni(st.y);
     const uint32_t Bv = qb_u32(nbv, (int)bk);
     const uint32_t Bp = PEERS ? (Bv >> MQ_PEER_SHIFT) : 0u, B = PEERS ? (Bv & MQ_ID_MASK) : Bv;
@@ -543,10 +559,11 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
         const uint32_t np = nb != QNONE ? (nb >> MQ_PEER_SHIFT) : 0u, ni = nb & MQ_ID_MASK;
         if (g < ngran && nb != QNONE) {
           if (np) tmp[j] = mq_ld_sys(a.peers.rec[np - 1u] + ((size_t)ni << rg2s) + part);
-          else if (ni <= c) tmp[j] = a.rec[((size_t)ni << rg2s) + part];
+          else if (ni <= c) tmp[j] = ntrust ? mq_ld_agent(a.rec + ((size_t)ni << rg2s) + part) : a.rec[((size_t)ni << rg2s) + part];
         }
       } else if (g < ngran && nb != QNONE && nb <= c) {
-        tmp[j] = a.rec[((size_t)nb << rg2s) + part];
+        // (a chained activation: the record its predecessor in the chain has just written must not come from this CU's L1)
+        tmp[j] = ntrust ? mq_ld_agent(a.rec + ((size_t)nb << rg2s) + part) : a.rec[((size_t)nb << rg2s) + part];
       }
     }
 #pragma unroll
@@ -573,7 +590,13 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   uint32_t n_pos = 0, n_cnt = 0, n_end = 0, pick = 0;
   if (valid) {
     const uint4 a0 = lds.stage[l << rg2s], a1 = lds.stage[(l << rg2s) + rg];
-    const uint32_t rr = (PEERS && nb_peer) ? r_before : round;  // stamps count in the owner's rounds
+    uint32_t rr = (PEERS && nb_peer) ? r_before : round;  // stamps count in the owner's rounds
+    if (ntrust && !(PEERS && nb_peer)) {
+      // a record this very wavefront wrote earlier in the launch is complete, whatever its stamp says to the others
+      bool mine = false;
+      for (uint32_t j = 0; j < ntrust; ++j) mine |= lds.trust[j] == nb_id;
+      if (mine) rr = round + 1u;
+    }
     pick = (a1.z < rr && (a0.z >= rr || a1.z > a0.z)) ? 1u : 0u;
     const uint4 hd = pick ? a1 : a0;
     n_pos = hd.x;
@@ -615,6 +638,9 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       if (PEERS && nb_peer) {
         if (ma) sa = mq_ld_sys(reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (ja - cap))));
         if (mb) sb = mq_ld_sys(reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (jb - cap))));
+      } else if (ntrust) {
+        if (ma) sa = mq_ld_agent(reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (ja - cap))));
+        if (mb) sb = mq_ld_agent(reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (jb - cap))));
       } else {
         if (ma) sa = *reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (ja - cap)));
         if (mb) sb = *reinterpret_cast<const uint4*>(ovf + (n_end - 1u - (jb - cap)));
@@ -910,7 +936,15 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     // (a blocker on a lower shard has no slot for this cell: it confirms itself every round until the point is passed)
     if (!(PEERS && (Bv >> MQ_PEER_SHIFT))) a.slot[(size_t)(PEERS ? (Bv & MQ_ID_MASK) : Bv) * 32 + (26u - b_k)] = ((unsigned long long)round << 32) | b_q;
   }
-  const uint64_t wm = __ballot(won);
+  uint64_t wm = __ballot(won);
+  if (may_chain && wm) {
+    // the first sleeper this activation has woken is run by this wavefront right away, in this launch: it will read the
+    // record just written (complete: same wavefront, program order) instead of waiting a round for it
+    const int first = __ffsll((unsigned long long)wm) - 1;
+    chain_next = qb_u32(nb_id, first);
+    wm &= wm - 1ull;
+    if ((int)l == first) won = false;
+  }
   const uint32_t self = fin ? 0u : 1u;
   const uint32_t total = (uint32_t)__popcll(wm) + self;
   if (total) {
@@ -954,6 +988,7 @@ __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t ro
   lds.list = reinterpret_cast<float4*>(mq_smem + 27u * 2u * a.rg);
   lds.fresh = lds.list + MQ_LIST_CAP;
   lds.tag = reinterpret_cast<uint8_t*>(lds.fresh + MQ_FRESH_CAP);
+  lds.trust = reinterpret_cast<uint32_t*>(lds.tag + MQ_LIST_CAP);
   const uint32_t r0 = round - MQ_FIRST_ROUND;
   const uint32_t ci = r0 % 3u, co = (r0 + 1u) % 3u, cz = (r0 + 2u) % 3u;
   if (blockIdx.x == 0) {  // the counters the round after the next will fill; this round's total for the host
@@ -984,7 +1019,20 @@ __global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t ro
   while (i < nq) {
     uint32_t next = 0;
     if (lane_id() == 0) next = atomicAdd(head, 1u);  // (the result is first looked at after the activation)
-    mq_activate<U, PEERS>(a, round, uni(entry), lds, qout, cout, seg);
+    // the entry, then -- one after the other -- a chain of cells each woken by the one before: a dependency that this
+    // wavefront resolves itself does not cost a round
+    uint32_t cur = uni(entry), ntrust = 0;
+    for (;;) {
+      uint32_t woke = QNONE;
+      mq_activate<U, PEERS>(a, round, cur, lds, qout, cout, seg, ntrust, ntrust + 1u < a.chain, woke);
+      woke = uni(woke);
+      if (woke == QNONE) break;
+      if (lane_id() == 0) lds.trust[ntrust] = cur & ~MQ_WOKEN;
+      ++ntrust;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // what the cell has published has reached the L2 the next one reads from
+      __builtin_amdgcn_wave_barrier();
+      cur = woke | MQ_WOKEN;
+    }
     i = wgs + qb_u32(next, 0);
     if (i < nq) entry = qin[i];
   }
@@ -1050,6 +1098,9 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   a.all_sampled = sample_nodes == nnodes ? 1u : 0u;
   a.no_dead_test = (c->opt("SWZ_MD_ABLATE") && (atoi(c->opt("SWZ_MD_ABLATE")) & 8)) ? 1u : 0u;
   a.stats = c->opt("SWZ_MD_STATS") ? 1u : 0u;
+  // (measured at 1 B points: 2 cells per chain root / level 0 / level 1 78 / 69 / 96 -> 73 / 62 / 91 ms; longer chains make
+  // launches as long as their longest chain and lose again)
+  a.chain = c->opt("SWZ_MD_CHAIN") ? std::min<uint32_t>(MQ_CHAIN, (uint32_t)std::max(1, atoi(c->opt("SWZ_MD_CHAIN")))) : 2u;
   if (a.cell_bits > 21u) return SWZ_OK;
 
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);

@@ -65,6 +65,10 @@ MODES = [
     {"SWZ_MD_GROUPS": "3", "SWZ_MD_LAZY": "0"},
     {"SWZ_MD_KEYS_RG": "4", "SWZ_MD_COARSEN": "1", "SWZ_MD_COARSEN_MIN": "0"},  # 3 inline accepted points, most in the overflow
     {"SWZ_MD_KEYS_RG": "8", "SWZ_MD_BATCH": "1"},
+    {"SWZ_MD_CHAIN": "1"},                                                   # no cell run by the wavefront that woke it
+    {"SWZ_MD_CHAIN": "8", "SWZ_MD_LAZY": "0", "SWZ_MD_PATIENT": "0"},        # chains of up to 8 such cells
+    {"SWZ_MD_CHAIN": "8", "SWZ_MD_GRID": "3"},
+    {"SWZ_MD_CHAIN": "8", "SWZ_MD_BIG": "1", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0", "SWZ_MD_LAZY": "0"},
 ]
 
 
