@@ -39,6 +39,13 @@ def test_group_rccl_transport(tmp_path):
     """With one GPU this runs the 1-shard group through ncclCommInitAll (librccl loaded on demand) and skips the
     larger groups; on a multi-GPU node the same binary covers them."""
     exe = _build(str(tmp_path))
-    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=900)
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=1800)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count(" ok") >= 4
+    # every group size the box has GPUs for must have run through ncclSend / ncclRecv, not been skipped
+    import torch
+    gpus = torch.cuda.device_count()
+    for shards in (2, 4, 8):
+        if gpus >= shards:
+            assert ("RCCL with %d shards skipped" % shards) not in r.stdout
+            assert r.stdout.count(" %d shard(s) ok" % shards) == 4

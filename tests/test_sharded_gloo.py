@@ -26,10 +26,10 @@ def _free_port():
     return p
 
 
-def _init(rank, world, port):
+def _init(rank, world, port, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world)
 
 
 def _cloud(n, seed):
@@ -141,13 +141,14 @@ def _corner_cloud(n, seed, world):
     return xyz
 
 
-def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False):
-    _init(rank, world, port)
+def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False, backend="gloo"):
     import schwarzwald_amd as swz
     from schwarzwald_amd import sharded
-    dev = torch.device("cuda", 0)
+    # gloo: all ranks share GPU 0 (what a one-GPU box can run); nccl (= RCCL): one GPU per rank
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
-    ctx = swz.Context(0)
+    _init(rank, world, port, backend)
+    ctx = swz.Context(dev.index)
     params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
     xyz = torch.from_numpy(_corner_cloud(n, 300 + rank, world) if corner else _cloud(n, 300 + rank)).to(dev)
     tiler = sharded.ShardedTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
@@ -159,15 +160,31 @@ def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=Fals
     dist.destroy_process_group()
 
 
+def _visible_gpus():
+    try:
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+# (sampler, diagonal fraction, points per rank, backend): MIN_DISTANCE at d = 60 (dense sweeps at this size) and at the
+# bench's d = 250; the last case runs the exchange over RCCL with one GPU per rank and enables itself where two GPUs are
+# visible (this pool's boxes have one)
+SHARDED_CASES = [(O.RANDOM_GRID, 250, 60000, "gloo"), (O.GRID_CENTER, 250, 60000, "gloo"), (O.MIN_DISTANCE, 60, 60000, "gloo"),
+                 (O.MIN_DISTANCE, 250, 150000, "gloo"), (O.JITTERED, 250, 60000, "gloo"), (O.MIN_DISTANCE, 250, 150000, "nccl")]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
-def test_sharded_tile_matches_oracle(sampler):
-    world, n, max_pts = 2, 60000, 500
-    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
+@pytest.mark.parametrize("sampler,d,n,backend", SHARDED_CASES)
+def test_sharded_tile_matches_oracle(sampler, d, n, backend):
+    if backend == "nccl" and _visible_gpus() < 2:
+        pytest.skip("the RCCL exchange needs one GPU per rank: fewer than two GPUs visible")
+    world, max_pts = 2, 500
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], d)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q))
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q, False, backend))
              for r in range(world)]
     for p in procs:
         p.start()
