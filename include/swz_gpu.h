@@ -274,10 +274,16 @@ int swz_tileset_build(uint64_t num_nodes, const int8_t* node_level, const uint64
  * header's bounding box) and las_read_points_into (:578-632: RGB >> 8, the other attributes copied).  LASzip
  * itself (github.com/LASzip/LASzip, built from LAStools per the reference's README.md:24-37, version not
  * pinned there) is not part of the reference tree; for UNCOMPRESSED files its reader only unpacks the fixed
- * point data record of the LAS 1.2 specification, which is restated here for formats 0-3:
- *   X,Y,Z i32 | intensity u16 | return number:3, number of returns:3, scan direction:1, edge of flight line:1 |
- *   classification:5 (+3 flag bits) | scan angle rank i8 | user data u8 | point source id u16  (20 bytes)
- *   | format 1,3: gps time f64 | format 2,3: R,G,B u16.
+ * point data record of the LAS specification, which is restated here for formats 0-10 (LASFile.cpp:421-426 lists the
+ * formats that carry RGB: 2, 3, 5, 7, 8, 10):
+ *   formats 0-5 (LAS 1.2 / 1.3): X,Y,Z i32 | intensity u16 | return number:3, number of returns:3, scan direction:1, edge
+ *   of flight line:1 | classification:5 (+3 flag bits) | scan angle rank i8 | user data u8 | point source id u16 (20
+ *   bytes) | format 1,3,4,5: gps time f64 | format 2,3,5: R,G,B u16 | format 4,5: 29 bytes of wave packet (skipped);
+ *   formats 6-10 (LAS 1.4): X,Y,Z i32 | intensity u16 | return number:4, number of returns:4 | classification flags:4,
+ *   scanner channel:2, scan direction:1, edge of flight line:1 | classification u8 | user data u8 | scan angle i16 (0.006
+ *   degree) | point source id u16 | gps time f64 (30 bytes) | format 7,8,10: R,G,B u16 | 8,10: NIR u16 | 9,10: wave
+ *   packet -- mapped onto the legacy fields the reference reads the way LASzip's raw reader does (returns above 7
+ *   saturate, classes above 31 read 0, the scan angle is rounded to degrees and clamped to a signed byte).
  * d_records: n records of record_bytes each (>= the format's size; trailing extra bytes are skipped), device
  * memory, 4-byte aligned.  Columns absent from d_out are skipped; attributes the format lacks (gps time in
  * format 0/2, RGB in 0/1) are written as 0 like an untouched laszip_point. */
@@ -286,7 +292,7 @@ typedef struct {
   double offset[3];      /* x_offset, ... */
   double min[3];         /* min_x, ... : positions are clamped into [min, max] */
   double max[3];
-  uint32_t point_format; /* 0..3 */
+  uint32_t point_format; /* 0..10 */
   uint32_t record_bytes; /* point data record length */
 } swz_las_layout;
 int swz_las_decode_device(swz_ctx* ctx, const uint8_t* d_records, uint64_t n, const swz_las_layout* layout,

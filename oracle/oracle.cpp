@@ -1362,7 +1362,7 @@ int32_t orc_bin_retrieve_points(const char* path, uint32_t* bitmask_out, uint64_
 
 /* ---- LAS records ------------------------------------------------------------------------------------ */
 namespace {
-/* what LASzip's reader leaves in a laszip_point for point data record formats 0-3 (LAS 1.2 specification,
+/* what LASzip's reader leaves in a laszip_point for point data record formats 0-5 (LAS 1.2 / 1.3 specification,
  * "Point Data Record Format 0..3"; laszip_api.h: return_number:3, number_of_returns:3, scan_direction_flag:1,
  * edge_of_flight_line:1, classification:5 + 3 flag bits) */
 struct LasPoint {
@@ -1381,6 +1381,36 @@ LasPoint las_read_record(const uint8_t* r, uint32_t format) {
   std::memcpy(&p.Y, r + 4, 4);
   std::memcpy(&p.Z, r + 8, 4);
   std::memcpy(&p.intensity, r + 12, 2);
+  if (format >= 6) {
+    /* LAS 1.4 point data record formats 6-10 ("Point Data Record Format 6": return number:4, number of returns:4 |
+     * classification flags:4, scanner channel:2, scan direction:1, edge of flight line:1 | classification u8 | user data |
+     * scan angle i16 in 0.006 degree | point source id | gps time), as LASzip's raw reader maps them onto the fields of
+     * a laszip_point the reference reads (LASzip src/lasreaditemraw.hpp, LASreadItemRaw_POINT14_LE::read -- LASzip is not
+     * part of the reference tree and its version is not pinned there: restated from its published source, PARITY
+     * UNPINNED): returns above 7 saturate, classifications above 31 do not fit the 5-bit field and read 0, the scan
+     * angle is rounded to whole degrees in float and clamped to a signed byte. */
+    const uint32_t rn = r[14] & 15u, nor = (r[14] >> 4) & 15u;
+    if (nor > 7) {
+      p.return_number = rn > 6 ? (rn >= nor ? 7 : 6) : (uint8_t)rn;
+      p.number_of_returns = 7;
+    } else {
+      p.return_number = (uint8_t)(rn & 7u);  /* (the field has 3 bits) */
+      p.number_of_returns = (uint8_t)nor;
+    }
+    p.scan_direction_flag = (r[15] >> 6) & 1;
+    p.edge_of_flight_line = (r[15] >> 7) & 1;
+    p.classification = r[16] < 32 ? r[16] : 0;
+    p.user_data = r[17];
+    int16_t angle;
+    std::memcpy(&angle, r + 18, 2);
+    const float deg = 0.006f * angle;
+    const int16_t q = deg >= 0 ? (int16_t)(deg + 0.5f) : (int16_t)(deg - 0.5f);      /* I16_QUANTIZE */
+    p.scan_angle_rank = (int8_t)(q <= -128 ? -128 : (q >= 127 ? 127 : q));            /* I8_CLAMP */
+    std::memcpy(&p.point_source_ID, r + 20, 2);
+    std::memcpy(&p.gps_time, r + 22, 8);
+    if (format == 7 || format == 8 || format == 10) std::memcpy(p.rgb, r + 30, 6);
+    return p;
+  }
   p.return_number = r[14] & 7;
   p.number_of_returns = (r[14] >> 3) & 7;
   p.scan_direction_flag = (r[14] >> 6) & 1;
@@ -1390,19 +1420,19 @@ LasPoint las_read_record(const uint8_t* r, uint32_t format) {
   p.user_data = r[17];
   std::memcpy(&p.point_source_ID, r + 18, 2);
   size_t at = 20;
-  if (format == 1 || format == 3) {
+  if (format == 1 || format == 3 || format == 4 || format == 5) {  /* 4, 5 (LAS 1.3): formats 1, 3 + 29 bytes of wave packet */
     std::memcpy(&p.gps_time, r + at, 8);
     at += 8;
   }
-  if (format == 2 || format == 3) std::memcpy(p.rgb, r + at, 6);
+  if (format == 2 || format == 3 || format == 5) std::memcpy(p.rgb, r + at, 6);
   return p;
 }
 }  // namespace
 
 int32_t orc_las_decode(const uint8_t* records, uint64_t n, const orc_las_layout* L, double* xyz_out,
                        void* const col[12]) {
-  static const uint32_t min_bytes[4] = {20, 28, 26, 34};
-  if (!L || L->point_format > 3 || L->record_bytes < min_bytes[L->point_format]) return ORC_ERR_BAD_ARG;
+  static const uint32_t min_bytes[11] = {20, 28, 26, 34, 57, 63, 30, 36, 38, 59, 67};
+  if (!L || L->point_format > 10 || L->record_bytes < min_bytes[L->point_format]) return ORC_ERR_BAD_ARG;
   for (uint64_t i = 0; i < n; ++i) {
     const LasPoint p = las_read_record(records + i * L->record_bytes, L->point_format);
     if (xyz_out) {

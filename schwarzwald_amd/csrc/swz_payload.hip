@@ -485,25 +485,66 @@ __device__ __forceinline__ void las_unpack(const LasArgs& a, const uint8_t* r, u
       a.xyz[(size_t)i * 3 + ax] = p;
     }
   }
-  const uint32_t bits = r[14], cls = r[15];
+  // the fields of a laszip_point the reference copies (las_read_points_into, LASFile.cpp:578-632), from the legacy record
+  // (formats 0-5, LAS 1.2 / 1.3) or from the LAS 1.4 record (formats 6-10) the way LASzip's raw reader maps it onto them
+  uint32_t ret, nret, dir, edge, cls, user, src_at, gps_at;
+  int32_t angle;
+  bool has_gps, has_rgb;
+  uint32_t rgb_at;
+  if (a.format >= 6u) {
+    const uint32_t rn = r[14] & 15u, nor = (r[14] >> 4) & 15u;
+    if (nor > 7u) {  // returns above 7 saturate (LASreadItemRaw_POINT14_LE::read)
+      ret = rn > 6u ? (rn >= nor ? 7u : 6u) : rn;
+      nret = 7u;
+    } else {
+      ret = rn & 7u;
+      nret = nor;
+    }
+    dir = (r[15] >> 6) & 1u;
+    edge = (r[15] >> 7) & 1u;
+    cls = r[16] < 32u ? r[16] : 0u;  // the 5-bit classification field holds the LAS 1.4 classes below 32 only
+    user = r[17];
+    const int32_t raw = (int32_t)(int16_t)las_u16(r + 18);
+    const float deg = 0.006f * (float)raw;                                     // I8_CLAMP(I16_QUANTIZE(0.006f * scan_angle))
+    const int32_t q = deg >= 0.f ? (int32_t)(int16_t)(deg + 0.5f) : (int32_t)(int16_t)(deg - 0.5f);
+    angle = q <= -128 ? -128 : (q >= 127 ? 127 : q);
+    src_at = 20u;
+    gps_at = 22u;
+    has_gps = true;
+    has_rgb = a.format == 7u || a.format == 8u || a.format == 10u;
+    rgb_at = 30u;
+  } else {
+    const uint32_t bits = r[14];
+    ret = bits & 7u;
+    nret = (bits >> 3) & 7u;
+    dir = (bits >> 6) & 1u;
+    edge = (bits >> 7) & 1u;
+    cls = r[15] & 31u;
+    angle = (int32_t)(int8_t)r[16];
+    user = r[17];
+    src_at = 18u;
+    gps_at = 20u;
+    has_gps = a.format == 1u || a.format == 3u || a.format == 4u || a.format == 5u;
+    has_rgb = a.format == 2u || a.format == 3u || a.format == 5u;
+    rgb_at = has_gps ? 28u : 20u;
+  }
   if (a.col[SWZ_ATTR_INTENSITY]) ((uint16_t*)a.col[SWZ_ATTR_INTENSITY])[i] = (uint16_t)las_u16(r + 12);
-  if (a.col[SWZ_ATTR_RETURN_NUMBER]) ((uint8_t*)a.col[SWZ_ATTR_RETURN_NUMBER])[i] = (uint8_t)(bits & 7u);
-  if (a.col[SWZ_ATTR_NUMBER_OF_RETURNS]) ((uint8_t*)a.col[SWZ_ATTR_NUMBER_OF_RETURNS])[i] = (uint8_t)((bits >> 3) & 7u);
-  if (a.col[SWZ_ATTR_SCAN_DIRECTION_FLAG]) ((uint8_t*)a.col[SWZ_ATTR_SCAN_DIRECTION_FLAG])[i] = (uint8_t)((bits >> 6) & 1u);
-  if (a.col[SWZ_ATTR_EDGE_OF_FLIGHT_LINE]) ((uint8_t*)a.col[SWZ_ATTR_EDGE_OF_FLIGHT_LINE])[i] = (uint8_t)((bits >> 7) & 1u);
-  if (a.col[SWZ_ATTR_CLASSIFICATION]) ((uint8_t*)a.col[SWZ_ATTR_CLASSIFICATION])[i] = (uint8_t)(cls & 31u);
-  if (a.col[SWZ_ATTR_SCAN_ANGLE_RANK]) ((int8_t*)a.col[SWZ_ATTR_SCAN_ANGLE_RANK])[i] = (int8_t)r[16];
-  if (a.col[SWZ_ATTR_USER_DATA]) ((uint8_t*)a.col[SWZ_ATTR_USER_DATA])[i] = r[17];
-  if (a.col[SWZ_ATTR_POINT_SOURCE_ID]) ((uint16_t*)a.col[SWZ_ATTR_POINT_SOURCE_ID])[i] = (uint16_t)las_u16(r + 18);
-  const bool has_gps = a.format == 1u || a.format == 3u, has_rgb = a.format == 2u || a.format == 3u;
+  if (a.col[SWZ_ATTR_RETURN_NUMBER]) ((uint8_t*)a.col[SWZ_ATTR_RETURN_NUMBER])[i] = (uint8_t)ret;
+  if (a.col[SWZ_ATTR_NUMBER_OF_RETURNS]) ((uint8_t*)a.col[SWZ_ATTR_NUMBER_OF_RETURNS])[i] = (uint8_t)nret;
+  if (a.col[SWZ_ATTR_SCAN_DIRECTION_FLAG]) ((uint8_t*)a.col[SWZ_ATTR_SCAN_DIRECTION_FLAG])[i] = (uint8_t)dir;
+  if (a.col[SWZ_ATTR_EDGE_OF_FLIGHT_LINE]) ((uint8_t*)a.col[SWZ_ATTR_EDGE_OF_FLIGHT_LINE])[i] = (uint8_t)edge;
+  if (a.col[SWZ_ATTR_CLASSIFICATION]) ((uint8_t*)a.col[SWZ_ATTR_CLASSIFICATION])[i] = (uint8_t)cls;
+  if (a.col[SWZ_ATTR_SCAN_ANGLE_RANK]) ((int8_t*)a.col[SWZ_ATTR_SCAN_ANGLE_RANK])[i] = (int8_t)angle;
+  if (a.col[SWZ_ATTR_USER_DATA]) ((uint8_t*)a.col[SWZ_ATTR_USER_DATA])[i] = (uint8_t)user;
+  if (a.col[SWZ_ATTR_POINT_SOURCE_ID]) ((uint16_t*)a.col[SWZ_ATTR_POINT_SOURCE_ID])[i] = (uint16_t)las_u16(r + src_at);
   if (a.col[SWZ_ATTR_GPS_TIME]) {
     uint64_t v = 0;
     if (has_gps)
-      for (int b = 7; b >= 0; --b) v = (v << 8) | r[20 + b];
+      for (int b = 7; b >= 0; --b) v = (v << 8) | r[gps_at + b];
     ((double*)a.col[SWZ_ATTR_GPS_TIME])[i] = __longlong_as_double((long long)v);
   }
   if (a.col[SWZ_ATTR_RGB]) {
-    const uint8_t* c = r + (has_gps ? 28 : 20);
+    const uint8_t* c = r + rgb_at;
     uint8_t* o = (uint8_t*)a.col[SWZ_ATTR_RGB] + (size_t)i * 3;
     // las_read_points_into (LASFile.cpp:592-597): static_cast<uint8_t>(rgb[k] >> 8)
     for (int k = 0; k < 3; ++k) o[k] = has_rgb ? c[2 * k + 1] : (uint8_t)0;
@@ -537,8 +578,8 @@ extern "C" int swz_las_decode_device(swz_ctx* c, const uint8_t* d_records, uint6
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
   if (!layout) return c->fail(SWZ_ERR_BAD_ARG, "swz_las_decode_device: NULL layout");
-  static const uint32_t kMinBytes[4] = {20, 28, 26, 34};
-  if (layout->point_format > 3) return c->fail(SWZ_ERR_BAD_ARG, "only LAS point data record formats 0-3 are decoded");
+  static const uint32_t kMinBytes[11] = {20, 28, 26, 34, 57, 63, 30, 36, 38, 59, 67};
+  if (layout->point_format > 10) return c->fail(SWZ_ERR_BAD_ARG, "LAS point data record formats 0-10 are decoded");
   if (layout->record_bytes < kMinBytes[layout->point_format])
     return c->fail(SWZ_ERR_BAD_ARG, "record length shorter than the point format");
   if (n == 0) return SWZ_OK;

@@ -1,5 +1,5 @@
 """LAS point records -> positions + attribute columns (core/io/LASFile.cpp:79-94,
-578-632).  Records are LAS 1.2 point data record formats 0-3, built here with numpy structured dtypes; the
+578-632).  Records are LAS point data record formats 0-10 (LAS 1.2 - 1.4), built here with numpy structured dtypes; the
 expected values are computed in this file with numpy, independently of both the oracle and the GPU."""
 import numpy as np
 import pytest
@@ -8,9 +8,17 @@ import oracle_lib as O
 
 CORE = [("X", "<i4"), ("Y", "<i4"), ("Z", "<i4"), ("intensity", "<u2"), ("bits", "u1"), ("classification", "u1"),
         ("scan_angle_rank", "i1"), ("user_data", "u1"), ("point_source_id", "<u2")]
+# LAS 1.4 "Point Data Record Format 6": returns byte = return number:4 | number of returns:4; flags byte = classification
+# flags:4 | scanner channel:2 | scan direction:1 | edge of flight line:1; scan angle in units of 0.006 degree
+CORE14 = [("X", "<i4"), ("Y", "<i4"), ("Z", "<i4"), ("intensity", "<u2"), ("returns", "u1"), ("flags", "u1"), ("classification", "u1"),
+          ("user_data", "u1"), ("scan_angle", "<i2"), ("point_source_id", "<u2"), ("gps_time", "<f8")]
+WAVE = [("wave_packet", "u1", 29)]
 FORMATS = {0: CORE, 1: CORE + [("gps_time", "<f8")], 2: CORE + [("rgb", "<u2", 3)],
-           3: CORE + [("gps_time", "<f8"), ("rgb", "<u2", 3)]}
-SIZES = {0: 20, 1: 28, 2: 26, 3: 34}
+           3: CORE + [("gps_time", "<f8"), ("rgb", "<u2", 3)],
+           4: CORE + [("gps_time", "<f8")] + WAVE, 5: CORE + [("gps_time", "<f8"), ("rgb", "<u2", 3)] + WAVE,
+           6: CORE14, 7: CORE14 + [("rgb", "<u2", 3)], 8: CORE14 + [("rgb", "<u2", 3), ("nir", "<u2")],
+           9: CORE14 + WAVE, 10: CORE14 + [("rgb", "<u2", 3), ("nir", "<u2")] + WAVE}
+SIZES = {0: 20, 1: 28, 2: 26, 3: 34, 4: 57, 5: 63, 6: 30, 7: 36, 8: 38, 9: 59, 10: 67}
 
 
 def make_records(rng, n, fmt, extra):
@@ -22,15 +30,25 @@ def make_records(rng, n, fmt, extra):
     ext = np.array([0, -2**31, 2**31 - 1, 123456])[:n]      # extremes: clamped into the header box
     r["X"][:len(ext)] = ext
     r["intensity"] = rng.integers(0, 65535, n, endpoint=True)
-    r["bits"] = rng.integers(0, 255, n, endpoint=True)
+    if fmt >= 6:
+        r["returns"] = rng.integers(0, 255, n, endpoint=True)
+        r["flags"] = rng.integers(0, 255, n, endpoint=True)
+        r["scan_angle"] = rng.integers(-32768, 32767, n, endpoint=True)
+        r["scan_angle"][:6] = np.array([0, 83, 84, -84, 30000, -30000])[:min(n, 6)]   # around a rounding step, the clamps
+    else:
+        r["bits"] = rng.integers(0, 255, n, endpoint=True)
+        r["scan_angle_rank"] = rng.integers(-128, 127, n, endpoint=True)
     r["classification"] = rng.integers(0, 255, n, endpoint=True)
-    r["scan_angle_rank"] = rng.integers(-128, 127, n, endpoint=True)
     r["user_data"] = rng.integers(0, 255, n, endpoint=True)
     r["point_source_id"] = rng.integers(0, 65535, n, endpoint=True)
     if "gps_time" in dt.names:
         r["gps_time"] = rng.random(n) * 1e9
     if "rgb" in dt.names:
         r["rgb"] = rng.integers(0, 65535, (n, 3), endpoint=True)
+    if "nir" in dt.names:
+        r["nir"] = rng.integers(0, 65535, n, endpoint=True)
+    if "wave_packet" in dt.names:
+        r["wave_packet"] = rng.integers(0, 255, (n, 29), endpoint=True)
     if extra:
         r["extra"] = rng.integers(0, 255, (n, extra), endpoint=True)
     return r
@@ -46,10 +64,24 @@ def expected(r):
         p = LAYOUT["offset"][k] + r[ax].astype(np.float64) * LAYOUT["scale"][k]
         xyz[:, k] = np.minimum(LAYOUT["bmax"][k], np.maximum(LAYOUT["bmin"][k], p))
     names = r.dtype.names
+    if "returns" in names:
+        # what LASzip's raw reader leaves in the legacy fields of a laszip_point for a LAS 1.4 record
+        # (LASreadItemRaw_POINT14_LE::read): more than 7 returns saturate, classes above 31 do not fit the 5-bit field,
+        # the scan angle becomes whole degrees (float product, rounded half away from zero, clamped to a signed byte)
+        rn, nor = (r["returns"] & 15).astype(np.int64), (r["returns"] >> 4).astype(np.int64)
+        ret = np.where(nor > 7, np.where(rn > 6, np.where(rn >= nor, 7, 6), rn), rn & 7)
+        nret = np.where(nor > 7, 7, nor)
+        deg = np.float32(0.006) * r["scan_angle"].astype(np.float32)
+        q = np.where(deg >= 0, np.trunc(deg + np.float32(0.5)), np.trunc(deg - np.float32(0.5))).astype(np.int64)
+        legacy = {"return_number": ret, "number_of_returns": nret, "scan_direction_flag": (r["flags"] >> 6) & 1,
+                  "edge_of_flight_line": (r["flags"] >> 7) & 1, "classification": np.where(r["classification"] < 32, r["classification"], 0),
+                  "scan_angle_rank": np.clip(q, -128, 127)}
+    else:
+        legacy = {"return_number": r["bits"] & 7, "number_of_returns": (r["bits"] >> 3) & 7, "scan_direction_flag": (r["bits"] >> 6) & 1,
+                  "edge_of_flight_line": (r["bits"] >> 7) & 1, "classification": r["classification"] & 31,
+                  "scan_angle_rank": r["scan_angle_rank"]}
     a = {
-        "intensity": r["intensity"], "return_number": r["bits"] & 7, "number_of_returns": (r["bits"] >> 3) & 7,
-        "scan_direction_flag": (r["bits"] >> 6) & 1, "edge_of_flight_line": (r["bits"] >> 7) & 1,
-        "classification": r["classification"] & 31, "scan_angle_rank": r["scan_angle_rank"], "user_data": r["user_data"],
+        "intensity": r["intensity"], **legacy, "user_data": r["user_data"],
         "point_source_id": r["point_source_id"],
         "gps_time": r["gps_time"] if "gps_time" in names else np.zeros(len(r)),
         "rgb": (r["rgb"] >> 8).astype(np.uint8) if "rgb" in names else np.zeros((len(r), 3), np.uint8),
@@ -57,7 +89,8 @@ def expected(r):
     return xyz, a
 
 
-@pytest.mark.parametrize("fmt,extra", [(0, 0), (1, 0), (2, 0), (3, 0), (3, 6), (0, 2)])
+@pytest.mark.parametrize("fmt,extra", [(0, 0), (1, 0), (2, 0), (3, 0), (3, 6), (0, 2), (4, 0), (5, 0), (6, 0), (7, 0), (8, 0), (9, 0), (10, 0),
+                                       (6, 4), (10, 3)])
 def test_oracle_decodes_las_records(fmt, extra):
     rng = np.random.default_rng(fmt * 10 + extra)
     r = make_records(rng, 1000, fmt, extra)
@@ -71,7 +104,9 @@ def test_oracle_decodes_las_records(fmt, extra):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt,extra,n", [(0, 0, 1), (1, 0, 255), (2, 0, 256), (3, 0, 100_003), (3, 6, 5000), (2, 80, 777), (0, 2, 4097)])
+@pytest.mark.parametrize("fmt,extra,n", [(0, 0, 1), (1, 0, 255), (2, 0, 256), (3, 0, 100_003), (3, 6, 5000), (2, 80, 777), (0, 2, 4097),
+                                         (4, 0, 3000), (5, 2, 3001), (6, 0, 100_001), (7, 0, 4096), (8, 0, 257), (9, 0, 1000), (10, 0, 65_537),
+                                         (6, 4, 999), (10, 40, 513)])
 def test_gpu_las_decode_matches_oracle(fmt, extra, n):
     import torch
     import schwarzwald_amd as swz
@@ -101,9 +136,11 @@ def test_gpu_las_decode_matches_oracle(fmt, extra, n):
     torch.cuda.synchronize()
     assert np.array_equal(part["intensity"].cpu().numpy(), want["intensity"])
     with pytest.raises(swz.SwzError):
-        ctx.las_decode_device(d_rec.data_ptr(), n, LAYOUT["scale"], LAYOUT["offset"], LAYOUT["bmin"], LAYOUT["bmax"], 6, 30, d_xyz.data_ptr())
+        ctx.las_decode_device(d_rec.data_ptr(), n, LAYOUT["scale"], LAYOUT["offset"], LAYOUT["bmin"], LAYOUT["bmax"], 11, 80, d_xyz.data_ptr())
     with pytest.raises(swz.SwzError):
         ctx.las_decode_device(d_rec.data_ptr(), n, LAYOUT["scale"], LAYOUT["offset"], LAYOUT["bmin"], LAYOUT["bmax"], 3, 30, d_xyz.data_ptr())
+    with pytest.raises(swz.SwzError):
+        ctx.las_decode_device(d_rec.data_ptr(), n, LAYOUT["scale"], LAYOUT["offset"], LAYOUT["bmin"], LAYOUT["bmax"], 10, 66, d_xyz.data_ptr())
     ctx.close()
 
 
