@@ -595,7 +595,9 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   SWZ_TRY(c->get(w.which ? "tl_surv_idx_1" : "tl_surv_idx_0", (size_t)ms.m, &w.surv_idx[w.which]));
   LevelBuffers lb;
   SWZ_TRY(alloc_level_buffers(c, ms.m, &lb));
-  const SortedPoints sp{w.wx, w.wy, w.wz};
+  // (exact positions for MIN_DISTANCE on key coordinates, swz_mdkeys.hip: working index -> point id -> position pool;
+  // ghosts of a sharded root lie outside the pool)
+  const SortedPoints sp{w.wx, w.wy, w.wz, ng ? nullptr : t->pool_xyz, w.wgid};
   SWZ_TRY(level_step(c, plan, ms, sp, lb, w.wlevel, w.surv_key[w.which], w.surv_idx[w.which], res));
 
   // ---- the nodes' new files, merged back between the files of the untouched nodes
