@@ -17,6 +17,16 @@ SWZ_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --steps 2 --warmup 1 --cpu
 timeout 600 python tools/clustered_probe.py 100000000 MIN_DISTANCE > $OUT/clustered_100M.txt 2>> $OUT/bench.err
 timeout 600 python tools/clustered_probe.py 100000000 MIN_DISTANCE property >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
 timeout 600 python tools/clustered_probe.py 100000000 GRID_CENTER >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
+# the reference's default batch size (10 M points): 100 M points in 10 batches, through the multi-batch tiler
+for s in MIN_DISTANCE RANDOM_GRID; do
+  timeout 900 python bench.py --points 100000000 --batches 10 --sampler $s --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_100M_10batches_$s.json 2>> $OUT/bench.err
+done
+# a batch sharded over 8 and 2 contexts of this one GPU from one C++ process: MIN_DISTANCE root swept by all shards at once / in turns
+bash tools/group_bench.sh > $OUT/group_joint_root_vs_turns.txt 2>> $OUT/bench.err
+# full-size verification at the size the GPU has room for (1 B points on a 288 GB part); the test logs what it verified
+rm -f $GRAFT_REPO_ROOT/gpurun_out/fullsize_verification.log
+timeout 1500 python -m pytest tests/test_gpu_fullsize.py -q > $OUT/fullsize_pytest.txt 2>&1
+cp $GRAFT_REPO_ROOT/gpurun_out/fullsize_verification.log $OUT/fullsize_verification_1B.log 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-sample 0 > $OUT/stats_run.json 2>/dev/null
 find $OUT/stats -name "*kernel_trace*" -delete
