@@ -43,6 +43,9 @@ constexpr unsigned long long QEMPTY = ~0ull;
 constexpr uint32_t MQ_WOKEN = 0x80000000u;  // queue entry: activated by a claimed slot (or never slept): no confirm step
 constexpr int MQ_LIST_CAP = 128;            // accepted points of the neighbourhood in LDS (window)
 constexpr int MQ_FRESH_CAP = 32;            // points a cell may accept per activation
+#ifndef MQ_MINW1
+#define MQ_MINW1 6
+#endif
 constexpr uint32_t MQ_FIRST_ROUND = 2;      // record buffers start with stamps 0 and 1
 
 enum : uint8_t { QS_OPEN = 0, QS_TAKEN = 1, QS_DEAD = 2 };
@@ -257,9 +260,18 @@ struct MqLds {
   float4* fresh;  // [MQ_FRESH_CAP]: accepted in this activation
   uint8_t* tag;   // [MQ_LIST_CAP]: sharded root: which shard a list entry comes from (0 = this one)
   uint32_t* trust;  // [MQ_CHAIN]: the cells this wavefront has run earlier in the launch, one after the other (see mq_sweep_kernel)
+  uint32_t* sid;    // [32]: the adjacent cells whose records are staged (the earlier ones and the cell itself: at most mq_staged()), by rank
 };
 constexpr uint32_t MQ_CHAIN = 8;
-static inline size_t mq_lds_bytes(uint32_t rg) { return (size_t)(27u * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u + MQ_LIST_CAP + MQ_CHAIN * 4u; }
+// Records staged per activation.  A cell has at most 19 adjacent cells before it in Morton order: the order of a cell and its
+// neighbour is decided by the axis whose coordinate changes at the highest bit, a step of -1 changes a higher bit than a step of
+// +1 only along axes where the coordinate is even, so the worst case is the cell with three even coordinates, where every offset
+// with a -1 in it (27 - 8) leads to an earlier cell.  Plus the cell itself.  Records of other shards are staged whatever their
+// place in the order: all 27 there.
+__host__ __device__ constexpr uint32_t mq_staged(bool peers) { return peers ? 27u : 20u; }
+static inline size_t mq_lds_bytes(uint32_t rg, bool peers) {
+  return (size_t)(mq_staged(peers) * 2u * rg + MQ_LIST_CAP + MQ_FRESH_CAP) * 16u + MQ_LIST_CAP + MQ_CHAIN * 4u + 128u;
+}
 
 __device__ __forceinline__ bool mq_is_head(const MqArgs& a, uint32_t i) {
   if (!a.all_sampled && a.nmode[a.nid[i]] != MODE_SAMPLE) return false;
@@ -542,32 +554,39 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     pv[u] = inb ? a.qpos[p] : 0ull;
     ps[u] = inb ? a.state[p] : (uint8_t)QS_DEAD;
   }
+  // Only the earlier adjacent cells and the cell itself are looked at: their records are staged side by side, by rank.
+  const bool valid = l < 27u && nb_have && (nb_peer != 0u || nb_id <= c);
+  const uint32_t vmask = (uint32_t)__ballot(valid);
+  const uint32_t srank = (uint32_t)__popc(vmask & ((1u << (l & 31u)) - 1u));
+  const uint32_t rank13 = (uint32_t)__popc(vmask & ((1u << 13) - 1u));
+  if (valid) lds.sid[srank] = nbv;
+  __builtin_amdgcn_wave_barrier();
   // (records of another shard: bracketed by that shard's round word -- a record stamped before the round it is in NOW is
   // complete, and it stays untouched while that round lasts; when the round has moved on meanwhile the look is repeated)
   uint32_t r_before = round;
   if (PEERS && nb_peer && l < 27u) r_before = mq_ld_sys(a.peers.round_word[nb_peer - 1u]);
   {
-    const uint32_t ngran = 27u << rg2s;
-    uint4 tmp[7];
+    const uint32_t ngran = (uint32_t)__popc(vmask) << rg2s;
+    constexpr int NT = (int)(mq_staged(PEERS) * 16u + WAVE - 1u) / (int)WAVE;  // (records of 8 granules per buffer at most)
+    uint4 tmp[NT];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const uint32_t g = (uint32_t)j * WAVE + l;
-      const uint32_t n = g >> rg2s, part = g & ((1u << rg2s) - 1u);
-      const uint32_t nb = (uint32_t)__shfl((int)nbv, (int)(n < 27u ? n : 0u), WAVE);
       tmp[j] = make_uint4(0u, 0u, 0u, 0u);
-      if (PEERS) {
-        const uint32_t np = nb != QNONE ? (nb >> MQ_PEER_SHIFT) : 0u, ni = nb & MQ_ID_MASK;
-        if (g < ngran && nb != QNONE) {
+      if (g < ngran) {
+        const uint32_t nb = lds.sid[g >> rg2s], part = g & ((1u << rg2s) - 1u);
+        if (PEERS) {
+          const uint32_t np = nb >> MQ_PEER_SHIFT, ni = nb & MQ_ID_MASK;
           if (np) tmp[j] = mq_ld_sys(a.peers.rec[np - 1u] + ((size_t)ni << rg2s) + part);
-          else if (ni <= c) tmp[j] = ntrust ? mq_ld_agent(a.rec + ((size_t)ni << rg2s) + part) : a.rec[((size_t)ni << rg2s) + part];
+          else tmp[j] = ntrust ? mq_ld_agent(a.rec + ((size_t)ni << rg2s) + part) : a.rec[((size_t)ni << rg2s) + part];
+        } else {
+          // (a chained activation: the record its predecessor in the chain has just written must not come from this CU's L1)
+          tmp[j] = ntrust ? mq_ld_agent(a.rec + ((size_t)nb << rg2s) + part) : a.rec[((size_t)nb << rg2s) + part];
         }
-      } else if (g < ngran && nb != QNONE && nb <= c) {
-        // (a chained activation: the record its predecessor in the chain has just written must not come from this CU's L1)
-        tmp[j] = ntrust ? mq_ld_agent(a.rec + ((size_t)nb << rg2s) + part) : a.rec[((size_t)nb << rg2s) + part];
       }
     }
 #pragma unroll
-    for (int j = 0; j < 7; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const uint32_t g = (uint32_t)j * WAVE + l;
       if (g < ngran) lds.stage[g] = tmp[j];
     }
@@ -585,11 +604,10 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   MQ_T(t_rt2);
   MQ_TACC(1, t_rt1, t_rt2);
   // lane k < 27: adjacent cell k (13: this cell).  Of its two records the newer one written before this round.
-  const bool valid = l < 27u && nb_have && (nb_peer != 0u || nb_id <= c);
   const bool earlier = valid && l != 13u;
   uint32_t n_pos = 0, n_cnt = 0, n_end = 0, pick = 0;
   if (valid) {
-    const uint4 a0 = lds.stage[l << rg2s], a1 = lds.stage[(l << rg2s) + rg];
+    const uint4 a0 = lds.stage[srank << rg2s], a1 = lds.stage[(srank << rg2s) + rg];
     uint32_t rr = (PEERS && nb_peer) ? r_before : round;  // stamps count in the owner's rounds
     if (ntrust && !(PEERS && nb_peer)) {
       // a record this very wavefront wrote earlier in the launch is complete, whatever its stamp says to the others
@@ -607,7 +625,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   // was written in or after the round this cell last ran in (its own newest record carries that round) -- it could not
   // see that record then.  The points this cell tested last time (those below `tested`) only meet the new entries.
   const uint32_t my_last = sbuf ? h1.z : h0.z;
-  const bool k_new = valid && l != 13u && (nb_peer != 0u || (pick ? lds.stage[(l << rg2s) + rg].z : lds.stage[l << rg2s].z) >= my_last);
+  const bool k_new = valid && l != 13u && (nb_peer != 0u || (pick ? lds.stage[(srank << rg2s) + rg].z : lds.stage[srank << rg2s].z) >= my_last);
   const uint32_t incl_new = mq_wave_scan(k_new ? n_cnt : 0u, MqAdd{}, 0u);
   const uint32_t incl_old = mq_wave_scan(k_new ? 0u : n_cnt, MqAdd{}, 0u);
   const uint32_t Tnew = qb_u32(incl_new, WAVE - 1);
@@ -622,7 +640,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     for (uint32_t j = 0; j < maxcnt && j < cap; ++j) {
       const uint32_t ti = off + j;
       if (j < n_cnt && ti >= base && ti < base + (uint32_t)MQ_LIST_CAP) {
-        *reinterpret_cast<uint4*>(&lds.list[ti - base]) = lds.stage[(l << rg2s) + pick * rg + 1u + j];
+        *reinterpret_cast<uint4*>(&lds.list[ti - base]) = lds.stage[(srank << rg2s) + pick * rg + 1u + j];
         if (PEERS) lds.tag[ti - base] = (uint8_t)nb_peer;
       }
     }
@@ -940,7 +958,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   __builtin_amdgcn_wave_barrier();
   for (uint32_t j = l; j < ncnt && j < cap; j += WAVE) {
     uint4 src;
-    if (j < CNT) src = lds.stage[(13u << rg2s) + sbuf * rg + 1u + j];
+    if (j < CNT) src = lds.stage[(rank13 << rg2s) + sbuf * rg + 1u + j];
     else src = *reinterpret_cast<const uint4*>(&lds.fresh[j - CNT]);
     myrec[wb * rg + 1u + j] = src;
   }
@@ -1010,14 +1028,15 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
 }
 
 template <int U, bool PEERS>
-__global__ __launch_bounds__(WAVE, 4) void mq_sweep_kernel(MqArgs a, uint32_t round) {
+__global__ __launch_bounds__(WAVE, (U == 1 && !PEERS) ? MQ_MINW1 : 4) void mq_sweep_kernel(MqArgs a, uint32_t round) {
   extern __shared__ uint4 mq_smem[];
   MqLds lds;
   lds.stage = mq_smem;
-  lds.list = reinterpret_cast<float4*>(mq_smem + 27u * 2u * a.rg);
+  lds.list = reinterpret_cast<float4*>(mq_smem + mq_staged(PEERS) * 2u * a.rg);
   lds.fresh = lds.list + MQ_LIST_CAP;
   lds.tag = reinterpret_cast<uint8_t*>(lds.fresh + MQ_FRESH_CAP);
   lds.trust = reinterpret_cast<uint32_t*>(lds.tag + MQ_LIST_CAP);
+  lds.sid = lds.trust + MQ_CHAIN;
   const uint32_t r0 = round - MQ_FIRST_ROUND;
   const uint32_t ci = r0 % 3u, co = (r0 + 1u) % 3u, cz = (r0 + 2u) % 3u;
   if (blockIdx.x == 0) {  // the counters the round after the next will fill; this round's total for the host
@@ -1274,7 +1293,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     (void)hipEventRecord(ev0, c->stream);
   }
   // one wavefront per workgroup, as many as are resident at once (registers and LDS decide), a multiple of the segments
-  const size_t lds_bytes = mq_lds_bytes(a.rg);
+  const size_t lds_bytes = mq_lds_bytes(a.rg, sharded);
   uint32_t sweep_grid = 0;
   {
     int dev = 0, cus = 0, per_cu = 0;
