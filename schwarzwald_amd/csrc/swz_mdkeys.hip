@@ -881,6 +881,9 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
         need = (uint32_t)__ballot(earlier && n_pos < n_end && gap2 < f_hi);
       }
       bool blocked = false;
+      // (Measured and dropped, both on the 100 M clustered cloud: not scanning an adjacent cell that still has thousands of
+      // undecided points within reach but waiting for all of it -- root 105 -> 140 .. 180 ms: dense cells overlap, a cell
+      // moves on as soon as the one point that blocks it has been passed --, and the reverse, cutting long scans short.)
       while (need && !blocked) {
         const int k = __ffs((int)need) - 1;
         need &= need - 1u;
@@ -943,6 +946,8 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
       }
     }
     if (stop) break;
+    // (Measured and dropped: cells of thousands of points taking their turn in slices of 1024 .. 4096 points, so that a
+    // launch does not last as long as its longest activation -- the clustered root went 105 -> 120 .. 153 ms.)
     if (fresh == (uint32_t)MQ_FRESH_CAP && W0 + (uint32_t)U * WAVE < e) {  // (full exactly at the end of a window)
       out_pos = W0 + (uint32_t)U * WAVE;
       out_status = QO_YIELD;

@@ -16,6 +16,11 @@ k = N // 3
 xyz[:k, 2] = 0.3 + 0.05 * torch.sin(6.0 * xyz[:k, 0]) * torch.cos(4.0 * xyz[:k, 1]) + 0.0005 * torch.randn(k, dtype=torch.float64, device=dev, generator=g)
 xyz[k:2 * k] = 0.6 + 0.03 * torch.randn((k, 3), dtype=torch.float64, device=dev, generator=g)
 xyz.clamp_(0.0, 1.0)
+part = os.environ.get('PROBE_PART')  # experiments: one component of the cloud only
+if part == 'sheet': xyz = xyz[:k].contiguous()
+elif part == 'blob': xyz = xyz[k:2 * k].contiguous()
+elif part == 'uniform': xyz = xyz[2 * k:].contiguous()
+N = xyz.shape[0]
 keys = torch.empty(N, dtype=torch.int64, device=dev); perm = torch.empty(N, dtype=torch.int32, device=dev); level = torch.empty(N, dtype=torch.int8, device=dev)
 p = swz.TileParams(sampler=getattr(swz, sampler), max_points_per_node=20000, spacing_at_root=swz.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250),
                    flags=swz.FLAG_MIN_DISTANCE_PROPERTY if len(sys.argv) > 3 and sys.argv[3] == 'property' else 0)
