@@ -319,16 +319,39 @@ __global__ __launch_bounds__(256) void mq_cell_end_kernel(MqArgs a, uint32_t nce
   a.qst[c] = make_uint4(QNONE, 0u, 0u, 0u);
 }
 
-// the 26 adjacent cells by direction (codes by arithmetic on the dilated coordinates, as md_nbr_build_kernel does)
-__global__ __launch_bounds__(256) void mq_nbr_build_kernel(MqArgs a, uint32_t ncells) {
+// append `value` of every lane with want == true to the queue: one atomic per wavefront
+__device__ __forceinline__ void mq_wave_push(bool want, uint32_t value, uint32_t* qout, uint32_t* cout) {
+  const uint64_t m = __ballot(want);
+  if (!m) return;
+  const int leader = __ffsll((unsigned long long)m) - 1;
+  uint32_t base = 0;
+  if ((int)lane_id() == leader) base = atomicAdd(cout, (uint32_t)__popcll(m));
+  base = __shfl(base, leader, WAVE);
+  if (want) qout[base + (uint32_t)__popcll(m & lanemask_lt())] = value;
+}
+
+// where a level starts: the first round's queue of every node group
+struct MqStart {
+  uint32_t* queue[8];
+  uint32_t* qctr[8];
+  uint32_t groups;
+  uint32_t lazy;
+};
+
+// The 26 adjacent cells by direction (codes by arithmetic on the dilated coordinates, as md_nbr_build_kernel does), 32
+// lanes per cell -- and the start of the level, from the same lanes: not lazy, every cell is queued; lazy, only the
+// cells without an earlier adjacent cell are, and every other cell sleeps on its latest earlier neighbour until that one
+// has decided the given fraction of its points (sleeping on a cell that is not the real blocker is always safe: the cell
+// looks again when it wakes up).
+__global__ __launch_bounds__(256) void mq_nbr_build_kernel(MqArgs a, uint32_t ncells, MqStart st) {
   for (uint64_t cbase = (uint64_t)blockIdx.x * 8u; cbase < ncells; cbase += (uint64_t)gridDim.x * 8u) {
     const uint32_t c = (uint32_t)cbase + threadIdx.x / 32u;
     const uint32_t k = threadIdx.x & 31u;
-    if (c >= ncells) continue;
+    const bool in = c < ncells;
     uint32_t nb = QNONE;
-    if (k == 13u) {
+    if (in && k == 13u) {
       nb = c;
-    } else if (k < 27u) {
+    } else if (in && k < 27u) {
       const uint32_t rel = a.crel[c];
       const uint32_t all = (uint32_t)(a.cells_per_node - 1ull);
       const uint32_t mz = all & 0x09249249u, my = mz << 1, mx = mz << 2;
@@ -365,49 +388,30 @@ __global__ __launch_bounds__(256) void mq_nbr_build_kernel(MqArgs a, uint32_t nc
         }
       }
     }
-    a.qnbr[(size_t)c * 32 + k] = nb;
-  }
-}
-
-// append `value` of every lane with want == true to the queue: one atomic per wavefront
-__device__ __forceinline__ void mq_wave_push(bool want, uint32_t value, uint32_t* qout, uint32_t* cout) {
-  const uint64_t m = __ballot(want);
-  if (!m) return;
-  const int leader = __ffsll((unsigned long long)m) - 1;
-  uint32_t base = 0;
-  if ((int)lane_id() == leader) base = atomicAdd(cout, (uint32_t)__popcll(m));
-  base = __shfl(base, leader, WAVE);
-  if (want) qout[base + (uint32_t)__popcll(m & lanemask_lt())] = value;
-}
-
-// Start of a level.  lazy: only the cells without an earlier adjacent cell are queued; every other cell sleeps on its
-// latest earlier neighbour until that one has decided the given fraction of its points (sleeping on a cell that is not
-// the real blocker is always safe: the cell looks again when it wakes up).  Otherwise every cell is queued.
-__global__ __launch_bounds__(256) void mq_start_kernel(MqArgs a, uint32_t ncells, int lazy) {
-  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-  bool push = false;
-  if (c < ncells && a.csnode[c] % a.groups == a.group) {
-    push = true;
-    if (lazy) {
-      uint32_t best = QNONE, bk = 0;
-      for (uint32_t k = 0; k < 27u; ++k) {
-        const uint32_t nb = a.qnbr[(size_t)c * 32 + k];
-        if (nb != QNONE && (a.peers.shards <= 1u || (nb >> MQ_PEER_SHIFT) == 0u) && nb < c && (best == QNONE || nb > best)) {  // (cells of this shard only)
-          best = nb;
-          bk = k;
-        }
-      }
-      if (best != QNONE) {
-        push = false;
-        const uint2 o = a.cinfo[best];
+    if (in) a.qnbr[(size_t)c * 32 + k] = nb;
+    // ---- the start: the latest earlier adjacent cell of this shard (the maximum over the cell's 32 lanes)
+    uint32_t best = 0;  // id + 1
+    if (st.lazy && in && k < 27u && nb != QNONE && (a.peers.shards <= 1u || (nb >> MQ_PEER_SHIFT) == 0u) && nb < c) best = nb + 1u;
+    if (st.lazy) {
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) best = max(best, (uint32_t)__shfl_xor((int)best, off, 32));
+      if (in && best && nb + 1u == best) {  // (the one lane that holds it: the ids of adjacent cells are distinct)
+        const uint2 o = a.cinfo[best - 1u];
         const uint32_t bq = o.x + (uint32_t)((float)(o.y - 1u - o.x) * a.lazy_frac);
-        a.slot[(size_t)best * 32 + (26u - bk)] = (unsigned long long)bq;  // stamp 0: written before the first round
-        a.qst[c] = make_uint4(a.cinfo[c].x, bk, bq, 0u);
+        a.slot[(size_t)(best - 1u) * 32 + (26u - k)] = (unsigned long long)bq;  // stamp 0: written before the first round
+        a.qst[c] = make_uint4(a.cinfo[c].x, k, bq, 0u);
       }
     }
+    const bool push = in && k == 13u && best == 0u;
+    const uint32_t seg = (uint32_t)(cbase >> 3) & (a.nseg - 1u);  // (eight entries per step, spread evenly: a segment cannot overflow)
+    if (st.groups == 1u) {
+      mq_wave_push(push, c | MQ_WOKEN, st.queue[0] + (size_t)seg * a.segcap, st.qctr[0] + (size_t)seg * 32u);
+    } else {
+      const uint32_t g = push ? a.csnode[c] % st.groups : 0u;
+      for (uint32_t gg = 0; gg < st.groups; ++gg)
+        mq_wave_push(push && g == gg, c | MQ_WOKEN, st.queue[gg] + (size_t)seg * a.segcap, st.qctr[gg] + (size_t)seg * 32u);
+    }
   }
-  const uint32_t seg = blockIdx.x & (a.nseg - 1u);  // (at most 256 entries per block: a segment cannot overflow here)
-  mq_wave_push(push, c | MQ_WOKEN, a.queue[0] + (size_t)seg * a.segcap, a.qctr + (size_t)seg * 32u);
 }
 
 // ----------------------------------------------------------------------------- the sweep
@@ -1236,10 +1240,6 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
       }
     }
   }
-  hipLaunchKernelGGL(mq_nbr_build_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, a, ncells);
-  SWZ_LAUNCH_CHECK(c);
-  SWZ_STAGE(c, "mq tables");
-
   // scheduling: the same rules as the sweep on positions (swz_mindist.hip)
   const bool many_small = ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0;
   a.patient = many_small ? 1u : 0u;
@@ -1282,8 +1282,19 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
       }
       gs[g] = c->aux_streams[g - 1];
     }
-    hipLaunchKernelGGL(mq_start_kernel, dim3(cb), dim3(256), 0, c->stream, ga[g], ncells, lazy ? 1 : 0);
+  }
+  {
+    // the adjacent cells of every cell and the first round's queues, in one pass
+    MqStart start{};
+    start.groups = groups;
+    start.lazy = lazy ? 1u : 0u;
+    for (uint32_t g = 0; g < groups; ++g) {
+      start.queue[g] = ga[g].queue[0];
+      start.qctr[g] = ga[g].qctr;
+    }
+    hipLaunchKernelGGL(mq_nbr_build_kernel, dim3(std::min<uint32_t>(div_up(ncells, 8), 1u << 20)), dim3(256), 0, c->stream, ga[0], ncells, start);
     SWZ_LAUNCH_CHECK(c);
+    SWZ_STAGE(c, "mq tables");
   }
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
   if (dbg)
