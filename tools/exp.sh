@@ -1,3 +1,5 @@
 export SWZ_MD_TIME_LIMIT=20
-timeout 900 python -m pytest tests/test_min_distance_keys.py tests/test_cpp_group.py -q -m gpu -x 2>&1 | grep -E "passed|failed|Error" | tail -5
-timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 2>&1 | grep -E "ms_per_step" | tail -4 | cut -c1-250
+for cfg in "SWZ_MD_DENSITY=7" "SWZ_MD_KEYS_RG=4" "SWZ_MD_KEYS_RG=8"; do
+echo "== $cfg"
+env $cfg SWZ_DEBUG=1 timeout 200 python bench.py --steps 1 --warmup 1 --cpu-sample 0 2>&1 | grep -E "sweep|ms_per_step|sparse" | tail -6 | cut -c1-200
+done
