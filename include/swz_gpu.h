@@ -65,7 +65,12 @@ int swz_abi_version(void);
 int swz_set_stream(swz_ctx* ctx, void* hip_stream);
 /* Debug / tuning switches ("SWZ_DEBUG", "SWZ_MD_*", ...).  A context reads the SWZ_* variables
  * of the environment once, when it is created; afterwards they change only through this call (value NULL removes the
- * switch).  None of them changes a result; production code never needs them. */
+ * switch).  None of them changes a result; production code never needs them.  Two can make a call FAIL instead:
+ * SWZ_MD_PERSISTENT=1 (an experiment that needs all its workgroups resident at once; SWZ_ERR_INTERNAL when the device
+ * is shared) and the limits SWZ_MD_TIME_LIMIT / SWZ_MD_ROUND_LIMIT (a level that exceeds them is abandoned with an
+ * error).  A NEGATIVE SWZ_MD_KEYS_BAND is the one exception to "no result changes": it narrows the band in which
+ * MIN_DISTANCE repeats a compare on the exact positions below its proven width and exists so that a test can show that
+ * the band is needed (tests/test_min_distance_keys.py). */
 int swz_set_option(swz_ctx* ctx, const char* name, const char* value);
 /* Frees all device workspace held by the context (it regrows on demand). */
 int swz_release_workspace(swz_ctx* ctx);
@@ -444,7 +449,8 @@ int swz_tiler_level_positions_device(swz_tiler* tiler, int level, double* d_xyz_
  *   swz_group_tile: d_xyz[s] / n[s] are the points that currently lie on shard s's device (any octants; clamped in
  *     place), d_attrs (may be NULL) is an array of num_shards column sets: d_attrs[s] holds shard s's attribute
  *     columns (device, n[s] rows; the same attributes on every shard), which travel with the points.  One host thread per shard: encode, group by destination, ONE exchange step, root node (for
- *     MIN_DISTANCE the chain of ghosts from lower to higher shards), levels.  results[s] describes what shard s
+ *     MIN_DISTANCE swept by all shards at once, cells at a lower octant's face reading that shard's records through peer
+ *     access -- cubic bounds, one address space; otherwise the chain of ghosts from lower to higher shards), levels.  results[s] describes what shard s
  *     ended up with, exactly as swz_shard_finish_device does: device pointers owned by the shard's context, valid
  *     until the group's next call.  ACCURATE strategy, exact samplers.
  *   swz_group_ctx: the shard's context, e.g. for swz_copy_to_host, swz_build_node_lists_device or
@@ -477,14 +483,19 @@ int swz_group_tile(swz_group* group, double* const* d_xyz, const swz_attribute_c
  * exchange step of the point rows and of every attribute column, then the root node -- its take-all / sample decision
  * uses the counts of the whole root, and for MIN_DISTANCE the shards take turns with the lower shards' root files as
  * ghosts -- and, without communication, the levels below.
- *   swz_group_tiler_open / _close: creates / destroys the shards' tilers (ACCURATE strategy, exact samplers).
+ *   swz_group_tiler_open / _close: creates / destroys the shards' tilers (ACCURATE or FAST strategy, exact samplers).
+ *     FAST: per batch every shard adds the prefix histogram of its keys, the sum over the shards gives the start level the
+ *     single tiler would choose (TilingAlgorithms.cpp:1473-1535), the levels below it run per shard.
  *   swz_group_add_batch: d_xyz[s] / n[s] / d_attrs[s] as in swz_group_tile; stats (may be NULL) receives one entry per shard.
  *   swz_group_stage_batch / swz_group_tile_staged: the same from PINNED host memory -- the copies of batch k + 1 run on a
  *     copy stream per shard (hipMemcpyAsync) beside the kernels of batch k; at most two batches are staged.
- *   swz_group_finalize: ends the data set (FAST would reconstruct here; ACCURATE has nothing left to do).
+ *   swz_group_finalize: ends the data set.  FAST rebuilds the skipped levels: each shard those of its octants down to
+ *     level 0, shard 0 the root from the level-0 files of all shards (TilingAlgorithms.cpp:1661-1784); ACCURATE has
+ *     nothing left to do.
  *   swz_group_tiler: shard s's tiler, for swz_tiler_node_table / _export_device / _pools_device / _get_info.  The
  *     root's file is the concatenation of the shards' parts in shard order.
- * A batch that fails on one shard poisons every shard's tiler (swz_tiler_poison). */
+ * Every exchange is preceded by a status vote: a shard that failed makes all shards skip the step and return its error
+ * (nobody waits for a peer that is gone).  A batch that fails on one shard poisons every shard's tiler (swz_tiler_poison). */
 int swz_group_tiler_open(swz_group* group, const double bounds_min[3], const double bounds_max[3], const swz_tile_params* params,
                          uint64_t capacity_hint_per_shard);
 int swz_group_tiler_close(swz_group* group);

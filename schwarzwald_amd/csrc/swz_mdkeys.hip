@@ -43,6 +43,9 @@ constexpr unsigned long long QEMPTY = ~0ull;
 constexpr uint32_t MQ_WOKEN = 0x80000000u;  // queue entry: activated by a claimed slot (or never slept): no confirm step
 constexpr int MQ_LIST_CAP = 128;            // accepted points of the neighbourhood in LDS (window)
 constexpr int MQ_FRESH_CAP = 32;            // points a cell may accept per activation
+#ifndef MQ_MINW4
+#define MQ_MINW4 4
+#endif
 #ifndef MQ_MINW1
 #define MQ_MINW1 6
 #endif
@@ -1037,7 +1040,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
 }
 
 template <int U, bool PEERS>
-__global__ __launch_bounds__(WAVE, (U == 1 && !PEERS) ? MQ_MINW1 : 4) void mq_sweep_kernel(MqArgs a, uint32_t round) {
+__global__ __launch_bounds__(WAVE, (U == 1 && !PEERS) ? MQ_MINW1 : ((U == 4 && !PEERS) ? MQ_MINW4 : 4)) void mq_sweep_kernel(MqArgs a, uint32_t round) {
   extern __shared__ uint4 mq_smem[];
   MqLds lds;
   lds.stage = mq_smem;

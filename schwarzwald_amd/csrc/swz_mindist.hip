@@ -847,8 +847,11 @@ __global__ __launch_bounds__(256) void md_commit_requeue_kernel(MdArgs a, uint32
 // over a thousand dependent rounds.  Here one workgroup per CU stays resident and the three steps of a round are
 // separated by grid barriers instead: every workgroup releases its stores at agent scope (buffer_wbl2), arrives on one
 // monotonic counter, polls it relaxed, and acquires (buffer_inv) -- cdna_hip_programming.md Guideline 16 in its counter
-// form; the state words are zeroed by the host before every launch and every spin is bounded (a workgroup that is not
-// resident would otherwise hang the others: the launch gives up and the host continues with plain launches).
+// form; the state words are zeroed by the host before every launch and every spin is bounded: a workgroup that is not
+// resident -- another context's kernels or a staged copy kernel on the device are enough -- would otherwise hang the
+// others.  When a spin runs out the launch gives up and the CALL FAILS with SWZ_ERR_INTERNAL (the steps of a round are
+// not restartable, so there is no falling back to plain launches): SWZ_MD_PERSISTENT=1 is an experiment switch that
+// never changes a result but may fail a call; it is off by default and slower than the plain rounds.
 struct MdBarrier {
   uint32_t arrived;   // monotonic over the launch
   uint32_t timeout;   // set when a spin ran out
