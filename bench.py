@@ -62,6 +62,14 @@ def parse_args():
                     "PINNED HOST memory through swz_tiler_stage_batch / swz_tiler_tile_staged (hipMemcpyAsync of batch "
                     "k+1 under the kernels of batch k; attribute columns of --payload travel along); reported under "
                     "\"staged\" (PCIe-inclusive, never `value`)")
+    ap.add_argument("--driver", default="torch", choices=["torch", "group"], help="with --gpus N: torch = one process per "
+                    "GPU (torch.distributed over RCCL, schwarzwald_amd/sharded.py; what the round's scaling run uses); group = "
+                    "ONE C++ process for all GPUs (swz_group_*, tools/group_bench.cpp: the shape of the reference's own host), "
+                    "started as a child process; with --batches k through swz_group_add_batch / swz_group_finalize")
+    ap.add_argument("--group-transport", default="rccl", choices=["rccl", "peer"], help="--driver group: exchange by grouped "
+                    "ncclSend / ncclRecv or by hipMemcpyPeerAsync (peer copies also work with all shards on ONE device)")
+    ap.add_argument("--group-devices", type=int, default=0, help="--driver group: devices the shards are dealt to (0 = as "
+                    "many as there are shards; 1 = all shards share device 0, the only way to run it on a one-GPU box)")
     return ap.parse_args()
 
 
@@ -105,6 +113,59 @@ def launch_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd).returncode
+
+
+def run_group_driver(args):
+    """`--driver group`: the sharded batch driven from ONE C++ process (swz_group_*).  Builds tools/group_bench.cpp against
+    the library, runs it as a child (this process never touches a GPU) and reports its wall times in the usual line."""
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.abspath(__file__))
+    shards = args.gpus
+    if shards not in (1, 2, 4, 8):
+        sys.stderr.write("bench.py --driver group: 1, 2, 4 or 8 shards\n")
+        return 2
+    devices = args.group_devices or shards
+    have = visible_gpus()
+    if have is not None and have < devices:
+        sys.stderr.write("bench.py: --driver group wants %d device(s) but only %d GPU(s) visible (--group-devices 1 puts all "
+                         "shards on one)\n" % (devices, have))
+        return 2
+    transport = 1 if (args.group_transport == "rccl" and devices == shards) else 0  # RCCL needs one device per shard
+    lib_dir = os.path.join(root, "schwarzwald_amd", "lib")
+    exe = os.path.join(tempfile.mkdtemp(prefix="swz_group_bench_"), "group_bench")
+    subprocess.run(["g++", "-std=c++17", "-O2", os.path.join(root, "tools", "group_bench.cpp"), "-o", exe, "-L" + lib_dir,
+                    "-lswz_gpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    sampler = ["RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED"].index(args.sampler)
+    cmd = [exe, str(shards), str(args.points), str(args.warmup + args.steps), str(devices), str(transport), str(args.batches),
+           str(sampler), "1" if args.strategy == "FAST" else "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    sys.stderr.write(r.stderr)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        return r.returncode
+    ms = [float(line.split(" points: ")[1].split(" ms")[0]) for line in r.stdout.splitlines() if line.startswith("rep ")]
+    timed = ms[args.warmup:]
+    if len(timed) != args.steps:
+        sys.stderr.write("bench.py --driver group: expected %d timed steps, the driver reported %d\n" % (args.steps, len(timed)))
+        return 1
+    total_ms = sum(timed)
+    line = {
+        "metric": "Mpoints/s end-to-end tile (Morton+sort+sample)", "value": round(shards * args.points * args.steps / total_ms / 1e3, 3),
+        "unit": "Mpoints/s", "n_gpus": shards, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 keys / f64 positions", "data": "synthetic",
+        "config": {"workload": "%d uniform points per shard in the unit cube, %s sampling, spacing = diagonal/250, "
+                               "max_points_per_node=20000, %s strategy, %d batch(es)" % (args.points, args.sampler, args.strategy, args.batches),
+                   "points_per_gpu": args.points, "sampler": args.sampler, "strategy": args.strategy, "batches": args.batches,
+                   "parallelism": "%d shards on %d device(s), ONE C++ process (swz_group_%s), exchange by %s" % (
+                       shards, devices, "add_batch" if args.batches > 1 else "tile", "RCCL send/recv" if transport else "peer copies")},
+        "driver": "group", "timed_region": "wall clock of the whole call(s) inside the child process: encode, partition, exchange, "
+                                           "sort, root, levels (inputs resident on the shards' devices)",
+        "steps_ms": [round(x, 3) for x in timed], "roofline": None, "cpu_baseline": None,
+        "driver_output": r.stdout.splitlines()[-min(len(ms), 3):],
+    }
+    print(json.dumps(line))
+    return 0
 
 
 def algorithmic_bytes_per_point(sampler, visit_factor):
@@ -254,6 +315,8 @@ def multibatch_leg(args, ctx, swz, torch, dev, xyz, n, bmin, bmax, params):
 
 def main():
     args = parse_args()
+    if args.driver == "group":
+        sys.exit(run_group_driver(args))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus and os.environ.get("SWZ_BENCH_FORCE_SHARDED") != "1":

@@ -393,6 +393,16 @@ int swz_tiler_add_batch(swz_tiler* tiler, const double* xyz_host, uint64_t n, co
                         swz_tile_stats* stats);
 int swz_tiler_finalize(swz_tiler* tiler, swz_tile_stats* stats);
 int swz_tiler_get_info(swz_tiler* tiler, swz_tiler_info* info);
+/* SPILL.  The pools (24 bytes + the attribute rows of every point of the data set, by point id) are the bulk of a
+ * tiler's memory.  When they cannot grow in device memory -- hipMalloc is out of memory, or the context's workspace
+ * would pass SWZ_TILER_DEVICE_BUDGET_MB -- they move to page-locked host memory that is mapped into the device's address
+ * space, and the kernels keep reading and writing them in place over the host link (a batch's own points once, the
+ * cached points a batch pulls in, by id; the attribute columns only when files are exported).  Results do not change;
+ * swz_tiler_pools_device then hands out device-accessible HOST pointers.  The node store (12 bytes per stored point and
+ * side) stays in device memory.  Option SWZ_TILER_SPILL: "auto" (default), "host" (from the start), "off" (fail with
+ * SWZ_ERR_HIP as before).  Replaces nothing in the reference, whose node files live on disk between batches
+ * (core/tiling/TilingAlgorithms.cpp:50-109); this is what bounds the size of a data set per GPU here. */
+int swz_tiler_pool_residency(swz_tiler* tiler, uint64_t* device_bytes_out, uint64_t* host_bytes_out);
 int swz_tiler_export_device(swz_tiler* tiler, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out);
 int swz_tiler_node_table(swz_tiler* tiler, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
                          uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out);

@@ -341,6 +341,7 @@ def load_library():
     L.swz_tiler_shard_finish.argtypes = [vp, C.POINTER(_TileStats)]
     L.swz_tiler_level_count.argtypes = [vp, C.c_int, _u64p]
     L.swz_tiler_poison.argtypes = [vp, C.c_char_p]
+    L.swz_tiler_pool_residency.argtypes = [vp, _u64p, _u64p]
     L.swz_tiler_level_positions_device.argtypes = [vp, C.c_int, vp]
     L.swz_host_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(vp)]
     L.swz_host_free_pinned.argtypes = [vp]
@@ -360,7 +361,7 @@ def load_library():
                  "swz_tiler_finalize", "swz_tiler_get_info", "swz_tiler_export_device", "swz_tiler_node_table",
                  "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned",
                  "swz_tiler_shard_begin_device", "swz_tiler_shard_finish", "swz_tiler_level_count",
-                 "swz_tiler_level_positions_device", "swz_tiler_poison"):
+                 "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -642,6 +643,12 @@ class Tiler:
     def poison(self, why="poisoned by the caller"):
         """Marks the tiler failed (what a failing batch does by itself): every later call raises ERR_TILER_FAILED."""
         self._ctx._check(self._lib.swz_tiler_poison(self._t, why.encode()))
+
+    def pool_residency(self):
+        """(bytes of the pools in device memory, bytes spilled to mapped page-locked host memory)"""
+        dev, host = C.c_uint64(), C.c_uint64()
+        self._ctx._check(self._lib.swz_tiler_pool_residency(self._t, C.byref(dev), C.byref(host)))
+        return int(dev.value), int(host.value)
 
     def close(self):
         if getattr(self, "_t", None):

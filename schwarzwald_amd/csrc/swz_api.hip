@@ -13,9 +13,7 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
   if (b.cap < bytes) {
     if (b.ptr) {
       SWZ_HIP(this, hipStreamSynchronize(stream));
-      SWZ_HIP(this, hipFree(b.ptr));
-      b.ptr = nullptr;
-      b.cap = 0;
+      free_buf(b);
     }
     // a little head-room so slowly growing requests do not reallocate every call
     size_t want = bytes + bytes / 16;
@@ -34,11 +32,7 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
       for (auto& kv : bufs) {
         const std::string& nm = kv.first;
         const bool level_scratch = nm.compare(0, 3, "md_") == 0 || nm.compare(0, 3, "sp_") == 0 || nm.compare(0, 3, "pm_") == 0;
-        if (level_scratch && kv.second.ptr && kv.second.epoch < scratch_epoch && &kv.second != &b) {
-          (void)hipFree(kv.second.ptr);
-          kv.second.ptr = nullptr;
-          kv.second.cap = 0;
-        }
+        if (level_scratch && kv.second.ptr && kv.second.epoch < scratch_epoch && &kv.second != &b) free_buf(kv.second);
       }
       e = hipMalloc(&b.ptr, want);
     }
@@ -48,6 +42,7 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
       std::vector<std::pair<size_t, std::string>> held;
       size_t total = 0;
       for (const auto& kv : bufs) {
+        if (kv.second.host) continue;
         total += kv.second.cap;
         if (kv.second.cap) held.emplace_back(kv.second.cap, kv.first);
       }
@@ -75,14 +70,28 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
 
 void swz_ctx::release_all() {
   if (stream) (void)hipStreamSynchronize(stream);
-  for (auto& kv : bufs)
-    if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+  for (auto& kv : bufs) free_buf(kv.second);
   bufs.clear();
+}
+
+void swz_ctx::free_buf(swz::DevBuf& b) {
+  if (b.ptr) (void)(b.host ? hipHostFree(b.ptr) : hipFree(b.ptr));
+  b.ptr = nullptr;
+  b.cap = 0;
+  b.host = false;
 }
 
 uint64_t swz_ctx::held_bytes() const {
   uint64_t s = 0;
-  for (const auto& kv : bufs) s += kv.second.cap;
+  for (const auto& kv : bufs)
+    if (!kv.second.host) s += kv.second.cap;
+  return s;
+}
+
+uint64_t swz_ctx::held_host_bytes() const {
+  uint64_t s = 0;
+  for (const auto& kv : bufs)
+    if (kv.second.host) s += kv.second.cap;
   return s;
 }
 

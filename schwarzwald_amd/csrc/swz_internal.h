@@ -20,6 +20,7 @@ struct DevBuf {
   void* ptr = nullptr;
   size_t cap = 0;
   uint64_t epoch = 0;  // swz_ctx::scratch_epoch at the last get()
+  bool host = false;   // page-locked host memory mapped into the device's address space (a spilled pool of swz_tiler)
 };
 
 struct KernelStat {
@@ -72,7 +73,9 @@ struct swz_ctx {
     return get(name, count * sizeof(T), reinterpret_cast<void**>(out));
   }
   void release_all();
-  uint64_t held_bytes() const;
+  void free_buf(swz::DevBuf& b);   // device or mapped host memory, whichever it is
+  uint64_t held_bytes() const;      // device memory only
+  uint64_t held_host_bytes() const; // spilled to page-locked host memory
 
   // ---- timing: bracket [begin, end) launches of one kernel class with events when profiling
   hipEvent_t take_event();

@@ -592,6 +592,342 @@ __global__ __launch_bounds__(256) void grid_resolve_kernel(const TileSummary* __
   if (i != NONE) taken[i] = 1;
 }
 
+// ----------------------------------------------------------------------------- GRID_CENTER / JITTERED on key coordinates
+// The arg-min above reads every point's position (24 bytes, in Morton order: a gather of the whole batch after the sort).
+// But the Morton key IS the position, quantised to 2^-21 of the bounds per axis (calculate_morton_index,
+// OctreeAlgorithms.h:64-87): a point with key coordinate i lies in [i, i + 1] key cells, so its distance to a target is
+// known to +- half a cell per axis from the key alone.  Per grid cell the kernel below keeps the point with the smallest
+// UPPER bound of that distance, that point's lower bound, and the smallest lower bound among all the others: when even
+// that exceeds the leader's upper bound the leader is the arg-min whatever the exact positions are (and the first one:
+// equal distances would overlap).  Otherwise -- two points whose distances to the target differ by less than the
+// quantisation -- the run goes on a list and a second kernel repeats it with the reference's own arithmetic (target from
+// the halving chain of the bounds, sq_dist in double on the ORIGINAL positions, read through the permutation;
+// Sampling.h:387-403 / :741-750).  No position is moved; runs of one point (most runs of the deeper levels) never need it.
+// hk = 0.5 + slack: the slack covers the rounding of the encoder's (p - min) * scale (1e-9 cells) and the difference
+// between the ideal target and the reference's, computed from bounds that went through up to 21 halvings (make_grid_keys).
+struct KAgg {
+  float ub, lb;    // leader: upper / lower bound of its squared distance (in units of the widest key cell, squared)
+  float m2;        // smallest lower bound among the run's other points
+  uint32_t i;      // leader (first one with the smallest upper bound)
+  uint32_t start;  // the run's first point, NONE when it lies before the covered range
+  uint32_t f;      // 1 when a run start lies inside the covered range
+};
+__device__ __forceinline__ KAgg kagg_combine(KAgg a, KAgg b) {  // a covers earlier points than b; selects only
+  const bool bwin = b.ub < a.ub || (b.ub == a.ub && b.i < a.i);
+  const bool bf = b.f != 0;
+  const float l_lb = bwin ? a.lb : b.lb;
+  KAgg r;
+  r.ub = (bf || bwin) ? b.ub : a.ub;
+  r.lb = (bf || bwin) ? b.lb : a.lb;
+  r.i = (bf || bwin) ? b.i : a.i;
+  r.m2 = bf ? b.m2 : fminf(fminf(a.m2, b.m2), l_lb);
+  r.start = bf ? b.start : a.start;
+  r.f = a.f | b.f;
+  return r;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ KAgg kagg_dpp_step(KAgg v) {
+  const int inf = 0x7F800000;
+  KAgg o;
+  o.ub = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v.ub), CTRL, ROW_MASK, 0xF, false));
+  o.lb = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v.lb), CTRL, ROW_MASK, 0xF, false));
+  o.m2 = __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v.m2), CTRL, ROW_MASK, 0xF, false));
+  o.i = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v.i, CTRL, ROW_MASK, 0xF, false);
+  o.start = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v.start, CTRL, ROW_MASK, 0xF, false);
+  o.f = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.f, CTRL, ROW_MASK, 0xF, false);
+  return kagg_combine(o, v);
+}
+__device__ __forceinline__ KAgg kagg_wave_incl_scan(KAgg v) {
+  v = kagg_dpp_step<0x111, 0xF>(v);
+  v = kagg_dpp_step<0x112, 0xF>(v);
+  v = kagg_dpp_step<0x114, 0xF>(v);
+  v = kagg_dpp_step<0x118, 0xF>(v);
+  v = kagg_dpp_step<0x142, 0xA>(v);
+  v = kagg_dpp_step<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ KAgg kagg_identity() { return KAgg{__builtin_inff(), __builtin_inff(), __builtin_inff(), NONE, NONE, 0u}; }
+
+struct KTileSummary {
+  KAgg head;          // leading partial run (continues a run of the previous tile), if the first point is no start
+  KAgg tail;          // trailing run that starts in this tile and continues into the next one (tail.start: where)
+  uint32_t head_end;  // where the leading partial run ends: the tile's first run start, or the tile's end
+  uint32_t has_start;
+  uint32_t last_open;
+  uint32_t pad;
+};
+
+struct GridKeys {
+  float w[3];   // key cell width per axis relative to the widest one
+  double hk;    // half a key cell plus the slack (see above)
+  uint2* amb;   // runs the keys cannot decide: {first, end} active index
+  uint32_t* amb_count;
+};
+
+// a run is closed: the leader is taken, or the run goes to the exact pass
+__device__ __forceinline__ void kagg_close(const KAgg& r, uint32_t end, const GridKeys& gk, uint8_t* __restrict__ taken) {
+  if (r.i == NONE) return;
+  if (r.m2 <= r.ub && r.ub < __builtin_inff()) {
+    const uint32_t at = atomicAdd(gk.amb_count, 1u);
+    gk.amb[at] = make_uint2(r.start, end);
+  } else {
+    taken[r.i] = 1;
+  }
+}
+
+__global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
+  const uint64_t* __restrict__ akey, uint32_t m, const uint32_t* __restrict__ nid, const uint8_t* __restrict__ nmode, GridParams g,
+  GridKeys gk, uint32_t node_shift, uint8_t* __restrict__ taken, KTileSummary* __restrict__ summaries, uint32_t* __restrict__ counters) {
+  __shared__ KAgg wave_tot[GA_THREADS / WAVE];
+  const uint32_t tid = threadIdx.x, w = tid / WAVE, l = lane_id();
+  const uint32_t tile_base = blockIdx.x * GA_TILE;
+  const uint32_t tile_end = (m - tile_base) < (uint32_t)GA_TILE ? m : tile_base + GA_TILE;
+  const uint32_t last_valid = tile_end - 1;
+  const uint32_t first = tile_base + tid * GA_IPT;
+  const bool all_sampled = counters[CTR_SAMPLE_NODES] == counters[CTR_NUM_NODES];
+
+  uint64_t key[GA_IPT];
+  bool sample[GA_IPT];
+  uint64_t prev_key = 0;
+  bool have_prev = false;
+  if (first < tile_end && first > 0) {
+    prev_key = akey[first - 1];
+    have_prev = true;
+  }
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gc = first + j < tile_end ? first + j : last_valid;
+    key[j] = akey[gc];
+    sample[j] = all_sampled || nmode[nid[gc]] == MODE_SAMPLE;
+  }
+  JitNode jn[GA_IPT];
+  if (g.sampler != SWZ_GRID_CENTER) {  // what JITTERED derives from the node's box: grid size, levels, error (as above)
+    if (g.jit_table) {
+      const uint32_t tsh = g.level < 0 ? 63u : level_shift(g.level);
+#pragma unroll
+      for (int j = 0; j < GA_IPT; ++j) jn[j] = g.jit_table[key[j] >> tsh];
+    } else {
+      Box kb[GA_IPT];
+      if (g.table_depth > 0) {
+        const uint32_t tsh = level_shift(g.table_depth - 1);
+#pragma unroll
+        for (int j = 0; j < GA_IPT; ++j) kb[j] = g.box_table[key[j] >> tsh];
+      } else {
+#pragma unroll
+        for (int j = 0; j < GA_IPT; ++j) kb[j] = g.root;
+      }
+      bounds_from_keys<GA_IPT>(key, g.table_depth, g.level + 1, kb);
+#pragma unroll
+      for (int j = 0; j < GA_IPT; ++j) jn[j] = jitter_node(kb[j], g.spacing_node, g.level);
+    }
+  }
+
+  float ub[GA_IPT], lb[GA_IPT];
+  bool head[GA_IPT];
+  uint32_t last_csh = node_shift;
+  uint64_t last_key = 0;
+  bool any_head = false;
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gi = first + j;
+    ub[j] = __builtin_inff();
+    lb[j] = __builtin_inff();
+    head[j] = false;
+    if (gi < tile_end) {
+      uint32_t csh = node_shift;
+      if (sample[j]) {
+        int err = 0;
+        // offset of the point's key cell centre from the target, per axis, in key cells
+        double ox = 0, oy = 0, oz = 0;
+        const uint32_t ix = (uint32_t)contract_bits_by_3(key[j] >> 2), iy = (uint32_t)contract_bits_by_3(key[j] >> 1),
+                       iz = (uint32_t)contract_bits_by_3(key[j]);
+        if (g.sampler == SWZ_GRID_CENTER) {
+          csh = level_shift(g.cand);
+          const uint32_t sbits = csh / 3u, mask = (1u << sbits) - 1u;
+          const double half = ldexp(1.0, (int)sbits - 1);  // (0.5 for a cell one key cell wide)
+          ox = (double)(ix & mask) + 0.5 - half;
+          oy = (double)(iy & mask) + 0.5 - half;
+          oz = (double)(iz & mask) + 0.5 - half;
+        } else {
+          err = jn[j].err;
+          if (!err) {
+            const uint32_t levels = jn[j].levels, cells = jn[j].cells;
+            csh = level_shift((int)((uint32_t)g.level + levels));
+            const uint32_t sbits = csh / 3u, mask = (1u << sbits) - 1u, gmask = cells - 1u;
+            const uint32_t gx = (ix >> sbits) & gmask, gy = (iy >> sbits) & gmask, gz = (iz >> sbits) & gmask;  // to_grid_index
+            const uint8_t* table;
+            uint32_t width;
+            if (cells <= 16) {
+              table = PERMUTATIONS_16;
+              width = 16;
+            } else if (cells <= 32) {
+              table = PERMUTATIONS_32;
+              width = 32;
+            } else {
+              table = PERMUTATIONS_64;
+              width = 64;
+            }
+            const uint32_t plen_mask = (cells < 64 ? cells : 64) - 1u;
+            const uint32_t s0 = g.jitter_start, s1 = (g.jitter_start + 1) % 16, s2 = (g.jitter_start + 2) % 16;
+            const uint32_t px = (uint32_t)table[s0 * width + ((gy + gz) & plen_mask)] - 1u;
+            const uint32_t py = (uint32_t)table[s1 * width + ((gx + gz) & plen_mask)] - 1u;
+            const uint32_t pz = (uint32_t)table[s2 * width + ((gx + gy) & plen_mask)] - 1u;
+            const double perm = ldexp(1.0, (int)sbits - (int)levels);  // perm_size = cell_size / cells, in key cells
+            ox = (double)(ix & mask) + 0.5 - (double)px * perm;
+            oy = (double)(iy & mask) + 0.5 - (double)py * perm;
+            oz = (double)(iz & mask) + 0.5 - (double)pz * perm;
+          }
+        }
+        if (err) {
+          atomicMax(&counters[CTR_ERROR], (uint32_t)err);
+          csh = node_shift;
+        } else {
+          const double ax = fabs(ox), ay = fabs(oy), az = fabs(oz);
+          const double lx = fmax(ax - gk.hk, 0.0) * gk.w[0], ly = fmax(ay - gk.hk, 0.0) * gk.w[1], lz = fmax(az - gk.hk, 0.0) * gk.w[2];
+          const double ux = (ax + gk.hk) * gk.w[0], uy = (ay + gk.hk) * gk.w[1], uz = (az + gk.hk) * gk.w[2];
+          // (rounded outwards: the conversions to float are off by 6e-8 relative at most)
+          lb[j] = (float)((lx * lx + ly * ly + lz * lz) * (1.0 - 0x1.0p-22));
+          ub[j] = (float)((ux * ux + uy * uy + uz * uz) * (1.0 + 0x1.0p-22));
+        }
+      } else {
+        taken[gi] = 1;  // take-all node
+      }
+      head[j] = !have_prev || ((key[j] >> csh) != (prev_key >> csh));
+      any_head |= head[j];
+      prev_key = key[j];
+      have_prev = true;
+      last_csh = csh;
+      last_key = key[j];
+    }
+  }
+
+  // thread aggregate over its items, then block-wide exclusive segmented scan
+  KAgg a = kagg_identity();
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gi = first + j;
+    if (gi < tile_end) {
+      KAgg it{ub[j], lb[j], __builtin_inff(), gi, head[j] ? gi : NONE, head[j] ? 1u : 0u};
+      a = kagg_combine(a, it);
+    }
+  }
+  const KAgg incl = kagg_wave_incl_scan(a);
+  if (l == WAVE - 1) wave_tot[w] = incl;
+  KAgg excl;
+  excl.ub = __shfl_up(incl.ub, 1, WAVE);
+  excl.lb = __shfl_up(incl.lb, 1, WAVE);
+  excl.m2 = __shfl_up(incl.m2, 1, WAVE);
+  excl.i = __shfl_up(incl.i, 1, WAVE);
+  excl.start = __shfl_up(incl.start, 1, WAVE);
+  excl.f = __shfl_up(incl.f, 1, WAVE);
+  if (l == 0) excl = kagg_identity();
+  const int tile_has_start = __syncthreads_or(any_head ? 1 : 0);
+  KAgg carry = kagg_identity();
+#pragma unroll
+  for (uint32_t i = 0; i + 1 < (uint32_t)(GA_THREADS / WAVE); ++i) {
+    const KAgg cc = kagg_combine(carry, wave_tot[i]);
+    if (i < w) carry = cc;
+  }
+  carry = kagg_combine(carry, excl);
+
+  // second pass: close runs, emit winners / undecided runs / partial aggregates
+  KAgg run = carry;
+  KTileSummary* sum = &summaries[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < GA_IPT; ++j) {
+    const uint32_t gi = first + j;
+    if (gi < tile_end) {
+      if (head[j] && gi != tile_base) {  // the run ending at gi - 1 closes inside this tile
+        if (run.f) {
+          kagg_close(run, gi, gk, taken);
+        } else {
+          sum->head = run;
+          sum->head_end = gi;
+        }
+      }
+      KAgg it{ub[j], lb[j], __builtin_inff(), gi, head[j] ? gi : NONE, head[j] ? 1u : 0u};
+      run = kagg_combine(run, it);
+      if (gi == last_valid) {
+        const bool last_open = (tile_end < m) && ((akey[tile_end] >> last_csh) == (last_key >> last_csh));
+        if (!last_open) {
+          if (run.f) {
+            kagg_close(run, tile_end, gk, taken);
+          } else {
+            sum->head = run;
+            sum->head_end = tile_end;
+          }
+        } else if (run.f) {
+          sum->tail = run;
+        } else {
+          sum->head = run;
+          sum->head_end = tile_end;
+        }
+        sum->has_start = (uint32_t)tile_has_start;
+        sum->last_open = last_open ? 1u : 0u;
+      }
+    }
+  }
+}
+
+// runs that cross tile borders: the thread of the tile in which the run starts walks forward
+__global__ __launch_bounds__(256) void grid_resolve_keys_kernel(const KTileSummary* __restrict__ summaries, uint32_t ntiles, GridKeys gk,
+                                                                uint8_t* __restrict__ taken) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  if (!(summaries[t].has_start && summaries[t].last_open)) return;
+  KAgg run = summaries[t].tail;
+  uint32_t end = 0;
+  for (uint32_t u = t + 1; u < ntiles; ++u) {
+    const KAgg h = summaries[u].head;  // (no run start inside: it continues this run)
+    run = kagg_combine(run, h);
+    end = summaries[u].head_end;
+    if (summaries[u].has_start || !summaries[u].last_open) break;
+  }
+  kagg_close(run, end, gk, taken);
+}
+
+// the runs the keys could not decide, one wavefront each, with the reference's arithmetic on the original positions
+__global__ __launch_bounds__(256) void grid_exact_runs_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ aidx,
+                                                              const double* __restrict__ xyz, const uint32_t* __restrict__ perm,
+                                                              GridParams g, GridKeys gk, uint8_t* __restrict__ taken) {
+  const uint32_t l = lane_id();
+  const uint32_t nruns = *gk.amb_count;
+  for (uint32_t r = blockIdx.x * (256u / WAVE) + threadIdx.x / WAVE; r < nruns; r += gridDim.x * (256u / WAVE)) {
+    const uint2 se = gk.amb[r];
+    double best = __builtin_inf();
+    uint32_t besti = NONE;
+    for (uint32_t i = se.x + l; i < se.y; i += WAVE) {
+      const uint64_t key = akey[i];
+      const uint32_t o = perm[aidx ? aidx[i] : i];
+      const double px = xyz[(size_t)o * 3], py = xyz[(size_t)o * 3 + 1], pz = xyz[(size_t)o * 3 + 2];
+      const Box kb = bounds_from_key(key, g.root, cell_box_depth(g));
+      double tx = 0, ty = 0, tz = 0;
+      if (g.sampler == SWZ_GRID_CENTER) {
+        grid_center_target(kb, tx, ty, tz);
+      } else {
+        const JitNode n = jitter_node(kb, g.spacing_node, g.level);
+        uint32_t csh;
+        jitter_target(g, key, n, csh, tx, ty, tz);
+      }
+      const double d = sq_dist(px, py, pz, tx, ty, tz);
+      if (agg_less(d, i, best, besti)) {
+        best = d;
+        besti = i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(best, off, WAVE);
+      const uint32_t oi = (uint32_t)__shfl_xor((int)besti, off, WAVE);
+      if (agg_less(od, oi, best, besti)) {
+        best = od;
+        besti = oi;
+      }
+    }
+    if (l == 0 && besti != NONE) taken[besti] = 1;
+  }
+}
+
 // ----------------------------------------------------------------------------- compaction (K5)
 __global__ __launch_bounds__(256) void keep_flags_kernel(const uint8_t* __restrict__ taken, uint32_t m,
                                                          uint32_t* __restrict__ flags) {
@@ -706,6 +1042,38 @@ LevelPlan make_plan(int level, int sampler, uint64_t max_points, float spacing_a
   return p;
 }
 
+// GRID_CENTER / JITTERED: can this level be decided on key coordinates?  Needs the original positions and the
+// permutation for the undecided runs; JITTERED additionally cubic bounds (its grid cells are cubes of the node's x-extent
+// along every axis, Sampling.h:621-668: with other bounds its targets do not sit where the key cells put them).
+// SWZ_GRID_KEYS=0 switches it off; SWZ_GRID_KEYS_SLACK adds to the slack (tests: a huge one sends every run of more than
+// one point through the exact pass, a negative one must change results).
+bool grid_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, GridKeys* out) {
+  if (plan.sampler != SWZ_GRID_CENTER && plan.sampler != SWZ_JITTERED) return false;
+  if (!sp.xyz || !sp.perm) return false;
+  if (const char* e = c->opt("SWZ_GRID_KEYS"))
+    if (atoi(e) == 0) return false;
+  const double ext[3] = {plan.root.maxx - plan.root.minx, plan.root.maxy - plan.root.miny, plan.root.maxz - plan.root.minz};
+  if (!(ext[0] > 0.0) || !(ext[1] > 0.0) || !(ext[2] > 0.0)) return false;
+  if (plan.sampler == SWZ_JITTERED && !(ext[0] == ext[1] && ext[1] == ext[2])) return false;
+  const double wmax = std::max(ext[0], std::max(ext[1], ext[2])), wmin = std::min(ext[0], std::min(ext[1], ext[2]));
+  const double max_abs = std::max(std::max(std::max(std::fabs(plan.root.minx), std::fabs(plan.root.maxx)),
+                                           std::max(std::fabs(plan.root.miny), std::fabs(plan.root.maxy))),
+                                  std::max(std::fabs(plan.root.minz), std::fabs(plan.root.maxz)));
+  // The reference's target comes out of bounds that went through up to 21 halvings and a few more operations, each
+  // rounding at the magnitude of the coordinates: 128 ulp of the largest one, in key cells of the narrowest axis; plus
+  // the rounding of the encoder's (p - min) * scale.
+  double slack = 1e-6 + 128.0 * 0x1.0p-52 * max_abs / (wmin / 2097152.0);
+  if (const char* e = c->opt("SWZ_GRID_KEYS_SLACK")) slack += atof(e);
+  if (!(slack < 0.25) && !c->opt("SWZ_GRID_KEYS_SLACK")) return false;  // bounds far from the origin relative to their size
+  if (out) {
+    for (int a = 0; a < 3; ++a) out->w[a] = (float)(ext[a] / wmax);
+    out->hk = 0.5 + slack;
+    out->amb = nullptr;
+    out->amb_count = nullptr;
+  }
+  return true;
+}
+
 // ----------------------------------------------------------------------------- one level
 // Samples every node of the level.  When okey/oidx are given the survivors are compacted into them
 // and level_out receives plan.level for the taken points; otherwise only lb.taken is produced.
@@ -786,12 +1154,30 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
         g.table_depth = td;
       }
     }
-    hipLaunchKernelGGL(grid_argmin_kernel, dim3(ntiles), dim3(GA_THREADS), 0, c->stream, as.akey, as.aidx, m, lb.nid,
-                       lb.nmode, sp.X, sp.Y, sp.Z, g, plan.node_shift, lb.taken, d_sum, lb.counters);
-    SWZ_LAUNCH_CHECK(c);
-    hipLaunchKernelGGL(grid_resolve_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, c->stream, d_sum, ntiles,
-                       lb.taken);
-    SWZ_LAUNCH_CHECK(c);
+    GridKeys gk;
+    if (grid_level_uses_keys(c, plan, sp, &gk)) {
+      // decided on the key coordinates; the runs they cannot decide repeated on the original positions
+      KTileSummary* d_ksum = nullptr;
+      SWZ_TRY(c->get("grid_key_summaries", (size_t)ntiles, &d_ksum));
+      SWZ_TRY(c->get("grid_key_undecided", (size_t)m / 2 + 1024, &gk.amb));  // (a run of one point is always decided)
+      gk.amb_count = lb.counters + CTR_NUM_CELLS;
+      hipLaunchKernelGGL(grid_argmin_keys_kernel, dim3(ntiles), dim3(GA_THREADS), 0, c->stream, as.akey, m, lb.nid, lb.nmode, g, gk,
+                         plan.node_shift, lb.taken, d_ksum, lb.counters);
+      SWZ_LAUNCH_CHECK(c);
+      hipLaunchKernelGGL(grid_resolve_keys_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, c->stream, d_ksum, ntiles, gk, lb.taken);
+      SWZ_LAUNCH_CHECK(c);
+      hipLaunchKernelGGL(grid_exact_runs_kernel, dim3(std::min<uint32_t>(div_up(m, 2048u), 4096u)), dim3(256), 0, c->stream, as.akey, as.aidx,
+                         sp.xyz, sp.perm, g, gk, lb.taken);
+      SWZ_LAUNCH_CHECK(c);
+    } else {
+      if (!sp.X) return c->fail(SWZ_ERR_INTERNAL, "GRID_CENTER / JITTERED: this level needs the positions in Morton order");
+      hipLaunchKernelGGL(grid_argmin_kernel, dim3(ntiles), dim3(GA_THREADS), 0, c->stream, as.akey, as.aidx, m, lb.nid,
+                         lb.nmode, sp.X, sp.Y, sp.Z, g, plan.node_shift, lb.taken, d_sum, lb.counters);
+      SWZ_LAUNCH_CHECK(c);
+      hipLaunchKernelGGL(grid_resolve_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, c->stream, d_sum, ntiles,
+                         lb.taken);
+      SWZ_LAUNCH_CHECK(c);
+    }
   } else {  // MIN_DISTANCE
     SWZ_HIP(c, hipMemsetAsync(lb.taken, 0, m, c->stream));
     uint32_t h[CTR_COUNT];
@@ -891,8 +1277,8 @@ static int session_gather_positions(swz_ctx* c, TileSession& t) {
 }
 // a level that cannot be decided on keys needs them
 static int session_need_positions(swz_ctx* c, TileSession& t, const LevelPlan& plan) {
-  if (t.sp.X || plan.sampler != SWZ_MIN_DISTANCE) return SWZ_OK;
-  if (min_distance_level_uses_keys(c, plan, t.sp)) return SWZ_OK;
+  if (t.sp.X || plan.sampler == SWZ_RANDOM_GRID) return SWZ_OK;
+  if (plan.sampler == SWZ_MIN_DISTANCE ? min_distance_level_uses_keys(c, plan, t.sp) : grid_level_uses_keys(c, plan, t.sp, nullptr)) return SWZ_OK;
   return session_gather_positions(c, t);
 }
 
@@ -934,7 +1320,8 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   t.front = front;
   if (p.sampler != SWZ_RANDOM_GRID) {
     const LevelPlan top = make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
-    const bool on_keys = p.sampler == SWZ_MIN_DISTANCE && !(p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && key_metric(c, top, t.sp).ok;
+    const bool on_keys = p.sampler == SWZ_MIN_DISTANCE ? (!(p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && key_metric(c, top, t.sp).ok)
+                                                       : grid_level_uses_keys(c, top, t.sp, nullptr);
     if (!on_keys) SWZ_TRY(session_gather_positions(c, t));
   }
   if (out.dup) SWZ_HIP(c, hipMemsetAsync(out.dup, 0, (size_t)n * 4, c->stream));

@@ -382,18 +382,46 @@ static void store_free(StoreLevel& s) {
   s.cnt = 0;
 }
 
-// grows a named workspace buffer keeping its first `keep` bytes
-static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t keep, void** out) {
+// Grows a named workspace buffer keeping its first `keep` bytes.  A POOL (spill == true) that finds no device memory
+// -- hipMalloc out of memory, or the workspace above SWZ_TILER_DEVICE_BUDGET_MB -- moves to page-locked host memory mapped
+// into the device's address space and stays there: the pools hold 24 bytes + the attribute rows of EVERY point of the
+// data set, the bulk of a tiler's memory, and the tiling touches them lightly -- a batch's own points once, in order
+// (clamp + index), the cached points a batch pulls in by id (re-key), MIN_DISTANCE's rare exact compares; the
+// attribute columns not at all until the files are exported.  The kernels read and write them in place over the host
+// link.  SWZ_TILER_SPILL: "auto" (default), "host" (pools on the host from the start), "off".
+static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t keep, void** out, bool spill = false) {
   swz::DevBuf& b = c->bufs[name];
   if (b.cap < bytes) {
     void* np = nullptr;
     const size_t want = (bytes + 255) & ~size_t(255);
-    const hipError_t e = hipMalloc(&np, want);
+    int policy = 1;
+    if (const char* e = c->opt("SWZ_TILER_SPILL")) policy = strcmp(e, "off") == 0 ? 0 : (strcmp(e, "host") == 0 ? 2 : 1);
+    if (!spill) policy = 0;
+    hipError_t e = hipErrorOutOfMemory;
+    if (policy != 2 && !b.host) {  // (a pool that has moved to the host does not come back)
+      bool over_budget = false;
+      if (const char* bm = c->opt("SWZ_TILER_DEVICE_BUDGET_MB"))
+        over_budget = policy != 0 && (c->held_bytes() + want) > (uint64_t)atoll(bm) * 1048576ull;
+      if (!over_budget) e = hipMalloc(&np, want);
+      if (const char* fa = c->opt("SWZ_FAIL_ALLOC"))
+        if (e == hipSuccess && strcmp(fa, name) == 0) {
+          (void)hipFree(np);
+          np = nullptr;
+          e = hipErrorOutOfMemory;
+        }
+    }
+    bool host = false;
+    if (e == hipErrorOutOfMemory && policy != 0) {
+      (void)hipGetLastError();
+      e = hipHostMalloc(&np, want, hipHostMallocMapped | hipHostMallocPortable);
+      host = e == hipSuccess;
+    }
     if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(") + name + "): " + hipGetErrorString(e));
-    if (b.ptr && keep) SWZ_HIP(c, hipMemcpy(np, b.ptr, keep, hipMemcpyDeviceToDevice));
-    if (b.ptr) SWZ_HIP(c, hipFree(b.ptr));
+    if (b.ptr && keep) SWZ_HIP(c, hipMemcpy(np, b.ptr, keep, hipMemcpyDefault));
+    c->free_buf(b);
     b.ptr = np;
     b.cap = want;
+    b.host = host;
   }
   *out = b.ptr;
   return SWZ_OK;
@@ -412,12 +440,12 @@ static int pool_reserve(swz_tiler* t, size_t points) {
   const size_t want = points <= have ? have : std::max(points, t->pool_cap + t->pool_cap / 2);
   const size_t used = t->staged_total;
   void* px = nullptr;
-  SWZ_TRY(grow_preserving(c, "tiler_pool_xyz", want * 24, used * 24, &px));
+  SWZ_TRY(grow_preserving(c, "tiler_pool_xyz", want * 24, used * 24, &px, true));
   t->pool_xyz = static_cast<double*>(px);
   for (int a = 0; a < SWZ_ATTR_COUNT; ++a) {
     if (!(t->attr_mask & (1u << a))) continue;
     const std::string name = "tiler_pool_attr" + std::to_string(a);
-    SWZ_TRY(grow_preserving(c, name.c_str(), want * TILER_ATTR_BYTES[a], used * TILER_ATTR_BYTES[a], &t->pool_attr[a]));
+    SWZ_TRY(grow_preserving(c, name.c_str(), want * TILER_ATTR_BYTES[a], used * TILER_ATTR_BYTES[a], &t->pool_attr[a], true));
   }
   t->pool_cap = want;
   return SWZ_OK;
@@ -856,7 +884,7 @@ static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t
       SWZ_TRY(radix_sort_pairs(c, keys, perm, keys_b, vals_b, n, true));
     }
     if (!in_pool)  // clamped positions (index_point clamps in place, OctreeAlgorithms.h:167-169) into the pool
-      SWZ_HIP(c, hipMemcpyAsync(slot, d_xyz, (size_t)n * 24, hipMemcpyDeviceToDevice, c->stream));
+      SWZ_HIP(c, hipMemcpyAsync(slot, d_xyz, (size_t)n * 24, hipMemcpyDefault, c->stream));
   }
   BatchWork& w = t->bw;
   w = BatchWork{};
@@ -1188,7 +1216,7 @@ int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const 
     if (!(t->attr_mask & (1u << a))) continue;
     const size_t rb = TILER_ATTR_BYTES[a];
     SWZ_HIP(c, hipMemcpyAsync((char*)t->pool_attr[a] + (size_t)t->total * rb, d_attrs->column[a], (size_t)n * rb,
-                              hipMemcpyDeviceToDevice, c->stream));
+                              hipMemcpyDefault, c->stream));
   }
   t->shard_fast = fast;
   int st = tiler_batch_prepare(t, d_xyz, (uint32_t)n, (uint32_t)info->num_ghosts);
@@ -1364,13 +1392,13 @@ int swz_tiler_stage_batch(swz_tiler* t, const double* xyz_host, uint64_t n, cons
   SWZ_TRY(pool_reserve(t, (size_t)t->staged_total + n));
   const size_t at = t->staged_total;
   if (n) {
-    SWZ_HIP(c, hipMemcpyAsync(t->pool_xyz + at * 3, xyz_host, (size_t)n * 24, hipMemcpyHostToDevice, t->copy_stream));
+    SWZ_HIP(c, hipMemcpyAsync(t->pool_xyz + at * 3, xyz_host, (size_t)n * 24, hipMemcpyDefault, t->copy_stream));
     t->staged_bytes += n * 24;
     for (int a = 0; a < SWZ_ATTR_COUNT; ++a) {
       if (!(mask & (1u << a))) continue;
       const size_t rb = TILER_ATTR_BYTES[a];
       SWZ_HIP(c, hipMemcpyAsync((char*)t->pool_attr[a] + at * rb, attrs_host->column[a], (size_t)n * rb,
-                                hipMemcpyHostToDevice, t->copy_stream));
+                                hipMemcpyDefault, t->copy_stream));
       t->staged_bytes += n * rb;
     }
   }
@@ -1438,6 +1466,22 @@ int swz_tiler_get_info(swz_tiler* t, swz_tiler_info* info) {
   uint64_t nn = 0;
   SWZ_TRY(tiler_node_table(t, nullptr, nullptr, nullptr, nullptr, &nn));
   info->num_nodes = nn;
+  return SWZ_OK;
+}
+
+int swz_tiler_pool_residency(swz_tiler* t, uint64_t* device_bytes_out, uint64_t* host_bytes_out) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  uint64_t dev = 0, host = 0;
+  auto add = [&](const std::string& name) {
+    auto it = t->c->bufs.find(name);
+    if (it == t->c->bufs.end()) return;
+    (it->second.host ? host : dev) += it->second.cap;
+  };
+  add("tiler_pool_xyz");
+  for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
+    if (t->attr_mask & (1u << a)) add("tiler_pool_attr" + std::to_string(a));
+  if (device_bytes_out) *device_bytes_out = dev;
+  if (host_bytes_out) *host_bytes_out = host;
   return SWZ_OK;
 }
 
@@ -1512,9 +1556,23 @@ int swz_device_alloc_on(swz_ctx* c, uint64_t bytes, void** d_out) {
   return SWZ_OK;
 }
 int swz_device_free(void* d_ptr) { return (!d_ptr || hipFree(d_ptr) == hipSuccess) ? SWZ_OK : SWZ_ERR_HIP; }
+// (a pointer the library hands out may be a spilled pool: page-locked HOST memory mapped into the device's address space)
+static bool is_mapped_host_memory(const void* p) {
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
 int swz_copy_to_host(swz_ctx* c, void* dst_host, const void* d_src, uint64_t bytes) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
+  if (bytes && is_mapped_host_memory(d_src)) {
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(dst_host, d_src, bytes);
+    return SWZ_OK;
+  }
   if (bytes) SWZ_HIP(c, hipMemcpyAsync(dst_host, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   return SWZ_OK;
@@ -1522,6 +1580,11 @@ int swz_copy_to_host(swz_ctx* c, void* dst_host, const void* d_src, uint64_t byt
 int swz_copy_to_device(swz_ctx* c, void* d_dst, const void* src_host, uint64_t bytes) {
   if (!c) return SWZ_ERR_BAD_ARG;
   SWZ_HIP(c, hipSetDevice(c->device));
+  if (bytes && is_mapped_host_memory(d_dst)) {
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(d_dst, src_host, bytes);
+    return SWZ_OK;
+  }
   if (bytes) SWZ_HIP(c, hipMemcpyAsync(d_dst, src_host, bytes, hipMemcpyHostToDevice, c->stream));
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
   return SWZ_OK;

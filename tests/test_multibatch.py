@@ -363,3 +363,60 @@ def test_gpu_rekey_inversion_is_counted_and_confined(ctx):
     for k in differing:
         moved |= set(gf.get(k, [])) ^ set(of.get(k, []))
     assert moved <= {ia, ib}, moved     # only a and b change files (one of them is displaced a level down in either order)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["host", "fail_alloc", "budget"])
+def test_gpu_tiler_spills_its_pools_to_pinned_host_memory(mode):
+    """A tiler whose pools find no device memory keeps them in mapped page-locked host memory: the node files are the
+    oracle's, positions and attribute rows come back from the pools unchanged.  "host": from the first batch on;
+    "fail_alloc": a growth of the position pool is refused in the second batch, so a pool with content MOVES; "budget":
+    the context's device workspace may not pass a budget that the pools never fit into."""
+    import schwarzwald_amd as swz
+    import torch
+    rng = np.random.default_rng(77)
+    n, k = 150000, 3
+    xyz = _points(rng, n, ODD, clustered=True)
+    rgb = rng.integers(0, 255, size=(n, 3), dtype=np.uint8)
+    gps = rng.random(n)
+    sp = O.spacing_from_diagonal(*ODD, 32)
+    ctx = swz.Context(0)  # a fresh workspace: the pools of an earlier tiler would simply be reused
+    try:
+        if mode == "host":
+            ctx.set_option("SWZ_TILER_SPILL", "host")
+        elif mode == "budget":
+            ctx.set_option("SWZ_TILER_DEVICE_BUDGET_MB", "1")
+        for sampler in (O.MIN_DISTANCE, O.GRID_CENTER):
+            ex, c = _oracle_files(ODD, xyz, k, sampler, 300, sp, O.ACCURATE, 2)
+            params = swz.TileParams(sampler=sampler, max_points_per_node=300, spacing_at_root=sp)
+            with swz.Tiler(ctx, ODD[0], ODD[1], params, capacity_hint=1000) as t:
+                parts = np.array_split(np.arange(n), k)
+                for i, idx in enumerate(parts):
+                    if mode == "fail_alloc" and i == 1:
+                        ctx.set_option("SWZ_FAIL_ALLOC", "tiler_pool_xyz")
+                    t.add_batch(xyz[idx], {"rgb": rgb[idx], "gps_time": gps[idx]})
+                    ctx.set_option("SWZ_FAIL_ALLOC", None)
+                t.finalize()
+                dev_b, host_b = t.pool_residency()
+                assert host_b >= n * 24, (dev_b, host_b)
+                if mode == "host":
+                    assert dev_b == 0
+                info, table = t.info(), t.node_table()
+                ns = int(info["num_stored"])
+                d_keys = torch.empty(ns, dtype=torch.int64, device="cuda")
+                d_ids = torch.empty(ns, dtype=torch.int32, device="cuda")
+                d_lvl = torch.empty(ns, dtype=torch.int8, device="cuda")
+                t.export_device(d_keys.data_ptr(), d_ids.data_ptr(), d_lvl.data_ptr())
+                g = dict(table=table, ids=d_ids.cpu().numpy().view(np.uint32), level=d_lvl.cpu().numpy(), info=info)
+                _compare(g, ex, c)
+                # the pools by point id: clamped positions and the rows of the attribute column, read through the library
+                p_xyz, p_attr = t.pools_device()
+                got_xyz = ctx.copy_to_host(p_xyz, n * 24).view(np.float64).reshape(n, 3)
+                got_rgb = ctx.copy_to_host(p_attr["rgb"], n * 3).reshape(n, 3)
+                got_gps = ctx.copy_to_host(p_attr["gps_time"], n * 8).view(np.float64)
+                lo, hi = np.array(ODD[0]), np.array(ODD[1])
+                assert np.array_equal(got_xyz, np.clip(xyz, lo, hi)) and np.array_equal(got_rgb, rgb) and np.array_equal(got_gps, gps)
+            if mode != "host":
+                ctx.release_workspace()  # the next tiler starts on the device again
+    finally:
+        ctx.close()

@@ -1,3 +1,2 @@
-export SWZ_MD_TIME_LIMIT=20
-SWZ_DEBUG=1 timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 2>&1 | grep -E "sweep|ms_per_step" | tail -4 | cut -c1-200
-SWZ_DEBUG=1 timeout 300 python tools/clustered_probe.py 100000000 MIN_DISTANCE 2>&1 | grep -E "sweep|N=" | cut -c1-100 | tail -6
+timeout 900 python -m pytest tests/test_multibatch.py -q -m gpu -x -k "spill" 2>&1 | tail -8
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -8

@@ -2,7 +2,11 @@
 // when the box has fewer -- each starting with P uniform points of the unit cube, exact MIN_DISTANCE, d = 250.
 // Prints the wall time of the call and every shard's root interval, with the root swept by all shards at once
 // (SWZ_GROUP_JOINT_ROOT unset) and in turns (SWZ_GROUP_JOINT_ROOT=0).
+//   group_bench SHARDS POINTS_PER_SHARD REPS DEVICES [TRANSPORT 0 = peer copies | 1 = RCCL] [BATCHES] [SAMPLER 0..3] [STRATEGY 0 | 1]
+// BATCHES > 1: the shard's points in that many batches through swz_group_add_batch (one swz_tiler per shard) and
+// swz_group_finalize.  `bench.py --driver group` runs this program and reports its timings.
 //   g++ -std=c++17 -O2 tools/group_bench.cpp -o /tmp/group_bench -Lschwarzwald_amd/lib -lswz_gpu -Wl,-rpath,$PWD/schwarzwald_amd/lib
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,11 +20,15 @@ int main(int argc, char** argv) {
   const uint64_t per = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 25000000ull;
   const int reps = argc > 3 ? std::atoi(argv[3]) : 3;
   const int ndev = argc > 4 ? std::atoi(argv[4]) : 1;
+  const int transport = argc > 5 ? std::atoi(argv[5]) : 0;
+  const int batches = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
+  const int sampler = argc > 7 ? std::atoi(argv[7]) : (int)SWZ_MIN_DISTANCE;
+  const int strategy = argc > 8 ? std::atoi(argv[8]) : (int)SWZ_ACCURATE;
   const double mn[3] = {0, 0, 0}, mx[3] = {1, 1, 1};
   std::vector<int> dev(shards);
   for (int s = 0; s < shards; ++s) dev[s] = s % ndev;
   swz_group* g = nullptr;
-  if (swz_group_create(shards, dev.data(), 0, &g) != SWZ_OK) {
+  if (swz_group_create(shards, dev.data(), transport, &g) != SWZ_OK) {
     std::fprintf(stderr, "swz_group_create: %s\n", swz_group_last_error(nullptr));
     return 1;
   }
@@ -31,18 +39,37 @@ int main(int argc, char** argv) {
     if (swz_device_alloc_on(c, per * 24, (void**)&d_xyz[s]) != SWZ_OK) return 2;
   }
   swz_tile_params p{};
-  p.sampler = SWZ_MIN_DISTANCE;
+  p.sampler = sampler;
   p.max_points_per_node = 20000;
   p.spacing_at_root = (float)(std::sqrt(3.0) / 250.0);
   p.max_depth = 100;
-  p.strategy = SWZ_ACCURATE;
+  p.strategy = strategy;
   p.fast_concurrency = 8;
   std::vector<swz_group_result> res(shards);
   for (int rep = 0; rep < reps; ++rep) {
     for (int s = 0; s < shards; ++s)
       if (swz_generate_uniform_device(swz_group_ctx(g, s), 0x5C4A72A1Dull + 3, (uint64_t)s * per, per, d_xyz[s]) != SWZ_OK) return 3;
     const auto t0 = std::chrono::steady_clock::now();
-    if (swz_group_tile(g, d_xyz.data(), nullptr, n.data(), mn, mx, &p, res.data()) != SWZ_OK) {
+    if (batches > 1) {
+      if (swz_group_tiler_open(g, mn, mx, &p, per) != SWZ_OK) {
+        std::fprintf(stderr, "swz_group_tiler_open: %s\n", swz_group_last_error(g));
+        return 4;
+      }
+      for (int b = 0; b < batches; ++b) {
+        const uint64_t lo = per * b / batches, hi = per * (b + 1) / batches;
+        std::vector<double*> bx(shards);
+        std::vector<uint64_t> bn(shards, hi - lo);
+        for (int s = 0; s < shards; ++s) bx[s] = d_xyz[s] + lo * 3;
+        if (swz_group_add_batch(g, bx.data(), nullptr, bn.data(), nullptr) != SWZ_OK) {
+          std::fprintf(stderr, "swz_group_add_batch: %s\n", swz_group_last_error(g));
+          return 4;
+        }
+      }
+      if (swz_group_finalize(g, nullptr) != SWZ_OK || swz_group_tiler_close(g) != SWZ_OK) {
+        std::fprintf(stderr, "swz_group_finalize: %s\n", swz_group_last_error(g));
+        return 4;
+      }
+    } else if (swz_group_tile(g, d_xyz.data(), nullptr, n.data(), mn, mx, &p, res.data()) != SWZ_OK) {
       std::fprintf(stderr, "swz_group_tile: %s\n", swz_group_last_error(g));
       return 4;
     }

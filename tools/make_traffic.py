@@ -47,8 +47,11 @@ rs_disp = sum(fetch.get(k, (0, 0))[0] for k in rs_k)
 rs_launches = rs_disp - 8 if rs_disp > 8 else max(1, rs_disp)
 md_lo = sum((fetch.get(k, (0, 0))[1] + write.get(k, (0, 0))[1]) * 1024.0 for k in md_k)
 import bench  # library_source_sha16(): bench.py only quotes these numbers for the kernel sources they were measured on
+# (the hash tools/profile_round.sh took on the GPU box next to the counters, if it did; else the sources as they are now)
+sha_file = os.path.join(d, "source_sha16.txt")
+source_sha16 = open(sha_file).read().strip() if os.path.exists(sha_file) else bench.library_source_sha16()
 out = {
-    "points": points, "sampler": "MIN_DISTANCE", "source_sha16": bench.library_source_sha16(),
+    "points": points, "sampler": "MIN_DISTANCE", "source_sha16": source_sha16,
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `bench.py --steps 1 --warmup 0`; "
               "bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md); "
               "check: corrected reads of the radix histogram kernel / its exact key bytes = %.4f.  The factor 2 also holds for "

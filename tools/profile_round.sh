@@ -3,6 +3,7 @@
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile
 rm -rf $OUT; mkdir -p $OUT
+python -c "import bench; print(bench.library_source_sha16())" > $OUT/source_sha16.txt
 timeout 600 python bench.py --md-mode both > $OUT/bench_1B_min_distance.json 2> $OUT/bench.err
 timeout 600 python bench.py --points 100000000 --sampler GRID_CENTER --steps 5 --warmup 2 --cpu-sample 2000000 > $OUT/bench_100M_grid_center.json 2>> $OUT/bench.err
 for s in RANDOM_GRID GRID_CENTER JITTERED; do
