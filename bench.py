@@ -168,6 +168,22 @@ def run_group_driver(args):
     return 0
 
 
+def implemented_sort_frac(prof, args, visit_factor, points, seconds_per_step):
+    """hbm_frac_end_to_end with the sort priced at what the IMPLEMENTED sort has to move instead of SURVEY's 8 + 8 x 24 =
+    200 B/pt (an eight-pass LSD sort): one histogram pass over the keys (8) + 24 B per scatter pass actually launched
+    (four over the top digits at 1 B uniform points) + 24 for the pass that orders the runs of equal top bits, if it ran.
+    None without the kernel profile."""
+    k = prof.get("radix_scatter") if prof else None
+    if not k or not seconds_per_step:
+        return None
+    passes = k["launches"] / float(args.steps)
+    sort_bytes = 8.0 + 24.0 * passes + (24.0 if "radix_runs" in prof else 0.0)
+    per_level = 33.0 if args.sampler == "RANDOM_GRID" else 57.0
+    alg = 32.0 + sort_bytes + per_level * visit_factor
+    return {"frac": round(alg * points / seconds_per_step / (HBM_PEAK_GBS * 1e9), 5), "bytes_per_point": round(alg, 1),
+            "sort_bytes_per_point": round(sort_bytes, 1), "scatter_passes": round(passes, 2)}
+
+
 def algorithmic_bytes_per_point(sampler, visit_factor):
     """encode 32 + sort 200 + per visited level 33 (RANDOM_GRID) or 57."""
     per_level = 33.0 if sampler == "RANDOM_GRID" else 57.0
@@ -503,6 +519,7 @@ def main():
             "visit_factor": round(visit, 4),
             "hbm_frac_end_to_end": round(alg * total_points / world / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "algorithmic_bytes_per_point": round(alg, 1),
+            "hbm_frac_end_to_end_implemented_sort": implemented_sort_frac(prof, args, visit, total_points / world, elapsed / args.steps),
             "tile_stats": stats,
             "roofline": roofline,
             "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},

@@ -48,7 +48,16 @@ struct SortedPoints {
   // few pairs inside the quantisation band here, so the positions are never brought into Morton order.
   const double* xyz = nullptr;
   const uint32_t* perm = nullptr;
+  // A sharded batch: the first `ghosts` sorted positions are points of lower shards (they sort first: lower octants); their
+  // perm entries index ghost_xyz instead.
+  const double* ghost_xyz = nullptr;
+  uint32_t ghosts = 0;
 };
+// exact position of sorted position s
+__host__ __device__ inline const double* sorted_point_xyz(const double* xyz, const uint32_t* perm, const double* ghost_xyz, uint32_t ghosts,
+                                                          uint32_t s) {
+  return (s < ghosts ? ghost_xyz : xyz) + (size_t)perm[s] * 3;
+}
 
 // What the host decides once per level (all float/libm corner cases of the reference live here,
 // evaluated with the host's glibc exactly like the reference evaluates them).

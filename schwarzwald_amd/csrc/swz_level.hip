@@ -888,8 +888,7 @@ __global__ __launch_bounds__(256) void grid_resolve_keys_kernel(const KTileSumma
 
 // the runs the keys could not decide, one wavefront each, with the reference's arithmetic on the original positions
 __global__ __launch_bounds__(256) void grid_exact_runs_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ aidx,
-                                                              const double* __restrict__ xyz, const uint32_t* __restrict__ perm,
-                                                              GridParams g, GridKeys gk, uint8_t* __restrict__ taken) {
+                                                              SortedPoints sp, GridParams g, GridKeys gk, uint8_t* __restrict__ taken) {
   const uint32_t l = lane_id();
   const uint32_t nruns = *gk.amb_count;
   for (uint32_t r = blockIdx.x * (256u / WAVE) + threadIdx.x / WAVE; r < nruns; r += gridDim.x * (256u / WAVE)) {
@@ -898,8 +897,8 @@ __global__ __launch_bounds__(256) void grid_exact_runs_kernel(const uint64_t* __
     uint32_t besti = NONE;
     for (uint32_t i = se.x + l; i < se.y; i += WAVE) {
       const uint64_t key = akey[i];
-      const uint32_t o = perm[aidx ? aidx[i] : i];
-      const double px = xyz[(size_t)o * 3], py = xyz[(size_t)o * 3 + 1], pz = xyz[(size_t)o * 3 + 2];
+      const double* pp = sorted_point_xyz(sp.xyz, sp.perm, sp.ghost_xyz, sp.ghosts, aidx ? aidx[i] : i);
+      const double px = pp[0], py = pp[1], pz = pp[2];
       const Box kb = bounds_from_key(key, g.root, cell_box_depth(g));
       double tx = 0, ty = 0, tz = 0;
       if (g.sampler == SWZ_GRID_CENTER) {
@@ -1167,7 +1166,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
       hipLaunchKernelGGL(grid_resolve_keys_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, c->stream, d_ksum, ntiles, gk, lb.taken);
       SWZ_LAUNCH_CHECK(c);
       hipLaunchKernelGGL(grid_exact_runs_kernel, dim3(std::min<uint32_t>(div_up(m, 2048u), 4096u)), dim3(256), 0, c->stream, as.akey, as.aidx,
-                         sp.xyz, sp.perm, g, gk, lb.taken);
+                         sp, g, gk, lb.taken);
       SWZ_LAUNCH_CHECK(c);
     } else {
       if (!sp.X) return c->fail(SWZ_ERR_INTERNAL, "GRID_CENTER / JITTERED: this level needs the positions in Morton order");
@@ -1264,11 +1263,20 @@ static int session_gather_positions(swz_ctx* c, TileSession& t) {
   SWZ_TRY(c->get("sorted_x", (size_t)t.n + t.front, &X));
   SWZ_TRY(c->get("sorted_y", (size_t)t.n + t.front, &Y));
   SWZ_TRY(c->get("sorted_z", (size_t)t.n + t.front, &Z));
-  X += t.front;
-  Y += t.front;
-  Z += t.front;
   SWZ_STAGE(c, "sort");
-  SWZ_TRY(gather_positions(c, t.xyz_in, t.perm, t.n, X, Y, Z));
+  const uint32_t g = t.sp.ghosts;
+  if (g) {
+    // ghosts are attached already (a sharded batch whose earlier levels were decided on keys): they lead the sorted
+    // order and their perm entries index the ghost array.  They matter at the root level only -- later the caller's
+    // ghost array may be gone, and nobody reads those entries any more.
+    if (t.next_level <= -1) SWZ_TRY(gather_positions(c, t.sp.ghost_xyz, t.perm, g, X, Y, Z));
+    SWZ_TRY(gather_positions(c, t.xyz_in, t.perm + g, t.n - g, X + g, Y + g, Z + g));
+  } else {
+    X += t.front;
+    Y += t.front;
+    Z += t.front;
+    SWZ_TRY(gather_positions(c, t.xyz_in, t.perm, t.n, X, Y, Z));
+  }
   SWZ_STAGE(c, "gather");
   t.sp.X = X;
   t.sp.Y = Y;
@@ -1315,8 +1323,9 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   // coordinates and looks up the pairs inside the quantisation band through the permutation (swz_mdkeys.hip): there
   // the gather is put off until a level asks for it (session_need_positions) -- for cubic bounds and exact mode that is
   // a level so deep that its spacing spans fewer than 64 key cells, which few clouds reach.  Sharded batches that
-  // prepend ghosts (front > 0) index two position arrays and always gather.
-  t.sp = SortedPoints{nullptr, nullptr, nullptr, front ? nullptr : d_xyz, out.perm};
+  // prepend ghosts (front > 0) look up two position arrays: the sorted positions in front are the ghosts
+  // (shard_attach_ghosts; sorted_point_xyz).
+  t.sp = SortedPoints{nullptr, nullptr, nullptr, d_xyz, out.perm};
   t.front = front;
   if (p.sampler != SWZ_RANDOM_GRID) {
     const LevelPlan top = make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
@@ -1585,16 +1594,20 @@ __global__ __launch_bounds__(256) void root_taken_count_kernel(const int8_t* __r
 }
 __global__ __launch_bounds__(256) void root_taken_gather_kernel(const int8_t* __restrict__ level, uint32_t first,
                                                                 uint32_t n, const uint32_t* __restrict__ pos,
-                                                                const double* __restrict__ X,
-                                                                const double* __restrict__ Y,
-                                                                const double* __restrict__ Z,
-                                                                double* __restrict__ out_xyz) {
+                                                                SortedPoints sp, double* __restrict__ out_xyz) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || i < first || level[i] != (int8_t)-1) return;
   const uint64_t o = pos[i];
-  out_xyz[3 * o] = X[i];
-  out_xyz[3 * o + 1] = Y[i];
-  out_xyz[3 * o + 2] = Z[i];
+  if (sp.X) {
+    out_xyz[3 * o] = sp.X[i];
+    out_xyz[3 * o + 1] = sp.Y[i];
+    out_xyz[3 * o + 2] = sp.Z[i];
+  } else {  // the positions were never brought into Morton order (the samplers decided on keys)
+    const double* p = sorted_point_xyz(sp.xyz, sp.perm, sp.ghost_xyz, sp.ghosts, i);
+    out_xyz[3 * o] = p[0];
+    out_xyz[3 * o + 1] = p[1];
+    out_xyz[3 * o + 2] = p[2];
+  }
 }
 __global__ __launch_bounds__(256) void shard_strip_kernel(const uint64_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ perm,
@@ -1662,7 +1675,14 @@ static int shard_attach_ghosts(swz_ctx* c, ShardState* s, const double* d_ghost_
     t.keys -= g;
     t.perm -= g;
     t.level -= g;
-    if (t.sp.X) t.sp = SortedPoints{t.sp.X - g, t.sp.Y - g, t.sp.Z - g};
+    if (t.sp.X) {
+      t.sp.X -= g;
+      t.sp.Y -= g;
+      t.sp.Z -= g;
+    }
+    t.sp.perm = t.perm;  // (now starts with the ghosts' entries, which index the ghost array)
+    t.sp.ghost_xyz = d_ghost_xyz;
+    t.sp.ghosts = g;
     t.n += g;
     t.as = ActiveSet{t.keys, nullptr, t.n};
   }
@@ -1701,7 +1721,6 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
   SWZ_TRY(c->get("shard_perm", (size_t)total, &out.perm));
   SWZ_TRY(c->get("shard_level", (size_t)total, &out.level));
   SWZ_TRY(session_prepare(c, s->t, xyz, total, bmin, bmax, p, out));
-  if (!c->md_shard_root) SWZ_TRY(session_gather_positions(c, s->t));  // swz_shard_root_taken hands out positions in Morton order
   s->t.ghosts = ghosts;
   s->n_local = n;
   }
@@ -1734,7 +1753,7 @@ int shard_root_taken_device(swz_ctx* c, double* d_xyz_out) {
   const uint32_t total = s->t.n;
   // lb.flags still holds the exclusive scan of the root-taken flags of swz_shard_begin
   hipLaunchKernelGGL(root_taken_gather_kernel, dim3(div_up(total, 256)), dim3(256), 0, c->stream, s->t.level,
-                     s->t.ghosts, total, s->t.lb.flags, s->t.sp.X, s->t.sp.Y, s->t.sp.Z, d_xyz_out);
+                     s->t.ghosts, total, s->t.lb.flags, s->t.sp, d_xyz_out);
   SWZ_LAUNCH_CHECK(c);
   return SWZ_OK;
 }

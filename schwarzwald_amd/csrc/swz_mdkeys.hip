@@ -90,19 +90,23 @@ KeyMetric key_metric(const swz_ctx* c, const LevelPlan& plan, const SortedPoints
   return k;
 }
 
+// (with ghosts in front -- a sharded batch --: ghost g keeps its index into the ghost array, local point p becomes
+// ghosts + p: one id space, see SpArgs)
 __global__ __launch_bounds__(256) void mq_point_ids_kernel(const uint32_t* __restrict__ aidx, const uint32_t* __restrict__ perm, uint32_t m,
-                                                           uint32_t* __restrict__ ids) {
+                                                           uint32_t ghosts, uint32_t* __restrict__ ids) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i < m) ids[i] = perm[aidx[i]];
+  if (i >= m) return;
+  const uint32_t s = aidx ? aidx[i] : i;
+  ids[i] = s < ghosts ? perm[s] : ghosts + perm[s];
 }
 int key_point_ids(swz_ctx* c, const ActiveSet& as, const SortedPoints& sp, const uint32_t** ids) {
-  if (!as.aidx) {
+  if (!as.aidx && !sp.ghosts) {
     *ids = sp.perm;
     return SWZ_OK;
   }
   uint32_t* d = nullptr;
   SWZ_TRY(c->get("md_qids", (size_t)as.m, &d));
-  hipLaunchKernelGGL(mq_point_ids_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, as.aidx, sp.perm, as.m, d);
+  hipLaunchKernelGGL(mq_point_ids_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, as.aidx, sp.perm, as.m, sp.ghosts, d);
   SWZ_LAUNCH_CHECK(c);
   *ids = d;
   return SWZ_OK;
@@ -134,6 +138,8 @@ struct MqArgs {
   const double* xyz;      // exact positions: point perm[aidx ? aidx[i] : i] of the caller's array (pairs inside the band are
                           // rare enough on dense levels that the three dependent loads do not matter)
   const uint32_t* perm;
+  const double* gxyz;     // a sharded batch: the first ng sorted positions are ghosts, their perm entries index gxyz
+  uint32_t ng;
   uint8_t* taken;
   uint32_t* counters;
   uint64_t* qpos;         // [m] key coordinates x | y << 21 | z << 42 of the active points
@@ -167,6 +173,12 @@ struct MqArgs {
   uint32_t no_dead_test;  // debugging / tests: blocker scans do not test for dead points
   uint32_t stats;         // SWZ_DEBUG: count activations by kind in counters[CTR_DBG_HIST ...]
   uint32_t chain;         // cells a wavefront may run one after the other in a launch, each woken by the one before (1: none)
+  // dense cells (thousands of points: the blobs and sheets of a clustered cloud), levels of large cells only -- see
+  // mq_dense_reject_kernel
+  uint32_t dense_min;     // a cell with at least this many points is dense (0: the level has none / the feature is off)
+  uint8_t* dirty;         // [cell] set when the cell or an adjacent one has published accepted points since its last reject pass
+  uint32_t* bulk_round;   // [cell] round of the cell's last reject pass + 1
+  const uint32_t* dlist;  // the dense cells
   uint32_t* round_word;   // sharded root: the round this shard's sweep is in, for the shards that read its records
   MqPeers peers;
 };
@@ -218,8 +230,8 @@ __device__ __forceinline__ float mq_d2(float ax, float ay, float az, float bx, f
 }
 // the reference's compare on the exact positions (GridCell.cpp:52) for active points i and j
 __device__ __forceinline__ bool mq_exact_near(const MqArgs& a, uint32_t i, uint32_t j) {
-  const double* p = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[i] : i] * 3;
-  const double* q = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[j] : j] * 3;
+  const double* p = sorted_point_xyz(a.xyz, a.perm, a.gxyz, a.ng, a.aidx ? a.aidx[i] : i);
+  const double* q = sorted_point_xyz(a.xyz, a.perm, a.gxyz, a.ng, a.aidx ? a.aidx[j] : j);
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 
@@ -252,8 +264,9 @@ __device__ __forceinline__ uint32_t mq_ld_sys(const uint32_t* p) { return __hip_
 
 // ... for a local point i and an accepted point j of shard `tag - 1` (0: this shard)
 __device__ __forceinline__ bool mq_exact_near_peer(const MqArgs& a, uint32_t i, uint32_t j, uint32_t tag) {
-  const double* p = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[i] : i] * 3;
-  const double* q = tag ? a.peers.xyz[tag - 1u] + (size_t)a.peers.perm[tag - 1u][j] * 3 : a.xyz + (size_t)a.perm[a.aidx ? a.aidx[j] : j] * 3;
+  const double* p = sorted_point_xyz(a.xyz, a.perm, a.gxyz, a.ng, a.aidx ? a.aidx[i] : i);
+  const double* q = tag ? a.peers.xyz[tag - 1u] + (size_t)a.peers.perm[tag - 1u][j] * 3
+                        : sorted_point_xyz(a.xyz, a.perm, a.gxyz, a.ng, a.aidx ? a.aidx[j] : j);
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 
@@ -455,6 +468,48 @@ __device__ __forceinline__ uint32_t mq_scan(const MqArgs& a, const uint64_t* __r
       }
       if (hb) return q0 + (uint32_t)u * WAVE + (uint32_t)__ffsll((unsigned long long)hb) - 1u;
     }
+  }
+  return QNONE;
+}
+
+// First point of [q0, qe) that is not known dead, by the state bytes alone: 1024 per look (16 bytes per lane).  qe when
+// there is none.
+__device__ __forceinline__ uint32_t mq_first_open(const uint8_t* __restrict__ state, uint32_t q0, uint32_t qe) {
+  const uint32_t l = lane_id();
+  while (q0 < qe) {
+    const uint32_t base = q0 & ~15u;
+    const uint32_t at = base + l * 16u;
+    uint4 sb = make_uint4(0x02020202u, 0x02020202u, 0x02020202u, 0x02020202u);  // QS_DEAD
+    if (at < qe) sb = *reinterpret_cast<const uint4*>(state + at);
+    const uint32_t w[4] = {sb.x, sb.y, sb.z, sb.w};
+    uint32_t first = 16u;  // first byte of this lane's 16 that is not dead and lies in [q0, qe)
+#pragma unroll
+    for (int q = 3; q >= 0; --q)
+#pragma unroll
+      for (int bt = 3; bt >= 0; --bt) {
+        const uint32_t idx = at + (uint32_t)q * 4u + (uint32_t)bt;
+        if (((w[q] >> (8 * bt)) & 0xFFu) != (uint32_t)QS_DEAD && idx >= q0 && idx < qe) first = (uint32_t)q * 4u + (uint32_t)bt;
+      }
+    const uint64_t hit = __ballot(first < 16u);
+    if (hit) {
+      const int hl = __ffsll((unsigned long long)hit) - 1;
+      return base + (uint32_t)hl * 16u + qb_u32(first, hl);
+    }
+    q0 = base + 1024u;
+  }
+  return qe;
+}
+
+// mq_scan over the undecided points of a DENSE adjacent cell: most of them have been killed by the cell's reject passes
+// (mq_dense_reject_kernel), so the walk jumps from one point that is not dead to the next on the state bytes.
+template <int SU>
+__device__ __forceinline__ uint32_t mq_scan_dense(const MqArgs& a, const uint64_t* __restrict__ qpos, const uint8_t* __restrict__ state,
+                                                  const MqLds& lds, uint32_t live_wn, uint32_t qs, uint32_t qe, float cx, float cy, float cz) {
+  for (uint32_t q0 = mq_first_open(state, qs, qe); q0 < qe;) {
+    const uint32_t wend = (qe - q0) > (uint32_t)SU * WAVE ? q0 + (uint32_t)SU * WAVE : qe;
+    const uint32_t hq = mq_scan<SU>(a, qpos, state, lds, live_wn, q0, wend, cx, cy, cz);
+    if (hq != QNONE) return hq;
+    q0 = mq_first_open(state, wend, qe);
   }
   return QNONE;
 }
@@ -900,8 +955,12 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
         // (Measured and dropped: a scan that reads the state bytes first and fetches the coordinates of the open points
         // only.  Where it would pay -- the dense blob of a clustered cloud -- the root went 107 -> 101 ms; on uniform data,
         // whose neighbours' points are mostly still open when they are scanned, 73 -> 113 ms.)
-        const uint32_t hq = mq_scan<(U > 1 ? 4 : 1)>(a, kp ? a.peers.qpos[kp - 1u] : a.qpos, kp ? a.peers.state[kp - 1u] : a.state, lds, live_wn, qs,
-                                                     qe, cx, cy, cz);
+        uint32_t hq;
+        if (U > 1 && a.dense_min && !kp && qe - qs >= a.dense_min)
+          hq = mq_scan_dense<4>(a, a.qpos, a.state, lds, live_wn, qs, qe, cx, cy, cz);
+        else
+          hq = mq_scan<(U > 1 ? 4 : 1)>(a, kp ? a.peers.qpos[kp - 1u] : a.qpos, kp ? a.peers.state[kp - 1u] : a.state, lds, live_wn, qs, qe,
+                                        cx, cy, cz);
         if (hq != QNONE) {
           blocked = true;
           b_k = (uint32_t)k;
@@ -955,7 +1014,10 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     if (stop) break;
     // (Measured and dropped: cells of thousands of points taking their turn in slices of 1024 .. 4096 points, so that a
     // launch does not last as long as its longest activation -- the clustered root went 105 -> 120 .. 153 ms.)
-    if (fresh == (uint32_t)MQ_FRESH_CAP && W0 + (uint32_t)U * WAVE < e) {  // (full exactly at the end of a window)
+    // (... or a dense cell that has accepted a point: what that point rejects in the thousands of points behind it is
+    // killed by a whole workgroup between the launches, mq_dense_reject_kernel, and the walk goes on next round)
+    if ((fresh == (uint32_t)MQ_FRESH_CAP || (U > 1 && fresh && a.dense_min && e - ci.x >= a.dense_min)) &&
+        W0 + (uint32_t)U * WAVE < e) {  // (full exactly at the end of a window)
       out_pos = W0 + (uint32_t)U * WAVE;
       out_status = QO_YIELD;
       break;
@@ -983,6 +1045,7 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     myrec[wb * rg] = make_uint4(fin ? e : out_pos, ncnt, round, e);
     a.qst[c] = out_status == QO_STALLED ? make_uint4(tested_now, b_k, b_q, round) : make_uint4(QNONE, 0u, 0u, 0u);
   }
+  if (U > 1 && a.dirty && fresh && l < 27u && nb_have && nb_peer == 0u) a.dirty[nb_id] = 1;  // (k = 13: the cell itself)
   // ---- wake the later adjacent cells that sleep on a point the frontier has passed (slots written in THIS round belong
   // to cells that confirm themselves next round); go to sleep / come back next round
   bool won = false;
@@ -1102,6 +1165,75 @@ __global__ __launch_bounds__(WAVE, (U == 1 && !PEERS) ? MQ_MINW1 : ((U == 4 && !
 // two rounds: when a reader sees round R here, every record stamped before R is complete (round R - 1 has finished and
 // written back) and round R only ever writes the OLDER buffer of a cell -- a store from inside the sweep would become
 // visible some time into the round, when that is no longer true.
+// ---- dense cells
+// A cell of thousands of points (a blob or a sheet of a clustered cloud) is walked by ONE wavefront, 256 points per
+// memory round trip, and a launch lasts as long as its longest activation.  Almost all of those points are rejected by
+// the handful of accepted points around them, so that part is taken out of the walk: a dense cell yields after it has
+// accepted a point, every activation that publishes accepted points marks the cells around it, and between two launches
+// one WORKGROUP per marked dense cell tests the cell's undecided points against the accepted points of the earlier
+// adjacent cells (and its own) that are new since its last pass, and marks what they reject dead.  That is all it does
+// -- a dead point is one that some published accepted earlier point rejects, which is what the state means anyway --, so
+// the walk and the blocker scans of the others then jump over the killed stretches on the state bytes, 1024 points per
+// look.  Pairs inside the band are left to the walk (it has the exact compare).
+__global__ __launch_bounds__(256) void mq_dense_list_kernel(MqArgs a, uint32_t ncells, uint32_t* __restrict__ list, uint32_t* __restrict__ count) {
+  const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= ncells) return;
+  const uint2 ci = a.cinfo[c];
+  if (ci.y - ci.x >= a.dense_min) list[atomicAdd(count, 1u)] = c;
+}
+
+constexpr uint32_t MQ_DENSE_LIST = 256;  // accepted points a reject pass looks at (the rest waits for the walk)
+__global__ __launch_bounds__(256) void mq_dense_reject_kernel(MqArgs a, uint32_t round) {
+  __shared__ float4 lst[MQ_DENSE_LIST];
+  __shared__ uint32_t cnt;
+  const uint32_t c = a.dlist[blockIdx.x];
+  if (!a.dirty[c]) return;  // (the same byte for the whole workgroup; cleared below, after everybody has read it)
+  const uint32_t tid = threadIdx.x;
+  const uint32_t rg = a.rg, rg2s = a.rg2_shift, cap = rg - 1u;
+  const uint4* myrec = a.rec + ((size_t)c << rg2s);
+  const uint4 h0 = myrec[0], h1 = myrec[rg];
+  const uint4 mine = h1.z > h0.z ? h1 : h0;  // (no launch is running: both records are complete, the newer one counts)
+  const uint32_t P = mine.x, e = a.cinfo[c].y;
+  const uint32_t since = a.bulk_round[c];
+  if (tid == 0) cnt = 0;
+  __syncthreads();
+  if (tid == 0) {
+    a.dirty[c] = 0;
+    a.bulk_round[c] = round + 1u;
+  }
+  if (P >= e) return;
+  // the accepted points of the earlier adjacent cells and of the cell itself whose record is new since the last pass
+  if (tid < 27u) {
+    const uint32_t nb = a.qnbr[(size_t)c * 32 + tid];
+    if (nb != QNONE && nb <= c) {
+      const uint4* r = a.rec + ((size_t)nb << rg2s);
+      const uint4 a0 = r[0], a1 = r[rg];
+      const uint32_t pick = a1.z > a0.z ? 1u : 0u;
+      const uint4 hd = pick ? a1 : a0;
+      if (hd.z >= since && hd.y) {
+        const uint32_t at = atomicAdd(&cnt, hd.y);
+        for (uint32_t j = 0; j < hd.y && at + j < MQ_DENSE_LIST; ++j) {
+          uint4 en;
+          if (j < cap) en = r[pick * rg + 1u + j];
+          else en = *reinterpret_cast<const uint4*>(a.ovf + (hd.w - 1u - (j - cap)));
+          lst[at + j] = make_float4(__uint_as_float(en.x), __uint_as_float(en.y), __uint_as_float(en.z), 0.f);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const uint32_t n = cnt < MQ_DENSE_LIST ? cnt : MQ_DENSE_LIST;
+  if (!n) return;
+  for (uint32_t p = P + tid; p < e; p += 256u) {
+    if (a.state[p] != QS_OPEN) continue;
+    float x, y, z;
+    mq_unpack(a.qpos[p], x, y, z);
+    bool dead = false;
+    for (uint32_t i = 0; i < n && !dead; ++i) dead = mq_d2(x, y, z, lst[i].x, lst[i].y, lst[i].z) < a.f_lo;
+    if (dead) a.state[p] = QS_DEAD;
+  }
+}
+
 __global__ void mq_round_word_kernel(uint32_t* word, uint32_t value) {
   __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -1143,6 +1275,8 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   a.nstart = lb.nstart;
   a.xyz = sp.xyz;
   a.perm = sp.perm;
+  a.gxyz = sp.ghost_xyz;
+  a.ng = sp.ghosts;
   a.taken = lb.taken;
   a.counters = lb.counters;
   a.snode_of = snode_of;
@@ -1249,16 +1383,47 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   const bool many_small = ncells >= (4u << 20) && (double)sample_points / (double)ncells <= 128.0;
   a.patient = many_small ? 1u : 0u;
   if (const char* e = c->opt("SWZ_MD_PATIENT")) a.patient = (uint32_t)atoi(e);
-  bool lazy = many_small || typical_pop <= 1024.0;
+  bool lazy = true;  // (on keys also for roots of thousands of points per cell: clustered root 99 -> 89 ms)
   if (const char* e = c->opt("SWZ_MD_LAZY")) lazy = atoi(e) != 0;
   a.lazy_frac = c->opt("SWZ_MD_LAZY_FRAC") ? (float)atof(c->opt("SWZ_MD_LAZY_FRAC")) : (many_small ? 0.5f : 0.0f);
-  bool big_cells = typical_pop > 64.0;
+  // (the build for large cells from a few hundred points per typical cell on: at 113 -- level 1 of the clustered cloud --
+  // the small-cell build is still ahead, 48 against 55 ms; at 478 and 710 the large-cell one, 72 / 81 against 100+)
+  bool big_cells = typical_pop > 256.0;
   if (const char* e = c->opt("SWZ_MD_BIG")) big_cells = atoi(e) != 0;
   uint32_t groups = 1;
   if (sample_nodes >= 2 && !big_cells) groups = 2;
   if (const char* e = c->opt("SWZ_MD_GROUPS")) groups = (uint32_t)std::max(1, std::min(8, atoi(e)));
   groups = std::min(groups, sample_nodes);
   if (sharded) groups = 1;
+  // dense cells: levels of large cells in one node group (mq_dense_reject_kernel)
+  uint32_t ndense = 0;
+  a.dense_min = 0;
+  a.dirty = nullptr;
+  if (big_cells && groups == 1 && !sharded) {
+    uint32_t dense_min = 2048;
+    if (const char* e = c->opt("SWZ_MD_DENSE_MIN")) dense_min = (uint32_t)std::max(0, atoi(e));
+    if (dense_min && m >= dense_min) {
+      uint32_t* dl = nullptr;
+      uint32_t* dcount = nullptr;
+      SWZ_TRY(c->get("md_qdense", (size_t)(m / dense_min + 1u), &dl));
+      SWZ_TRY(c->get("md_qdense_count", (size_t)4, &dcount));
+      SWZ_HIP(c, hipMemsetAsync(dcount, 0, 4, c->stream));
+      a.dense_min = dense_min;
+      hipLaunchKernelGGL(mq_dense_list_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells, dl, dcount);
+      SWZ_LAUNCH_CHECK(c);
+      SWZ_HIP(c, hipMemcpyAsync(&ndense, dcount, 4, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      if (ndense) {
+        SWZ_TRY(c->get("md_qdirty", (size_t)ncells, &a.dirty));
+        SWZ_TRY(c->get("md_qbulk", (size_t)ncells, &a.bulk_round));
+        SWZ_HIP(c, hipMemsetAsync(a.dirty, 0, (size_t)ncells, c->stream));
+        SWZ_HIP(c, hipMemsetAsync(a.bulk_round, 0, (size_t)ncells * 4, c->stream));
+        a.dlist = dl;
+      } else {
+        a.dense_min = 0;
+      }
+    }
+  }
   // the round's queue in segments with a counter each (a single counter word takes ~90 atomics per microsecond, and
   // every activation pushes): workgroup b reads segment b % nseg and pushes into it
   a.nseg_shift = 5;
@@ -1304,9 +1469,9 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
   if (dbg)
     fprintf(stderr, "[swz] MIN_DISTANCE level %d on keys: %u pts in %u nodes, %u cells (cell levels %d), spacing %.1f key cells, band "
-                    "[%.0f, %.0f), records of %u, typical cell %.0f pts, lazy %d (%.2f) patient %u groups %u big %d\n",
+                    "[%.0f, %.0f), records of %u, typical cell %.0f pts, lazy %d (%.2f) patient %u groups %u big %d dense cells %u\n",
             plan.level, sample_points, sample_nodes, ncells, cl, km.T, (double)km.f_lo, (double)km.f_hi, a.rg - 1u, typical_pop, (int)lazy,
-            (double)a.lazy_frac, a.patient, groups, (int)big_cells);
+            (double)a.lazy_frac, a.patient, groups, (int)big_cells, ndense);
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg) {
     ev0 = c->take_event();
@@ -1357,6 +1522,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
             hipLaunchKernelGGL((mq_sweep_kernel<1, true>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
         } else if (big_cells) {
           hipLaunchKernelGGL((mq_sweep_kernel<4, false>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+          if (ndense) hipLaunchKernelGGL(mq_dense_reject_kernel, dim3(ndense), dim3(256), 0, gs[g], ga[g], round);
         } else {
           hipLaunchKernelGGL((mq_sweep_kernel<1, false>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
         }

@@ -460,6 +460,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   double limit = 2.0;  // per occupied cell; a uniform level with 1.5 points per cell of volume has 1.93
   if (const char* e = c->opt("SWZ_MD_SPARSE_LIMIT")) limit = atof(e);
   if (!(per_cell < limit)) return SWZ_OK;
+  // the root of a sharded batch with ghosts in front, decided on keys: the sweep looks up two position arrays, this path one
+  if (sp.ghosts && plan.level == -1 && !sp.X) return SWZ_OK;
   const uint32_t m = as.m;
 
   SpArgs a{};
@@ -497,7 +499,10 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   const KeyMetric km = key_metric(c, plan, sp);
   if (!km.ok && !sp.X) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE: this level needs the positions in Morton order and they were not gathered");
   if (km.ok) {
-    a.xyz = sp.xyz;
+    // (A sharded batch: the ghosts in front of the sorted order have their own position array and ids below sp.ghosts,
+    // local point p has id ghosts + p, see key_point_ids.  Ghosts are accepted again at the root and never reach a level
+    // below it, and the root level of a batch with ghosts is left to the sweep -- above --, so only local ids occur here.)
+    a.xyz = sp.xyz - (size_t)sp.ghosts * 3;
     SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
     a.f_lo = km.f_lo;
     a.f_hi = km.f_hi;

@@ -35,6 +35,17 @@ def test_group_peer_copies_match_the_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_group_with_the_root_taken_in_turns(tmp_path):
+    """SWZ_GROUP_JOINT_ROOT=0: the MIN_DISTANCE root as a chain from shard to shard, every shard with the lower shards' root
+    samples as ghosts in front of its own points (the path the torch driver takes) -- decided on keys as well, with the
+    ghosts' exact positions looked up in their own array."""
+    exe = _build(str(tmp_path))
+    r = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SWZ_GROUP_JOINT_ROOT="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count(" ok") == 96
+
+
+@pytest.mark.gpu
 def test_group_rccl_transport(tmp_path):
     """With one GPU this runs the 1-shard group through ncclCommInitAll (librccl loaded on demand) and skips the
     larger groups; on a multi-GPU node the same binary covers them."""

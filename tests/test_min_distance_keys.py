@@ -69,6 +69,10 @@ MODES = [
     {"SWZ_MD_CHAIN": "8", "SWZ_MD_LAZY": "0", "SWZ_MD_PATIENT": "0"},        # chains of up to 8 such cells
     {"SWZ_MD_CHAIN": "8", "SWZ_MD_GRID": "3"},
     {"SWZ_MD_CHAIN": "8", "SWZ_MD_BIG": "1", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0", "SWZ_MD_LAZY": "0"},
+    # dense cells: every cell of 64 / 200 points and more yields after an accept and is thinned by the reject passes
+    {"SWZ_MD_DENSE_MIN": "64", "SWZ_MD_BIG": "1", "SWZ_MD_GROUPS": "1"},
+    {"SWZ_MD_DENSE_MIN": "200", "SWZ_MD_BIG": "1", "SWZ_MD_GROUPS": "1", "SWZ_MD_COARSEN": "2", "SWZ_MD_COARSEN_MIN": "0", "SWZ_MD_LAZY": "0"},
+    {"SWZ_MD_DENSE_MIN": "0", "SWZ_MD_BIG": "1", "SWZ_MD_GROUPS": "1"},
 ]
 
 
@@ -124,6 +128,20 @@ def test_key_sweep_clustered_and_duplicates(ctx):
     for d, mppn in ((250, 1000), (120, 400)):
         _check(ctx, xyz, *UNIT, d, mppn, {"SWZ_MD_SPARSE_LIMIT": "0"})
         _check(ctx, xyz, *UNIT, d, mppn, {})  # sparse levels on their own path, dense ones on the key sweep
+
+
+def test_key_sweep_dense_cells(ctx):
+    """Blobs of tens of thousands of points inside single cells (and a sheet): dense cells yield after every accepted point
+    and a workgroup per cell kills what the accepted points around it reject between the launches."""
+    rng = np.random.default_rng(2048)
+    xyz = np.vstack([rng.random((150000, 3)),
+                     0.31 + 0.002 * rng.standard_normal((120000, 3)),
+                     0.72 + 0.004 * rng.standard_normal((150000, 3)),
+                     np.column_stack([0.1 + 0.05 * rng.random(80000), 0.1 + 0.05 * rng.random(80000), 0.555 + 1e-4 * rng.standard_normal(80000)])])
+    xyz = np.clip(xyz, 0.0, 1.0)
+    for opts in ({"SWZ_MD_SPARSE_LIMIT": "0"}, {"SWZ_MD_SPARSE_LIMIT": "0", "SWZ_MD_DENSE_MIN": "512", "SWZ_MD_CHAIN": "1"}, {}):
+        g = _check(ctx, xyz, *UNIT, 250, 3000, opts)
+    assert g.stats["max_level"] >= 5
 
 
 def test_key_sweep_deep_levels_fall_back_to_positions(ctx):

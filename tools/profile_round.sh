@@ -22,6 +22,13 @@ timeout 600 python tools/clustered_probe.py 100000000 GRID_CENTER >> $OUT/cluste
 for s in MIN_DISTANCE RANDOM_GRID; do
   timeout 900 python bench.py --points 100000000 --batches 10 --sampler $s --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_100M_10batches_$s.json 2>> $OUT/bench.err
 done
+# ... and the whole 1 B points in 100 batches of 10 M
+for s in MIN_DISTANCE RANDOM_GRID; do
+  timeout 1200 python bench.py --points 1000000000 --batches 100 --sampler $s --steps 1 --warmup 0 --cpu-sample 0 > $OUT/bench_1B_100batches_$s.json 2>> $OUT/bench.err
+done
+# the one-process C++ driver through bench.py (all shards on this one device): single batch, and FAST in three batches
+timeout 600 python bench.py --driver group --gpus 8 --group-devices 1 --points 25000000 --steps 2 --warmup 1 > $OUT/bench_group_driver_8shards_1device.json 2>> $OUT/bench.err
+timeout 600 python bench.py --driver group --gpus 8 --group-devices 1 --points 25000000 --batches 3 --strategy FAST --steps 2 --warmup 1 > $OUT/bench_group_driver_8shards_1device_FAST_3batches.json 2>> $OUT/bench.err
 # a batch sharded over 8 and 2 contexts of this one GPU from one C++ process: MIN_DISTANCE root swept by all shards at once / in turns
 bash tools/group_bench.sh > $OUT/group_joint_root_vs_turns.txt 2>> $OUT/bench.err
 # full-size verification at the size the GPU has room for (1 B points on a 288 GB part); the test logs what it verified
