@@ -176,7 +176,9 @@ def implemented_sort_frac(prof, args, visit_factor, points, seconds_per_step):
     k = prof.get("radix_scatter") if prof else None
     if not k or not seconds_per_step:
         return None
-    passes = k["launches"] / float(args.steps)
+    # (full passes over the data: the bracket also holds the eight tiny passes that sort the sample which picks the number
+    # of top digits, so the launches are not the passes -- the bytes are)
+    passes = k["algorithmic_bytes"] / float(args.steps) / (24.0 * points)
     sort_bytes = 8.0 + 24.0 * passes + (24.0 if "radix_runs" in prof else 0.0)
     per_level = 33.0 if args.sampler == "RANDOM_GRID" else 57.0
     alg = 32.0 + sort_bytes + per_level * visit_factor

@@ -1,0 +1,34 @@
+"""bench.py's host-side bookkeeping (no GPU): what the JSON line derives from the kernel profile and from profiles/."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_end_to_end_fraction_against_the_implemented_sort():
+    """One histogram pass + 24 B per scatter pass launched + the run pass, instead of SURVEY's eight-pass 200 B/pt."""
+    args = argparse.Namespace(steps=3, sampler="RANDOM_GRID")
+    # (12 brackets per step: four passes over 1 B points and the eight tiny passes over the 32 768-key sample)
+    prof = {"radix_scatter": {"launches": 36, "total_ms": 99.0, "algorithmic_bytes": 3 * (4 * 24 * 10**9 + 8 * 24 * 32768)},
+            "radix_runs": {"launches": 3, "total_ms": 17.0}}
+    r = bench.implemented_sort_frac(prof, args, 4.0, 1e9, 0.1)
+    assert r["scatter_passes"] == 4.0 and abs(r["sort_bytes_per_point"] - (8 + 4 * 24 + 24)) < 0.1
+    assert abs(r["bytes_per_point"] - (32 + 128 + 4 * 33)) < 0.1
+    assert abs(r["frac"] - (292.0 * 1e9 / 0.1) / (bench.HBM_PEAK_GBS * 1e9)) < 1e-4
+    args.sampler = "MIN_DISTANCE"
+    assert abs(bench.implemented_sort_frac(prof, args, 4.0, 1e9, 0.1)["bytes_per_point"] - (32 + 128 + 4 * 57)) < 0.1
+    assert bench.implemented_sort_frac({}, args, 4.0, 1e9, 0.1) is None
+
+
+def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from profiles/rNN/traffic.json only while schwarzwald_amd/csrc still hashes to the stamp."""
+    sha = bench.library_source_sha16()
+    assert len(sha) == 16
+    value, source = bench.measured_traffic("sample_min_distance", 1_000_000_000, "MIN_DISTANCE")
+    assert value is None or "profiles/" in source
+    if value is None:
+        assert "stale" in source or "no " in source or source
