@@ -169,6 +169,9 @@ KeyMetric key_metric(const swz_ctx* c, const LevelPlan& plan, const SortedPoints
 int key_point_ids(swz_ctx* c, const ActiveSet& as, const SortedPoints& sp, const uint32_t** ids);
 // true when min_distance_level will not need sp.X / sp.Y / sp.Z for this level
 bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp);
+// no sampler of this level reads sp.X / Y / Z: RANDOM_GRID never does, the others decide on key coordinates and look up
+// sp.xyz through sp.perm (swz_mdkeys.hip, grid_argmin_keys_kernel)
+bool level_decides_on_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp);
 // Frontier sweep on key coordinates for a dense level; *used = false when the level does not qualify.
 // cl: cell levels below the node chosen by the caller; typical_pop: points-weighted mean cell population.
 int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,

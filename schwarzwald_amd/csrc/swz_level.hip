@@ -1073,6 +1073,12 @@ bool grid_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedP
   return true;
 }
 
+bool level_decides_on_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp) {
+  if (plan.sampler == SWZ_RANDOM_GRID) return true;
+  if (plan.sampler == SWZ_MIN_DISTANCE) return !plan.md_property && min_distance_level_uses_keys(c, plan, sp);
+  return grid_level_uses_keys(c, plan, sp, nullptr);
+}
+
 // ----------------------------------------------------------------------------- one level
 // Samples every node of the level.  When okey/oidx are given the survivors are compacted into them
 // and level_out receives plan.level for the taken points; otherwise only lb.taken is produced.

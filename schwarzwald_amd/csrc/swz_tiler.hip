@@ -44,7 +44,8 @@ struct BatchWork {
   uint32_t n = 0;          // points of the batch
   uint32_t wused = 0;      // working-pool entries in use
   uint32_t wcap = 0;
-  double *wx = nullptr, *wy = nullptr, *wz = nullptr;
+  double *wx = nullptr, *wy = nullptr, *wz = nullptr;  // positions by working index -- filled on demand, see work_need_positions
+  bool have_pos = false;
   int8_t* wlevel = nullptr;
   uint32_t* wgid = nullptr;
   uint64_t* surv_key[2] = {nullptr, nullptr};
@@ -123,17 +124,27 @@ __global__ __launch_bounds__(256) void tl_wgid_kernel(const uint32_t* __restrict
 }
 
 // store entry j lies in a node the active set reaches <=> some active key has the same node prefix
+// (the entries of a workgroup are consecutive store entries, sorted by node prefix: the searches of its first and last
+// entry bracket all others, as in tl_merge_rank_kernel)
 __global__ __launch_bounds__(256) void tl_touch_kernel(const uint64_t* __restrict__ skey, uint32_t cnt,
                                                        const uint64_t* __restrict__ akey, uint32_t m, uint32_t nsh,
                                                        uint8_t* __restrict__ touch) {
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  __shared__ uint32_t s_lo, s_hi;
+  const uint32_t j0 = blockIdx.x * 256u, j = j0 + threadIdx.x;
+  const uint32_t last = (cnt - j0) > 256u ? j0 + 255u : cnt - 1u;
+  auto lower = [&](uint32_t lo, uint32_t hi, uint64_t prefix) {
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if ((akey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  if (threadIdx.x == 0) s_lo = lower(0u, m, skey[j0] >> nsh);
+  if (threadIdx.x == 64) s_hi = lower(0u, m, skey[last] >> nsh);
+  __syncthreads();
   if (j >= cnt) return;
   const uint64_t prefix = skey[j] >> nsh;
-  uint32_t lo = 0, hi = m;
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if ((akey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
-  }
+  const uint32_t lo = lower(s_lo, s_hi, prefix);
   touch[j] = (lo < m && (akey[lo] >> nsh) == prefix) ? 1 : 0;
 }
 struct TouchF {
@@ -222,7 +233,8 @@ __global__ __launch_bounds__(256) void tl_inversion_kernel(const uint64_t* __res
   if (lane_id() == 0 && b) atomicAdd(count, (uint32_t)__popcll(b));
 }
 
-// positions of the pulled points into the working pool (SoA), behind the batch's own points
+// point ids of the pulled points into the working pool, behind the batch's own points -- and their positions (SoA) when
+// the working pool keeps positions (X != null; see work_need_positions)
 __global__ __launch_bounds__(256) void tl_fill_kernel(const uint32_t* __restrict__ cgid, uint32_t nc,
                                                       const double* __restrict__ pool, double* __restrict__ X,
                                                       double* __restrict__ Y, double* __restrict__ Z,
@@ -230,46 +242,58 @@ __global__ __launch_bounds__(256) void tl_fill_kernel(const uint32_t* __restrict
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= nc) return;
   const size_t g = cgid[j];
+  if (wgid) wgid[j] = (uint32_t)g;
+  if (!X || g == 0xFFFFFFFFu) return;  // (the ghosts of a sharded root have no id: their positions were written with them)
   X[j] = pool[3 * g];
   Y[j] = pool[3 * g + 1];
   Z[j] = pool[3 * g + 2];
-  wgid[j] = (uint32_t)g;
 }
 
 // std::merge(first, second, comp = key <): elements of `first` precede equal elements of `second`.
 // Keys are compared after >> sh (sh = node shift merges by node only: merge_node_data_unsorted's "new ++ cached").
-__global__ __launch_bounds__(256) void tl_merge_first_kernel(const uint64_t* __restrict__ k1,
-                                                             const uint32_t* __restrict__ v1, uint32_t n1,
-                                                             const uint64_t* __restrict__ k2, uint32_t n2, uint32_t sh,
-                                                             uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
-  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n1) return;
-  const uint64_t k = k1[i];
-  const uint64_t ks = k >> sh;
-  uint32_t lo = 0, hi = n2;  // number of second elements strictly below
+// Stable merge of two sorted runs by rank: an element's place is its own index plus the number of elements of the other
+// run that go before it (first run: strictly smaller keys; second run: smaller or equal -- the first run wins ties, like
+// std::merge).  The 256 consecutive elements of a workgroup are sorted, so the ranks of its first and last element bracket
+// all others: two searches over the whole other run per workgroup, then every thread searches that bracket only -- out of
+// LDS when it holds at most 1024 keys (runs of similar length interleave: a few hundred), instead of ~25 dependent probes
+// all over a run of tens of millions of keys per element.
+constexpr uint32_t TL_MERGE_LDS = 1024;
+template <bool UPPER>
+__device__ __forceinline__ uint32_t tl_rank(const uint64_t* __restrict__ k, uint32_t lo, uint32_t hi, uint64_t ks, uint32_t sh) {
   while (lo < hi) {
     const uint32_t mid = lo + (hi - lo) / 2;
-    if ((k2[mid] >> sh) < ks) lo = mid + 1; else hi = mid;
+    const uint64_t v = k[mid] >> sh;
+    if (UPPER ? (v <= ks) : (v < ks)) lo = mid + 1; else hi = mid;
   }
-  ok[i + lo] = k;
-  ov[i + lo] = v1 ? v1[i] : i;
+  return lo;
 }
-__global__ __launch_bounds__(256) void tl_merge_second_kernel(const uint64_t* __restrict__ k2,
-                                                              const uint32_t* __restrict__ v2, uint32_t n2,
-                                                              const uint64_t* __restrict__ k1, uint32_t n1, uint32_t sh,
-                                                              uint32_t base, uint64_t* __restrict__ ok,
-                                                              uint32_t* __restrict__ ov) {
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n2) return;
-  const uint64_t k = k2[j];
+// run `a` (n_a elements, values va or `base + index`) against the other run `b`; UPPER: a is the second run
+template <bool UPPER>
+__global__ __launch_bounds__(256) void tl_merge_rank_kernel(const uint64_t* __restrict__ ka, const uint32_t* __restrict__ va, uint32_t na,
+                                                            const uint64_t* __restrict__ kb, uint32_t nb, uint32_t sh, uint32_t base,
+                                                            uint64_t* __restrict__ ok, uint32_t* __restrict__ ov) {
+  __shared__ uint32_t s_lo, s_hi;
+  __shared__ uint64_t sk[TL_MERGE_LDS];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i0 = blockIdx.x * 256u;
+  const uint32_t i = i0 + tid;
+  const uint32_t last = (na - i0) > 256u ? i0 + 255u : na - 1u;
+  if (tid == 0) s_lo = tl_rank<UPPER>(kb, 0u, nb, ka[i0] >> sh, sh);
+  if (tid == 64) s_hi = tl_rank<UPPER>(kb, 0u, nb, ka[last] >> sh, sh);
+  __syncthreads();
+  const uint32_t lo = s_lo, hi = s_hi;
+  const bool in_lds = hi - lo <= TL_MERGE_LDS;
+  if (in_lds)
+    for (uint32_t j = tid; j < hi - lo; j += 256u) sk[j] = kb[lo + j] >> sh;
+  __syncthreads();
+  if (i >= na) return;
+  const uint64_t k = ka[i];
   const uint64_t ks = k >> sh;
-  uint32_t lo = 0, hi = n1;  // number of first elements below or equal
-  while (lo < hi) {
-    const uint32_t mid = lo + (hi - lo) / 2;
-    if ((k1[mid] >> sh) <= ks) lo = mid + 1; else hi = mid;
-  }
-  ok[j + lo] = k;
-  ov[j + lo] = v2 ? v2[j] : base + j;
+  uint32_t r;
+  if (in_lds) r = lo + tl_rank<UPPER>(sk, 0u, hi - lo, ks, 0u);
+  else r = tl_rank<UPPER>(kb, lo, hi, ks, sh);
+  ok[i + r] = k;
+  ov[i + r] = va ? va[i] : base + i;
 }
 
 struct TakenF {
@@ -454,12 +478,11 @@ static int pool_reserve(swz_tiler* t, size_t points) {
 static int merge_pairs(swz_ctx* c, const uint64_t* k1, const uint32_t* v1, uint32_t n1, const uint64_t* k2,
                        const uint32_t* v2, uint32_t n2, uint32_t sh, uint32_t base2, uint64_t* ok, uint32_t* ov) {
   if (n1) {
-    hipLaunchKernelGGL(tl_merge_first_kernel, dim3(div_up(n1, 256)), dim3(256), 0, c->stream, k1, v1, n1, k2, n2, sh, ok, ov);
+    hipLaunchKernelGGL(tl_merge_rank_kernel<false>, dim3(div_up(n1, 256)), dim3(256), 0, c->stream, k1, v1, n1, k2, n2, sh, 0u, ok, ov);
     SWZ_LAUNCH_CHECK(c);
   }
   if (n2) {
-    hipLaunchKernelGGL(tl_merge_second_kernel, dim3(div_up(n2, 256)), dim3(256), 0, c->stream, k2, v2, n2, k1, n1, sh,
-                       base2, ok, ov);
+    hipLaunchKernelGGL(tl_merge_rank_kernel<true>, dim3(div_up(n2, 256)), dim3(256), 0, c->stream, k2, v2, n2, k1, n1, sh, base2, ok, ov);
     SWZ_LAUNCH_CHECK(c);
   }
   return SWZ_OK;
@@ -511,6 +534,23 @@ __global__ __launch_bounds__(256) void tl_count_untaken_kernel(const uint8_t* __
 // sr != nullptr: the ROOT level of a sharded batch (the node spans all shards: its take-all / sample decision is
 // the global one, its whole local file takes part even without new local points, and for MIN_DISTANCE what the root
 // took on lower shards in this batch sorts first as ghosts -- swz_tiler_shard_begin_device)
+// The working pool keeps positions (SoA, by working index) only from the first level on that reads them: RANDOM_GRID never
+// does, MIN_DISTANCE / GRID_CENTER / JITTERED decide on key coordinates and look up the position pool through the point ids
+// (level_decides_on_keys) -- a batch of a usual data set never fills them.  Levels that do read them (bounds that are no
+// cube, spacings of fewer than 64 key cells, re-rooted nodes, the ghosts of a sharded root) fill everything that is in the
+// working pool by then, from the ids; entries pulled in later are filled as they come.
+static int work_need_positions(swz_tiler* t, BatchWork& w) {
+  if (w.have_pos) return SWZ_OK;
+  swz_ctx* c = t->c;
+  if (w.wused) {
+    hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(w.wused, 256)), dim3(256), 0, c->stream, w.wgid, w.wused, t->pool_xyz, w.wx, w.wy, w.wz,
+                       (uint32_t*)nullptr);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  w.have_pos = true;
+  return SWZ_OK;
+}
+
 static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, ActiveSet& as, LevelResult* res,
                        uint32_t* merged_out, const ShardRoot* sr = nullptr) {
   swz_ctx* c = t->c;
@@ -570,7 +610,7 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     if (w.wused + nc + ng > w.wcap) return c->fail(SWZ_ERR_INTERNAL, "working pool overflow");
     if (nc) {
       hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, cgid, nc, t->pool_xyz,
-                         w.wx + w.wused, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
+                         w.have_pos ? w.wx + w.wused : nullptr, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
       SWZ_LAUNCH_CHECK(c);
     }
     uint64_t* mkey = nullptr;
@@ -625,7 +665,13 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   SWZ_TRY(alloc_level_buffers(c, ms.m, &lb));
   // (exact positions for MIN_DISTANCE on key coordinates, swz_mdkeys.hip: working index -> point id -> position pool;
   // ghosts of a sharded root lie outside the pool)
-  const SortedPoints sp{w.wx, w.wy, w.wz, ng ? nullptr : t->pool_xyz, w.wgid};
+  SortedPoints sp{nullptr, nullptr, nullptr, ng ? nullptr : t->pool_xyz, w.wgid};
+  if (!level_decides_on_keys(c, plan, sp)) SWZ_TRY(work_need_positions(t, w));
+  if (w.have_pos) {
+    sp.X = w.wx;
+    sp.Y = w.wy;
+    sp.Z = w.wz;
+  }
   SWZ_TRY(level_step(c, plan, ms, sp, lb, w.wlevel, w.surv_key[w.which], w.surv_idx[w.which], res));
 
   // ---- the nodes' new files, merged back between the files of the untouched nodes
@@ -691,6 +737,7 @@ static int rr_node(swz_tiler* t, BatchWork& w, const RrNode& node, double root_e
                    const uint32_t* d_idx, uint32_t cnt, int depth, RrTotals& tot) {
   swz_ctx* c = t->c;
   if (depth > 24) return c->fail(SWZ_ERR_INTERNAL, "re-rooting recursed too deep");
+  SWZ_TRY(work_need_positions(t, w));  // re-indexing against the node's box reads the positions
   const uint32_t nsh = level_shift(node.level);
   uint32_t* counters = nullptr;
   SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
@@ -897,8 +944,7 @@ static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t
   SWZ_TRY(c->get("tl_wz", (size_t)w.wcap, &w.wz));
   SWZ_TRY(c->get("tl_wlevel", (size_t)w.wcap, &w.wlevel));
   SWZ_TRY(c->get("tl_wgid", (size_t)w.wcap, &w.wgid));
-  if (n) {
-    SWZ_TRY(gather_positions(c, d_xyz, perm, n, w.wx, w.wy, w.wz));
+  if (n) {  // (positions: on demand, work_need_positions)
     hipLaunchKernelGGL(tl_wgid_kernel, dim3(div_up(n, 256)), dim3(256), 0, c->stream, perm, n, base, w.wgid);
     SWZ_LAUNCH_CHECK(c);
   }

@@ -1,6 +1,4 @@
-export SWZ_MD_TIME_LIMIT=20
-for cfg in "SWZ_MD_BIG=0 SWZ_MD_GROUPS=1" "SWZ_MD_GROUPS=1"; do
-echo "== $cfg"
-env $cfg SWZ_DEBUG=1 timeout 300 python tools/clustered_probe.py 100000000 MIN_DISTANCE 2>&1 | grep -E "sweep|N=" | cut -c1-100 | tail -6
-done
-SWZ_DEBUG=1 timeout 200 python bench.py --steps 2 --warmup 1 --cpu-sample 0 2>&1 | grep -E "sweep|ms_per_step" | tail -4 | cut -c1-200
+cd /tmp && export TMPDIR=/tmp
+rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_mb
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_mb -o mb -- python3 $GRAFT_REPO_ROOT/bench.py --points 100000000 --batches 10 --sampler RANDOM_GRID --steps 2 --warmup 1 --cpu-sample 0 > $GRAFT_REPO_ROOT/gpurun_out/mb_run.json 2>/dev/null
+find $GRAFT_REPO_ROOT/gpurun_out/prof_mb -name "*kernel_trace*" -delete
