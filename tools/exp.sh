@@ -1,5 +1,8 @@
-export SWZ_MD_TIME_LIMIT=20
-for cfg in "SWZ_MD_MAX_POP=160" "SWZ_MD_MAX_POP=400" "SWZ_MD_MAX_POP=3000" "SWZ_MD_COARSEN=1 SWZ_MD_COARSEN_MIN=0"; do
-echo "== $cfg"
-env $cfg SWZ_DEBUG=1 timeout 600 python bench.py --points 100000000 --batches 10 --sampler MIN_DISTANCE --steps 1 --warmup 1 --cpu-sample 0 2>&1 | grep -E "level -1 on keys|ms_per_step" | cut -c1-200 | tail -3
+for s in MIN_DISTANCE; do
+timeout 900 python bench.py --points 1000000000 --batches 100 --sampler $s --steps 1 --warmup 0 --cpu-sample 0 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$s 1B/100 cold', d['ms_per_step'], 'ms', d['value'], 'Mpts/s')"
 done
+timeout 600 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --md-mode both 2>/dev/null | cut -c1-160
+timeout 1200 python -m pytest tests/test_gpu_fullsize.py tests/test_multibatch.py tests/test_min_distance_property.py -q -m gpu -x 2>&1 | tail -2
