@@ -431,7 +431,7 @@ def main():
                 for key in ("points_visited", "num_levels", "min_distance_rounds"):
                     tot[key] += st[key]
                 tot["max_level"] = max(tot["max_level"], st["max_level"])
-            runner.tiler.finalize()
+            runner.finalize()
             tot["num_nodes"] = int(runner.tiler.info()["num_nodes"])
             runner.close()
             return tot

@@ -15,6 +15,7 @@ SAMPLERS = {"RANDOM_GRID": RANDOM_GRID, "GRID_CENTER": GRID_CENTER, "MIN_DISTANC
             "JITTERED": JITTERED}
 TAKE_ALL_WHEN_COUNT_BELOW_MAX_POINTS, ALWAYS_ADHERE_TO_MIN_SPACING = 0, 1
 ACCURATE, FAST = 0, 1
+ERR_BAD_ARG = 2
 ERR_INTERNAL = 7
 ERR_TILER_FAILED = 8
 ERR_PEER_FAILED = 100  # raised by the multi-GPU driver on the ranks that did not fail themselves
@@ -342,6 +343,11 @@ def load_library():
     L.swz_tiler_level_count.argtypes = [vp, C.c_int, _u64p]
     L.swz_tiler_poison.argtypes = [vp, C.c_char_p]
     L.swz_tiler_pool_residency.argtypes = [vp, _u64p, _u64p]
+    L.swz_tiler_shard_fast_histogram.argtypes = [vp, _u32p]
+    L.swz_fast_start_level_from_counts.argtypes = [_u64p, C.c_uint32, C.POINTER(C.c_int32)]
+    L.swz_tiler_shard_set_start_level.argtypes = [vp, C.c_int32]
+    L.swz_tiler_shard_fast_finalize_local.argtypes = [vp, C.POINTER(_TileStats)]
+    L.swz_tiler_shard_fast_set_root.argtypes = [vp, vp]
     L.swz_tiler_level_positions_device.argtypes = [vp, C.c_int, vp]
     L.swz_host_alloc_pinned.argtypes = [C.c_uint64, C.POINTER(vp)]
     L.swz_host_free_pinned.argtypes = [vp]
@@ -361,7 +367,9 @@ def load_library():
                  "swz_tiler_finalize", "swz_tiler_get_info", "swz_tiler_export_device", "swz_tiler_node_table",
                  "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned",
                  "swz_tiler_shard_begin_device", "swz_tiler_shard_finish", "swz_tiler_level_count",
-                 "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency"):
+                 "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency",
+                 "swz_tiler_shard_fast_histogram", "swz_fast_start_level_from_counts", "swz_tiler_shard_set_start_level",
+                 "swz_tiler_shard_fast_finalize_local", "swz_tiler_shard_fast_set_root"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -609,6 +617,19 @@ class Context:
         return _stats_dict(stats)
 
 
+def fast_start_level_from_counts(counts, fast_concurrency):
+    """The start level TilingAlgorithmV3 derives from the 2^18-bin prefix histogram of a batch's keys
+    (TilingAlgorithms.cpp:1473-1535); counts: the histogram summed over all shards."""
+    L = load_library()
+    c = np.ascontiguousarray(counts, dtype=np.uint64)
+    assert c.shape[0] == 1 << 18
+    out = C.c_int32(-1)
+    st = L.swz_fast_start_level_from_counts(c.ctypes.data_as(_u64p), int(fast_concurrency), C.byref(out))
+    if st != 0:
+        raise SwzError(st, "swz_fast_start_level_from_counts failed")
+    return int(out.value)
+
+
 def pinned_empty(shape, dtype):
     """numpy array over page-locked host memory (swz_host_alloc_pinned).  The memory is released when the array
     and all its views are gone; keep it alive while asynchronous copies from it are in flight."""
@@ -732,6 +753,24 @@ class Tiler:
         stats = _TileStats()
         self._ctx._check(self._lib.swz_tiler_shard_finish(self._t, C.byref(stats)))
         return _stats_dict(stats)
+
+    # -- FAST (TilingAlgorithmV3) on a sharded data set: the driver sums the shards' prefix histograms, derives the start
+    # level, and at the end samples the root from the level-0 files of all shards (sharded.ShardedBatchTiler)
+    def shard_fast_histogram(self):
+        counts = np.zeros(1 << 18, dtype=np.uint32)
+        self._ctx._check(self._lib.swz_tiler_shard_fast_histogram(self._t, counts.ctypes.data_as(_u32p)))
+        return counts
+
+    def shard_set_start_level(self, start_level):
+        self._ctx._check(self._lib.swz_tiler_shard_set_start_level(self._t, int(start_level)))
+
+    def shard_fast_finalize_local(self):
+        stats = _TileStats()
+        self._ctx._check(self._lib.swz_tiler_shard_fast_finalize_local(self._t, C.byref(stats)))
+        return _stats_dict(stats)
+
+    def shard_fast_set_root(self, d_taken):
+        self._ctx._check(self._lib.swz_tiler_shard_fast_set_root(self._t, C.c_void_p(d_taken)))
 
     def level_count(self, level):
         out = C.c_uint64()

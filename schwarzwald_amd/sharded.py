@@ -18,6 +18,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -297,6 +298,7 @@ class ShardedBatchTiler:
             ctx.set_stream(torch.cuda.current_stream(device).cuda_stream)
         self.tiler = api.Tiler(ctx, bmin, bmax, params, capacity_hint)
         self._keep = None
+        self.fast_start = -1  # FAST: the start level, known after the first batch
 
     def close(self):
         self.tiler.close()
@@ -340,6 +342,8 @@ class ShardedBatchTiler:
             assert rc == recv_counts
             cols[name] = got.contiguous()
         del order
+        if self.params.strategy == api.FAST:
+            return self._add_batch_fast(recv, m, cols, global_new)
         root_stored = self._all_sum(self.tiler.level_count(-1))
         sample = root_stored > 0 or global_new + root_stored > self.params.max_points_per_node
         sequential_root = self.params.sampler == api.MIN_DISTANCE and sample and global_new > 0
@@ -392,4 +396,108 @@ class ShardedBatchTiler:
             raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
         self._keep = (recv, cols)
         stats["shard_points"] = m
+        return stats
+
+    # -- FAST (TilingAlgorithmV3, the reference's default): no root step per batch.  The start level comes from the FIRST
+    # batch's distribution over all shards (TilingAlgorithms.cpp:1473-1535) and is kept; the skipped levels are rebuilt at
+    # the end of the data set (finalize below).
+    def _vote(self, failure):
+        if self._all_sum(1 if failure else 0):
+            try:
+                self.tiler.poison("a rank of the sharded run failed to tile this batch")
+            except api.SwzError:
+                pass
+            if failure:
+                raise failure[0]
+            raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
+
+    def _add_batch_fast(self, recv, m, cols, global_new):
+        failure = []
+        ptrs = {name: t.data_ptr() for name, t in cols.items()}
+        try:
+            if global_new < self.params.fast_concurrency:
+                raise api.SwzError(api.ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points")
+            self.tiler.shard_begin_device(recv.data_ptr(), m, ptrs, global_new, 0)
+        except api.SwzError as e:
+            failure.append(e)
+        if self.fast_start < 0:
+            hist = np.zeros(1 << 18, dtype=np.int64)
+            if not failure:
+                try:
+                    hist = self.tiler.shard_fast_histogram().astype(np.int64)
+                except api.SwzError as e:
+                    failure.append(e)
+            t = torch.from_numpy(hist)
+            if dist.get_backend(self.group) == "nccl":
+                t = t.to(self.device)
+            dist.all_reduce(t, group=self.group)
+            self._vote(failure)
+            self.fast_start = api.fast_start_level_from_counts(t.cpu().numpy().astype(np.uint64), self.params.fast_concurrency)
+        stats = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
+        if not failure:
+            try:
+                self.tiler.shard_set_start_level(self.fast_start)
+                stats = self.tiler.shard_finish()
+            except api.SwzError as e:
+                failure.append(e)
+        self._vote(failure)
+        self._keep = (recv, cols)
+        stats["shard_points"] = m
+        return stats
+
+    def finalize(self):
+        """Ends the data set.  ACCURATE: nothing is left to do beyond the tiler's own finalize.  FAST: every rank rebuilds the
+        skipped levels of its octants down to level 0; the root (reconstruct_single_node, TilingAlgorithms.cpp:1661-1715)
+        samples what its eight children hold, and they lie on different ranks: their level-0 files come together on rank 0
+        in rank order (= octant order, the order the reference appends them in), are indexed against the root bounds and
+        sampled with AlwaysAdhereToMinSpacing there; every rank keeps the part of the root's file that comes from its points."""
+        if self.params.strategy != api.FAST or self.fast_start <= 0:
+            return self.tiler.finalize()
+        dev, world = self.device, self.world
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        stats = self.tiler.shard_fast_finalize_local()
+        cnt = self.tiler.level_count(0)
+        counts = torch.zeros(world, dtype=torch.int64, device=dev if on_gpu else "cpu")
+        counts[self.rank] = cnt
+        dist.all_reduce(counts, group=self.group)
+        counts = [int(c) for c in counts.cpu()]
+        mine = torch.empty((max(cnt, 1), 3), dtype=torch.float64, device=dev)
+        if cnt:
+            self.tiler.level_positions_device(0, mine.data_ptr())
+            torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+        mine = mine[:cnt]
+        wire = (lambda t: t) if on_gpu else (lambda t: t.cpu())
+        flags = None
+        if self.rank == 0:
+            parts = [mine.cpu()]
+            for r in range(1, world):
+                buf = torch.empty((counts[r], 3), dtype=torch.float64, device=dev if on_gpu else "cpu")
+                if counts[r]:
+                    dist.recv(buf, src=r, group=self.group)
+                parts.append(buf.cpu())
+            allp = torch.cat(parts).numpy()
+            taken = np.zeros(allp.shape[0], dtype=np.uint8)
+            if allp.shape[0]:
+                keys, clamped = self.ctx.morton_encode(allp, self.bmin, self.bmax)
+                perm, skeys = self.ctx.sort_by_key(keys)
+                t_sorted = self.ctx.sample_points(self.params.sampler, self.params.max_points_per_node, skeys, perm, clamped, 0, -1,
+                                                  self.bmin, self.bmax, self.params.spacing_at_root, api.ALWAYS_ADHERE_TO_MIN_SPACING)
+                taken[perm] = t_sorted
+            off = 0
+            for r in range(world):
+                part = torch.from_numpy(taken[off:off + counts[r]].copy())
+                off += counts[r]
+                if r == 0:
+                    flags = part.to(dev)
+                elif counts[r]:
+                    dist.send(wire(part.to(dev)), dst=r, group=self.group)
+        else:
+            if cnt:
+                dist.send(wire(mine), dst=0, group=self.group)
+                buf = torch.empty(cnt, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+                dist.recv(buf, src=0, group=self.group)
+                flags = buf.to(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        self.tiler.shard_fast_set_root(flags.data_ptr() if (flags is not None and cnt) else None)
         return stats

@@ -260,21 +260,22 @@ def _mb_cloud(n, batch, rank, corner_world=0):
     return xyz
 
 
-def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner):
+def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, strategy=0, concurrency=8):
     _init(rank, world, port)
     import schwarzwald_amd as swz
     from schwarzwald_amd import sharded
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     ctx = swz.Context(0)
-    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
+    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing, strategy=strategy,
+                            fast_concurrency=concurrency)
     st = sharded.ShardedBatchTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
     for b in range(k):
         xyz = torch.from_numpy(_mb_cloud(n, b, rank, world if corner else 0)).to(dev)
         ids = torch.arange(n, dtype=torch.int64) + (b * world * n + rank * n)     # id in the single-process batch order
         attrs = {"intensity": (ids & 0xFFFF).to(torch.int16).to(dev), "point_source_id": (ids >> 16).to(torch.int16).to(dev)}
         st.add_batch(xyz, attrs)
-    st.tiler.finalize()
+    st.finalize()
     info = st.tiler.info()
     table = st.tiler.node_table()
     ns = int(info["num_stored"])
@@ -329,6 +330,46 @@ def test_sharded_multibatch_matches_the_multibatch_oracle(sampler, corner):
     assert sum(got[r][2] for r in range(world)) == world * n * k
     if corner:
         assert got[1][2] == 0
+    assert set(have) == set(want)
+    for node, parts in have.items():
+        assert node[0] == -1 or len(parts) == 1          # only the root spans shards
+        assert np.array_equal(np.concatenate(parts), want[node]), node
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("k", [1, 3])
+def test_sharded_fast_strategy_matches_the_multibatch_oracle(sampler, k):
+    """FAST (TilingAlgorithmV3, the reference's default) on two ranks: the start level from the summed prefix histograms of
+    the first batch, the levels below it per rank, the skipped levels rebuilt at the end -- the root on rank 0 from the
+    level-0 files of both ranks.  Node files = the single-process FAST oracle's, file by file and in file order."""
+    world, n, max_pts, conc = 2, 20000, 400, 2
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    port = _free_port()
+    procs = [mpctx.Process(target=_mb_worker, args=(r, world, port, n, k, sampler, max_pts, spacing, q, False, O.FAST, conc)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=300)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    oracle = O.Tiler([0, 0, 0], [1, 1, 1], sampler, max_pts, spacing, strategy=O.FAST, fast_concurrency=conc)
+    for b in range(k):
+        assert oracle.add_batch(np.vstack([_mb_cloud(n, b, r, 0) for r in range(world)])) == 0
+    assert oracle.finalize() == 0
+    ex = oracle.export()
+    want = {(int(l), int(key)): ex["ids"][int(o):int(o + c)].astype(np.int64)
+            for l, key, o, c in zip(ex["level"], ex["key"], ex["offset"], ex["count"])}
+    have = {}
+    for r in range(world):
+        table, gids, npts = got[r]
+        for l, key, o, c in zip(table["level"], table["key"], table["offset"], table["count"]):
+            have.setdefault((int(l), int(key)), []).append(gids[int(o):int(o + c)])
     assert set(have) == set(want)
     for node, parts in have.items():
         assert node[0] == -1 or len(parts) == 1          # only the root spans shards
