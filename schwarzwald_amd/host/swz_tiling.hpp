@@ -23,6 +23,7 @@
 // reference reports tiler failures (executable/main.cpp:599-602).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <stdexcept>
@@ -222,33 +223,44 @@ public:
     _ctx.check(swz_tiler_get_info(_tiler, &info));
     const uint64_t ns = info.num_stored, nn = info.num_nodes;
     if (ns == 0) return 0;
-    // node order on the device: ids, then the positions gathered by id
-    void *d_ids = nullptr, *d_xyz = nullptr;
-    DeviceBuffer ids_buf(ns * 4), xyz_buf(ns * 24);
-    d_ids = ids_buf.ptr;
-    d_xyz = xyz_buf.ptr;
-    _ctx.check(swz_tiler_export_device(_tiler, nullptr, static_cast<uint32_t*>(d_ids), nullptr));
+    // The ids of all files in node order (4 bytes per stored point), then the files in CHUNKS of whole nodes: positions
+    // gathered by id on the device, copied, handed to the persistence -- host and device hold ns * 4 + chunk * 24 bytes
+    // instead of all ns * 28 at once, and the persistence starts writing while later chunks are still on the device.
+    DeviceBuffer ids_buf(ns * 4);
+    uint32_t* d_ids = static_cast<uint32_t*>(ids_buf.ptr);
+    _ctx.check(swz_tiler_export_device(_tiler, nullptr, d_ids, nullptr));
     const double* pool = nullptr;
     _ctx.check(swz_tiler_pools_device(_tiler, &pool, nullptr));
-    _ctx.check(swz_gather_payload_device(_ctx.get(), static_cast<const uint32_t*>(d_ids), nullptr, ns, pool, nullptr,
-                                         static_cast<double*>(d_xyz), nullptr));
     std::vector<uint32_t> ids(ns);
-    std::vector<double> xyz(ns * 3);
     _ctx.check(swz_copy_to_host(_ctx.get(), ids.data(), d_ids, ns * 4));
-    _ctx.check(swz_copy_to_host(_ctx.get(), xyz.data(), d_xyz, ns * 24));
     std::vector<int8_t> nl(nn);
     std::vector<uint64_t> nk(nn), no(nn), nc(nn);
     uint64_t got = 0;
     _ctx.check(swz_tiler_node_table(_tiler, nn, nl.data(), nk.data(), no.data(), nc.data(), &got));
-    for (uint64_t j = 0; j < got; ++j) {
-      std::string name = "r";  // node names: "r" + octant digits, TilingAlgorithms.cpp:139
-      AABB b = _bounds;
-      for (int l = 0; l <= nl[j]; ++l) {
-        const uint8_t o = get_octant_at_level(nk[j], static_cast<uint32_t>(l));
-        name.push_back(static_cast<char>('0' + o));
-        b = get_octant_bounds(o, b);
+    uint64_t largest = 0;
+    for (uint64_t j = 0; j < got; ++j) largest = std::max<uint64_t>(largest, nc[j]);
+    const uint64_t chunk_cap = std::max<uint64_t>(std::max<uint64_t>(_export_chunk_points, 1), largest);
+    DeviceBuffer xyz_buf(std::min(chunk_cap, ns) * 24);
+    std::vector<double> xyz(std::min(chunk_cap, ns) * 3);
+    for (uint64_t j0 = 0; j0 < got;) {
+      uint64_t j1 = j0, cnt = 0;  // nodes [j0, j1): consecutive files, stored back to back from no[j0] on
+      while (j1 < got && cnt + nc[j1] <= chunk_cap) cnt += nc[j1++];
+      if (cnt) {
+        _ctx.check(swz_gather_payload_device(_ctx.get(), d_ids + no[j0], nullptr, cnt, pool, nullptr, static_cast<double*>(xyz_buf.ptr),
+                                             nullptr));
+        _ctx.check(swz_copy_to_host(_ctx.get(), xyz.data(), xyz_buf.ptr, cnt * 24));
       }
-      _persistence.persist_points(ids.data() + no[j], ids.data() + no[j] + nc[j], xyz.data() + 3 * no[j], b, name);
+      for (uint64_t j = j0; j < j1; ++j) {
+        std::string name = "r";  // node names: "r" + octant digits, TilingAlgorithms.cpp:139
+        AABB b = _bounds;
+        for (int l = 0; l <= nl[j]; ++l) {
+          const uint8_t o = get_octant_at_level(nk[j], static_cast<uint32_t>(l));
+          name.push_back(static_cast<char>('0' + o));
+          b = get_octant_bounds(o, b);
+        }
+        _persistence.persist_points(ids.data() + no[j], ids.data() + no[j] + nc[j], xyz.data() + 3 * (no[j] - no[j0]), b, name);
+      }
+      j0 = j1;
     }
     return static_cast<size_t>(got);
   }
@@ -258,6 +270,8 @@ public:
     if (_tiler) _ctx.check(swz_tiler_get_info(_tiler, &i));
     return i;
   }
+  // stored points per export chunk of finalize() (whole node files; at least the largest file)
+  void set_export_chunk_points(uint64_t n) { _export_chunk_points = n; }
 
 private:
   struct DeviceBuffer {  // device scratch through the ABI (no HIP headers needed by the host code)
@@ -275,6 +289,7 @@ private:
   swz_tiler* _tiler = nullptr;
   AABB _bounds;
   bool _finalized = false;
+  uint64_t _export_chunk_points = 16u << 20;
 };
 
 // One batch over several GPUs from this one process (swz_group_*): the batch is cut into equal pieces in input

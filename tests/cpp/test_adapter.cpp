@@ -45,6 +45,7 @@ int main() {
       meta.spacing_at_root = spacing;
       meta.max_points_per_node = 1000;
       TilingAlgorithmGPU tiler(make_sampling_strategy_from_name(names[s], 1000), sink, meta);
+      if (batches == 3) tiler.set_export_chunk_points(2500);  // finalize() hands the files over in many small chunks of whole nodes
       orc_tile_params p{s, 1000, spacing, 100, ORC_ACCURATE, 8};
       orc_tiler* oracle = orc_tiler_create(mn, mx, &p);
       for (int b = 0; b < batches; ++b) {
