@@ -114,6 +114,7 @@ struct swz_group {
   std::chrono::steady_clock::time_point t_call;
   std::vector<swz::MdPeerView> views;        // MIN_DISTANCE root swept by all shards at once: what every shard publishes
   int fast_start = -1;                       // FAST: the start level, known after the first batch
+  bool peer_access = true;                   // kernels of one shard may read the memory of every other (the joint MIN_DISTANCE root does)
   std::vector<std::vector<uint32_t>> hist;   // FAST, first batch: every shard's points per 6-octant prefix
   // batches staged from pinned host memory: two device buffers per shard, filled on a copy stream of their own
   struct Staged {
@@ -325,7 +326,7 @@ void shard_thread(ShardCall a) {
   if (!sequential_root) {
     swz_shard_info info{global_points, nullptr, 0};
     GRP_TRY(swz_shard_begin_device(c, recv, m, a.bmin, a.bmax, a.params, &info, &taken));
-  } else if (N > 1 && joint_root_possible(c, *a.params, a.bmin, a.bmax)) {
+  } else if (N > 1 && g->peer_access && joint_root_possible(c, *a.params, a.bmin, a.bmax)) {
     // All shards sweep the root cells of their own octants at the same time; a cell at the face of a lower octant reads
     // that shard's records through peer access (swz_mdkeys.hip).  No ghosts, no turns.
     swz::MdShardRoot sr;
@@ -524,11 +525,22 @@ int swz_group_create(int num_shards, const int* devices, int transport, swz_grou
       delete g;
       return SWZ_ERR_HIP;
     }
-  } else if (distinct && num_shards > 1) {
-    for (int i = 0; i < num_shards; ++i) {  // peer copies between distinct devices want peer access enabled
-      (void)hipSetDevice(devices[i]);
-      for (int j = 0; j < num_shards; ++j)
-        if (i != j) (void)hipDeviceEnablePeerAccess(devices[j], 0);
+  }
+  // Peer access between all pairs of distinct devices, whatever the transport: peer copies want it, and the MIN_DISTANCE
+  // root that all shards sweep at once has cells READ the lower shards' records in place (swz_mdkeys.hip).  Shards that
+  // share a device share its memory.  Without it (no xGMI / PCIe peer path) the root is taken in turns instead.
+  for (int i = 0; i < num_shards; ++i) {
+    (void)hipSetDevice(devices[i]);
+    for (int j = 0; j < num_shards; ++j) {
+      if (devices[i] == devices[j]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess || !can) {
+        g->peer_access = false;
+        continue;
+      }
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) g->peer_access = false;
+      (void)hipGetLastError();
     }
   }
   g->send_counts.assign(num_shards, std::vector<uint64_t>(num_shards, 0));
