@@ -382,7 +382,8 @@ def main():
     ctx.generate_uniform_device(SEED + 3, rank * n, n, xyz.data_ptr())
 
     mb = None
-    if distributed and args.batches > 1:
+    if distributed and (args.batches > 1 or args.strategy == "FAST"):
+        # (FAST on several GPUs goes through the batch tiler also with ONE batch: the single-batch sharded call is ACCURATE only)
         # BASELINE config 5's shape: every rank feeds its points in `batches` batches (attribute columns of --payload
         # along) to a sharded multi-batch tiler; with --staged the batches come from pinned host memory, the copy of
         # batch i+1 on a side stream under the tiling of batch i

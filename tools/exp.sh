@@ -1,4 +1,3 @@
-# scratch script for one-off experiments through gpurun (`gpurun -- 'bash tools/exp.sh > gpurun_out/exp.log 2>&1'`);
-# always bound what it runs: SWZ_MD_TIME_LIMIT (seconds per MIN_DISTANCE level) and `timeout` around every command
-export SWZ_MD_TIME_LIMIT=20
-SWZ_DEBUG=1 timeout 300 python bench.py --steps 1 --warmup 1 --cpu-sample 0 2>&1 | grep -E "MIN_DISTANCE level|ms_per_step" | cut -c1-230 | tail -30
+SWZ_BENCH_FORCE_SHARDED=1 timeout 600 python bench.py --strategy FAST --points 200000000 --steps 1 --warmup 1 --cpu-sample 0 > gpurun_out/fast_sharded.out 2> gpurun_out/fast_sharded.err
+echo rc=$?
+tail -c 600 gpurun_out/fast_sharded.out; grep -v amdgpu.ids gpurun_out/fast_sharded.err | tail -15
