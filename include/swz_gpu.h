@@ -516,6 +516,26 @@ int swz_group_stage_batch(swz_group* group, const double* const* xyz_host, const
 int swz_group_tile_staged(swz_group* group, swz_tile_stats* stats_per_shard);
 int swz_group_finalize(swz_group* group, swz_tile_stats* stats_per_shard);
 
+/* ---- the MIN_DISTANCE root of a sharded batch swept by all ranks at once, ONE PROCESS PER GPU (the torch driver;
+ * swz_group_tile does this by itself for the shards of one process).  Instead of the chain of ghosts from rank to rank
+ * (swz_shard_begin_device with ghosts), every rank sweeps the root cells of its own octants concurrently and cells at the
+ * face of a lower octant read that rank's records in place, through IPC mappings (hipIpcGetMemHandle /
+ * hipIpcOpenMemHandle) that the library exchanges through the driver's all-gather:
+ *   swz_shard_joint_root_possible: exact MIN_DISTANCE, cubic bounds, a root that can be decided on key coordinates.
+ *   swz_shard_joint_root_begin: before swz_shard_begin_device (without ghosts).  exchange(arg, mine, bytes, all) must
+ *     all-gather `bytes` bytes of every rank into all[rank * bytes] and return 0; the library calls it twice per batch
+ *     on every rank, from inside swz_shard_begin_device (or from swz_shard_joint_root_meet).
+ *   swz_shard_joint_root_meet: a rank whose swz_shard_begin_device was not called (it owns no points) or failed before
+ *     its sweep began calls this instead, so that the others are not left waiting in the exchange.
+ *   swz_shard_joint_root_end: after a barrier of the driver behind swz_shard_begin_device (the other ranks may read this
+ *     rank's root arrays until they have finished theirs); unmaps.
+ * Results are those of the chain, point for point (tests/test_sharded_gloo.py, two processes on one GPU). */
+typedef int (*swz_exchange_fn)(void* arg, const void* mine, uint64_t bytes, void* all);
+int swz_shard_joint_root_possible(swz_ctx* ctx, const swz_tile_params* params, const double bounds_min[3], const double bounds_max[3]);
+int swz_shard_joint_root_begin(swz_ctx* ctx, int shard, int num_shards, swz_exchange_fn exchange, void* arg);
+int swz_shard_joint_root_meet(swz_ctx* ctx, int ok);
+int swz_shard_joint_root_end(swz_ctx* ctx);
+
 /* page-locked host memory for the staging entry points (hipHostMalloc / hipHostFree) */
 int swz_host_alloc_pinned(uint64_t bytes, void** out);
 int swz_host_free_pinned(void* p);

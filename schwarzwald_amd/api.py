@@ -240,6 +240,9 @@ def library_path():
     return os.environ.get("SWZ_GPU_LIBRARY", os.path.join(_HERE, "lib", "libswz_gpu.so"))
 
 
+# the all-gather callback of swz_shard_joint_root_begin: int (*)(void* arg, const void* mine, uint64_t bytes, void* all)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
 _lib = None
 _dp, _u64p, _u32p = C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
 _i8p, _u8p = C.POINTER(C.c_int8), C.POINTER(C.c_uint8)
@@ -343,6 +346,10 @@ def load_library():
     L.swz_tiler_level_count.argtypes = [vp, C.c_int, _u64p]
     L.swz_tiler_poison.argtypes = [vp, C.c_char_p]
     L.swz_tiler_pool_residency.argtypes = [vp, _u64p, _u64p]
+    L.swz_shard_joint_root_possible.argtypes = [vp, C.POINTER(_TileParams), _dp, _dp]
+    L.swz_shard_joint_root_begin.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
+    L.swz_shard_joint_root_meet.argtypes = [vp, C.c_int]
+    L.swz_shard_joint_root_end.argtypes = [vp]
     L.swz_tiler_shard_fast_histogram.argtypes = [vp, _u32p]
     L.swz_fast_start_level_from_counts.argtypes = [_u64p, C.c_uint32, C.POINTER(C.c_int32)]
     L.swz_tiler_shard_set_start_level.argtypes = [vp, C.c_int32]
@@ -369,7 +376,8 @@ def load_library():
                  "swz_tiler_shard_begin_device", "swz_tiler_shard_finish", "swz_tiler_level_count",
                  "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency",
                  "swz_tiler_shard_fast_histogram", "swz_fast_start_level_from_counts", "swz_tiler_shard_set_start_level",
-                 "swz_tiler_shard_fast_finalize_local", "swz_tiler_shard_fast_set_root"):
+                 "swz_tiler_shard_fast_finalize_local", "swz_tiler_shard_fast_set_root", "swz_shard_joint_root_possible",
+                 "swz_shard_joint_root_begin", "swz_shard_joint_root_meet", "swz_shard_joint_root_end"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -615,6 +623,30 @@ class Context:
         self._check(self._lib.swz_shard_finish_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_perm),
                                                       C.c_void_p(d_level), C.byref(stats)))
         return _stats_dict(stats)
+
+    # -- the MIN_DISTANCE root of a sharded batch swept by all ranks at once (one process per GPU; include/swz_gpu.h)
+    def shard_joint_root_possible(self, bmin, bmax, params):
+        p = params._c()
+        return bool(self._lib.swz_shard_joint_root_possible(self._ctx, C.byref(p), _vec3(bmin), _vec3(bmax)))
+
+    def shard_joint_root_begin(self, shard, num_shards, all_gather_bytes):
+        """all_gather_bytes(mine: bytes) -> list of every rank's bytes, in rank order (a collective of the driver)."""
+        def cb(_arg, mine, nbytes, out):
+            try:
+                parts = all_gather_bytes(C.string_at(mine, nbytes))
+                C.memmove(out, b"".join(parts), nbytes * len(parts))
+                return 0
+            except Exception:  # the library turns this into an error status on every rank
+                return 1
+        self._joint_cb = EXCHANGE_FN(cb)  # must outlive the calls that use it
+        self._check(self._lib.swz_shard_joint_root_begin(self._ctx, int(shard), int(num_shards), self._joint_cb, None))
+
+    def shard_joint_root_meet(self, ok=True):
+        self._check(self._lib.swz_shard_joint_root_meet(self._ctx, 1 if ok else 0))
+
+    def shard_joint_root_end(self):
+        self._check(self._lib.swz_shard_joint_root_end(self._ctx))
+        self._joint_cb = None
 
 
 def fast_start_level_from_counts(counts, fast_concurrency):

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -910,6 +911,186 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
     const int rc = swz_tiler_shard_fast_set_root(g->tiler[r], mine);
     if (rc != SWZ_OK) return shard_fail(r, rc);
   }
+  return SWZ_OK;
+}
+
+
+// ------------------------------------------------------------------------- the joint root for one PROCESS per GPU
+// swz_group sweeps the MIN_DISTANCE root with all shards at once because its shards share an address space.  A driver
+// with one process per GPU (torch.distributed) gets the same through IPC: inside swz_shard_begin_device every rank
+// exports the arrays of its root level (hipIpcGetMemHandle on the allocations they live in + offsets), the driver's
+// all-gather callback passes the blobs round, and every rank maps the arrays of the LOWER ranks (hipIpcOpenMemHandle).
+// From there on the sweep is the one of swz_mdkeys.hip: remote records bracketed by the owner's round word, system-scope
+// loads, cells at the faces polling.  swz_shard_joint_root_end -- after the driver's barrier, when every rank has
+// finished its root -- unmaps.
+}  // extern "C"
+namespace {
+struct JointBlob {
+  hipIpcMemHandle_t handle[8];
+  uint64_t offset[8];
+  uint8_t has[8];
+  uint32_t ncells, rg, cell_shift;
+  int32_t status, entered;
+};
+struct JointState {
+  swz::MdShardRoot sr;
+  std::vector<swz::MdPeerView> views;
+  swz_exchange_fn exchange = nullptr;
+  void* exchange_arg = nullptr;
+  std::vector<std::pair<hipIpcMemHandle_t, void*>> opened;  // one mapping per allocation
+  std::string err;
+  swz_ctx* c = nullptr;
+};
+std::map<swz_ctx*, JointState*>& joint_states() {
+  static std::map<swz_ctx*, JointState*> m;
+  return m;
+}
+std::mutex joint_m;
+
+void* joint_open(JointState* js, const hipIpcMemHandle_t& h) {
+  for (auto& kv : js->opened)
+    if (std::memcmp(&kv.first, &h, sizeof(h)) == 0) return kv.second;
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  js->opened.emplace_back(h, p);
+  return p;
+}
+
+// the "barrier" of MdShardRoot: every rank has published its view in views[shard] -- exchange them
+void joint_exchange(void* arg) {
+  JointState* js = static_cast<JointState*>(arg);
+  const int N = js->sr.shards, r = js->sr.shard;
+  swz::MdPeerView& mine = js->views[r];
+  JointBlob blob{};
+  const void* ptrs[8] = {mine.rec, mine.qpos, mine.state, mine.ovf, mine.gridmap, mine.round_word, mine.perm, mine.xyz};
+  blob.ncells = mine.ncells;
+  blob.rg = mine.rg;
+  blob.cell_shift = mine.cell_shift;
+  blob.status = mine.status;
+  blob.entered = 1;
+  for (int k = 0; k < 8 && mine.ncells; ++k) {
+    if (!ptrs[k]) continue;
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, const_cast<void*>(ptrs[k])) != hipSuccess ||
+        hipIpcGetMemHandle(&blob.handle[k], base) != hipSuccess) {
+      (void)hipGetLastError();
+      blob.status = SWZ_ERR_HIP;  // (e.g. memory that does not come from hipMalloc)
+      continue;
+    }
+    blob.offset[k] = (uint64_t)((const char*)ptrs[k] - (const char*)base);
+    blob.has[k] = 1;
+  }
+  std::vector<JointBlob> all((size_t)N);
+  if (js->exchange(js->exchange_arg, &blob, sizeof(JointBlob), all.data()) != 0) {
+    for (int p = 0; p < N; ++p) js->views[p].status = SWZ_ERR_INTERNAL;  // nobody sweeps
+    return;
+  }
+  for (int p = 0; p < N; ++p) {
+    if (p == r) {
+      js->views[p].status = blob.status;
+      continue;
+    }
+    swz::MdPeerView v{};
+    v.ncells = all[p].ncells;
+    v.rg = all[p].rg;
+    v.cell_shift = all[p].cell_shift;
+    v.status = all[p].status;
+    v.entered = all[p].entered;
+    if (p < r && v.ncells && v.status == SWZ_OK) {  // only the lower ranks' arrays are read
+      const void* got[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      for (int k = 0; k < 8; ++k) {
+        if (!all[p].has[k]) continue;
+        char* base = static_cast<char*>(joint_open(js, all[p].handle[k]));
+        if (!base) {
+          v.status = SWZ_ERR_HIP;
+          break;
+        }
+        got[k] = base + all[p].offset[k];
+      }
+      v.rec = static_cast<const uint4*>(got[0]);
+      v.qpos = static_cast<const uint64_t*>(got[1]);
+      v.state = static_cast<const uint8_t*>(got[2]);
+      v.ovf = static_cast<const float4*>(got[3]);
+      v.gridmap = static_cast<const uint32_t*>(got[4]);
+      v.round_word = static_cast<const uint32_t*>(got[5]);
+      v.perm = static_cast<const uint32_t*>(got[6]);
+      v.xyz = static_cast<const double*>(got[7]);
+    }
+    js->views[p] = v;
+  }
+  // (a mapping that failed on ONE rank must stop all of them, or the others sweep against a rank that has given up: the
+  // statuses are voted on)
+  int32_t my_ok = 1;
+  for (int p = 0; p < N; ++p) my_ok &= js->views[p].status == SWZ_OK ? 1 : 0;
+  JointBlob vote{};
+  vote.status = my_ok ? SWZ_OK : SWZ_ERR_INTERNAL;
+  std::vector<JointBlob> votes((size_t)N);
+  if (js->exchange(js->exchange_arg, &vote, sizeof(JointBlob), votes.data()) != 0) vote.status = SWZ_ERR_INTERNAL;
+  for (int p = 0; p < N; ++p)
+    if (votes[p].status != SWZ_OK || vote.status != SWZ_OK) js->views[p].status = SWZ_ERR_INTERNAL;
+}
+}  // namespace
+extern "C" {
+
+int swz_shard_joint_root_possible(swz_ctx* c, const swz_tile_params* p, const double bmin[3], const double bmax[3]) {
+  if (!c || !p) return 0;
+  return joint_root_possible(c, *p, bmin, bmax) ? 1 : 0;
+}
+
+int swz_shard_joint_root_begin(swz_ctx* c, int shard, int shards, swz_exchange_fn exchange, void* arg) {
+  if (!c || !exchange || shards < 2 || shards > 8 || shard < 0 || shard >= shards) return SWZ_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(joint_m);
+  JointState*& js = joint_states()[c];
+  if (!js) js = new JointState;
+  if (!js->opened.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_joint_root_begin: the previous joint root was not ended");
+  js->c = c;
+  js->views.assign((size_t)shards, swz::MdPeerView{});
+  js->sr.shard = shard;
+  js->sr.shards = shards;
+  js->sr.views = js->views.data();
+  js->sr.barrier = joint_exchange;
+  js->sr.barrier_arg = js;
+  js->exchange = exchange;
+  js->exchange_arg = arg;
+  c->md_shard_root = &js->sr;
+  return SWZ_OK;
+}
+
+// A rank whose swz_shard_begin_device did not reach the sweep (no points, or an error before it) meets the others here.
+int swz_shard_joint_root_meet(swz_ctx* c, int ok) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  JointState* js = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(joint_m);
+    auto it = joint_states().find(c);
+    if (it != joint_states().end()) js = it->second;
+  }
+  if (!js || !c->md_shard_root) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_joint_root_meet: no joint root is open");
+  swz::MdPeerView& mine = js->views[js->sr.shard];
+  if (mine.entered) return SWZ_OK;
+  mine = swz::MdPeerView{};
+  mine.status = ok ? SWZ_OK : SWZ_ERR_INTERNAL;
+  mine.entered = 1;
+  joint_exchange(js);
+  return SWZ_OK;
+}
+
+int swz_shard_joint_root_end(swz_ctx* c) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> lk(joint_m);
+  auto it = joint_states().find(c);
+  c->md_shard_root = nullptr;
+  if (it == joint_states().end()) return SWZ_OK;
+  JointState* js = it->second;
+  (void)hipSetDevice(c->device);
+  for (auto& kv : js->opened) (void)hipIpcCloseMemHandle(kv.second);
+  js->opened.clear();
+  delete js;
+  joint_states().erase(it);
   return SWZ_OK;
 }
 

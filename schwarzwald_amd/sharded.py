@@ -140,6 +140,9 @@ class ShardedTiler:
         self.result = None
         self._keepalive = None
         self._batches = 0
+        # The MIN_DISTANCE root swept by all ranks at once (IPC mappings of the lower ranks' root arrays) instead of the
+        # chain of ghosts from rank to rank.  Off unless asked for: it has run with two processes on ONE GPU only.
+        self.joint_root = os.environ.get("SWZ_SHARD_JOINT_ROOT", "0") not in ("", "0")
         if device.type == "cuda":
             # the context otherwise runs on its own non-blocking stream: torch's kernels (grouping, exchange) and the
             # library's must be ordered, so both use torch's current stream
@@ -154,6 +157,21 @@ class ShardedTiler:
         dist.broadcast(t, src, group=self.group)
         tensor.copy_(t)
         return tensor
+
+    def _all_gather_bytes(self, mine):
+        """every rank's bytes in rank order (equal lengths); the collective behind swz_shard_joint_root_begin"""
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        n = torch.tensor([len(mine)], dtype=torch.int64, device=self.device if on_gpu else "cpu")
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
+        size = int(n.item())
+        t = torch.zeros(max(size, 1), dtype=torch.uint8)
+        if mine:
+            t[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+        if on_gpu:
+            t = t.to(self.device)
+        out = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(out, t, group=self.group)
+        return [bytes(o.cpu().numpy().tobytes()[:size]) for o in out]
 
     def tile(self, xyz):
         """xyz: [n, 3] float64 tensor on this rank's GPU (any points of the batch).  Returns the tile stats of this
@@ -224,8 +242,30 @@ class ShardedTiler:
 
         # 3. root node.  m == 0 (this rank's octants are empty, e.g. the upper half of a cubic box around flat
         # terrain) is an ordinary shard: the library takes nothing of the root and reports zero points.
+        joint = (sequential_root and world > 1 and self.joint_root and
+                 ctx.shard_joint_root_possible(self.bmin, self.bmax, self.params))
+        self.used_joint_root = bool(joint)
         if not sequential_root:
             guarded(lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points), 0)
+        elif joint:
+            # All ranks sweep the root cells of their own octants at once; cells at the face of a lower octant read that
+            # rank's records in place through IPC mappings (include/swz_gpu.h, swz_shard_joint_root_*): no ghosts, no turns.
+            entered = guarded(lambda: ctx.shard_joint_root_begin(self.rank, world, self._all_gather_bytes) or True, False)
+            if entered:  # (m == 0 is an ordinary shard: nothing to sweep, it meets the others below)
+                guarded(lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points), 0)
+            if entered:
+                try:  # (a rank without points, or one that failed before its sweep met the others, meets them here)
+                    ctx.shard_joint_root_meet(ok=not failure)
+                except api.SwzError as e:
+                    failure.append(e)
+            else:  # the two exchanges of a batch are collectives: take part (an all-zero blob reads as a shard without points)
+                self._all_gather_bytes(b"")
+                self._all_gather_bytes(b"")
+            dist.barrier(group=self.group)  # the others may read this rank's root arrays until they are done
+            try:
+                ctx.shard_joint_root_end()
+            except api.SwzError as e:
+                failure.append(e)
         else:
             if m > 0:
                 # everything that does not depend on the ghosts happens on all ranks at once; only the root

@@ -141,7 +141,9 @@ def _corner_cloud(n, seed, world):
     return xyz
 
 
-def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False, backend="gloo"):
+def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False, backend="gloo", joint=False):
+    if joint:
+        os.environ["SWZ_SHARD_JOINT_ROOT"] = "1"
     import schwarzwald_amd as swz
     from schwarzwald_amd import sharded
     # gloo: all ranks share GPU 0 (what a one-GPU box can run); nccl (= RCCL): one GPU per rank
@@ -152,7 +154,9 @@ def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=Fals
     params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
     xyz = torch.from_numpy(_corner_cloud(n, 300 + rank, world) if corner else _cloud(n, 300 + rank)).to(dev)
     tiler = sharded.ShardedTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
+    assert tiler.joint_root == joint
     stats = tiler.tile(xyz)
+    assert tiler.used_joint_root == (joint and sampler == swz.MIN_DISTANCE)
     recv, keys, perm, level = tiler.result
     q.put((rank, recv.cpu().numpy(), keys.cpu().numpy().view(np.uint64), perm.cpu().numpy().view(np.uint32),
            level.cpu().numpy(), stats))
@@ -171,7 +175,9 @@ def _visible_gpus():
 # bench's d = 250; the last case runs the exchange over RCCL with one GPU per rank and enables itself where two GPUs are
 # visible (this pool's boxes have one)
 SHARDED_CASES = [(O.RANDOM_GRID, 250, 60000, "gloo"), (O.GRID_CENTER, 250, 60000, "gloo"), (O.MIN_DISTANCE, 60, 60000, "gloo"),
-                 (O.MIN_DISTANCE, 250, 150000, "gloo"), (O.JITTERED, 250, 60000, "gloo"), (O.MIN_DISTANCE, 250, 150000, "nccl")]
+                 (O.MIN_DISTANCE, 250, 150000, "gloo"), (O.JITTERED, 250, 60000, "gloo"), (O.MIN_DISTANCE, 250, 150000, "nccl"),
+                 # the MIN_DISTANCE root swept by both ranks at once, each reading the other's root arrays through IPC mappings
+                 (O.MIN_DISTANCE, 60, 60000, "gloo+joint"), (O.MIN_DISTANCE, 250, 150000, "gloo+joint")]
 
 
 @pytest.mark.gpu
@@ -179,12 +185,14 @@ SHARDED_CASES = [(O.RANDOM_GRID, 250, 60000, "gloo"), (O.GRID_CENTER, 250, 60000
 def test_sharded_tile_matches_oracle(sampler, d, n, backend):
     if backend == "nccl" and _visible_gpus() < 2:
         pytest.skip("the RCCL exchange needs one GPU per rank: fewer than two GPUs visible")
+    joint = backend.endswith("+joint")
+    backend = backend.split("+")[0]
     world, max_pts = 2, 500
     spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], d)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q, False, backend))
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q, False, backend, joint))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -218,15 +226,18 @@ def test_sharded_tile_matches_oracle(sampler, d, n, backend):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED, "MIN_DISTANCE+joint"])
 def test_sharded_tile_with_empty_shards(sampler, world):
-    """Ranks whose octants hold no point must neither fail nor hang the others (all ranks share cuda:0 here)."""
+    """Ranks whose octants hold no point must neither fail nor hang the others (all ranks share cuda:0 here) -- also when
+    the MIN_DISTANCE root is swept by all ranks at once: a rank without points meets the others in the exchange."""
+    joint = sampler == "MIN_DISTANCE+joint"
+    sampler = O.MIN_DISTANCE if joint else sampler
     n, max_pts = 30000, 500
     spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q, True))
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, q, True, "gloo", joint))
              for r in range(world)]
     for p in procs:
         p.start()
