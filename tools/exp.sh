@@ -1,1 +1,2 @@
-timeout 600 python -m pytest tests/test_sharded_gloo.py -q -m gpu -x -k "empty_shards and joint" 2>&1 | tail -5
+timeout 600 python tools/shard_joint_probe.py 2 50000000 2>&1 | grep "ranks x" 
+timeout 600 python tools/shard_joint_probe.py 4 25000000 2>&1 | grep "ranks x"
