@@ -90,6 +90,37 @@ def test_exchange_moves_points_to_octant_owner(world, chunk_bytes):
     assert sum(len(got[r][0]) for r in range(world)) == world * n
 
 
+def _gather_bytes_worker(rank, world, port, q):
+    _init(rank, world, port)
+    from schwarzwald_amd import sharded
+
+    class Stub:  # what ShardedTiler._all_gather_bytes looks at
+        group, device = None, torch.device("cpu")
+    Stub.world = world
+    mine = bytes([rank + 1]) * (40 + 7 * 0) if rank != 1 else b""   # rank 1 contributes nothing: padded with zeros
+    q.put((rank, sharded.ShardedTiler._all_gather_bytes(Stub, mine)))
+    dist.destroy_process_group()
+
+
+def test_all_gather_of_byte_blobs_behind_the_joint_root_exchange():
+    """The collective the library's IPC exchange runs on (swz_shard_joint_root_begin's callback): every rank's bytes in
+    rank order; a rank with nothing to say reads as zeros of the common length."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_bytes_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = [bytes([1]) * 40, bytes(40), bytes([3]) * 40]
+    for r in range(world):
+        assert got[r] == want
+
+
 def test_exchange_plan_covers_every_row_exactly_once():
     """The per-rank plans of all ranks, executed together in one process, are an all-to-all."""
     from schwarzwald_amd import sharded
