@@ -866,6 +866,9 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
         c0->get("grp_root_skeys", (size_t)total, &skeys) != SWZ_OK || c0->get("grp_root_perm", (size_t)total, &perm) != SWZ_OK ||
         c0->get("grp_root_taken", (size_t)total, &taken) != SWZ_OK || c0->get("grp_root_flags", (size_t)total, &d_flags0) != SWZ_OK)
       return shard_fail(0, SWZ_ERR_HIP);
+    // (the peer copies below run on the default stream: nothing queued on shard 0's own stream -- the SWZ_POISON fill of a
+    // buffer that has just been allocated -- may still be writing the destination)
+    (void)hipStreamSynchronize(c0->stream);
     for (int r = 0; r < g->n; ++r) {
       if (!cnt[r]) continue;
       (void)hipSetDevice(g->devices[r]);
@@ -902,6 +905,7 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
         mine = d_flags0;
       } else {
         if (c->get("grp_l0_flags", (size_t)cnt[r], &mine) != SWZ_OK) return shard_fail(r, SWZ_ERR_HIP);
+        (void)hipStreamSynchronize(c->stream);  // (as above: the copy is not ordered with this shard's stream)
         if (hipMemcpyPeer(mine, g->devices[r], d_flags0 + off[r], g->devices[0], (size_t)cnt[r]) != hipSuccess) {
           c->err = "copy of the root flags failed";
           return shard_fail(r, SWZ_ERR_HIP);

@@ -332,7 +332,13 @@ int main(int argc, char** argv) {
           const std::map<std::string, std::vector<uint32_t>>& expect = g_expect[std::make_tuple(sampler, strategy, k)];
           if (got_files != expect) {
             size_t bad = 0;
-            for (const auto& kv : expect) bad += !got_files.count(kv.first) || got_files.at(kv.first) != kv.second;
+            for (const auto& kv : expect) {
+              const bool differs = !got_files.count(kv.first) || got_files.at(kv.first) != kv.second;
+              if (differs && bad < 4)
+                std::fprintf(stderr, "  node %s: %zu points expected, %zu here\n", kv.first.c_str(), kv.second.size(),
+                             got_files.count(kv.first) ? got_files.at(kv.first).size() : (size_t)0);
+              bad += differs;
+            }
             std::fprintf(stderr, "%s %s, %d shards, %d batches: %zu of %zu node files differ (%zu files here)\n", names[sampler],
                          strategy == SWZ_FAST ? "FAST" : "ACCURATE", shards, k, bad, expect.size(), got_files.size());
             return fail("node files of the sharded multi-batch tilers differ from the oracle");
