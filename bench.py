@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--payload", default="", help="comma separated attribute columns (e.g. rgb,intensity): after the "
                     "timed region also build the node lists and gather the node payload on the device; reported "
                     "separately under \"payload\", never part of `value`")
-    ap.add_argument("--md-mode", default="exact", choices=["exact", "property", "both"], help="MIN_DISTANCE: exact = the "
+    ap.add_argument("--md-mode", default="both", choices=["exact", "property", "both"], help="MIN_DISTANCE: exact = the "
                     "reference's Morton-order greedy set, bit-identical (the headline `value`); property = "
                     "SWZ_FLAG_MIN_DISTANCE_PROPERTY (same spacing + maximality guarantees, different priority order); "
                     "both = `value` is exact and the property-mode timing of the same workload is reported beside it "
@@ -485,6 +485,16 @@ def main():
         elapsed = float(t.item())
 
     prof = {} if args.no_profile else ctx.profile_get()
+    # the sharded single-batch driver: what every rank's last step spent where (events on the launch stream), which way the
+    # MIN_DISTANCE root went, how many points the rank ended up owning
+    shard_report = None
+    if distributed and args.batches <= 1 and hasattr(runner, "stage_timings"):
+        mine = {"rank": rank, "root_mode": getattr(runner, "root_mode", None),
+                "shard_points": int(stats.get("shard_points", 0)) if stats else 0}
+        mine.update(runner.stage_timings())
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        shard_report = gathered
     total_points = n * world
     ms_per_step = elapsed * 1e3 / args.steps
     value = total_points / (elapsed / args.steps) / 1e6
@@ -519,6 +529,8 @@ def main():
                        "payload_columns": [a for a in args.payload.split(",") if a] if (distributed and args.batches > 1) else None,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
             "ranks_in_process_group": dist.get_world_size() if distributed else 1,
+            "root_mode": shard_report[0]["root_mode"] if shard_report else None,
+            "shards": shard_report,
             "visit_factor": round(visit, 4),
             "hbm_frac_end_to_end": round(alg * total_points / world / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
             "algorithmic_bytes_per_point": round(alg, 1),
@@ -536,18 +548,20 @@ def main():
             pstep()
             ctx.profile_reset()
             torch.cuda.synchronize(dev)
+            psteps = max(1, min(args.steps, 5))  # (beside the headline, after the timed region: a handful of steps is enough)
             t0 = time.perf_counter()
-            for _ in range(args.steps):
+            for _ in range(psteps):
                 pstats = pstep()
             torch.cuda.synchronize(dev)
-            pdt = (time.perf_counter() - t0) / args.steps
+            pdt = (time.perf_counter() - t0) / psteps
             pprof = ctx.profile_get()
             pvisit = pstats["points_visited"] / float(n)
             palg = algorithmic_bytes_per_point(args.sampler, pvisit)
             out["min_distance_property"] = {
                 "ms_per_step": round(pdt * 1e3, 3), "Mpoints_per_s": round(n / pdt / 1e6, 3), "visit_factor": round(pvisit, 4),
                 "hbm_frac_end_to_end": round(palg * n / pdt / (HBM_PEAK_GBS * 1e9), 5), "tile_stats": pstats,
-                "kernels_ms_per_step": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(pprof.items())},
+                "steps": psteps,
+                "kernels_ms_per_step": {k: round(v["total_ms"] / psteps, 3) for k, v in sorted(pprof.items())},
                 "note": "same workload with SWZ_FLAG_MIN_DISTANCE_PROPERTY: spacing and maximality guaranteed "
                         "(tests/test_min_distance_property.py), taken set differs from the reference's"}
         if mb is not None and "run_staged" in mb:

@@ -533,6 +533,10 @@ int swz_group_finalize(swz_group* group, swz_tile_stats* stats_per_shard);
 typedef int (*swz_exchange_fn)(void* arg, const void* mine, uint64_t bytes, void* all);
 int swz_shard_joint_root_possible(swz_ctx* ctx, const swz_tile_params* params, const double bounds_min[3], const double bounds_max[3]);
 int swz_shard_joint_root_begin(swz_ctx* ctx, int shard, int num_shards, swz_exchange_fn exchange, void* arg);
+/* Collective, before the first batch: can every rank map and read the lower ranks' device memory (IPC handles through the
+ * same all-gather callback: two exchanges, then one per rank while the mappings are closed in turns)?  *usable = 1 only when all ranks could; a driver that gets 0 keeps the chain of
+ * ghosts -- nothing has been started that would have to be undone. */
+int swz_shard_joint_root_probe(swz_ctx* ctx, int shard, int num_shards, swz_exchange_fn exchange, void* arg, int* usable);
 int swz_shard_joint_root_meet(swz_ctx* ctx, int ok);
 int swz_shard_joint_root_end(swz_ctx* ctx);
 

@@ -348,6 +348,7 @@ def load_library():
     L.swz_tiler_pool_residency.argtypes = [vp, _u64p, _u64p]
     L.swz_shard_joint_root_possible.argtypes = [vp, C.POINTER(_TileParams), _dp, _dp]
     L.swz_shard_joint_root_begin.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
+    L.swz_shard_joint_root_probe.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp, C.POINTER(C.c_int)]
     L.swz_shard_joint_root_meet.argtypes = [vp, C.c_int]
     L.swz_shard_joint_root_end.argtypes = [vp]
     L.swz_tiler_shard_fast_histogram.argtypes = [vp, _u32p]
@@ -377,7 +378,7 @@ def load_library():
                  "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency",
                  "swz_tiler_shard_fast_histogram", "swz_fast_start_level_from_counts", "swz_tiler_shard_set_start_level",
                  "swz_tiler_shard_fast_finalize_local", "swz_tiler_shard_fast_set_root", "swz_shard_joint_root_possible",
-                 "swz_shard_joint_root_begin", "swz_shard_joint_root_meet", "swz_shard_joint_root_end"):
+                 "swz_shard_joint_root_begin", "swz_shard_joint_root_probe", "swz_shard_joint_root_meet", "swz_shard_joint_root_end"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -640,6 +641,20 @@ class Context:
                 return 1
         self._joint_cb = EXCHANGE_FN(cb)  # must outlive the calls that use it
         self._check(self._lib.swz_shard_joint_root_begin(self._ctx, int(shard), int(num_shards), self._joint_cb, None))
+
+    def shard_joint_root_probe(self, shard, num_shards, all_gather_bytes):
+        """Collective: True when every rank can map and read the lower ranks' device memory (the joint root needs that)."""
+        def cb(_arg, mine, nbytes, out):
+            try:
+                parts = all_gather_bytes(C.string_at(mine, nbytes))
+                C.memmove(out, b"".join(parts), nbytes * len(parts))
+                return 0
+            except Exception:
+                return 1
+        fn = EXCHANGE_FN(cb)
+        usable = C.c_int(0)
+        self._check(self._lib.swz_shard_joint_root_probe(self._ctx, int(shard), int(num_shards), fn, None, C.byref(usable)))
+        return bool(usable.value)
 
     def shard_joint_root_meet(self, ok=True):
         self._check(self._lib.swz_shard_joint_root_meet(self._ctx, 1 if ok else 0))

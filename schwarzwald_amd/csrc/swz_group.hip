@@ -338,6 +338,7 @@ void shard_thread(ShardCall a) {
     sr.barrier_arg = g;
     g->views[r] = swz::MdPeerView{};
     c->md_shard_root = &sr;
+    c->md_shard_root_published = true;  // the higher shards read this root's "md_*_sr" arrays until the barrier at the end of the batch
     swz_shard_info info{global_points, nullptr, 0};
     if (m) GRP_TRY(swz_shard_begin_device(c, recv, m, a.bmin, a.bmax, a.params, &info, &taken));
     c->md_shard_root = nullptr;
@@ -481,6 +482,7 @@ void shard_thread(ShardCall a) {
     }
   }
   g->barrier.wait();  // ---- nobody reads a neighbour's buffers any more
+  c->md_shard_root_published = false;
 }
 
 // flag of the i-th sorted element back to the position its element had before the sort
@@ -933,7 +935,7 @@ struct JointBlob {
   hipIpcMemHandle_t handle[8];
   uint64_t offset[8];
   uint8_t has[8];
-  uint32_t ncells, rg, cell_shift;
+  uint32_t ncells, rg, cell_shift, npoints;
   int32_t status, entered;
 };
 struct JointState {
@@ -971,6 +973,7 @@ void joint_exchange(void* arg) {
   JointBlob blob{};
   const void* ptrs[8] = {mine.rec, mine.qpos, mine.state, mine.ovf, mine.gridmap, mine.round_word, mine.perm, mine.xyz};
   blob.ncells = mine.ncells;
+  blob.npoints = mine.npoints;
   blob.rg = mine.rg;
   blob.cell_shift = mine.cell_shift;
   blob.status = mine.status;
@@ -990,7 +993,13 @@ void joint_exchange(void* arg) {
   }
   std::vector<JointBlob> all((size_t)N);
   if (js->exchange(js->exchange_arg, &blob, sizeof(JointBlob), all.data()) != 0) {
-    for (int p = 0; p < N; ++p) js->views[p].status = SWZ_ERR_INTERNAL;  // nobody sweeps
+    // Nobody sweeps.  The other ranks still run the vote below: take part in it (with an error), or this rank would be one
+    // collective behind for everything that follows.
+    for (int p = 0; p < N; ++p) js->views[p].status = SWZ_ERR_INTERNAL;
+    JointBlob vote{};
+    vote.status = SWZ_ERR_INTERNAL;
+    std::vector<JointBlob> votes((size_t)N);
+    (void)js->exchange(js->exchange_arg, &vote, sizeof(JointBlob), votes.data());
     return;
   }
   for (int p = 0; p < N; ++p) {
@@ -1001,6 +1010,7 @@ void joint_exchange(void* arg) {
     swz::MdPeerView v{};
     v.ncells = all[p].ncells;
     v.rg = all[p].rg;
+    v.npoints = all[p].npoints;
     v.cell_shift = all[p].cell_shift;
     v.status = all[p].status;
     v.entered = all[p].entered;
@@ -1045,6 +1055,78 @@ int swz_shard_joint_root_possible(swz_ctx* c, const swz_tile_params* p, const do
   return joint_root_possible(c, *p, bmin, bmax) ? 1 : 0;
 }
 
+// Can the ranks of this run map each other's device memory at all?  Every rank exports a small buffer of its workspace that
+// holds a pattern, the lower ranks' buffers are opened and read back, and the outcome is voted on -- two exchanges, like the
+// real thing -- so that a driver can settle for the chain of ghosts BEFORE a batch depends on the mappings (containers
+// without a shared /dev/shm, devices without a peer path, IPC switched off).  *usable = 1 only when every rank could map
+// and read every lower rank's buffer.
+int swz_shard_joint_root_probe(swz_ctx* c, int shard, int shards, swz_exchange_fn exchange, void* arg, int* usable) {
+  if (!c || !exchange || !usable || shards < 1 || shards > 8 || shard < 0 || shard >= shards) return SWZ_ERR_BAD_ARG;
+  *usable = 0;
+  (void)hipSetDevice(c->device);
+  struct ProbeBlob {
+    hipIpcMemHandle_t handle;
+    uint64_t offset;
+    int32_t status;
+    uint32_t pattern;
+  };
+  ProbeBlob mine{};
+  mine.pattern = 0x5C4A0000u + (uint32_t)shard;
+  uint32_t* buf = nullptr;
+  mine.status = c->get("grp_ipc_probe", (size_t)64, &buf);
+  if (mine.status == SWZ_OK) {
+    void* base = nullptr;
+    size_t size = 0;
+    if (hipMemcpy(buf, &mine.pattern, 4, hipMemcpyHostToDevice) != hipSuccess || hipMemGetAddressRange(&base, &size, buf) != hipSuccess ||
+        hipIpcGetMemHandle(&mine.handle, base) != hipSuccess) {
+      (void)hipGetLastError();
+      mine.status = SWZ_ERR_HIP;
+    } else {
+      mine.offset = (uint64_t)((const char*)buf - (const char*)base);
+    }
+  }
+  std::vector<ProbeBlob> all((size_t)shards);
+  int32_t ok = mine.status == SWZ_OK ? 1 : 0;
+  std::vector<void*> opened;
+  if (exchange(arg, &mine, sizeof(ProbeBlob), all.data()) != 0) {
+    ok = 0;
+  } else {
+    for (int p = 0; p < shards && ok; ++p) ok &= all[p].status == SWZ_OK ? 1 : 0;
+    for (int p = 0; p < shard && ok; ++p) {  // only the lower ranks' arrays are ever read
+      void* base = nullptr;
+      uint32_t got = 0;
+      if (hipIpcOpenMemHandle(&base, all[p].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess) {
+        (void)hipGetLastError();
+        ok = 0;
+        break;
+      }
+      opened.push_back(base);
+      if (hipMemcpy(&got, (const char*)base + all[p].offset, 4, hipMemcpyDeviceToHost) != hipSuccess || got != all[p].pattern) {
+        (void)hipGetLastError();
+        ok = 0;
+      }
+    }
+  }
+  ProbeBlob vote{};
+  vote.status = ok ? SWZ_OK : SWZ_ERR_INTERNAL;
+  std::vector<ProbeBlob> votes((size_t)shards);
+  int all_ok = ok;
+  if (exchange(arg, &vote, sizeof(ProbeBlob), votes.data()) != 0) all_ok = 0;
+  for (int p = 0; p < shards && all_ok; ++p) all_ok &= votes[p].status == SWZ_OK ? 1 : 0;
+  // Unmap, one rank at a time (the exchange is the barrier between them): with several processes closing mappings of one
+  // allocation at the same moment the runtime was seen to abort ("Memobj map does not have ptr", one run in four with
+  // four processes on one GPU) -- never with the closes taken in turns.
+  for (int p = 0; p < shards; ++p) {
+    if (p == shard)
+      for (void* b : opened) (void)hipIpcCloseMemHandle(b);
+    ProbeBlob turn{};
+    std::vector<ProbeBlob> turns((size_t)shards);
+    if (exchange(arg, &turn, sizeof(ProbeBlob), turns.data()) != 0) all_ok = 0;
+  }
+  *usable = all_ok;
+  return SWZ_OK;
+}
+
 int swz_shard_joint_root_begin(swz_ctx* c, int shard, int shards, swz_exchange_fn exchange, void* arg) {
   if (!c || !exchange || shards < 2 || shards > 8 || shard < 0 || shard >= shards) return SWZ_ERR_BAD_ARG;
   std::lock_guard<std::mutex> lk(joint_m);
@@ -1061,6 +1143,7 @@ int swz_shard_joint_root_begin(swz_ctx* c, int shard, int shards, swz_exchange_f
   js->exchange = exchange;
   js->exchange_arg = arg;
   c->md_shard_root = &js->sr;
+  c->md_shard_root_published = true;  // (until swz_shard_joint_root_end, which the driver calls after its barrier)
   return SWZ_OK;
 }
 
@@ -1088,6 +1171,7 @@ int swz_shard_joint_root_end(swz_ctx* c) {
   std::lock_guard<std::mutex> lk(joint_m);
   auto it = joint_states().find(c);
   c->md_shard_root = nullptr;
+  c->md_shard_root_published = false;
   if (it == joint_states().end()) return SWZ_OK;
   JointState* js = it->second;
   (void)hipSetDevice(c->device);

@@ -85,6 +85,7 @@ struct swz_ctx {
   hipEvent_t cur_e0_ = nullptr;
   void* shard = nullptr;  // swz::ShardState of an open sharded batch (swz_level.hip)
   const void* md_shard_root = nullptr;  // swz::MdShardRoot while swz_group runs the MIN_DISTANCE root of a sharded batch on all shards at once
+  bool md_shard_root_published = false;  // the "md_*_sr" arrays of this context are mapped by other shards: they stay (see get())
   bool tiler_active = false;  // a swz_tiler lives on this context: its node store is part of the workspace
   // Debug / tuning switches ("SWZ_DEBUG", "SWZ_MD_*", ...): read from the environment ONCE, when the context is
   // created, and changed afterwards only through swz_set_option -- no entry point looks at the environment.

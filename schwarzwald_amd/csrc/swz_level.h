@@ -141,6 +141,7 @@ struct MdPeerView {
   const uint32_t* perm = nullptr;    // exact positions of its points: xyz[3 * perm[i]]
   const double* xyz = nullptr;
   uint32_t ncells = 0, rg = 0, cell_shift = 0;
+  uint32_t npoints = 0;              // points of its root level (the readers size their round limit by the lower shards' work too)
   int status = 0;                    // SWZ_OK, or why this shard cannot take part
   int entered = 0;                   // the shard's sweep has met the others at the barrier (else its driver does so for it)
 };

@@ -50,6 +50,8 @@ constexpr int MQ_FRESH_CAP = 32;            // points a cell may accept per acti
 #define MQ_MINW1 6
 #endif
 constexpr uint32_t MQ_FIRST_ROUND = 2;      // record buffers start with stamps 0 and 1
+constexpr uint32_t MQ_ROUND_DONE = 0xFFFFFFF0u;    // a shard's round word after its sweep: every record is complete
+constexpr uint32_t MQ_ROUND_FAILED = 0xFFFFFFF1u;  // ... after it has given up: whoever waits for its cells gives up too
 
 enum : uint8_t { QS_OPEN = 0, QS_TAKEN = 1, QS_DEAD = 2 };
 
@@ -570,6 +572,10 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
     if (PEERS && Bp) {
       // a cell of a lower shard: nobody wakes this one, it looks again every round
       const uint32_t rb = mq_ld_sys(a.peers.round_word[Bp - 1u]);
+      if (rb == MQ_ROUND_FAILED) {  // that shard's sweep has failed: nobody will ever pass the point this cell waits for
+        if (l == 0) atomicMax(&a.counters[CTR_ERROR], (uint32_t)SWZ_ERR_INTERNAL);
+        return;
+      }
       const uint4* brec = a.peers.rec[Bp - 1u] + ((size_t)B << rg2s);
       const uint4 b0 = mq_ld_sys(brec), b1 = mq_ld_sys(brec + rg);
       const uint32_t ra = mq_ld_sys(a.peers.round_word[Bp - 1u]);
@@ -657,6 +663,10 @@ __device__ void mq_activate(const MqArgs& a, uint32_t round, uint32_t qentry, co
   if (PEERS) {
     bool late = false;
     if (nb_peer && l < 27u) late = mq_ld_sys(a.peers.round_word[nb_peer - 1u]) != r_before;
+    if (__ballot(PEERS && nb_peer && l < 27u && r_before == MQ_ROUND_FAILED)) {  // a lower shard has given up
+      if (l == 0) atomicMax(&a.counters[CTR_ERROR], (uint32_t)SWZ_ERR_INTERNAL);
+      return;
+    }
     if (__ballot(late)) {
       push_again(claimed ? (c | MQ_WOKEN) : c);
       return;
@@ -1339,6 +1349,19 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   const uint32_t cb = div_up(ncells, 256);
   hipLaunchKernelGGL(mq_cell_end_kernel, dim3(cb), dim3(256), 0, c->stream, a, ncells);
   SWZ_LAUNCH_CHECK(c);
+  // From the moment its views are published, a shard that leaves this function early says so in its round word: the
+  // higher shards' face cells poll that word and would otherwise spin until their own limits.
+  struct WordGuard {
+    swz_ctx* c;
+    uint32_t* word = nullptr;
+    bool done = false;
+    ~WordGuard() {
+      if (word && !done) {
+        hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, c->stream, word, MQ_ROUND_FAILED);
+        (void)hipStreamSynchronize(c->stream);
+      }
+    }
+  } word_guard{c};
   if (sharded) {
     // publish this shard's root level, meet the others, take the lower shards' views
     MdPeerView& mine = shard_root->views[shard_root->shard];
@@ -1357,10 +1380,12 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     mine.perm = a.perm;
     mine.xyz = a.xyz;
     mine.ncells = ncells;
+    mine.npoints = m;
     mine.rg = a.rg;
     mine.cell_shift = a.cell_shift;
     mine.status = my_status;
     mine.entered = 1;
+    word_guard.word = a.round_word;
     shard_root->barrier(shard_root->barrier_arg);
     for (int p = 0; p < shard_root->shards; ++p) {
       const MdPeerView& v = shard_root->views[p];
@@ -1500,6 +1525,15 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   double wall_limit = 900.0;
   if (const char* e = c->opt("SWZ_MD_TIME_LIMIT")) wall_limit = atof(e);
   uint64_t max_rounds = 8ull * m + 1024;
+  if (sharded) {
+    // A cell at the face of a lower shard looks again every round until that shard's sweep has got there, and a level only
+    // ends with an empty queue: a shard of a few points beside a lower shard of 1e8 spends (cheap, nearly empty) rounds
+    // for as long as the lower sweeps take.  Its limit therefore covers their work as well -- an empty round is ~10 us
+    // against the >= 20 us of a working one, so their rounds count several times.
+    uint64_t below = 0;
+    for (int p = 0; p < shard_root->shard; ++p) below += shard_root->views[p].npoints;
+    max_rounds += 64ull * below + 65536ull;
+  }
   if (const char* e = c->opt("SWZ_MD_ROUND_LIMIT")) max_rounds = (uint64_t)atoll(e);
   hipEvent_t fork = nullptr;
   if (groups > 1) {
@@ -1532,11 +1566,14 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     if (!fixed_batch && ++batches_done % 4u == 0u && batch < 128u) batch *= 2u;
     for (uint32_t g = 0; g < groups; ++g)  // what the last launched round started with
       SWZ_HIP(c, hipMemcpyAsync(&gleft[g], ga[g].qtotal + (round - 1u - MQ_FIRST_ROUND) % 3u, 4, hipMemcpyDeviceToHost, gs[g]));
+    uint32_t peer_err = 0;
+    if (sharded) SWZ_HIP(c, hipMemcpyAsync(&peer_err, ga[0].counters + CTR_ERROR, 4, hipMemcpyDeviceToHost, gs[0]));
     running = false;
     for (uint32_t g = 0; g < groups; ++g) {
       SWZ_HIP(c, hipStreamSynchronize(gs[g]));
       running |= gleft[g] != 0u;
     }
+    if (peer_err) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE root of a sharded batch: a lower shard's sweep failed (or a queue overflowed); this shard gives up as well");
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > wall_limit) {
       char msg[200];
       snprintf(msg, sizeof(msg), "MIN_DISTANCE sweep on keys exceeded %.0f s: level %d, %u cells, %u rounds", wall_limit, plan.level,
@@ -1551,7 +1588,8 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   }
   if (fork) c->event_pool.push_back(fork);
   if (sharded) {  // everything this shard has written is complete now
-    hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, c->stream, a.round_word, 0xFFFFFFF0u);
+    hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, c->stream, a.round_word, MQ_ROUND_DONE);
+    word_guard.done = true;
     SWZ_LAUNCH_CHECK(c);
   }
   {  // every cell at its end, no queue segment ever full everywhere

@@ -118,6 +118,34 @@ def exchange_rows(rows, send_counts, group=None, headroom=0, chunk_bytes=None):
     return buf, recv_counts
 
 
+class _Stages:
+    """Time stamps at the stage boundaries of a sharded batch: events on the stream the library runs on (no
+    synchronisation inside the batch), read after it -- what bench.py reports per rank."""
+
+    def __init__(self, dev):
+        self.dev, self.marks = dev, []
+        self.mark("start")
+
+    def mark(self, name):
+        if self.dev.type == "cuda":
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.dev))
+            self.marks.append((name, ev, time.perf_counter()))
+        else:
+            self.marks.append((name, None, time.perf_counter()))
+
+    def ms(self):
+        """{stage: milliseconds} (device time between the marks; host time where the stage waited on the host)"""
+        if self.dev.type == "cuda":
+            torch.cuda.synchronize(self.dev)
+        out = {}
+        for (_, e0, t0), (name, e1, t1) in zip(self.marks[:-1], self.marks[1:]):
+            dev_ms = e0.elapsed_time(e1) if e0 is not None else 0.0
+            out[name] = round(max(dev_ms, (t1 - t0) * 1e3 if e0 is None else dev_ms), 3)
+            out[name + "_host"] = round((t1 - t0) * 1e3, 3)
+        return out
+
+
 def _trace(dev, what, t0):
     """SWZ_DEBUG=1: stage timings on stderr (synchronises the device, debugging only)."""
     if os.environ.get("SWZ_DEBUG"):
@@ -141,8 +169,13 @@ class ShardedTiler:
         self._keepalive = None
         self._batches = 0
         # The MIN_DISTANCE root swept by all ranks at once (IPC mappings of the lower ranks' root arrays) instead of the
-        # chain of ghosts from rank to rank.  Off unless asked for: it has run with two processes on ONE GPU only.
-        self.joint_root = os.environ.get("SWZ_SHARD_JOINT_ROOT", "0") not in ("", "0")
+        # chain of ghosts from rank to rank, whose time grows with the number of ranks.  On by default
+        # (SWZ_SHARD_JOINT_ROOT=0: the chain); before the first batch that would use it the ranks PROBE whether they can map
+        # each other's memory at all -- a collective with a vote -- and keep the chain when one of them cannot.
+        self.joint_root = os.environ.get("SWZ_SHARD_JOINT_ROOT", "1") not in ("", "0")
+        self._joint_usable = None  # unknown until probed
+        self.root_mode = "local"   # what the last batch did: local | chain | joint (| chain (...reason))
+        self.stage_ms = {}
         if device.type == "cuda":
             # the context otherwise runs on its own non-blocking stream: torch's kernels (grouping, exchange) and the
             # library's must be ordered, so both use torch's current stream
@@ -196,6 +229,7 @@ class ShardedTiler:
                     if os.environ.get("SWZ_DEBUG"):
                         sys.stderr.write("[swz sharded] workspace released: %.1f GB were free\n" % (free / 1e9))
         t0 = time.perf_counter()
+        stages = _Stages(dev)
         # 1. encode locally, group by destination
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         ctx.morton_encode_device(xyz.data_ptr(), n, self.bmin, self.bmax, keys.data_ptr())
@@ -207,6 +241,7 @@ class ShardedTiler:
         send = xyz.index_select(0, perm.long())
         del perm
         t0 = _trace(dev, "group rows by destination", t0)
+        stages.mark("encode_partition_group_ms")
         # 2. the one exchange step
         total = torch.tensor([n], dtype=torch.int64, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(total, group=self.group)
@@ -217,6 +252,7 @@ class ShardedTiler:
         recv_counts_total = sum(recv_counts)
         del send
         t0 = _trace(dev, "exchange", t0)
+        stages.mark("exchange_ms")
         if dev.type == "cuda" and self._batches == 0:
             # first batch: the context is about to grow its workspace with hipMalloc (up to ~160 B per point for
             # MIN_DISTANCE); hand torch's cached send buffers back only when that would not fit otherwise --
@@ -242,9 +278,20 @@ class ShardedTiler:
 
         # 3. root node.  m == 0 (this rank's octants are empty, e.g. the upper half of a cubic box around flat
         # terrain) is an ordinary shard: the library takes nothing of the root and reports zero points.
-        joint = (sequential_root and world > 1 and self.joint_root and
-                 ctx.shard_joint_root_possible(self.bmin, self.bmax, self.params))
-        self.used_joint_root = bool(joint)
+        possible = (sequential_root and world > 1 and self.joint_root and dev.type == "cuda" and
+                    ctx.shard_joint_root_possible(self.bmin, self.bmax, self.params))
+        joint = possible
+        if joint and self._joint_usable is None:
+            try:
+                self._joint_usable = ctx.shard_joint_root_probe(self.rank, world, self._all_gather_bytes)
+            except api.SwzError:
+                self._joint_usable = False  # (the probe's own collectives ran on every rank: all of them land here together or not at all)
+            if os.environ.get("SWZ_DEBUG"):
+                sys.stderr.write("[swz sharded] rank %d: device memory of the other ranks %s be mapped: MIN_DISTANCE root %s\n" % (
+                    self.rank, "can" if self._joint_usable else "cannot", "swept by all ranks at once" if self._joint_usable else "in turns"))
+        joint = bool(joint and self._joint_usable)
+        self.used_joint_root = joint
+        self.root_mode = "local" if not sequential_root else ("joint" if joint else ("chain (no IPC mapping)" if possible else "chain"))
         if not sequential_root:
             guarded(lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points), 0)
         elif joint:
@@ -262,10 +309,15 @@ class ShardedTiler:
                 self._all_gather_bytes(b"")
                 self._all_gather_bytes(b"")
             dist.barrier(group=self.group)  # the others may read this rank's root arrays until they are done
-            try:
-                ctx.shard_joint_root_end()
-            except api.SwzError as e:
-                failure.append(e)
+            # (the mappings are closed one rank at a time: processes that unmap the same allocation at the same moment were
+            # seen to abort inside the runtime -- see swz_shard_joint_root_probe)
+            for r in range(world):
+                if r == self.rank:
+                    try:
+                        ctx.shard_joint_root_end()
+                    except api.SwzError as e:
+                        failure.append(e)
+                dist.barrier(group=self.group)
         else:
             if m > 0:
                 # everything that does not depend on the ghosts happens on all ranks at once; only the root
@@ -301,6 +353,7 @@ class ShardedTiler:
                 if self.rank > r:
                     ghosts.append(b)
         t0 = _trace(dev, "root node", t0)
+        stages.mark("root_ms")
         # 4. everything below the root is local
         okeys = torch.empty(m, dtype=torch.int64, device=dev)
         operm = torch.empty(m, dtype=torch.int32, device=dev)
@@ -308,6 +361,8 @@ class ShardedTiler:
         zero = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
         stats = guarded(lambda: ctx.shard_finish_device(okeys.data_ptr(), operm.data_ptr(), olevel.data_ptr()), zero)
         _trace(dev, "levels below the root", t0)
+        stages.mark("levels_ms")
+        self._stages = stages
         flag = torch.tensor([1 if failure else 0], dtype=torch.int64,
                             device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
@@ -318,7 +373,12 @@ class ShardedTiler:
         self.result = (recv, okeys, operm, olevel)
         self._keepalive = buf  # the context reads the points until shard_finish returned
         stats["shard_points"] = m
+        stats["root_mode"] = self.root_mode
         return stats
+
+    def stage_timings(self):
+        """Milliseconds per stage of the last batch on this rank (synchronises the device)."""
+        return self._stages.ms() if getattr(self, "_stages", None) else {}
 
 
 class ShardedBatchTiler:
@@ -495,16 +555,28 @@ class ShardedBatchTiler:
             return self.tiler.finalize()
         dev, world = self.device, self.world
         on_gpu = dist.get_backend(self.group) == "nccl"
-        stats = self.tiler.shard_fast_finalize_local()
-        cnt = self.tiler.level_count(0)
+        # Every collective phase below is preceded by a vote (like add_batch): a rank whose local step raised must not leave
+        # the others waiting in all_reduce / recv / send for a peer that is gone.
+        failure = []
+        stats, cnt = None, 0
+        try:
+            stats = self.tiler.shard_fast_finalize_local()
+            cnt = self.tiler.level_count(0)
+        except api.SwzError as e:
+            failure.append(e)
+        self._vote(failure)
         counts = torch.zeros(world, dtype=torch.int64, device=dev if on_gpu else "cpu")
         counts[self.rank] = cnt
         dist.all_reduce(counts, group=self.group)
         counts = [int(c) for c in counts.cpu()]
         mine = torch.empty((max(cnt, 1), 3), dtype=torch.float64, device=dev)
-        if cnt:
-            self.tiler.level_positions_device(0, mine.data_ptr())
-            torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+        try:
+            if cnt:
+                self.tiler.level_positions_device(0, mine.data_ptr())
+                torch.cuda.synchronize(dev) if dev.type == "cuda" else None
+        except api.SwzError as e:
+            failure.append(e)
+        self._vote(failure)
         mine = mine[:cnt]
         wire = (lambda t: t) if on_gpu else (lambda t: t.cpu())
         flags = None
@@ -517,12 +589,21 @@ class ShardedBatchTiler:
                 parts.append(buf.cpu())
             allp = torch.cat(parts).numpy()
             taken = np.zeros(allp.shape[0], dtype=np.uint8)
-            if allp.shape[0]:
-                keys, clamped = self.ctx.morton_encode(allp, self.bmin, self.bmax)
-                perm, skeys = self.ctx.sort_by_key(keys)
-                t_sorted = self.ctx.sample_points(self.params.sampler, self.params.max_points_per_node, skeys, perm, clamped, 0, -1,
-                                                  self.bmin, self.bmax, self.params.spacing_at_root, api.ALWAYS_ADHERE_TO_MIN_SPACING)
-                taken[perm] = t_sorted
+            try:
+                if allp.shape[0]:
+                    keys, clamped = self.ctx.morton_encode(allp, self.bmin, self.bmax)
+                    perm, skeys = self.ctx.sort_by_key(keys)
+                    t_sorted = self.ctx.sample_points(self.params.sampler, self.params.max_points_per_node, skeys, perm, clamped, 0, -1,
+                                                      self.bmin, self.bmax, self.params.spacing_at_root, api.ALWAYS_ADHERE_TO_MIN_SPACING)
+                    taken[perm] = t_sorted
+            except api.SwzError as e:
+                failure.append(e)
+        else:
+            if cnt:
+                dist.send(wire(mine), dst=0, group=self.group)
+        # (rank 0 has sampled the root, or failed to: the others learn which before they wait for their flags)
+        self._vote(failure)
+        if self.rank == 0:
             off = 0
             for r in range(world):
                 part = torch.from_numpy(taken[off:off + counts[r]].copy())
@@ -531,13 +612,16 @@ class ShardedBatchTiler:
                     flags = part.to(dev)
                 elif counts[r]:
                     dist.send(wire(part.to(dev)), dst=r, group=self.group)
-        else:
-            if cnt:
-                dist.send(wire(mine), dst=0, group=self.group)
-                buf = torch.empty(cnt, dtype=torch.uint8, device=dev if on_gpu else "cpu")
-                dist.recv(buf, src=0, group=self.group)
-                flags = buf.to(dev)
+        elif cnt:
+            buf = torch.empty(cnt, dtype=torch.uint8, device=dev if on_gpu else "cpu")
+            dist.recv(buf, src=0, group=self.group)
+            flags = buf.to(dev)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
-        self.tiler.shard_fast_set_root(flags.data_ptr() if (flags is not None and cnt) else None)
+        try:
+            self.tiler.shard_fast_set_root(flags.data_ptr() if (flags is not None and cnt) else None)
+        except api.SwzError as e:
+            failure.append(e)
+        self._vote(failure)
         return stats
+

@@ -181,6 +181,62 @@ int main(int argc, char** argv) {
       }
     }
 
+    // ---- a lopsided cloud: nearly all points in the lowest shard's octants, a handful in the others.  In the
+    // joint MIN_DISTANCE root the nearly empty shards' face cells look at the busy shard every round for as long as its
+    // sweep takes: their round limit has to cover that, and the result must still be the oracle's.
+    if (shards > 1) {
+      std::vector<double> lop(xyz);
+      for (size_t i = 0; i < n; ++i)
+        if (i % 6000 != 0) {  // (50 points stay where they are, anywhere in the cube)
+          lop[3 * i] *= 0.49;
+          if (shards > 2) lop[3 * i + 1] *= 0.49;
+          if (shards > 4) lop[3 * i + 2] *= 0.49;
+        }
+      std::vector<double*> d_xyz(shards, nullptr);
+      std::vector<swz_attribute_columns> d_attrs(shards);
+      std::vector<uint64_t> cnt(shards, 0);
+      for (int s = 0; s < shards; ++s) {
+        cnt[s] = cut[s + 1] - cut[s];
+        d_attrs[s] = swz_attribute_columns{};
+        swz_ctx* c = swz_group_ctx(g, s);
+        if (swz_device_alloc_on(c, std::max<uint64_t>(cnt[s], 1) * 24, (void**)&d_xyz[s]) != SWZ_OK) return fail("device alloc");
+        if (cnt[s] && swz_copy_to_device(c, d_xyz[s], lop.data() + 3 * cut[s], cnt[s] * 24) != SWZ_OK) return fail("upload");
+      }
+      swz_tile_params p{};
+      p.sampler = SWZ_MIN_DISTANCE;
+      p.max_points_per_node = 2000;
+      p.spacing_at_root = spacing;
+      p.max_depth = 100;
+      p.strategy = SWZ_ACCURATE;
+      p.fast_concurrency = 8;
+      std::vector<swz_group_result> res(shards);
+      if (swz_group_tile(g, d_xyz.data(), d_attrs.data(), cnt.data(), mn, mx, &p, res.data()) != SWZ_OK) return fail("swz_group_tile (lopsided cloud)", swz_group_last_error(g));
+      std::vector<std::pair<uint64_t, int>> got, want;
+      uint64_t smallest = n;
+      for (int s = 0; s < shards; ++s) {
+        const uint64_t m = res[s].num_points;
+        if (m) smallest = std::min(smallest, m);
+        std::vector<uint64_t> k(m);
+        std::vector<int8_t> lv(m);
+        swz_ctx* c = swz_group_ctx(g, s);
+        if (m && (swz_copy_to_host(c, k.data(), res[s].d_keys, m * 8) || swz_copy_to_host(c, lv.data(), res[s].d_level, m))) return fail("download");
+        for (uint64_t i = 0; i < m; ++i) got.emplace_back(k[i], (int)lv[i]);
+      }
+      std::vector<double> copy(lop);
+      std::vector<uint64_t> ok(n);
+      std::vector<uint32_t> operm(n);
+      std::vector<int8_t> olv(n);
+      orc_tile_params op{SWZ_MIN_DISTANCE, 2000, spacing, 100, ORC_ACCURATE, 8};
+      orc_tile_stats ost;
+      if (orc_tile(copy.data(), n, mn, mx, &op, ok.data(), operm.data(), olv.data(), nullptr, &ost) != 0) return fail("oracle");
+      for (size_t i = 0; i < n; ++i) want.emplace_back(ok[i], (int)olv[i]);
+      std::sort(got.begin(), got.end());
+      std::sort(want.begin(), want.end());
+      if (got != want) return fail("lopsided cloud: sharded MIN_DISTANCE differs from the oracle");
+      std::printf("MIN_DISTANCE %d shard(s), lopsided cloud (smallest shard with points: %llu) ok\n", shards, (unsigned long long)smallest);
+      for (int s = 0; s < shards; ++s) swz_device_free(d_xyz[s]);
+    }
+
     // ---- the same group, a data set in several batches (swz_group_add_batch / _stage_batch, one swz_tiler per shard):
     // the union of the shards' node files = the multi-batch oracle's, file by file and in file order; the root's file
     // is the concatenation of the shards' parts in shard order.  k = 1 from device buffers, k = 3 staged from pinned memory.

@@ -32,13 +32,25 @@ def _points():
     global _N
     if _N is None:
         env = int(os.environ.get("SWZ_FULLSIZE_POINTS", "0"))
+        import torch
+        free, _ = torch.cuda.mem_get_info(0)
         if env:
             _N = env
+            # a part that has room for the bench size is checked AT the bench size: a smaller run there must be asked for
+            if env < 1_000_000_000 and free >= 230e9 and not os.environ.get("SWZ_FULLSIZE_ALLOW_SMALL"):
+                pytest.fail("SWZ_FULLSIZE_POINTS=%d on a GPU with %.0f GB free: the full-size checks run at 1 B points there "
+                            "(set SWZ_FULLSIZE_ALLOW_SMALL=1 to shrink them on purpose)" % (env, free / 1e9))
         else:
-            import torch
-            free, _ = torch.cuda.mem_get_info(0)
             _N = 1_000_000_000 if free >= 230e9 else (500_000_000 if free >= 120e9 else 100_000_000)
     return _N
+
+
+def _record(check, cloud, n, levels, points_checked):
+    """One line per full-size check for the terminal summary (tests/conftest.py prints them at the end of the run, so that
+    what was verified at which size shows in the captured tail of `pytest -m gpu`)."""
+    import conftest
+    conftest.FULLSIZE_RECORDS.append({"check": check, "cloud": cloud, "points": int(n), "levels": int(levels),
+                                      "points_checked": int(points_checked)})
 
 
 def _log(msg):
@@ -119,6 +131,7 @@ def test_output_is_a_sorted_permutation_with_matching_keys(tiled):
     assert stats["points_visited"] >= N
     _log("%s cloud, %d points: output sorted with the canonical tie order, perm is a permutation, %d sampled keys equal the "
          "oracle's encoder" % (tiled["cloud"], N, pick.numel()))
+    _record("sorted permutation, keys = oracle encoder on a sample", tiled["cloud"], N, stats["num_levels"], N)
 
 
 def _check_level(tiled, L, rng, target_points=1_500_000):
@@ -194,6 +207,8 @@ def test_min_distance_levels_obey_the_greedy_rule(tiled):
                  "%d of them taken" % (tiled["cloud"], tiled["n"], L, n, t))
             checked += n
     assert checked > 1_000_000
+    _record("exact MIN_DISTANCE: taken(p) <=> no earlier taken point within the spacing, random boxes of every level",
+            tiled["cloud"], tiled["n"], stats["max_level"] + 2, checked)
 
 
 def test_random_grid_takes_the_first_point_of_every_cell(tiled):
@@ -201,6 +216,7 @@ def test_random_grid_takes_the_first_point_of_every_cell(tiled):
     the first points of the runs of equal key prefix at level L + 7 (d = 250 on a cube: 128 cells per axis)."""
     torch, swz = tiled["torch"], tiled["swz"]
     keys, perm, level, stats = tiled["out"][swz.RANDOM_GRID]
+    checked_rg, levels_rg = 0, 0
     for L in range(-1, stats["max_level"] + 1):
         active = level >= L
         k = keys[active]
@@ -219,6 +235,9 @@ def test_random_grid_takes_the_first_point_of_every_cell(tiled):
         assert bool(((lv == L) == want_taken).all()), "level %d" % L
         _log("%s cloud, %d points, RANDOM_GRID level %d: %d active points, %d taken = the heads of the cell runs (every point checked)" % (
             tiled["cloud"], tiled["n"], L, int(active.sum()), int((lv == L).sum())))
+        checked_rg += int(active.sum())
+        levels_rg += 1
+    _record("RANDOM_GRID: taken = heads of the cell runs, every point of every level", tiled["cloud"], tiled["n"], levels_rg, checked_rg)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -275,10 +294,12 @@ def test_grid_samplers_take_the_first_argmin_of_every_cell(sampler_name):
     tables = _jitter_tables()
     levels_grid = 7  # prev_pow2((uint32)(extent / spacing)) = 128 cells per axis and node at d = 250
     checked = 0
+    nlevels_checked = 0
     for L in range(-1, stats["max_level"] + 1):
         active = torch.nonzero(level >= L).squeeze(1)
         if active.numel() == 0:
             continue
+        nlevels_checked += 1
         k = keys[active]
         shift = 63 - 3 * (L + 1)
         node = (k >> shift) if shift < 63 else torch.zeros_like(k)
@@ -330,4 +351,5 @@ def test_grid_samplers_take_the_first_argmin_of_every_cell(sampler_name):
         checked += int(sampling.sum())
         del k, node, cell, d2, cinv, dmin, cand_idx, first, want, bad
     _log("%s, %d uniform points: %d point decisions verified against the torch evaluation (first arg-min per cell)" % (sampler_name, n, checked))
+    _record("%s: first arg-min per cell against an independent torch evaluation, every sampled node" % sampler_name, "uniform", n, nlevels_checked, checked)
     assert checked >= n

@@ -161,6 +161,9 @@ def test_owner_map_is_monotone_and_balanced():
         assert sharded.rank_send_counts([1] * 8, world) == [8 // world] * world
 
 
+_QUEUE_TIMEOUT = int(os.environ.get("SWZ_TEST_QUEUE_TIMEOUT", "300"))  # seconds a test waits for a worker's result
+
+
 # ------------------------------------------------------------------ GPU: full sharded tiler, 2 ranks on one GPU
 def _corner_cloud(n, seed, world):
     """Points in the octants of rank 0 only: every other rank's shard is empty (flat terrain in a cubic
@@ -173,8 +176,13 @@ def _corner_cloud(n, seed, world):
 
 
 def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False, backend="gloo", joint=False):
-    if joint:
-        os.environ["SWZ_SHARD_JOINT_ROOT"] = "1"
+    # the joint root is the default (after a collective probe of the IPC mappings); "0" keeps the chain of ghosts
+    # (joint = None: the variable is left alone -- the default must sweep the root jointly after its probe)
+    if joint is None:
+        os.environ.pop("SWZ_SHARD_JOINT_ROOT", None)
+        joint = True
+    else:
+        os.environ["SWZ_SHARD_JOINT_ROOT"] = "1" if joint else "0"
     import schwarzwald_amd as swz
     from schwarzwald_amd import sharded
     # gloo: all ranks share GPU 0 (what a one-GPU box can run); nccl (= RCCL): one GPU per rank
@@ -188,6 +196,8 @@ def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=Fals
     assert tiler.joint_root == joint
     stats = tiler.tile(xyz)
     assert tiler.used_joint_root == (joint and sampler == swz.MIN_DISTANCE)
+    assert stats["root_mode"] == ("joint" if tiler.used_joint_root else ("chain" if sampler == swz.MIN_DISTANCE else "local"))
+    assert set(tiler.stage_timings()) >= {"exchange_ms", "root_ms", "levels_ms"}
     recv, keys, perm, level = tiler.result
     q.put((rank, recv.cpu().numpy(), keys.cpu().numpy().view(np.uint64), perm.cpu().numpy().view(np.uint32),
            level.cpu().numpy(), stats))
@@ -208,7 +218,9 @@ def _visible_gpus():
 SHARDED_CASES = [(O.RANDOM_GRID, 250, 60000, "gloo"), (O.GRID_CENTER, 250, 60000, "gloo"), (O.MIN_DISTANCE, 60, 60000, "gloo"),
                  (O.MIN_DISTANCE, 250, 150000, "gloo"), (O.JITTERED, 250, 60000, "gloo"), (O.MIN_DISTANCE, 250, 150000, "nccl"),
                  # the MIN_DISTANCE root swept by both ranks at once, each reading the other's root arrays through IPC mappings
-                 (O.MIN_DISTANCE, 60, 60000, "gloo+joint"), (O.MIN_DISTANCE, 250, 150000, "gloo+joint")]
+                 (O.MIN_DISTANCE, 60, 60000, "gloo+joint"), (O.MIN_DISTANCE, 250, 150000, "gloo+joint"),
+                 # ... which is what a driver gets that sets nothing (probe of the IPC mappings, then the joint sweep)
+                 (O.MIN_DISTANCE, 250, 150000, "gloo+default")]
 
 
 @pytest.mark.gpu
@@ -216,7 +228,7 @@ SHARDED_CASES = [(O.RANDOM_GRID, 250, 60000, "gloo"), (O.GRID_CENTER, 250, 60000
 def test_sharded_tile_matches_oracle(sampler, d, n, backend):
     if backend == "nccl" and _visible_gpus() < 2:
         pytest.skip("the RCCL exchange needs one GPU per rank: fewer than two GPUs visible")
-    joint = backend.endswith("+joint")
+    joint = None if backend.endswith("+default") else backend.endswith("+joint")
     backend = backend.split("+")[0]
     world, max_pts = 2, 500
     spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], d)
@@ -229,7 +241,7 @@ def test_sharded_tile_matches_oracle(sampler, d, n, backend):
         p.start()
     got = {}
     for _ in range(world):
-        item = q.get(timeout=300)
+        item = q.get(timeout=_QUEUE_TIMEOUT)
         got[item[0]] = item[1:]
     for p in procs:
         p.join(60)
@@ -274,7 +286,7 @@ def test_sharded_tile_with_empty_shards(sampler, world):
         p.start()
     got = {}
     for _ in range(world):
-        item = q.get(timeout=300)
+        item = q.get(timeout=_QUEUE_TIMEOUT)
         got[item[0]] = item[1:]
     for p in procs:
         p.join(60)
@@ -352,7 +364,7 @@ def test_sharded_multibatch_matches_the_multibatch_oracle(sampler, corner):
         p.start()
     got = {}
     for _ in range(world):
-        item = q.get(timeout=300)
+        item = q.get(timeout=_QUEUE_TIMEOUT)
         got[item[0]] = item[1:]
     for p in procs:
         p.join(60)
@@ -395,7 +407,7 @@ def test_sharded_fast_strategy_matches_the_multibatch_oracle(sampler, k):
         p.start()
     got = {}
     for _ in range(world):
-        item = q.get(timeout=300)
+        item = q.get(timeout=_QUEUE_TIMEOUT)
         got[item[0]] = item[1:]
     for p in procs:
         p.join(60)
