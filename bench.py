@@ -58,6 +58,10 @@ def parse_args():
     ap.add_argument("--batches", type=int, default=1, help="tile the points in this many batches through the multi-batch "
                     "tiler (swz_tiler_*: cached-point re-read + merge like the reference with internal_cache_size < N); "
                     "a step is then the whole data set, batch after batch, into a fresh tiler")
+    ap.add_argument("--batch-order", default="uniform", choices=["uniform", "tiles"], help="with --batches k: uniform = every "
+                    "batch is cut out of the whole cloud (each batch reaches every node: the worst case for a multi-batch "
+                    "tiler); tiles = batch i holds the points of the i-th tile of a regular x-y grid over the bounds, the "
+                    "way a data set arrives as LAS tiles (spatially coherent: a batch reaches a small part of the tree)")
     ap.add_argument("--staged", action="store_true", help="with --batches: additionally time the batches coming from "
                     "PINNED HOST memory through swz_tiler_stage_batch / swz_tiler_tile_staged (hipMemcpyAsync of batch "
                     "k+1 under the kernels of batch k; attribute columns of --payload travel along); reported under "
@@ -380,6 +384,18 @@ def main():
     # synthetic input, resident in HBM before the timed region
     xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
     ctx.generate_uniform_device(SEED + 3, rank * n, n, xyz.data_ptr())
+    if args.batches > 1 and args.batch_order == "tiles":
+        # the same uniform points, batch i squeezed into tile i of a gx x gy grid over x and y (the whole z range): the
+        # union is still uniform in the cube when the batches have equal sizes
+        k = args.batches
+        gx = int(np.ceil(np.sqrt(k)))
+        gy = (k + gx - 1) // gx
+        for i in range(k):
+            lo, hi = (i * n) // k, ((i + 1) * n) // k
+            tx, ty = i % gx, i // gx
+            xyz[lo:hi, 0].mul_(args.bounds_scale / gx).add_(tx * args.bounds_scale / gx)
+            xyz[lo:hi, 1].mul_(args.bounds_scale / gy).add_(ty * args.bounds_scale / gy)
+        torch.cuda.synchronize(dev)
 
     mb = None
     if distributed and (args.batches > 1 or args.strategy == "FAST"):
@@ -521,10 +537,11 @@ def main():
             "config": {"workload": "%d uniform points per GPU in the unit cube, %s sampling, spacing = diagonal/%g, "
                                    "max_points_per_node=%d, %s strategy, %s" % (
                                        n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy,
-                                       "one batch" if args.batches <= 1 else "%d batches through the multi-batch tiler" % args.batches),
+                                       "one batch" if args.batches <= 1 else "%d batches through the multi-batch tiler (%s)" % (
+                                           args.batches, "cut out of the whole cloud" if args.batch_order == "uniform" else "one x-y tile each")),
                        "points_per_gpu": n, "sampler": args.sampler, "strategy": args.strategy,
                        "min_distance_mode": ("property" if args.md_mode == "property" else "exact") if args.sampler == "MIN_DISTANCE" else None,
-                       "batches": args.batches,
+                       "batches": args.batches, "batch_order": args.batch_order if args.batches > 1 else None,
                        "staged_from_pinned_host": bool(args.staged and distributed and args.batches > 1) or None,
                        "payload_columns": [a for a in args.payload.split(",") if a] if (distributed and args.batches > 1) else None,
                        "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},

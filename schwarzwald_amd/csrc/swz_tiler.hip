@@ -575,6 +575,8 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     SWZ_HIP(c, hipMemcpyAsync(cgid, st.gid[st.cur], (size_t)st.cnt * 4, hipMemcpyDeviceToDevice, c->stream));
     nc = st.cnt;
   } else if (st.cnt) {
+    // (profile class "tiler_pull": which store entries lie in nodes the active set reaches, and the split)
+    ProfScope ps(c, "tiler_pull", (uint64_t)st.cnt * 33ull + (uint64_t)as.m * 8ull, 3);
     uint8_t* touch = nullptr;
     SWZ_TRY(c->get("tl_touch", (size_t)st.cnt, &touch));
     SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
@@ -592,6 +594,8 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   ActiveSet ms = as;
   if (nc || ng) {
     if (nc) {
+      // ("tiler_rekey": the pulled points' keys against their NODE's bounds -- a random 24-byte read per point from the pool)
+      ProfScope ps(c, "tiler_rekey", (uint64_t)nc * 44ull, 1);
       hipLaunchKernelGGL(tl_rekey_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, cgid, nc, t->pool_xyz,
                          root_box(t), plan.level);
       SWZ_LAUNCH_CHECK(c);
@@ -619,7 +623,10 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     SWZ_TRY(c->get("tl_midx", (size_t)as.m + nc + ng, &midx));
     // tile_node :421-442: terminal nodes append (new ++ cached), the others std::merge by key; ghosts lie in lower
     // octants, so their keys are smaller than every local key: sorted ghosts ++ merged locals is the merged whole
-    SWZ_TRY(merge_pairs(c, as.akey, as.aidx, as.m, ckey, nullptr, nc, plan.terminal ? nsh : 0u, w.wused, mkey + ng, midx + ng));
+    {
+      ProfScope ps(c, "tiler_merge", ((uint64_t)as.m + nc) * 24ull, 2);
+      SWZ_TRY(merge_pairs(c, as.akey, as.aidx, as.m, ckey, nullptr, nc, plan.terminal ? nsh : 0u, w.wused, mkey + ng, midx + ng));
+    }
     w.wused += nc;
     if (ng) {
       uint64_t *gk = nullptr, *gkb = nullptr;
@@ -680,7 +687,10 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   uint32_t* tgid = nullptr;
   SWZ_TRY(c->get("tl_tkey", (size_t)nt, &tkey));
   SWZ_TRY(c->get("tl_tgid", (size_t)nt, &tgid));
-  SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{ms.akey, ms.aidx, w.wgid, tkey, tgid}, ms.m, counters + 2, "tl"));
+  {
+    ProfScope ps(c, "tiler_store", (uint64_t)ms.m * 14ull + (uint64_t)nt * 12ull, 2);
+    SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{ms.akey, ms.aidx, w.wgid, tkey, tgid}, ms.m, counters + 2, "tl"));
+  }
   if (ng) {  // the ghosts lead the merged range and are all taken again: they are not part of the local file
     SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
     hipLaunchKernelGGL(tl_count_untaken_kernel, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, lb.taken, ng, counters + 1);
@@ -692,7 +702,10 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   }
   const int dst = st.cur ^ 1;
   SWZ_TRY(store_reserve(c, st, plan.level + 1, dst, (size_t)nr + nt - ng));
-  SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey + ng, tgid + ng, nt - ng, nsh, 0u, st.key[dst], st.gid[dst]));
+  {
+    ProfScope ps(c, "tiler_store", ((uint64_t)nr + nt - ng) * 24ull, 2);
+    SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey + ng, tgid + ng, nt - ng, nsh, 0u, st.key[dst], st.gid[dst]));
+  }
   st.cur = dst;
   st.cnt = nr + nt - ng;
 
