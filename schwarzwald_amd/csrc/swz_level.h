@@ -180,6 +180,12 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
                             const uint32_t* snode_of, int cl, double typical_pop, uint32_t* rounds_out, bool* used,
                             const MdShardRoot* shard_root = nullptr);
 
+// Property mode on key coordinates in data-parallel rounds (swz_mdrounds.hip): candidates per cell, winners by a hashed
+// priority, a kill pass; *used = false when the level does not qualify (then nothing has been decided).
+int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+                              uint32_t num_nodes, uint32_t sample_nodes, uint32_t sample_points, const uint32_t* snode_of, uint32_t* rounds_out,
+                              bool* used);
+
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
 // qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,

@@ -1075,7 +1075,7 @@ bool grid_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedP
 
 bool level_decides_on_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp) {
   if (plan.sampler == SWZ_RANDOM_GRID) return true;
-  if (plan.sampler == SWZ_MIN_DISTANCE) return !plan.md_property && min_distance_level_uses_keys(c, plan, sp);
+  if (plan.sampler == SWZ_MIN_DISTANCE) return min_distance_level_uses_keys(c, plan, sp);
   return grid_level_uses_keys(c, plan, sp, nullptr);
 }
 
@@ -1335,7 +1335,7 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
   t.front = front;
   if (p.sampler != SWZ_RANDOM_GRID) {
     const LevelPlan top = make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, false, true);
-    const bool on_keys = p.sampler == SWZ_MIN_DISTANCE ? (!(p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && key_metric(c, top, t.sp).ok)
+    const bool on_keys = p.sampler == SWZ_MIN_DISTANCE ? key_metric(c, top, t.sp).ok
                                                        : grid_level_uses_keys(c, top, t.sp, nullptr);
     if (!on_keys) SWZ_TRY(session_gather_positions(c, t));
   }

@@ -1264,7 +1264,7 @@ __global__ __launch_bounds__(256) void mq_verify_kernel(MqArgs a, uint32_t ncell
 
 // ----------------------------------------------------------------------------- host
 bool min_distance_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp) {
-  return !plan.md_property && key_metric(c, plan, sp).ok;
+  return key_metric(c, plan, sp).ok;  // (property mode decides on keys as well: swz_mdrounds.hip, or the exact set)
 }
 
 int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,

@@ -430,13 +430,13 @@ __global__ __launch_bounds__(256) void pm_gather_active_kernel(const uint32_t* _
 // occupied cells per candidate cell level (same counting as the exact path's md_cell_hist_kernel)
 __global__ __launch_bounds__(256) void pm_cell_hist_kernel(const uint64_t* __restrict__ akey, const uint32_t* __restrict__ nid,
                                                            const uint8_t* __restrict__ nmode, uint32_t m, uint32_t node_shift,
-                                                           uint32_t cl_geo, uint32_t* __restrict__ hist) {
+                                                           uint32_t cl_geo, uint32_t skip, uint32_t* __restrict__ hist) {
   __shared__ uint32_t lh[16];
   if (threadIdx.x < 16) lh[threadIdx.x] = 0;
   __syncthreads();
   uint32_t mine = 0;
-  for (uint32_t i0 = blockIdx.x * 256; i0 < m; i0 += gridDim.x * 256) {
-    const uint32_t i = i0 + threadIdx.x;
+  for (uint64_t i0 = (uint64_t)blockIdx.x * 256u * skip; i0 < m; i0 += (uint64_t)gridDim.x * 256u * skip) {  // every skip-th tile
+    const uint32_t i = (uint32_t)i0 + threadIdx.x;
     uint32_t bin = 0xFFu;
     if (i < m && nmode[nid[i]] == MODE_SAMPLE) {
       if (i == 0 || nid[i - 1] != nid[i]) {
@@ -494,22 +494,31 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
   const auto wall0 = std::chrono::steady_clock::now();
   c->next_scratch_epoch();  // what the level before asked for ("md_*", "sp_*", "pm_*") may go if memory runs out
   uint32_t occupied[12] = {0};
-  {
+  bool sampled_hist = false;
+  auto count_cells = [&](bool exact) -> int {
     uint32_t* d_hist = nullptr;
     SWZ_TRY(c->get("md_hist", (size_t)16, &d_hist));
     SWZ_HIP(c, hipMemsetAsync(d_hist, 0, 64, c->stream));
-    hipLaunchKernelGGL(pm_cell_hist_kernel, dim3(std::min<uint32_t>(div_up(m, 256), 4096u)), dim3(256), 0, c->stream,
-                       as.akey, lb.nid, lb.nmode, m, nsh, (uint32_t)plan.cell_levels_geo, d_hist);
+    // (about 8 M points are looked at on large levels: the counts only steer the choice of path and cell size -- the
+    // coloured phases below size buffers by them and count again, exactly)
+    const uint32_t skip = exact ? 1u : std::max(1u, m >> 23);
+    sampled_hist = skip > 1u;
+    const uint32_t tiles = div_up(m, 256), sampled_tiles = div_up(tiles, skip);
+    hipLaunchKernelGGL(pm_cell_hist_kernel, dim3(std::min<uint32_t>(sampled_tiles, 4096u)), dim3(256), 0, c->stream,
+                       as.akey, lb.nid, lb.nmode, m, nsh, (uint32_t)plan.cell_levels_geo, skip, d_hist);
     SWZ_LAUNCH_CHECK(c);
     uint32_t h[16];
     SWZ_HIP(c, hipMemcpyAsync(h, d_hist, 64, hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    uint32_t run = 0;
+    const double scale = skip == 1 ? 1.0 : (double)m / (double)std::min<uint64_t>(m, (uint64_t)sampled_tiles * 256u);
+    double run = 0;
     for (int b = 0; b < 12; ++b) {
       run += h[b];
-      occupied[b] = run;
+      occupied[b] = (uint32_t)std::min<double>(run * scale, (double)m);
     }
-  }
+    return SWZ_OK;
+  };
+  SWZ_TRY(count_cells(false));
   // Cell size: coarser cells mean fewer, better filled cells, but every point is tested against the taken points of
   // 27 cells: keep the expected number of taken points per cell small (<= 8).  A cell of side r spacings holds at
   // most about 0.75 r^3 points that are pairwise a spacing apart (and never more than it has points).
@@ -569,6 +578,16 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
     hipLaunchKernelGGL(pm_clear_taken_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, lb.nid, lb.nmode, m, lb.taken);
     SWZ_LAUNCH_CHECK(c);
   }
+  if (key_metric(c, plan, sp).ok) {
+    // On key coordinates (cubic bounds, as the Tiler's are): a maximal independent set grown in data-parallel rounds, no
+    // positions in Morton order, no dependent phases (swz_mdrounds.hip).  Levels it does not take get the exact set
+    // below -- it has the property a fortiori and decides on the keys as well.
+    bool used = false;
+    SWZ_TRY(min_distance_rounds_level(c, plan, as, sp, lb, nnodes, sample_nodes, sample_points, snode, phases_out, &used));
+    if (used) return SWZ_OK;
+    if (!sp.X) return min_distance_level(c, plan, as, sp, lb, nnodes, sample_nodes, sample_points, phases_out);
+  }
+  if (sampled_hist) SWZ_TRY(count_cells(true));  // the coloured phases size their per-cell arrays by these counts
   if (as.aidx) {  // below the root the survivors are a subsequence: positions into active order
     double* ax = nullptr;
     SWZ_TRY(c->get("md_pos", (size_t)m * 4, &ax));

@@ -1,0 +1,439 @@
+// swz_mdrounds.hip -- MIN_DISTANCE in "property" mode (SWZ_FLAG_MIN_DISTANCE_PROPERTY) on KEY COORDINATES, without any
+// dependency chain: a maximal independent set grown in a handful of data-parallel rounds.
+//
+// The reference's PoissonDiskSampling (core/tiling/Sampling.h:421-471 + SparseGrid.cpp:116-146) is the greedy set in
+// Morton order; what the sampler is FOR -- and what its author checks, test/TestTiler.cpp:361-421 -- is the property:
+// inside a sampled node no two taken points closer than the node's spacing, and every point left out closer than the
+// spacing to a taken one, with the reference's compare (squared double distance < float-squared spacing,
+// GridCell.cpp:43-58).  Any maximal independent set of the "closer than the spacing" graph has it.  This file builds
+// one like this (Luby's scheme on a grid; deterministic):
+//
+//   * every sampled node is cut into octree cells at least one spacing wide: only points of the same or of adjacent
+//     cells can conflict.  All points start alive.
+//   * a round: (1) every cell's first alive point is its CANDIDATE; (2) a candidate WINS when no candidate of an adjacent
+//     cell is closer than the spacing and has the better priority (a hash of the cell number: no spatial order, hence no
+//     chains) -- two conflicting candidates never both win, and the best candidate anywhere always does; (3) every alive
+//     point that is closer than the spacing to a winner of its own or an adjacent cell dies, the winners are taken.
+//     Candidates are alive, i.e. at least the spacing away from everything taken before, so the taken set stays
+//     independent; rounds go on until nothing is alive, so it ends maximal.
+//   * the compares are taken on the key coordinates (the Morton key IS the position, quantised to 2^-21 of the cubic
+//     bounds; swz_mdkeys.hip: key_metric) and repeated with the reference's arithmetic on the original positions for the
+//     pairs inside the quantisation band.  Nothing is gathered or sorted; a round is three streaming kernels (one thread
+//     per cell twice, one per alive point), and the number of alive points falls by about half per round.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+#include "swz_level.h"
+#include "swz_scan.h"
+
+namespace swz {
+
+constexpr uint32_t PR_NONE = 0xFFFFFFFFu;
+constexpr int PR_WL = 8;  // winners around a cell kept side by side (more than that: the cell's points look them up by direction)
+enum : uint8_t { PR_ALIVE = 0, PR_DEAD = 1 };
+enum { PRC_ALIVE = CTR_DBG_HIST, PRC_LIST = CTR_DBG_HIST + 1, PRC_BAND = CTR_DBG_HIST + 2, PRC_WON = CTR_DBG_HIST + 3 };
+
+struct PrArgs {
+  const uint64_t* akey;
+  uint32_t m;
+  const uint32_t* nid;
+  const uint8_t* nmode;
+  const uint32_t* snode_of;
+  uint32_t all_sampled;
+  const uint32_t* ids;   // caller's index of active point i: exact positions at xyz[3 * ids[i]]
+  const double* xyz;
+  uint8_t* taken;
+  uint8_t* state;        // [m] PR_*
+  uint32_t* counters;
+  uint32_t* cand[2];     // [cell] first alive point of the cell (this round's candidates / the next round's)
+  uint64_t* candq;       // [cell] the candidate's key coordinates x | y << 21 | z << 42, bit 63 set (0: none)
+  uint64_t* wonq;        // [cell] this round's winner (same packing), 0: none
+  uint32_t* woni;        // [cell] ... its active index
+  uint32_t* wmask;       // [cell] bit k: the adjacent cell in direction k holds a winner of this round; bits 28-31: how many (15: 15 or more)
+  unsigned long long* wl; // [cell][PR_WL] those winners' coordinates, when there are at most PR_WL
+  uint32_t* list[2];     // alive points (compacted once few are left)
+  uint64_t ncells;       // sampled nodes x cells per node
+  uint32_t cell_shift;
+  uint64_t cells_per_node;
+  float f_lo, f_hi;
+  double sq_spacing;
+};
+
+// Key coordinates of a key with 32-bit arithmetic (the 64-bit bit trick costs twice as much and the kill pass of the first
+// round runs it for every point of the level): bit 3j+2 of the key is bit j of x, 3j+1 of y, 3j of z (MortonIndex.h:62-79).
+// The low word holds x bits 0-9, y bits 0-10, z bits 0-10; the high word (bit 32 on) the rest.
+__device__ __forceinline__ void pr_coords_u(uint64_t key, uint32_t& x, uint32_t& y, uint32_t& z) {
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  x = contract_bits_by_3_u32(lo >> 2) | (contract_bits_by_3_u32(hi) << 10);
+  y = contract_bits_by_3_u32(lo >> 1) | (contract_bits_by_3_u32(hi >> 2) << 11);
+  z = contract_bits_by_3_u32(lo) | (contract_bits_by_3_u32(hi >> 1) << 11);
+}
+__device__ __forceinline__ uint64_t pr_pack(uint64_t key) {
+  uint32_t x, y, z;
+  pr_coords_u(key, x, y, z);
+  return (uint64_t)x | ((uint64_t)y << 21) | ((uint64_t)z << 42);
+}
+__device__ __forceinline__ void pr_unpack(uint64_t v, float& x, float& y, float& z) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  x = (float)(lo & 0x1FFFFFu);
+  y = (float)(((lo >> 21) | (hi << 11)) & 0x1FFFFFu);
+  z = (float)((hi >> 10) & 0x1FFFFFu);
+}
+__device__ __forceinline__ float pr_d2(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = ax - bx, dy = ay - by, dz = az - bz;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+// the reference's compare on the exact positions (GridCell.cpp:52) for active points i and j
+__device__ __forceinline__ bool pr_exact_near(const PrArgs& a, uint32_t i, uint32_t j) {
+  const double* p = a.xyz + (size_t)a.ids[i] * 3;
+  const double* q = a.xyz + (size_t)a.ids[j] * 3;
+  return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
+}
+__device__ __forceinline__ bool pr_sampled(const PrArgs& a, uint32_t i) { return a.all_sampled || a.nmode[a.nid[i]] == MODE_SAMPLE; }
+__device__ __forceinline__ uint64_t pr_cell_of(const PrArgs& a, uint32_t i) {
+  const uint32_t sn = a.all_sampled ? a.nid[i] : a.snode_of[a.nid[i]];
+  return (uint64_t)sn * a.cells_per_node + ((a.akey[i] >> a.cell_shift) & (a.cells_per_node - 1ull));
+}
+// priority of a cell's candidate: smaller wins.  An odd multiplier permutes the 32-bit numbers, so no two cells tie.
+__device__ __forceinline__ uint32_t pr_prio(uint64_t cell) { return (uint32_t)cell * 0x9E3779B1u; }
+
+// The 27 cells around code (inside the node) by arithmetic on the dilated coordinates: dx/dy/dz[0..2] = minus one, same,
+// plus one per axis; NONE when outside the node.
+struct PrNbr {
+  uint32_t dx[3], dy[3], dz[3];
+};
+__device__ __forceinline__ PrNbr pr_nbr(const PrArgs& a, uint32_t code) {
+  const uint32_t all = (uint32_t)(a.cells_per_node - 1ull);
+  const uint32_t mz = all & 0x09249249u, my = mz << 1, mx = mz << 2;
+  const uint32_t vx = code & mx, vy = code & my, vz = code & mz;
+  PrNbr n;
+  n.dx[0] = vx ? ((vx - 1u) & mx) : PR_NONE; n.dx[1] = vx; n.dx[2] = vx != mx ? (((vx | ~mx) + 1u) & mx) : PR_NONE;
+  n.dy[0] = vy ? ((vy - 1u) & my) : PR_NONE; n.dy[1] = vy; n.dy[2] = vy != my ? (((vy | ~my) + 1u) & my) : PR_NONE;
+  n.dz[0] = vz ? ((vz - 1u) & mz) : PR_NONE; n.dz[1] = vz; n.dz[2] = vz != mz ? (((vz | ~mz) + 1u) & mz) : PR_NONE;
+  return n;
+}
+
+// all points alive; the first point of every cell is its first candidate (cells = runs of the sorted keys)
+__global__ __launch_bounds__(256) void pr_init_kernel(PrArgs a) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.m) return;
+  if (!pr_sampled(a, i)) {
+    a.state[i] = PR_DEAD;
+    return;
+  }
+  a.state[i] = PR_ALIVE;
+  const bool head = i == 0 || a.nid[i - 1] != a.nid[i] || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
+  if (head) a.cand[0][pr_cell_of(a, i)] = i;
+}
+
+// (1) the candidates' coordinates beside their index; the next round's candidate slots emptied
+__global__ __launch_bounds__(256) void pr_candidates_kernel(PrArgs a, uint32_t cur) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.ncells) return;
+  const uint32_t i = a.cand[cur][c];
+  a.candq[c] = i != PR_NONE ? (pr_pack(a.akey[i]) | (1ull << 63)) : 0ull;
+  a.cand[cur ^ 1u][c] = PR_NONE;
+}
+
+// (2) a candidate wins unless a conflicting candidate of an adjacent cell has the better priority
+__global__ __launch_bounds__(256) void pr_winners_kernel(PrArgs a, uint32_t cur) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.ncells) return;
+  const uint64_t mine = a.candq[c];
+  uint64_t won = 0ull;
+  if (mine) {
+    const uint32_t i = a.cand[cur][c];
+    float x, y, z;
+    pr_unpack(mine, x, y, z);
+    const uint64_t base = c & ~(a.cells_per_node - 1ull);
+    const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
+    const uint32_t my_prio = pr_prio(c);
+    bool lose = false;
+    uint32_t nband = 0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      if (k == 13) continue;
+      const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
+      if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE || lose) continue;
+      const uint64_t nc = base + (X | Y | Z);
+      const uint64_t q = a.candq[nc];
+      if (!q || pr_prio(nc) > my_prio) continue;
+      float qx, qy, qz;
+      pr_unpack(q, qx, qy, qz);
+      const float d2 = pr_d2(x, y, z, qx, qy, qz);
+      if (d2 < a.f_lo) lose = true;
+      else if (d2 < a.f_hi) {
+        ++nband;
+        lose = pr_exact_near(a, i, a.cand[cur][nc]);
+      }
+    }
+    if (nband) atomicAdd(&a.counters[PRC_BAND], nband);
+    if (!lose) {
+      won = mine;
+      a.woni[c] = i;
+      a.taken[i] = 1;
+      a.state[i] = PR_DEAD;
+    }
+  }
+  a.wonq[c] = won;
+}
+
+// (2b) per cell that still has alive points: which of the 27 cells around it hold a winner of this round -- 27 lookups per
+// cell instead of 27 per alive point in (3)
+__global__ __launch_bounds__(256) void pr_mask_kernel(PrArgs a) {
+  const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= a.ncells) return;
+  uint32_t mask = 0, cnt = 0;
+  if (a.candq[c]) {  // (a cell without a candidate has no alive point: nobody reads its mask)
+    const uint64_t base = c & ~(a.cells_per_node - 1ull);
+    const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
+    unsigned long long* wl = a.wl + c * PR_WL;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
+      if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE) continue;
+      const unsigned long long q = a.wonq[base + (X | Y | Z)];
+      if (q) {
+        mask |= 1u << k;
+        if (cnt < (uint32_t)PR_WL) wl[cnt] = q;  // the winners around this cell side by side: what its points read in (3)
+        ++cnt;
+      }
+    }
+  }
+  a.wmask[c] = mask | (min(cnt, 15u) << 28);
+}
+
+// (3) alive points closer than the spacing to a winner around them die; the first survivor of every cell is the next
+// candidate.  use_list: the alive points come from a list (and the survivors go to the next one).
+__global__ __launch_bounds__(256) void pr_kill_kernel(PrArgs a, uint32_t cur, uint32_t use_list, uint32_t nlist) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t limit = use_list ? nlist : a.m;
+  bool alive = false;
+  uint32_t i = 0;
+  if (t < limit) {
+    i = use_list ? a.list[cur][t] : t;
+    alive = a.state[i] == PR_ALIVE;
+  }
+  uint64_t cell = 0;
+  if (alive) {
+    cell = pr_cell_of(a, i);
+    const uint64_t base = cell & ~(a.cells_per_node - 1ull);
+    const PrNbr n = pr_nbr(a, (uint32_t)(cell & (a.cells_per_node - 1ull)));
+    float x, y, z;
+    {
+      uint32_t ux, uy, uz;
+      pr_coords_u(a.akey[i], ux, uy, uz);
+      x = (float)ux;
+      y = (float)uy;
+      z = (float)uz;
+    }
+    bool dead = false;
+    uint32_t nband = 0;
+    const uint32_t wm = a.wmask[cell];
+    const uint32_t wcnt = wm >> 28;
+    uint32_t mask = wm & 0x7FFFFFFu;
+    if (wcnt <= (uint32_t)PR_WL) {
+      // the usual case: the winners around the cell lie side by side (the cell's points read the same 64 bytes)
+      mask = 0;
+      const unsigned long long* wl = a.wl + cell * PR_WL;
+      for (uint32_t j = 0; j < wcnt && !dead; ++j) {
+        const unsigned long long q = wl[j];
+        float qx, qy, qz;
+        pr_unpack(q, qx, qy, qz);
+        const float d2 = pr_d2(x, y, z, qx, qy, qz);
+        if (d2 < a.f_lo) dead = true;
+        else if (d2 < a.f_hi) {  // inside the band: which cell was that winner's?  (rare: its index is looked up there)
+          ++nband;
+          const uint32_t cb = a.cell_shift / 3u;
+          const uint32_t ux = (uint32_t)qx >> cb, uy = (uint32_t)qy >> cb, uz = (uint32_t)qz >> cb;
+          const uint64_t code = ((expand_bits_by_3(ux) << 2) | (expand_bits_by_3(uy) << 1) | expand_bits_by_3(uz)) & (a.cells_per_node - 1ull);
+          dead = pr_exact_near(a, i, a.woni[base + code]);
+        }
+      }
+    }
+    while (mask && !dead) {
+      const uint32_t k = (uint32_t)__ffs((int)mask) - 1u;
+      mask &= mask - 1u;
+      const uint32_t kx = k % 3u, ky = (k / 3u) % 3u, kz = k / 9u;
+      const uint32_t X = kx == 0u ? n.dx[0] : (kx == 1u ? n.dx[1] : n.dx[2]);
+      const uint32_t Y = ky == 0u ? n.dy[0] : (ky == 1u ? n.dy[1] : n.dy[2]);
+      const uint32_t Z = kz == 0u ? n.dz[0] : (kz == 1u ? n.dz[1] : n.dz[2]);
+      const uint64_t nc = base + (X | Y | Z);
+      const uint64_t q = a.wonq[nc];
+      float qx, qy, qz;
+      pr_unpack(q, qx, qy, qz);
+      const float d2 = pr_d2(x, y, z, qx, qy, qz);
+      if (d2 < a.f_lo) dead = true;
+      else if (d2 < a.f_hi) {
+        ++nband;
+        dead = pr_exact_near(a, i, a.woni[nc]);
+      }
+    }
+    if (nband) atomicAdd(&a.counters[PRC_BAND], nband);
+    if (dead) {
+      a.state[i] = PR_DEAD;
+      alive = false;
+    }
+  }
+  // survivors: the next round's candidate of their cell is the smallest index (one atomic per run of a cell in the
+  // wavefront: a cell's points are consecutive -- the lists keep the order of the points)
+  const uint64_t am = __ballot(alive);
+  if (!am) return;
+  {
+    // (every lane takes part in the shuffles; the lane they read is an alive one)
+    const uint64_t before = am & lanemask_lt();
+    const int prev = before ? 63 - __clzll((unsigned long long)before) : 0;
+    const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)cell, prev, WAVE), phi = (uint32_t)__shfl((int)(uint32_t)(cell >> 32), prev, WAVE);
+    const bool head = alive && (before == 0ull || (((uint64_t)phi << 32) | plo) != cell);
+    if (head) atomicMin(&a.cand[cur ^ 1u][cell], i);
+  }
+}
+
+// The alive points after a round, counted and -- once they are few -- listed in their order by a scan (no atomics: a
+// single counter word under every wavefront of a billion-point level was what the first version of this file spent its
+// time on, and appends in arrival order made the result depend on the scheduling).
+struct PrAliveF {  // state byte == PR_ALIVE (0): the tile sums come from 16-byte loads (swz_scan.h, FsCountsZeroBytes)
+  const uint8_t* taken;
+  __device__ uint32_t operator()(uint32_t i) const { return taken[i] == PR_ALIVE ? 1u : 0u; }
+};
+template <>
+struct FsCountsZeroBytes<PrAliveF> {
+  static constexpr bool value = true;
+};
+struct PrListG {  // point i is alive: the next list's entry
+  uint32_t* out;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t alive) const {
+    if (alive) out[excl] = i;
+  }
+};
+struct PrAliveOfListF {  // the same over a list of points
+  const uint8_t* state;
+  const uint32_t* list;
+  __device__ uint32_t operator()(uint32_t t) const { return state[list[t]] == PR_ALIVE ? 1u : 0u; }
+};
+struct PrListOfListG {
+  const uint32_t* list;
+  uint32_t* out;
+  __device__ void operator()(uint32_t t, uint32_t excl, uint32_t alive) const {
+    if (alive) out[excl] = list[t];
+  }
+};
+
+__global__ __launch_bounds__(256) void pr_snode_flag_kernel(const uint8_t* __restrict__ nmode, uint32_t nnodes, uint32_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < nnodes) out[j] = nmode[j] == MODE_SAMPLE ? 1u : 0u;
+}
+
+// One level.  *used = false when the level cannot be decided on keys or its cell grid would be too large.
+int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+                              uint32_t nnodes, uint32_t sample_nodes, uint32_t sample_points, const uint32_t* snode_of, uint32_t* rounds_out,
+                              bool* used) {
+  *used = false;
+  const KeyMetric km = key_metric(c, plan, sp);
+  if (!km.ok || sp.ghosts) return SWZ_OK;
+  if (const char* e = c->opt("SWZ_MD_ROUNDS"))
+    if (atoi(e) == 0) return SWZ_OK;
+  const uint32_t m = as.m;
+  const uint32_t nsh = plan.node_shift == 63u ? 63u : plan.node_shift;
+  // the finest cells the spacing allows give the most candidates per round; on sparse levels the dense cell grid would
+  // dwarf the points, so cells are doubled while they hold fewer than four points on average
+  int cl = plan.cell_levels_geo;
+  if (cl < 0 || 3u * (uint32_t)cl > nsh || cl > 10) return SWZ_OK;
+  double min_pop = 0.0;  // (measured: coarser cells mean one candidate per LARGER cell and round -- 57 rounds instead of 7)
+  if (const char* e = c->opt("SWZ_MD_ROUNDS_MIN_POP")) min_pop = atof(e);
+  while (cl > 1 && (double)sample_points / ((double)sample_nodes * std::pow(8.0, cl)) < min_pop) --cl;
+  PrArgs a{};
+  a.cells_per_node = 1ull << (3 * cl);
+  a.ncells = (uint64_t)sample_nodes * a.cells_per_node;
+  if (a.ncells > 2147483648ull) return SWZ_OK;
+  a.akey = as.akey;
+  a.m = m;
+  a.nid = lb.nid;
+  a.nmode = lb.nmode;
+  a.snode_of = snode_of;
+  a.all_sampled = sample_nodes == nnodes ? 1u : 0u;
+  a.xyz = sp.xyz;
+  a.taken = lb.taken;
+  a.counters = lb.counters;
+  a.cell_shift = nsh - 3u * (uint32_t)cl;
+  a.f_lo = km.f_lo;
+  a.f_hi = km.f_hi;
+  a.sq_spacing = plan.sq_spacing;
+  // a cell must be at least one spacing wide on the key grid, band included (cell_levels_geo guarantees it geometrically)
+  if (std::ldexp(1.0, (int)(a.cell_shift / 3u)) < km.T + 4.0) return SWZ_OK;
+  SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
+
+  ProfScope ps(c, "sample_min_distance_property", (uint64_t)sample_points * 33ull, 1);
+  const auto wall0 = std::chrono::steady_clock::now();
+  SWZ_TRY(c->get("md_pr_state", (size_t)m, &a.state));
+  SWZ_TRY(c->get("md_pr_cand0", (size_t)a.ncells, &a.cand[0]));
+  SWZ_TRY(c->get("md_pr_cand1", (size_t)a.ncells, &a.cand[1]));
+  SWZ_TRY(c->get("md_pr_candq", (size_t)a.ncells, &a.candq));
+  SWZ_TRY(c->get("md_pr_wonq", (size_t)a.ncells, &a.wonq));
+  SWZ_TRY(c->get("md_pr_woni", (size_t)a.ncells, &a.woni));
+  SWZ_TRY(c->get("md_pr_wmask", (size_t)a.ncells, &a.wmask));
+  SWZ_TRY(c->get("md_pr_wl", (size_t)a.ncells * PR_WL, &a.wl));
+  SWZ_HIP(c, memset_large(a.cand[0], 0xFF, (size_t)a.ncells * 4, c->stream));
+  SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_DBG_HIST, 0, 8 * sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(pr_init_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, a);
+  SWZ_LAUNCH_CHECK(c);
+  const uint32_t cblocks = div_up(a.ncells, 256);
+  uint32_t cur = 0, rounds = 0, alive = sample_points, nlist = 0;
+  bool use_list = false;
+  const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
+  const bool lists = !(c->opt("SWZ_MD_ROUNDS_LIST") && atoi(c->opt("SWZ_MD_ROUNDS_LIST")) == 0);
+  std::string trace;
+  uint32_t* d_total = lb.counters + PRC_ALIVE;
+  for (;;) {
+    ++rounds;
+    hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+    hipLaunchKernelGGL(pr_winners_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+    hipLaunchKernelGGL(pr_mask_kernel, dim3(cblocks), dim3(256), 0, c->stream, a);
+    const uint32_t threads = use_list ? nlist : m;
+    if (threads) hipLaunchKernelGGL(pr_kill_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, use_list ? 1u : 0u, nlist);
+    SWZ_LAUNCH_CHECK(c);
+    // who is alive now: a count while they are many, a list (in order) once they are few
+    const bool make_list = lists && (use_list || alive < m / 4u);
+    if (make_list && !a.list[0]) {
+      SWZ_TRY(c->get("md_pr_list0", (size_t)alive + 64, &a.list[0]));
+      SWZ_TRY(c->get("md_pr_list1", (size_t)alive + 64, &a.list[1]));
+    }
+    if (use_list) SWZ_TRY(fused_scan(c, PrAliveOfListF{a.state, a.list[cur]}, PrListOfListG{a.list[cur], a.list[cur ^ 1u]}, nlist, d_total, "mdpr"));
+    else if (make_list) SWZ_TRY(fused_scan(c, PrAliveF{a.state}, PrListG{a.list[cur ^ 1u]}, m, d_total, "mdpr"));
+    else {
+      uint32_t* d_partial = nullptr;
+      SWZ_TRY(fused_scan_sums(c, PrAliveF{a.state}, m, d_total, "mdpr", &d_partial));
+    }
+    uint32_t now = 0;
+    SWZ_HIP(c, hipMemcpyAsync(&now, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (dbg && rounds <= 24) trace += " " + std::to_string(now);
+    if (now >= alive && rounds > 1)
+      return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE property rounds: a round without progress at level " + std::to_string(plan.level));
+    alive = now;
+    if (make_list) {
+      use_list = true;
+      nlist = now;
+    }
+    cur ^= 1u;
+    if (alive == 0) break;
+    if (rounds > 4096) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE property rounds did not terminate");
+  }
+  *used = true;
+  if (rounds_out) *rounds_out += rounds;
+  if (dbg) {
+    uint32_t hc[CTR_COUNT];
+    SWZ_HIP(c, hipMemcpy(hc, lb.counters, sizeof(hc), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[swz] MIN_DISTANCE property level %d in rounds: %u pts in %u nodes, %llu cells (cell levels %d, %.1f pts each), spacing %.1f key cells, "
+                    "%u rounds, %u exact compares, %.1f ms; alive after each round:%s\n",
+            plan.level, sample_points, sample_nodes, (unsigned long long)a.ncells, cl, (double)sample_points / (double)a.ncells, km.T, rounds, hc[PRC_BAND],
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count(), trace.c_str());
+  }
+  SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_DBG_HIST, 0, 8 * sizeof(uint32_t), c->stream));
+  return SWZ_OK;
+}
+
+}  // namespace swz
