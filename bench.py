@@ -142,7 +142,7 @@ def run_group_driver(args):
                     "-lswz_gpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     sampler = ["RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED"].index(args.sampler)
     cmd = [exe, str(shards), str(args.points), str(args.warmup + args.steps), str(devices), str(transport), str(args.batches),
-           str(sampler), "1" if args.strategy == "FAST" else "0"]
+           str(sampler), "1" if args.strategy == "FAST" else "0", str(args.warmup)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     sys.stderr.write(r.stderr)
     if r.returncode != 0:
@@ -154,6 +154,28 @@ def run_group_driver(args):
         sys.stderr.write("bench.py --driver group: expected %d timed steps, the driver reported %d\n" % (args.steps, len(timed)))
         return 1
     total_ms = sum(timed)
+    # shard 0's kernel classes over the timed steps (HIP events on its stream) -> the roofline object; every shard's
+    # critical-path stamps of the last step
+    prof = {}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("class "):
+            _, name, launches, ms_, nbytes = ln.split()
+            prof[name] = {"launches": int(launches), "total_ms": float(ms_), "algorithmic_bytes": int(nbytes)}
+    roofline = None
+    if prof:
+        name, k = max(prof.items(), key=lambda kv: kv[1]["total_ms"])
+        avg_ms = k["total_ms"] / max(k["launches"], 1)
+        achieved = k["algorithmic_bytes"] / max(k["launches"], 1) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": name, "shard": 0, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "launches": k["launches"], "avg_launch_ms": round(avg_ms, 4)}
+    last_rep = args.warmup + args.steps - 1
+    shard_rows = []
+    for ln in r.stdout.splitlines():
+        if ln.startswith("shard "):
+            f = ln.split()
+            if int(f[1]) == last_rep:
+                shard_rows.append({"shard": int(f[2]), "exchange_done_ms": float(f[3]), "root_begun_ms": float(f[4]),
+                                   "root_done_ms": float(f[5]), "levels_done_ms": float(f[6])})
     line = {
         "metric": "Mpoints/s end-to-end tile (Morton+sort+sample)", "value": round(shards * args.points * args.steps / total_ms / 1e3, 3),
         "unit": "Mpoints/s", "n_gpus": shards, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms / args.steps, 3),
@@ -165,7 +187,9 @@ def run_group_driver(args):
                        shards, devices, "add_batch" if args.batches > 1 else "tile", "RCCL send/recv" if transport else "peer copies")},
         "driver": "group", "timed_region": "wall clock of the whole call(s) inside the child process: encode, partition, exchange, "
                                            "sort, root, levels (inputs resident on the shards' devices)",
-        "steps_ms": [round(x, 3) for x in timed], "roofline": None, "cpu_baseline": None,
+        "steps_ms": [round(x, 3) for x in timed], "roofline": roofline,
+        "kernels_ms_per_step_shard0": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+        "shards": shard_rows, "cpu_baseline": None,
         "driver_output": r.stdout.splitlines()[-min(len(ms), 3):],
     }
     print(json.dumps(line))

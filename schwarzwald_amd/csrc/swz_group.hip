@@ -141,7 +141,7 @@ void group_barrier(void* p) { static_cast<swz_group*>(p)->barrier.wait(); }
 // Can the shards sweep the MIN_DISTANCE root together (swz_mdkeys.hip, MdShardRoot)?  The same answer on every shard: it
 // hangs on the bounds, the spacing and the options only.
 bool joint_root_possible(const swz_ctx* c, const swz_tile_params& p, const double bmin[3], const double bmax[3]) {
-  if (p.sampler != SWZ_MIN_DISTANCE || (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY)) return false;
+  if (p.sampler != SWZ_MIN_DISTANCE) return false;  // (with SWZ_FLAG_MIN_DISTANCE_PROPERTY too: the root is always sampled exactly)
   if (const char* e = c->opt("SWZ_GROUP_JOINT_ROOT"))
     if (atoi(e) == 0) return false;
   const swz::LevelPlan plan = swz::make_plan(-1, p.sampler, p.max_points_per_node, p.spacing_at_root, p.max_depth, bmin, bmax, true, true);
@@ -653,10 +653,6 @@ int swz_group_tiler_open(swz_group* g, const double bmin[3], const double bmax[3
   if (!g || !bmin || !bmax || !params) return SWZ_ERR_BAD_ARG;
   if (!g->tiler.empty()) {
     g->err = "swz_group_tiler_open: a data set is open already (swz_group_tiler_close)";
-    return SWZ_ERR_BAD_ARG;
-  }
-  if (params->flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) {
-    g->err = "sharded batches support exact MIN_DISTANCE only";
     return SWZ_ERR_BAD_ARG;
   }
   g->fast_start = -1;

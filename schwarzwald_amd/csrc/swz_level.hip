@@ -1362,6 +1362,9 @@ static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int fi
     LevelPlan plan = make_plan(level, t.params.sampler, t.params.max_points_per_node, t.params.spacing_at_root,
                                t.params.max_depth, t.bmin, t.bmax, false, true);
     plan.md_property = (t.params.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
+    // (the root of a sharded batch spans the shards: it is sampled exactly -- the lower shards' samples as ghosts, or all
+    // shards sweeping together -- which has the property a fortiori; the flag decides the levels below)
+    if (first_mode >= 0 && level == t.next_level) plan.md_property = false;
     if (first_mode >= 0 && level == t.next_level && !plan.terminal) {
       if (first_mode == 1) {
         plan.force_sample = true;
@@ -1634,7 +1637,6 @@ __global__ __launch_bounds__(256) void shard_strip_kernel(const uint64_t* __rest
 int shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
                          const swz_tile_params& p, uint32_t ghost_capacity) {
   if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
-  if (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
   if ((uint64_t)n + ghost_capacity > 0xFFFFFFFEull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "shard + ghosts exceed 2^32-2 points");
   ShardState* s = shard_state(c);
   s->open = false;
@@ -1700,7 +1702,6 @@ int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const 
                        const double bmax[3], const swz_tile_params& p, uint64_t global_points,
                        const double* d_ghost_xyz, uint32_t ghosts, uint64_t* num_root_taken) {
   if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
-  if (p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
   ShardState* s = shard_state(c);
   s->open = false;
   s->empty = false;

@@ -987,7 +987,7 @@ static int tiler_batch_run(swz_tiler* t, int last_level, const ShardRoot* sr) {
     if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
     LevelPlan plan = make_plan(level, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
                                t->bmin, t->bmax, false, true);
-    plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
+    plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0 && !shard_root;  // (a sharded root is sampled exactly)
     if (plan.reroot && !plan.terminal && t->p.sampler != SWZ_MIN_DISTANCE) {
       RrTotals tot;
       SWZ_TRY(tiler_reroot_level(t, w, plan, as, tot));
@@ -1249,8 +1249,6 @@ int swz_tiler_shard_begin_device(swz_tiler* t, double* d_xyz, uint64_t n, const 
   SWZ_HIP(c, hipSetDevice(c->device));
   SWZ_TRY(tiler_guard(t));
   if (!info) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL shard info");
-  if ((t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) && t->p.sampler == SWZ_MIN_DISTANCE)
-    return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support exact MIN_DISTANCE only");
   const bool fast = t->p.strategy == SWZ_FAST;
   if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: staged batches are pending");
   if ((n && !d_xyz) || (info->num_ghosts && !info->d_ghost_xyz)) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_begin_device: NULL buffer");

@@ -175,7 +175,7 @@ def _corner_cloud(n, seed, world):
     return xyz
 
 
-def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False, backend="gloo", joint=False):
+def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=False, backend="gloo", joint=False, flags=0):
     # the joint root is the default (after a collective probe of the IPC mappings); "0" keeps the chain of ghosts
     # (joint = None: the variable is left alone -- the default must sweep the root jointly after its probe)
     if joint is None:
@@ -190,7 +190,7 @@ def _tile_worker(rank, world, port, n, sampler, max_pts, spacing, q, corner=Fals
     torch.cuda.set_device(dev)
     _init(rank, world, port, backend)
     ctx = swz.Context(dev.index)
-    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing)
+    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing, flags=flags)
     xyz = torch.from_numpy(_corner_cloud(n, 300 + rank, world) if corner else _cloud(n, 300 + rank)).to(dev)
     tiler = sharded.ShardedTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
     assert tiler.joint_root == joint
@@ -265,6 +265,42 @@ def test_sharded_tile_matches_oracle(sampler, d, n, backend):
     a, b = canon(keys, level, pos), canon(ref["keys"], ref["level"], ref_xyz)
     assert np.array_equal(a, b)
     assert sum(got[r][4]["num_nodes"] for r in range(world)) - (world - 1) == ref["stats"]["num_nodes"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("joint", [False, True])
+def test_sharded_property_mode_keeps_spacing_and_maximality(joint):
+    """SWZ_FLAG_MIN_DISTANCE_PROPERTY on a sharded batch: the root, which spans the ranks, is sampled exactly (in turns or by
+    all ranks at once), the levels below in property mode.  The union must have the property on every sampled node: no two
+    taken points closer than the node's spacing, every point handed down closer than that to a taken one."""
+    from test_min_distance_property import _check_property
+    import schwarzwald_amd as swz
+    world, n, d, max_pts = 2, 150000, 250, 500
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], d)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, n, O.MIN_DISTANCE, max_pts, spacing, q, False, "gloo", joint,
+                                                    swz.FLAG_MIN_DISTANCE_PROPERTY)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=_QUEUE_TIMEOUT)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    keys = np.concatenate([got[r][1] for r in range(world)])
+    level = np.concatenate([got[r][3] for r in range(world)])
+    pos = np.vstack([got[r][0][got[r][2]] for r in range(world)])
+    assert np.all(keys[1:] >= keys[:-1])
+    a, b = _check_property(keys, level, pos, spacing, max_pts, int(level.max()))
+    assert a > 0 and b > 0
+    # the root is the exact one: what the single-process oracle takes there
+    union = np.vstack([_cloud(n, 300 + r) for r in range(world)])
+    ref = O.tile(union, [0, 0, 0], [1, 1, 1], O.MIN_DISTANCE, max_pts, spacing)
+    assert np.array_equal(np.sort(keys[level == -1]), np.sort(ref["keys"][ref["level"] == -1]))
 
 
 @pytest.mark.gpu

@@ -24,6 +24,7 @@ int main(int argc, char** argv) {
   const int batches = argc > 6 ? std::max(1, std::atoi(argv[6])) : 1;
   const int sampler = argc > 7 ? std::atoi(argv[7]) : (int)SWZ_MIN_DISTANCE;
   const int strategy = argc > 8 ? std::atoi(argv[8]) : (int)SWZ_ACCURATE;
+  const int warmup = argc > 9 ? std::atoi(argv[9]) : 0;  // reps before the kernel classes of shard 0 are timed (HIP events)
   const double mn[3] = {0, 0, 0}, mx[3] = {1, 1, 1};
   std::vector<int> dev(shards);
   for (int s = 0; s < shards; ++s) dev[s] = s % ndev;
@@ -47,6 +48,10 @@ int main(int argc, char** argv) {
   p.fast_concurrency = 8;
   std::vector<swz_group_result> res(shards);
   for (int rep = 0; rep < reps; ++rep) {
+    if (rep == warmup) {
+      swz_profile_enable(swz_group_ctx(g, 0), 1);
+      swz_profile_reset(swz_group_ctx(g, 0));
+    }
     for (int s = 0; s < shards; ++s)
       if (swz_generate_uniform_device(swz_group_ctx(g, s), 0x5C4A72A1Dull + 3, (uint64_t)s * per, per, d_xyz[s]) != SWZ_OK) return 3;
     const auto t0 = std::chrono::steady_clock::now();
@@ -85,6 +90,20 @@ int main(int argc, char** argv) {
       last_all = std::max(last_all, t[3]);
     }
     std::printf(" root phase %.1f ms, all done at %.1f ms\n", last_root - first_root, last_all);
+    // one line per shard for bench.py: ms since the call began -- exchange done, root begun, root done, levels done
+    for (int s = 0; s < shards; ++s) {
+      double t[4];
+      swz_group_shard_timing(g, s, t);
+      std::printf("shard %d %d %.3f %.3f %.3f %.3f\n", rep, s, t[0], t[1], t[2], t[3]);
+    }
+  }
+  {
+    // the kernel classes of shard 0 over the timed reps (its own stream's HIP events: what bench.py's roofline is made of)
+    swz_kernel_stat ks[64];
+    uint32_t nk = 0;
+    if (swz_profile_get(swz_group_ctx(g, 0), ks, 64, &nk) == SWZ_OK)
+      for (uint32_t i = 0; i < nk && i < 64; ++i)
+        std::printf("class %s %llu %.4f %llu\n", ks[i].name, (unsigned long long)ks[i].launches, ks[i].total_ms, (unsigned long long)ks[i].algorithmic_bytes);
   }
   swz_group_destroy(g);
   return 0;
