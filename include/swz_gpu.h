@@ -403,6 +403,10 @@ int swz_tiler_get_info(swz_tiler* tiler, swz_tiler_info* info);
  * SWZ_ERR_HIP as before).  Replaces nothing in the reference, whose node files live on disk between batches
  * (core/tiling/TilingAlgorithms.cpp:50-109); this is what bounds the size of a data set per GPU here. */
 int swz_tiler_pool_residency(swz_tiler* tiler, uint64_t* device_bytes_out, uint64_t* host_bytes_out);
+/* The same for the node store (the files' {key, point id} entries, two sides per octree level): a side that finds no device
+ * memory, or would push the workspace over SWZ_TILER_DEVICE_BUDGET_MB, is placed in mapped pinned host memory like a pool
+ * and the merges stream through it over the host link. */
+int swz_tiler_store_residency(swz_tiler* tiler, uint64_t* device_bytes_out, uint64_t* host_bytes_out);
 int swz_tiler_export_device(swz_tiler* tiler, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out);
 int swz_tiler_node_table(swz_tiler* tiler, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
                          uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out);

@@ -346,6 +346,7 @@ def load_library():
     L.swz_tiler_level_count.argtypes = [vp, C.c_int, _u64p]
     L.swz_tiler_poison.argtypes = [vp, C.c_char_p]
     L.swz_tiler_pool_residency.argtypes = [vp, _u64p, _u64p]
+    L.swz_tiler_store_residency.argtypes = [vp, _u64p, _u64p]
     L.swz_shard_joint_root_possible.argtypes = [vp, C.POINTER(_TileParams), _dp, _dp]
     L.swz_shard_joint_root_begin.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
     L.swz_shard_joint_root_probe.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp, C.POINTER(C.c_int)]
@@ -375,7 +376,7 @@ def load_library():
                  "swz_tiler_finalize", "swz_tiler_get_info", "swz_tiler_export_device", "swz_tiler_node_table",
                  "swz_tiler_pools_device", "swz_host_alloc_pinned", "swz_host_free_pinned",
                  "swz_tiler_shard_begin_device", "swz_tiler_shard_finish", "swz_tiler_level_count",
-                 "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency",
+                 "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency", "swz_tiler_store_residency",
                  "swz_tiler_shard_fast_histogram", "swz_fast_start_level_from_counts", "swz_tiler_shard_set_start_level",
                  "swz_tiler_shard_fast_finalize_local", "swz_tiler_shard_fast_set_root", "swz_shard_joint_root_possible",
                  "swz_shard_joint_root_begin", "swz_shard_joint_root_probe", "swz_shard_joint_root_meet", "swz_shard_joint_root_end"):
@@ -716,6 +717,12 @@ class Tiler:
         """(bytes of the pools in device memory, bytes spilled to mapped page-locked host memory)"""
         dev, host = C.c_uint64(), C.c_uint64()
         self._ctx._check(self._lib.swz_tiler_pool_residency(self._t, C.byref(dev), C.byref(host)))
+        return int(dev.value), int(host.value)
+
+    def store_residency(self):
+        """(bytes of the node store in device memory, bytes placed in mapped page-locked host memory)"""
+        dev, host = C.c_uint64(), C.c_uint64()
+        self._ctx._check(self._lib.swz_tiler_store_residency(self._t, C.byref(dev), C.byref(host)))
         return int(dev.value), int(host.value)
 
     def close(self):

@@ -32,7 +32,6 @@
 namespace swz {
 
 constexpr uint32_t PR_NONE = 0xFFFFFFFFu;
-constexpr int PR_WL = 8;  // winners around a cell kept side by side (more than that: the cell's points look them up by direction)
 enum : uint8_t { PR_ALIVE = 0, PR_DEAD = 1 };
 enum { PRC_ALIVE = CTR_DBG_HIST, PRC_LIST = CTR_DBG_HIST + 1, PRC_BAND = CTR_DBG_HIST + 2, PRC_WON = CTR_DBG_HIST + 3 };
 
@@ -52,8 +51,7 @@ struct PrArgs {
   uint64_t* candq;       // [cell] the candidate's key coordinates x | y << 21 | z << 42, bit 63 set (0: none)
   uint64_t* wonq;        // [cell] this round's winner (same packing), 0: none
   uint32_t* woni;        // [cell] ... its active index
-  uint32_t* wmask;       // [cell] bit k: the adjacent cell in direction k holds a winner of this round; bits 28-31: how many (15: 15 or more)
-  unsigned long long* wl; // [cell][PR_WL] those winners' coordinates, when there are at most PR_WL
+  uint32_t* wmask;       // [cell] bit k: the adjacent cell in direction k holds a winner of this round
   uint32_t* list[2];     // alive points (compacted once few are left)
   uint64_t ncells;       // sampled nodes x cells per node
   uint32_t cell_shift;
@@ -186,24 +184,18 @@ __global__ __launch_bounds__(256) void pr_winners_kernel(PrArgs a, uint32_t cur)
 __global__ __launch_bounds__(256) void pr_mask_kernel(PrArgs a) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= a.ncells) return;
-  uint32_t mask = 0, cnt = 0;
+  uint32_t mask = 0;
   if (a.candq[c]) {  // (a cell without a candidate has no alive point: nobody reads its mask)
     const uint64_t base = c & ~(a.cells_per_node - 1ull);
     const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
-    unsigned long long* wl = a.wl + c * PR_WL;
 #pragma unroll
     for (int k = 0; k < 27; ++k) {
       const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
       if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE) continue;
-      const unsigned long long q = a.wonq[base + (X | Y | Z)];
-      if (q) {
-        mask |= 1u << k;
-        if (cnt < (uint32_t)PR_WL) wl[cnt] = q;  // the winners around this cell side by side: what its points read in (3)
-        ++cnt;
-      }
+      if (a.wonq[base + (X | Y | Z)]) mask |= 1u << k;
     }
   }
-  a.wmask[c] = mask | (min(cnt, 15u) << 28);
+  a.wmask[c] = mask;
 }
 
 // (3) alive points closer than the spacing to a winner around them die; the first survivor of every cell is the next
@@ -232,28 +224,10 @@ __global__ __launch_bounds__(256) void pr_kill_kernel(PrArgs a, uint32_t cur, ui
     }
     bool dead = false;
     uint32_t nband = 0;
-    const uint32_t wm = a.wmask[cell];
-    const uint32_t wcnt = wm >> 28;
-    uint32_t mask = wm & 0x7FFFFFFu;
-    if (wcnt <= (uint32_t)PR_WL) {
-      // the usual case: the winners around the cell lie side by side (the cell's points read the same 64 bytes)
-      mask = 0;
-      const unsigned long long* wl = a.wl + cell * PR_WL;
-      for (uint32_t j = 0; j < wcnt && !dead; ++j) {
-        const unsigned long long q = wl[j];
-        float qx, qy, qz;
-        pr_unpack(q, qx, qy, qz);
-        const float d2 = pr_d2(x, y, z, qx, qy, qz);
-        if (d2 < a.f_lo) dead = true;
-        else if (d2 < a.f_hi) {  // inside the band: which cell was that winner's?  (rare: its index is looked up there)
-          ++nband;
-          const uint32_t cb = a.cell_shift / 3u;
-          const uint32_t ux = (uint32_t)qx >> cb, uy = (uint32_t)qy >> cb, uz = (uint32_t)qz >> cb;
-          const uint64_t code = ((expand_bits_by_3(ux) << 2) | (expand_bits_by_3(uy) << 1) | expand_bits_by_3(uz)) & (a.cells_per_node - 1ull);
-          dead = pr_exact_near(a, i, a.woni[base + code]);
-        }
-      }
-    }
+    // (Measured and dropped: the winners around a cell copied side by side into a per-cell list of 8 or 16 entries, four
+    // points per thread with the cell's list unpacked once per run, branch-free tests of all entries: every variant cost
+    // more than this loop -- the pass is bound by its ~300 vector instructions per point, not by the lookups.)
+    uint32_t mask = a.wmask[cell];
     while (mask && !dead) {
       const uint32_t k = (uint32_t)__ffs((int)mask) - 1u;
       mask &= mask - 1u;
@@ -375,7 +349,6 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_TRY(c->get("md_pr_wonq", (size_t)a.ncells, &a.wonq));
   SWZ_TRY(c->get("md_pr_woni", (size_t)a.ncells, &a.woni));
   SWZ_TRY(c->get("md_pr_wmask", (size_t)a.ncells, &a.wmask));
-  SWZ_TRY(c->get("md_pr_wl", (size_t)a.ncells * PR_WL, &a.wl));
   SWZ_HIP(c, memset_large(a.cand[0], 0xFF, (size_t)a.ncells * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_DBG_HIST, 0, 8 * sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(pr_init_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, a);

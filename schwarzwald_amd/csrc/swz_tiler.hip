@@ -386,13 +386,23 @@ static Box root_box(const swz_tiler* t) { return Box{t->bmin[0], t->bmin[1], t->
 // The node store and the pools live in the context's grow-only workspace under fixed names, so a tiler created after
 // another one on the same context reuses the memory (hipMalloc / hipFree of multi-GB blocks were measured to stall for
 // seconds now and then).  One tiler per context at a time.
+static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t keep, void** out, bool spill);
 static int store_reserve(swz_ctx* c, StoreLevel& s, int level_index, int which, size_t count) {
   if (s.cap[which] >= count && s.key[which]) return SWZ_OK;
   const size_t want = count + count / 4 + 1024;
   const std::string kn = "tiler_store_key_" + std::to_string(level_index) + "_" + std::to_string(which);
   const std::string gn = "tiler_store_gid_" + std::to_string(level_index) + "_" + std::to_string(which);
-  SWZ_TRY(c->get(kn.c_str(), want, &s.key[which]));  // the side being written holds nothing that is still needed
-  SWZ_TRY(c->get(gn.c_str(), want, &s.gid[which]));
+  // (the side being written holds nothing that is still needed: nothing is kept.  Like the pools, a store side that finds
+  // no device memory -- or would push the workspace over SWZ_TILER_DEVICE_BUDGET_MB -- is placed in mapped pinned host
+  // memory: the merges then stream through it over the host link, slowly, but a data set whose node store outgrows the
+  // device still tiles.  The growth policy of the workspace (twice the old capacity) applies here as well.)
+  const size_t old_k = c->bufs[kn].cap / sizeof(uint64_t);
+  const size_t grown = std::max(want, std::min<size_t>(2 * old_k, want + (size_t(1) << 27)));
+  void *pk = nullptr, *pg = nullptr;
+  SWZ_TRY(grow_preserving(c, kn.c_str(), grown * sizeof(uint64_t), 0, &pk, true));
+  SWZ_TRY(grow_preserving(c, gn.c_str(), grown * sizeof(uint32_t), 0, &pg, true));
+  s.key[which] = static_cast<uint64_t*>(pk);
+  s.gid[which] = static_cast<uint32_t*>(pg);
   s.cap[which] = std::min(c->bufs[kn].cap / sizeof(uint64_t), c->bufs[gn].cap / sizeof(uint32_t));
   return SWZ_OK;
 }
@@ -413,7 +423,7 @@ static void store_free(StoreLevel& s) {
 // (clamp + index), the cached points a batch pulls in by id (re-key), MIN_DISTANCE's rare exact compares; the
 // attribute columns not at all until the files are exported.  The kernels read and write them in place over the host
 // link.  SWZ_TILER_SPILL: "auto" (default), "host" (pools on the host from the start), "off".
-static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t keep, void** out, bool spill = false) {
+static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t keep, void** out, bool spill) {
   swz::DevBuf& b = c->bufs[name];
   if (b.cap < bytes) {
     void* np = nullptr;
@@ -1537,6 +1547,16 @@ int swz_tiler_pool_residency(swz_tiler* t, uint64_t* device_bytes_out, uint64_t*
   add("tiler_pool_xyz");
   for (int a = 0; a < SWZ_ATTR_COUNT; ++a)
     if (t->attr_mask & (1u << a)) add("tiler_pool_attr" + std::to_string(a));
+  if (device_bytes_out) *device_bytes_out = dev;
+  if (host_bytes_out) *host_bytes_out = host;
+  return SWZ_OK;
+}
+
+int swz_tiler_store_residency(swz_tiler* t, uint64_t* device_bytes_out, uint64_t* host_bytes_out) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  uint64_t dev = 0, host = 0;
+  for (const auto& kv : t->c->bufs)
+    if (kv.first.compare(0, 11, "tiler_store") == 0) (kv.second.host ? host : dev) += kv.second.cap;
   if (device_bytes_out) *device_bytes_out = dev;
   if (host_bytes_out) *host_bytes_out = host;
   return SWZ_OK;

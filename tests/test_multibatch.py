@@ -401,6 +401,11 @@ def test_gpu_tiler_spills_its_pools_to_pinned_host_memory(mode):
                 assert host_b >= n * 24, (dev_b, host_b)
                 if mode == "host":
                     assert dev_b == 0
+                # the node store follows the same rule: with a budget it never fits into, its sides live on the host too
+                # (the merges stream through them over the host link); "host" leaves nothing of the tiler on the device
+                sdev_b, shost_b = t.store_residency()
+                if mode in ("host", "budget"):
+                    assert shost_b > 0 and (sdev_b == 0 or mode == "budget"), (sdev_b, shost_b)
                 info, table = t.info(), t.node_table()
                 ns = int(info["num_stored"])
                 d_keys = torch.empty(ns, dtype=torch.int64, device="cuda")
