@@ -446,6 +446,27 @@ void shard_thread(ShardCall a) {
     uint64_t have = 0;
     if (!sequential_root) {
       if (ok) tiler_try(swz_tiler_shard_begin_device(t, recv, m, &recv_attr, &info, &have));
+    } else if (N > 1 && g->peer_access && joint_root_possible(c, g->tparams, g->tbmin, g->tbmax)) {
+      // All shards sweep the root level of their tilers -- the batch's points merged with the shard's part of the root's
+      // file -- at the same time; a cell at the face of a lower octant reads that shard's records through peer access, exact
+      // positions through its working index (MdPeerView::aidx).  No ghosts, no turns: like swz_group_tile.
+      swz::MdShardRoot sr;
+      sr.shard = r;
+      sr.shards = N;
+      sr.views = g->views.data();
+      sr.barrier = group_barrier;
+      sr.barrier_arg = g;
+      g->views[r] = swz::MdPeerView{};
+      c->md_shard_root = &sr;
+      c->md_shard_root_published = true;
+      if (ok) tiler_try(swz_tiler_shard_begin_device(t, recv, m, &recv_attr, &info, &have));
+      c->md_shard_root = nullptr;
+      if (!g->views[r].entered) {  // nothing to sample here, or the call failed before its sweep met the others: meet them for it
+        g->views[r].ncells = 0;
+        g->views[r].status = ok ? SWZ_OK : SWZ_ERR_INTERNAL;
+        g->views[r].entered = 1;
+        g->barrier.wait();
+      }
     } else {
       {
         std::unique_lock<std::mutex> lk(g->turn_m);
@@ -928,9 +949,9 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
 }  // extern "C"
 namespace {
 struct JointBlob {
-  hipIpcMemHandle_t handle[8];
-  uint64_t offset[8];
-  uint8_t has[8];
+  hipIpcMemHandle_t handle[9];
+  uint64_t offset[9];
+  uint8_t has[9];
   uint32_t ncells, rg, cell_shift, npoints;
   int32_t status, entered;
 };
@@ -967,14 +988,14 @@ void joint_exchange(void* arg) {
   const int N = js->sr.shards, r = js->sr.shard;
   swz::MdPeerView& mine = js->views[r];
   JointBlob blob{};
-  const void* ptrs[8] = {mine.rec, mine.qpos, mine.state, mine.ovf, mine.gridmap, mine.round_word, mine.perm, mine.xyz};
+  const void* ptrs[9] = {mine.rec, mine.qpos, mine.state, mine.ovf, mine.gridmap, mine.round_word, mine.perm, mine.xyz, mine.aidx};
   blob.ncells = mine.ncells;
   blob.npoints = mine.npoints;
   blob.rg = mine.rg;
   blob.cell_shift = mine.cell_shift;
   blob.status = mine.status;
   blob.entered = 1;
-  for (int k = 0; k < 8 && mine.ncells; ++k) {
+  for (int k = 0; k < 9 && mine.ncells; ++k) {
     if (!ptrs[k]) continue;
     void* base = nullptr;
     size_t size = 0;
@@ -1011,8 +1032,8 @@ void joint_exchange(void* arg) {
     v.status = all[p].status;
     v.entered = all[p].entered;
     if (p < r && v.ncells && v.status == SWZ_OK) {  // only the lower ranks' arrays are read
-      const void* got[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-      for (int k = 0; k < 8; ++k) {
+      const void* got[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      for (int k = 0; k < 9; ++k) {
         if (!all[p].has[k]) continue;
         char* base = static_cast<char*>(joint_open(js, all[p].handle[k]));
         if (!base) {
@@ -1029,6 +1050,7 @@ void joint_exchange(void* arg) {
       v.round_word = static_cast<const uint32_t*>(got[5]);
       v.perm = static_cast<const uint32_t*>(got[6]);
       v.xyz = static_cast<const double*>(got[7]);
+      v.aidx = static_cast<const uint32_t*>(got[8]);
     }
     js->views[p] = v;
   }

@@ -138,8 +138,10 @@ struct MdPeerView {
   const float4* ovf = nullptr;
   const uint32_t* gridmap = nullptr; // [cell code of the root node] -> cell
   const uint32_t* round_word = nullptr;  // the round its sweep is in: records stamped with an earlier round are complete
-  const uint32_t* perm = nullptr;    // exact positions of its points: xyz[3 * perm[i]]
+  const uint32_t* perm = nullptr;    // exact positions of its points: xyz[3 * perm[aidx ? aidx[i] : i]]
   const double* xyz = nullptr;
+  const uint32_t* aidx = nullptr;    // null: the active points are the sorted points (the root of a single batch); a tiler's root
+                                     // level -- batch + cached root file, merged -- has an index into its working arrays
   uint32_t ncells = 0, rg = 0, cell_shift = 0;
   uint32_t npoints = 0;              // points of its root level (the readers size their round limit by the lower shards' work too)
   int status = 0;                    // SWZ_OK, or why this shard cannot take part

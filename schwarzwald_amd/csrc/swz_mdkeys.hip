@@ -127,6 +127,7 @@ struct MqPeers {
   const uint32_t* round_word[8];
   const uint32_t* perm[8];
   const double* xyz[8];
+  const uint32_t* aidx[8];
   uint32_t shard, shards;
 };
 
@@ -267,7 +268,7 @@ __device__ __forceinline__ uint32_t mq_ld_sys(const uint32_t* p) { return __hip_
 // ... for a local point i and an accepted point j of shard `tag - 1` (0: this shard)
 __device__ __forceinline__ bool mq_exact_near_peer(const MqArgs& a, uint32_t i, uint32_t j, uint32_t tag) {
   const double* p = sorted_point_xyz(a.xyz, a.perm, a.gxyz, a.ng, a.aidx ? a.aidx[i] : i);
-  const double* q = tag ? a.peers.xyz[tag - 1u] + (size_t)a.peers.perm[tag - 1u][j] * 3
+  const double* q = tag ? a.peers.xyz[tag - 1u] + (size_t)a.peers.perm[tag - 1u][a.peers.aidx[tag - 1u] ? a.peers.aidx[tag - 1u][j] : j] * 3
                         : sorted_point_xyz(a.xyz, a.perm, a.gxyz, a.ng, a.aidx ? a.aidx[j] : j);
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
@@ -1366,7 +1367,16 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     // publish this shard's root level, meet the others, take the lower shards' views
     MdPeerView& mine = shard_root->views[shard_root->shard];
     int my_status = SWZ_OK;
-    if (cl < 1 || ncells >= (1u << MQ_PEER_SHIFT) || sample_nodes != 1 || as.aidx) my_status = SWZ_ERR_INTERNAL;
+    if (cl < 1 || ncells >= (1u << MQ_PEER_SHIFT) || sample_nodes != 1) my_status = SWZ_ERR_INTERNAL;
+    // (a tiler's root level -- the batch merged with the cached root file -- indexes its working arrays through aidx, a
+    // buffer the next level reuses while higher shards may still look up exact positions here: a copy that stays)
+    const uint32_t* aidx_sr = nullptr;
+    if (as.aidx) {
+      uint32_t* cp = nullptr;
+      SWZ_TRY(c->get("md_qaidx_sr", (size_t)m, &cp));
+      SWZ_HIP(c, hipMemcpyAsync(cp, as.aidx, (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
+      aidx_sr = cp;
+    }
     SWZ_TRY(c->get("md_qround_sr", (size_t)32, &a.round_word));
     hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, c->stream, a.round_word, MQ_FIRST_ROUND);
     SWZ_LAUNCH_CHECK(c);
@@ -1379,6 +1389,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     mine.round_word = a.round_word;
     mine.perm = a.perm;
     mine.xyz = a.xyz;
+    mine.aidx = aidx_sr;
     mine.ncells = ncells;
     mine.npoints = m;
     mine.rg = a.rg;
@@ -1401,6 +1412,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
         a.peers.round_word[p] = v.round_word;
         a.peers.perm[p] = v.perm;
         a.peers.xyz[p] = v.xyz;
+        a.peers.aidx[p] = v.aidx;
       }
     }
   }

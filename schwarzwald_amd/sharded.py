@@ -156,6 +156,72 @@ def _trace(dev, what, t0):
     return time.perf_counter()
 
 
+def _all_gather_bytes(mine, group, device, world):
+    """every rank's bytes in rank order (equal lengths); the collective behind swz_shard_joint_root_begin / _probe"""
+    on_gpu = dist.get_backend(group) == "nccl"
+    n = torch.tensor([len(mine)], dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+    size = int(n.item())
+    t = torch.zeros(max(size, 1), dtype=torch.uint8)
+    if mine:
+        t[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+    if on_gpu:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return [bytes(o.cpu().numpy().tobytes()[:size]) for o in out]
+
+
+def _joint_root_usable(ctx, rank, world, gather):
+    """The collective probe before the first joint root: can every rank map the lower ranks' device memory?"""
+    try:
+        usable = ctx.shard_joint_root_probe(rank, world, gather)
+    except api.SwzError:
+        usable = False  # (the probe's own collectives ran on every rank: all of them land here together or not at all)
+    if os.environ.get("SWZ_DEBUG"):
+        sys.stderr.write("[swz sharded] rank %d: device memory of the other ranks %s be mapped: MIN_DISTANCE root %s\n" % (
+            rank, "can" if usable else "cannot", "swept by all ranks at once" if usable else "in turns"))
+    return usable
+
+
+def _joint_root_step(ctx, rank, world, group, gather, begin, failure):
+    """The MIN_DISTANCE root of a sharded batch swept by all ranks at once (include/swz_gpu.h, swz_shard_joint_root_*):
+    begin() is the library call that samples this rank's root (swz_shard_begin_device / swz_tiler_shard_begin_device,
+    without ghosts); a rank whose call never reached the sweep -- no points, or an error -- meets the others here."""
+    entered = False
+    if not failure:
+        try:
+            ctx.shard_joint_root_begin(rank, world, gather)
+            entered = True
+        except api.SwzError as e:
+            failure.append(e)
+    result = None
+    if entered:
+        if not failure:
+            try:
+                result = begin()
+            except api.SwzError as e:
+                failure.append(e)
+        try:  # (a rank without points, or one that failed before its sweep met the others, meets them here)
+            ctx.shard_joint_root_meet(ok=not failure)
+        except api.SwzError as e:
+            failure.append(e)
+    else:  # the two exchanges of a batch are collectives: take part (an all-zero blob reads as a shard without points)
+        gather(b"")
+        gather(b"")
+    dist.barrier(group=group)  # the others may read this rank's root arrays until they are done
+    # (the mappings are closed one rank at a time: processes that unmap the same allocation at the same moment were seen to
+    # abort inside the runtime -- see swz_shard_joint_root_probe)
+    for r in range(world):
+        if r == rank:
+            try:
+                ctx.shard_joint_root_end()
+            except api.SwzError as e:
+                failure.append(e)
+        dist.barrier(group=group)
+    return result
+
+
 class ShardedTiler:
     """Tiles one batch whose points are spread over the ranks of a process group."""
 
@@ -192,19 +258,7 @@ class ShardedTiler:
         return tensor
 
     def _all_gather_bytes(self, mine):
-        """every rank's bytes in rank order (equal lengths); the collective behind swz_shard_joint_root_begin"""
-        on_gpu = dist.get_backend(self.group) == "nccl"
-        n = torch.tensor([len(mine)], dtype=torch.int64, device=self.device if on_gpu else "cpu")
-        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=self.group)
-        size = int(n.item())
-        t = torch.zeros(max(size, 1), dtype=torch.uint8)
-        if mine:
-            t[:len(mine)] = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
-        if on_gpu:
-            t = t.to(self.device)
-        out = [torch.empty_like(t) for _ in range(self.world)]
-        dist.all_gather(out, t, group=self.group)
-        return [bytes(o.cpu().numpy().tobytes()[:size]) for o in out]
+        return _all_gather_bytes(mine, self.group, self.device, self.world)
 
     def tile(self, xyz):
         """xyz: [n, 3] float64 tensor on this rank's GPU (any points of the batch).  Returns the tile stats of this
@@ -282,13 +336,7 @@ class ShardedTiler:
                     ctx.shard_joint_root_possible(self.bmin, self.bmax, self.params))
         joint = possible
         if joint and self._joint_usable is None:
-            try:
-                self._joint_usable = ctx.shard_joint_root_probe(self.rank, world, self._all_gather_bytes)
-            except api.SwzError:
-                self._joint_usable = False  # (the probe's own collectives ran on every rank: all of them land here together or not at all)
-            if os.environ.get("SWZ_DEBUG"):
-                sys.stderr.write("[swz sharded] rank %d: device memory of the other ranks %s be mapped: MIN_DISTANCE root %s\n" % (
-                    self.rank, "can" if self._joint_usable else "cannot", "swept by all ranks at once" if self._joint_usable else "in turns"))
+            self._joint_usable = _joint_root_usable(ctx, self.rank, world, self._all_gather_bytes)
         joint = bool(joint and self._joint_usable)
         self.used_joint_root = joint
         self.root_mode = "local" if not sequential_root else ("joint" if joint else ("chain (no IPC mapping)" if possible else "chain"))
@@ -297,27 +345,8 @@ class ShardedTiler:
         elif joint:
             # All ranks sweep the root cells of their own octants at once; cells at the face of a lower octant read that
             # rank's records in place through IPC mappings (include/swz_gpu.h, swz_shard_joint_root_*): no ghosts, no turns.
-            entered = guarded(lambda: ctx.shard_joint_root_begin(self.rank, world, self._all_gather_bytes) or True, False)
-            if entered:  # (m == 0 is an ordinary shard: nothing to sweep, it meets the others below)
-                guarded(lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points), 0)
-            if entered:
-                try:  # (a rank without points, or one that failed before its sweep met the others, meets them here)
-                    ctx.shard_joint_root_meet(ok=not failure)
-                except api.SwzError as e:
-                    failure.append(e)
-            else:  # the two exchanges of a batch are collectives: take part (an all-zero blob reads as a shard without points)
-                self._all_gather_bytes(b"")
-                self._all_gather_bytes(b"")
-            dist.barrier(group=self.group)  # the others may read this rank's root arrays until they are done
-            # (the mappings are closed one rank at a time: processes that unmap the same allocation at the same moment were
-            # seen to abort inside the runtime -- see swz_shard_joint_root_probe)
-            for r in range(world):
-                if r == self.rank:
-                    try:
-                        ctx.shard_joint_root_end()
-                    except api.SwzError as e:
-                        failure.append(e)
-                dist.barrier(group=self.group)
+            _joint_root_step(ctx, self.rank, world, self.group, self._all_gather_bytes,
+                             lambda: ctx.shard_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params, global_points), failure)
         else:
             if m > 0:
                 # everything that does not depend on the ghosts happens on all ranks at once; only the root
@@ -399,6 +428,10 @@ class ShardedBatchTiler:
         self.tiler = api.Tiler(ctx, bmin, bmax, params, capacity_hint)
         self._keep = None
         self.fast_start = -1  # FAST: the start level, known after the first batch
+        # the MIN_DISTANCE root of every batch swept by all ranks at once (like ShardedTiler): on by default, after a probe
+        self.joint_root = os.environ.get("SWZ_SHARD_JOINT_ROOT", "1") not in ("", "0")
+        self._joint_usable = None
+        self.root_mode = "local"
 
     def close(self):
         self.tiler.close()
@@ -459,8 +492,19 @@ class ShardedBatchTiler:
                 failure.append(e)
                 return default
 
+        gather = lambda mine: _all_gather_bytes(mine, self.group, dev, world)
+        possible = (sequential_root and world > 1 and self.joint_root and dev.type == "cuda" and
+                    ctx.shard_joint_root_possible(self.bmin, self.bmax, self.params))
+        if possible and self._joint_usable is None:
+            self._joint_usable = _joint_root_usable(ctx, self.rank, world, gather)
+        joint = bool(possible and self._joint_usable)
+        self.root_mode = "local" if not sequential_root else ("joint" if joint else ("chain (no IPC mapping)" if possible else "chain"))
         if not sequential_root:
             guarded(lambda: self.tiler.shard_begin_device(recv.data_ptr(), m, ptrs, global_new, root_stored), 0)
+        elif joint:
+            # the batch's points merged with this rank's part of the root's file, swept together with the other ranks' parts
+            _joint_root_step(ctx, self.rank, world, self.group, gather,
+                             lambda: self.tiler.shard_begin_device(recv.data_ptr(), m, ptrs, global_new, root_stored), failure)
         else:
             ghosts = []
             for r in range(world):
@@ -496,6 +540,7 @@ class ShardedBatchTiler:
             raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
         self._keep = (recv, cols)
         stats["shard_points"] = m
+        stats["root_mode"] = self.root_mode
         return stats
 
     # -- FAST (TilingAlgorithmV3, the reference's default): no root step per batch.  The start level comes from the FIRST
@@ -543,6 +588,7 @@ class ShardedBatchTiler:
         self._vote(failure)
         self._keep = (recv, cols)
         stats["shard_points"] = m
+        stats["root_mode"] = self.root_mode
         return stats
 
     def finalize(self):

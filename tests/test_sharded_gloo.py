@@ -350,7 +350,12 @@ def _mb_cloud(n, batch, rank, corner_world=0):
     return xyz
 
 
-def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, strategy=0, concurrency=8):
+def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, strategy=0, concurrency=8, root="default"):
+    # the MIN_DISTANCE root of every batch: swept by all ranks at once (the default, after the IPC probe) or in turns
+    if root == "chain":
+        os.environ["SWZ_SHARD_JOINT_ROOT"] = "0"
+    else:
+        os.environ.pop("SWZ_SHARD_JOINT_ROOT", None)
     _init(rank, world, port)
     import schwarzwald_amd as swz
     from schwarzwald_amd import sharded
@@ -364,7 +369,9 @@ def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, st
         xyz = torch.from_numpy(_mb_cloud(n, b, rank, world if corner else 0)).to(dev)
         ids = torch.arange(n, dtype=torch.int64) + (b * world * n + rank * n)     # id in the single-process batch order
         attrs = {"intensity": (ids & 0xFFFF).to(torch.int16).to(dev), "point_source_id": (ids >> 16).to(torch.int16).to(dev)}
-        st.add_batch(xyz, attrs)
+        bstats = st.add_batch(xyz, attrs)
+        if sampler == swz.MIN_DISTANCE and strategy == 0 and bstats["root_mode"] != "local":
+            assert bstats["root_mode"] == ("chain" if root == "chain" else "joint"), bstats["root_mode"]
     st.finalize()
     info = st.tiler.info()
     table = st.tiler.node_table()
@@ -384,18 +391,20 @@ def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, st
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED, "MIN_DISTANCE+chain"])
 @pytest.mark.parametrize("corner", [False, True])
 def test_sharded_multibatch_matches_the_multibatch_oracle(sampler, corner):
     """Two ranks (sharing cuda:0, collectives over gloo), three batches each: the union of the shards' node files must
     be the single-process multi-batch oracle's, file by file and in file order; the root's file is the concatenation of
     the shards' parts in rank order.  corner: rank 1 never owns a point."""
+    root = "chain" if sampler == "MIN_DISTANCE+chain" else "default"   # (MIN_DISTANCE alone: every batch's root swept jointly)
+    sampler = O.MIN_DISTANCE if root == "chain" else sampler
     world, n, k, max_pts = 2, 20000, 3, 400
     spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     port = _free_port()
-    procs = [mpctx.Process(target=_mb_worker, args=(r, world, port, n, k, sampler, max_pts, spacing, q, corner)) for r in range(world)]
+    procs = [mpctx.Process(target=_mb_worker, args=(r, world, port, n, k, sampler, max_pts, spacing, q, corner, 0, 8, root)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
