@@ -574,9 +574,16 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
     bool used = false;
     SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, sample_nodes, sample_points, occupied, phases_out, &used));
     if (used) return SWZ_OK;
-    // it may have given up half way (locally dense data): its decisions are those of ANOTHER priority order
-    hipLaunchKernelGGL(pm_clear_taken_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, lb.nid, lb.nmode, m, lb.taken);
-    SWZ_LAUNCH_CHECK(c);
+    // it may have given up half way (locally dense data): its decisions are those of ANOTHER priority order.  (A level it
+    // declined at the door -- two or more points per occupied cell, the same test as in swz_mdsparse.hip -- is untouched.)
+    int scl = plan.cell_levels_geo;
+    while (scl > 0 && (double)sample_nodes * std::pow(8.0, scl) > 2147483648.0) --scl;
+    double limit = 2.0;
+    if (const char* e = c->opt("SWZ_MD_SPARSE_LIMIT")) limit = atof(e);
+    if ((double)sample_points / (double)std::max(1u, occupied[scl]) < limit) {
+      hipLaunchKernelGGL(pm_clear_taken_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, lb.nid, lb.nmode, m, lb.taken);
+      SWZ_LAUNCH_CHECK(c);
+    }
   }
   if (key_metric(c, plan, sp).ok) {
     // On key coordinates (cubic bounds, as the Tiler's are): a maximal independent set grown in data-parallel rounds, no
