@@ -239,7 +239,7 @@ def measured_traffic(kernel_class, n, sampler):
     command, corrected as MI355X_MICROARCH.md prescribes) -- only when that profile was taken on the kernel sources this
     run uses (traffic.json carries their hash).  Returns (bytes or None, where the number comes from / why there is none)."""
     sha = library_source_sha16()
-    for rnd in ("r03", "r02", "r01"):  # the newest committed profile of this configuration
+    for rnd in ("r04", "r03", "r02", "r01"):  # the newest committed profile of this configuration
         path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         try:
             t = json.load(open(path))

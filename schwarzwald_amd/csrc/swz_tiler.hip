@@ -8,11 +8,12 @@
 // with the taken points (BinaryPersistence.h:46-57) and hands the rest -- new and displaced old points alike -- to
 // the children.  Nodes no point of the batch reaches are not touched.
 //
-// Here the "files" are a device-resident node store: per octree level one array of (key, point id) ordered by node
-// prefix and, inside a node, in file order; positions (and attribute columns) of all points ever added live in pools
-// indexed by point id (= running index over all batches).  A batch runs the same level-synchronous loop as a single
-// batch (swz_level.hip); per level the store entries of the nodes the active set touches are pulled out, re-keyed,
-// merged in, and the level's taken points are merged back into the store.  FAST (TilingAlgorithmV3) later iterations
+// Here the "files" are a device-resident node store: per octree level the (key, point id) entries of its nodes' files,
+// each file contiguous and in file order, found through a node table (StoreLevel); positions (and attribute columns) of
+// all points ever added live in pools indexed by point id (= running index over all batches).  A batch runs the same
+// level-synchronous loop as a single batch (swz_level.hip); per level the files of the nodes the active set touches are
+// copied out and merged in, and the level's taken points are appended as those nodes' new files -- carrying the key the
+// reference computes when it reads a file back, so that the re-keying is paid once per stored entry, not per pull.  FAST (TilingAlgorithmV3) later iterations
 // (:1362-1453, 1620-1659: per-thread chunks sorted, split at the start level, k-way merged, earlier chunk first on
 // ties) are the stable sort of the batch; finalize (:1661-1784) rebuilds the skipped levels from the store.
 //
@@ -30,12 +31,32 @@ namespace swz {
 
 static const uint32_t TILER_ATTR_BYTES[SWZ_ATTR_COUNT] = {3, 12, 2, 1, 1, 8, 1, 1, 2, 1, 1, 1};
 
+// The files of one octree level.  Two forms:
+//   linear: side `cur` holds exactly the `cnt` live entries, node after node in node order (what every reader but the
+//           level loop wants: export, node table, finalize, re-rooting);
+//   log:    a batch must not move the files of the nodes it does not reach (batches of a real data set -- LAS tiles --
+//           reach a small part of the tree), so the level loop only APPENDS the new versions of the files it rewrites at
+//           `end` and keeps a node table {node key, offset, count} that says where each node's current file lies; the
+//           old versions stay behind as garbage until the side is full, then the live files are gathered into the other
+//           side (store_compact).  Per batch and level the store costs what the batch pulls and writes, not what it holds.
+// store_table() / store_linearize() convert between the two.
 struct StoreLevel {
   uint64_t* key[2] = {nullptr, nullptr};
   uint32_t* gid[2] = {nullptr, nullptr};
   size_t cap[2] = {0, 0};
   int cur = 0;
-  uint32_t cnt = 0;
+  uint32_t cnt = 0;          // live entries
+  uint32_t end = 0;          // entries of side `cur` in use (live + garbage)
+  bool linear = true;
+  bool table_valid = false;
+  uint64_t* nkey[2] = {nullptr, nullptr};  // node table, ascending by node key (the key with the bits below the node cleared)
+  uint64_t* noff[2] = {nullptr, nullptr};
+  uint32_t* ncnt[2] = {nullptr, nullptr};
+  int ncur = 0;
+  uint32_t nn = 0;
+  // every entry carries the key read_pnts_from_disk would give it (relative to its NODE's bounds): files written by the
+  // level loop do (TakeStoreG), files written by finalize / re-rooting do not and are re-keyed when they are pulled
+  bool rekeyed = true;
 };
 
 // One batch on its way through the levels.  `as` (kept beside it) is the active set handed down -- new points and
@@ -190,18 +211,21 @@ __device__ __forceinline__ uint64_t morton_in_box(double x, double y, double z, 
 
 // read_pnts_from_disk, TilingAlgorithms.cpp:80-99: idx = node.morton_index; levels node.level+1 .. 20 are levels
 // 0 .. of the index of the position inside node.bounds (bounds by descending octant by octant from the root).
+// The result depends on the point's position and on the NODE (the top level+1 digits of `old`) only, not on the lower
+// digits of `old`: re-keying a re-keyed entry of the same node changes nothing.
+__device__ __forceinline__ uint64_t rekey_one(uint64_t old, const double* __restrict__ pool, size_t g, const Box& root, int level) {
+  const Box nb = bounds_from_key(old, root, level + 1);
+  const uint64_t rel = morton_in_box(pool[3 * g], pool[3 * g + 1], pool[3 * g + 2], nb);
+  const uint32_t start_level = (uint32_t)(level + 1);
+  const uint64_t prefix = start_level == 0 ? 0ull : ((old >> level_shift(level)) << level_shift(level));
+  return prefix | (rel >> (3u * start_level));
+}
 __global__ __launch_bounds__(256) void tl_rekey_kernel(uint64_t* __restrict__ ckey, const uint32_t* __restrict__ cgid,
                                                        uint32_t nc, const double* __restrict__ pool, Box root,
                                                        int level) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= nc) return;
-  const uint64_t old = ckey[j];
-  const Box nb = bounds_from_key(old, root, level + 1);
-  const size_t g = cgid[j];
-  const uint64_t rel = morton_in_box(pool[3 * g], pool[3 * g + 1], pool[3 * g + 2], nb);
-  const uint32_t start_level = (uint32_t)(level + 1);
-  const uint64_t prefix = start_level == 0 ? 0ull : ((old >> level_shift(level)) << level_shift(level));
-  ckey[j] = prefix | (rel >> (3u * start_level));
+  ckey[j] = rekey_one(ckey[j], pool, cgid[j], root, level);
 }
 
 // index_points<21>(root bounds, ClampToBounds) on a COPY of the positions (reconstruct_single_node :1682-1688)
@@ -330,6 +354,169 @@ struct HeadG {
   }
 };
 
+// The level loop's store step: the taken points of the merged range become the new files of their nodes, written
+// straight behind the files the side already holds.  An entry that did not come out of this level's files (a point of
+// the batch, or one an ancestor handed down) gets the key the reference would compute when it reads the file back
+// (rekey_one) -- once, here, instead of with every later batch that pulls the file; entries pulled from this level's
+// files carry that key already.  The first `ghosts` taken entries are a sharded root's ghosts: not part of the file.
+struct TakeStoreG {
+  const uint64_t* mkey;
+  const uint32_t* midx;
+  const uint32_t* wgid;
+  uint32_t pull_lo, pull_hi;  // working indices of what this level pulled
+  uint32_t ghosts;
+  const double* pool;
+  Box root;
+  int level;
+  uint64_t* okey;
+  uint32_t* ogid;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t t) const {
+    if (!t || excl < ghosts) return;
+    const uint32_t w = midx ? midx[i] : i;
+    const uint32_t g = wgid[w];
+    uint64_t k = mkey[i];
+    if ((w < pull_lo || w >= pull_hi) && g != 0xFFFFFFFFu) k = rekey_one(k, pool, g, root, level);
+    okey[excl - ghosts] = k;
+    ogid[excl - ghosts] = g;
+  }
+};
+
+// ---- node table of a level store (log form)
+__global__ __launch_bounds__(256) void tl_table_build_kernel(const uint64_t* __restrict__ hk, const uint32_t* __restrict__ hp,
+                                                             uint32_t heads, uint32_t cnt, uint64_t* __restrict__ nkey,
+                                                             uint64_t* __restrict__ noff, uint32_t* __restrict__ ncnt) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= heads) return;
+  nkey[j] = hk[j];
+  noff[j] = hp[j];
+  ncnt[j] = (j + 1 < heads ? hp[j + 1] : cnt) - hp[j];
+}
+__device__ __forceinline__ uint32_t tl_lower_u64(const uint64_t* __restrict__ a, uint32_t n, uint64_t k) {
+  uint32_t lo = 0, hi = n;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (a[mid] < k) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+// the files of the nodes the active set reaches: head j of the active set -> its node's file (if it has one)
+struct PullCntF {
+  const uint64_t* hk;
+  const uint64_t* nkey;
+  const uint32_t* ncnt;
+  uint32_t nn;
+  __device__ uint32_t find(uint64_t k) const {
+    const uint32_t r = tl_lower_u64(nkey, nn, k);
+    return (r < nn && nkey[r] == k) ? r : 0xFFFFFFFFu;
+  }
+  __device__ uint32_t operator()(uint32_t j) const {
+    const uint32_t r = find(hk[j]);
+    return r == 0xFFFFFFFFu ? 0u : ncnt[r];
+  }
+};
+struct PullSegG {
+  PullCntF f;
+  const uint64_t* noff;
+  uint32_t* poff;
+  uint64_t* psrc;
+  uint8_t* touched;
+  __device__ void operator()(uint32_t j, uint32_t excl, uint32_t) const {
+    const uint32_t r = f.find(f.hk[j]);
+    poff[j] = excl;
+    psrc[j] = r == 0xFFFFFFFFu ? 0ull : noff[r];
+    if (r != 0xFFFFFFFFu) touched[r] = 1;
+  }
+};
+// segments j = 0 .. segs-1 of a source array, segment j = [psrc[j], +len_j) with len_j = poff[j+1] - poff[j]
+// (poff[segs] = total), copied one behind the other: output element e belongs to the last segment that starts at or
+// before e.  A workgroup's 256 consecutive outputs lie in consecutive segments: two searches over all of poff bracket
+// them, every thread then searches the bracket (out of LDS when it is short).
+constexpr uint32_t TL_SEG_LDS = 1024;
+__device__ __forceinline__ uint32_t tl_upper_u32(const uint32_t* __restrict__ a, uint32_t lo, uint32_t hi, uint32_t k) {
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (a[mid] <= k) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void tl_gather_files_kernel(const uint32_t* __restrict__ poff, const uint64_t* __restrict__ psrc,
+                                                              uint32_t segs, uint32_t total, const uint64_t* __restrict__ skey,
+                                                              const uint32_t* __restrict__ sgid, uint64_t* __restrict__ okey,
+                                                              uint32_t* __restrict__ ogid) {
+  __shared__ uint32_t s_lo, s_hi;
+  __shared__ uint32_t so[TL_SEG_LDS];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t e0 = blockIdx.x * 256u, e = e0 + tid;
+  const uint32_t last = (total - e0) > 256u ? e0 + 255u : total - 1u;
+  if (tid == 0) s_lo = tl_upper_u32(poff, 0u, segs, e0) - 1u;
+  if (tid == 64) s_hi = tl_upper_u32(poff, 0u, segs, last) - 1u;
+  __syncthreads();
+  const uint32_t lo = s_lo, span = s_hi - s_lo + 1u;
+  const bool in_lds = span <= TL_SEG_LDS;
+  if (in_lds)
+    for (uint32_t j = tid; j < span; j += 256u) so[j] = poff[lo + j];
+  __syncthreads();
+  if (e >= total) return;
+  const uint32_t j = in_lds ? lo + tl_upper_u32(so, 0u, span, e) - 1u : tl_upper_u32(poff, lo, lo + span, e) - 1u;
+  const uint64_t src = psrc[j] + (e - poff[j]);
+  okey[e] = skey[src];
+  ogid[e] = sgid[src];
+}
+struct UntouchedF {
+  const uint8_t* touched;  // null: every node counts
+  __device__ uint32_t operator()(uint32_t i) const { return (touched && touched[i]) ? 0u : 1u; }
+};
+struct TableFilterG {
+  const uint64_t* nkey;
+  const uint64_t* noff;
+  const uint32_t* ncnt;
+  uint64_t* fkey;
+  uint64_t* foff;
+  uint32_t* fcnt;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t keep) const {
+    if (!keep) return;
+    fkey[excl] = nkey[i];
+    foff[excl] = noff[i];
+    fcnt[excl] = ncnt[i];
+  }
+};
+struct SegCntF {
+  const uint32_t* cnt;
+  __device__ uint32_t operator()(uint32_t i) const { return cnt[i]; }
+};
+struct SegMoveG {  // the files of a table, gathered one behind the other: where each goes, where it came from
+  uint64_t* off;
+  uint32_t* poff;
+  uint64_t* psrc;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t) const {
+    poff[i] = excl;
+    psrc[i] = off[i];
+    off[i] = excl;
+  }
+};
+// two node tables with disjoint keys, both ascending, into one: the entries the batch left alone (f*) and the heads of
+// the files it wrote (keys hk at positions hp of the `added` entries appended at `base`)
+__global__ __launch_bounds__(256) void tl_table_merge_kernel(const uint64_t* __restrict__ fkey, const uint64_t* __restrict__ foff,
+                                                             const uint32_t* __restrict__ fcnt, uint32_t nf,
+                                                             const uint64_t* __restrict__ hk, const uint32_t* __restrict__ hp,
+                                                             uint32_t heads, uint32_t added, uint64_t base,
+                                                             uint64_t* __restrict__ okey, uint64_t* __restrict__ ooff,
+                                                             uint32_t* __restrict__ ocnt) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < nf) {
+    const uint32_t o = i + tl_lower_u64(hk, heads, fkey[i]);
+    okey[o] = fkey[i];
+    ooff[o] = foff[i];
+    ocnt[o] = fcnt[i];
+  } else if (i < nf + heads) {
+    const uint32_t j = i - nf;
+    const uint32_t o = j + tl_lower_u64(fkey, nf, hk[j]);
+    okey[o] = hk[j];
+    ooff[o] = base + hp[j];
+    ocnt[o] = (j + 1 < heads ? hp[j + 1] : added) - hp[j];
+  }
+}
+
 // ---- re-rooting (tile_node, TilingAlgorithms.cpp:444-483)
 // calculate_morton_index<21>(position, new_root.bounds), no clamp (:470-473)
 __global__ __launch_bounds__(256) void rr_encode_kernel(const uint32_t* __restrict__ idx, uint32_t m,
@@ -407,13 +594,89 @@ static int store_reserve(swz_ctx* c, StoreLevel& s, int level_index, int which, 
   return SWZ_OK;
 }
 
-static void store_free(StoreLevel& s) {
-  for (int w = 0; w < 2; ++w) {
-    s.key[w] = nullptr;
-    s.gid[w] = nullptr;
-    s.cap[w] = 0;
+static void store_free(StoreLevel& s) { s = StoreLevel{}; }
+
+// side `which` has just been written as a whole: `cnt` entries, node after node
+static void store_written_linear(StoreLevel& s, int which, uint32_t cnt, bool rekeyed) {
+  s.cur = which;
+  s.cnt = s.end = cnt;
+  s.linear = true;
+  s.table_valid = false;
+  s.nn = 0;
+  s.rekeyed = rekeyed || cnt == 0;
+}
+
+static int read_u32(swz_ctx* c, const uint32_t* d, uint32_t* h);
+static int table_reserve(swz_ctx* c, StoreLevel& s, int level_index, int which, size_t count) {
+  // (part of the store: placed like its sides -- SWZ_TILER_SPILL=host leaves nothing of a tiler on the device)
+  const std::string sfx = std::to_string(level_index) + "_" + std::to_string(which);
+  auto one = [&](const std::string& name, size_t elem, void** out) -> int {
+    const size_t have = c->bufs[name].cap / elem;
+    const size_t want = have >= count && c->bufs[name].ptr ? have : count + count / 2 + 1024;
+    return grow_preserving(c, name.c_str(), want * elem, 0, out, true);
+  };
+  void *pk = nullptr, *po = nullptr, *pc = nullptr;
+  SWZ_TRY(one("tiler_store_tab_key_" + sfx, 8, &pk));
+  SWZ_TRY(one("tiler_store_tab_off_" + sfx, 8, &po));
+  SWZ_TRY(one("tiler_store_tab_cnt_" + sfx, 4, &pc));
+  s.nkey[which] = static_cast<uint64_t*>(pk);
+  s.noff[which] = static_cast<uint64_t*>(po);
+  s.ncnt[which] = static_cast<uint32_t*>(pc);
+  return SWZ_OK;
+}
+// the node table of a level in linear form: the runs of equal node prefix
+static int store_table(swz_ctx* c, StoreLevel& s, int level_index) {
+  if (s.table_valid) return SWZ_OK;
+  if (!s.linear) return c->fail(SWZ_ERR_INTERNAL, "node store: neither linear nor indexed");
+  s.nn = 0;
+  if (s.cnt) {
+    const int level = level_index - 1;
+    const uint32_t nsh = level < 0 ? 63u : level_shift(level);
+    uint32_t *counters = nullptr, *hp = nullptr;
+    uint64_t* hk = nullptr;
+    SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+    SWZ_TRY(c->get("tl_head_pos", (size_t)s.cnt, &hp));
+    SWZ_TRY(c->get("tl_head_key", (size_t)s.cnt, &hk));
+    SWZ_TRY(fused_scan(c, HeadF{s.key[s.cur], nsh}, HeadG{s.key[s.cur], nsh, hp, hk}, s.cnt, counters + 3, "tl"));
+    uint32_t heads = 0;
+    SWZ_TRY(read_u32(c, counters + 3, &heads));
+    SWZ_TRY(table_reserve(c, s, level_index, s.ncur, heads));
+    hipLaunchKernelGGL(tl_table_build_kernel, dim3(div_up(heads, 256)), dim3(256), 0, c->stream, hk, hp, heads, s.cnt,
+                       s.nkey[s.ncur], s.noff[s.ncur], s.ncnt[s.ncur]);
+    SWZ_LAUNCH_CHECK(c);
+    s.nn = heads;
   }
-  s.cnt = 0;
+  s.table_valid = true;
+  return SWZ_OK;
+}
+// Gathers the files a table lists (ntab entries, `live` entries in all, in table order) into the other side, which gets
+// room for `room` entries, and makes it the current one; off[] (device) is rewritten to the new places.
+static int store_compact(swz_ctx* c, StoreLevel& s, int level_index, uint64_t* off, const uint32_t* cnt, uint32_t ntab,
+                         uint32_t live, size_t room) {
+  const int dst = s.cur ^ 1;
+  SWZ_TRY(store_reserve(c, s, level_index, dst, std::max<size_t>(room, live)));
+  if (ntab && live) {
+    uint32_t *poff = nullptr, *counters = nullptr;
+    uint64_t* psrc = nullptr;
+    SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
+    SWZ_TRY(c->get("tl_poff", (size_t)ntab, &poff));
+    SWZ_TRY(c->get("tl_psrc", (size_t)ntab, &psrc));
+    SWZ_TRY(fused_scan(c, SegCntF{cnt}, SegMoveG{off, poff, psrc}, ntab, counters + 2, "tl"));
+    hipLaunchKernelGGL(tl_gather_files_kernel, dim3(div_up(live, 256)), dim3(256), 0, c->stream, poff, psrc, ntab, live,
+                       s.key[s.cur], s.gid[s.cur], s.key[dst], s.gid[dst]);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  s.cur = dst;
+  s.end = live;
+  return SWZ_OK;
+}
+// log form -> linear form (the table stays valid)
+static int store_linearize(swz_ctx* c, StoreLevel& s, int level_index) {
+  if (s.linear) return SWZ_OK;
+  if (!s.table_valid) return c->fail(SWZ_ERR_INTERNAL, "node store: log without a table");
+  SWZ_TRY(store_compact(c, s, level_index, s.noff[s.ncur], s.ncnt[s.ncur], s.nn, s.cnt, s.cnt));
+  s.linear = true;
+  return SWZ_OK;
 }
 
 // Grows a named workspace buffer keeping its first `keep` bytes.  A POOL (spill == true) that finds no device memory
@@ -575,36 +838,61 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   }
 
   // ---- pull the files of the nodes this level's active set reaches
-  uint64_t *ckey = nullptr, *rkey = nullptr;
-  uint32_t *cgid = nullptr, *rgid = nullptr;
-  uint32_t nc = 0, nr = 0;
+  uint64_t* ckey = nullptr;
+  uint32_t* cgid = nullptr;
+  uint32_t nc = 0;
+  uint8_t* touched = nullptr;  // per node of the level's table: the batch rewrites its file
+  bool all_touched = false;
+  const int lvi = plan.level + 1;
   if (st.cnt && sr) {  // the root is reached by the batch as a whole: all of its local file
+    SWZ_TRY(store_linearize(c, st, lvi));
+    SWZ_TRY(store_table(c, st, lvi));
     SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
     SWZ_TRY(c->get("tl_cgid", (size_t)st.cnt, &cgid));
     SWZ_HIP(c, hipMemcpyAsync(ckey, st.key[st.cur], (size_t)st.cnt * 8, hipMemcpyDeviceToDevice, c->stream));
     SWZ_HIP(c, hipMemcpyAsync(cgid, st.gid[st.cur], (size_t)st.cnt * 4, hipMemcpyDeviceToDevice, c->stream));
     nc = st.cnt;
+    all_touched = true;
   } else if (st.cnt) {
-    // (profile class "tiler_pull": which store entries lie in nodes the active set reaches, and the split)
-    ProfScope ps(c, "tiler_pull", (uint64_t)st.cnt * 33ull + (uint64_t)as.m * 8ull, 3);
-    uint8_t* touch = nullptr;
-    SWZ_TRY(c->get("tl_touch", (size_t)st.cnt, &touch));
-    SWZ_TRY(c->get("tl_ckey", (size_t)st.cnt, &ckey));
-    SWZ_TRY(c->get("tl_cgid", (size_t)st.cnt, &cgid));
-    SWZ_TRY(c->get("tl_rkey", (size_t)st.cnt, &rkey));
-    SWZ_TRY(c->get("tl_rgid", (size_t)st.cnt, &rgid));
-    hipLaunchKernelGGL(tl_touch_kernel, dim3(div_up(st.cnt, 256)), dim3(256), 0, c->stream, st.key[st.cur], st.cnt,
-                       as.akey, as.m, nsh, touch);
-    SWZ_LAUNCH_CHECK(c);
-    SWZ_TRY(fused_scan(c, TouchF{touch}, SplitG{st.key[st.cur], st.gid[st.cur], ckey, cgid, rkey, rgid}, st.cnt,
-                       counters, "tl"));
+    // (profile class "tiler_pull": the nodes of the active set, their files looked up in the level's node table and
+    // copied out -- what the batch reaches, not what the level holds)
+    SWZ_TRY(store_table(c, st, lvi));
+    uint32_t* hp = nullptr;
+    uint64_t* hk = nullptr;
+    SWZ_TRY(c->get("tl_head_pos", (size_t)as.m, &hp));
+    SWZ_TRY(c->get("tl_head_key", (size_t)as.m, &hk));
+    SWZ_TRY(c->get("tl_ntouch", (size_t)st.nn, &touched));
+    uint32_t heads = 0;
+    {
+      ProfScope ps(c, "tiler_pull", (uint64_t)as.m * 8ull, 2);
+      SWZ_TRY(fused_scan(c, HeadF{as.akey, nsh}, HeadG{as.akey, nsh, hp, hk}, as.m, counters + 3, "tl"));
+      SWZ_HIP(c, hipMemsetAsync(touched, 0, (size_t)st.nn, c->stream));
+    }
+    SWZ_TRY(read_u32(c, counters + 3, &heads));
+    uint32_t* poff = nullptr;
+    uint64_t* psrc = nullptr;
+    SWZ_TRY(c->get("tl_poff", (size_t)heads, &poff));
+    SWZ_TRY(c->get("tl_psrc", (size_t)heads, &psrc));
+    const PullCntF pf{hk, st.nkey[st.ncur], st.ncnt[st.ncur], st.nn};
+    SWZ_TRY(fused_scan(c, pf, PullSegG{pf, st.noff[st.ncur], poff, psrc, touched}, heads, counters, "tl"));
     SWZ_TRY(read_u32(c, counters, &nc));
-    nr = st.cnt - nc;
+    if (nc) {
+      ProfScope ps(c, "tiler_pull", (uint64_t)nc * 24ull, 1);
+      SWZ_TRY(c->get("tl_ckey", (size_t)nc, &ckey));
+      SWZ_TRY(c->get("tl_cgid", (size_t)nc, &cgid));
+      hipLaunchKernelGGL(tl_gather_files_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, poff, psrc, heads, nc,
+                         st.key[st.cur], st.gid[st.cur], ckey, cgid);
+      SWZ_LAUNCH_CHECK(c);
+    }
+  } else {
+    SWZ_TRY(store_table(c, st, lvi));  // (an empty level: an empty table)
   }
+  const uint32_t pull_lo = w.wused;  // working indices of the pulled entries, below
   ActiveSet ms = as;
   if (nc || ng) {
-    if (nc) {
-      // ("tiler_rekey": the pulled points' keys against their NODE's bounds -- a random 24-byte read per point from the pool)
+    if (nc && !st.rekeyed) {
+      // ("tiler_rekey": the pulled points' keys against their NODE's bounds -- a random 24-byte read per point from the
+      // pool; only for files the level loop did not write itself, see TakeStoreG)
       ProfScope ps(c, "tiler_rekey", (uint64_t)nc * 44ull, 1);
       hipLaunchKernelGGL(tl_rekey_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, cgid, nc, t->pool_xyz,
                          root_box(t), plan.level);
@@ -691,33 +979,80 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   }
   SWZ_TRY(level_step(c, plan, ms, sp, lb, w.wlevel, w.surv_key[w.which], w.surv_idx[w.which], res));
 
-  // ---- the nodes' new files, merged back between the files of the untouched nodes
-  const uint32_t nt = ms.m - res->remaining;
-  uint64_t* tkey = nullptr;
-  uint32_t* tgid = nullptr;
-  SWZ_TRY(c->get("tl_tkey", (size_t)nt, &tkey));
-  SWZ_TRY(c->get("tl_tgid", (size_t)nt, &tgid));
+  // ---- the nodes' new files: appended behind what the side holds, the node table points at them
+  const uint32_t nt = ms.m - res->remaining - ng;  // (the ghosts lead the merged range and are all taken again)
+  const uint32_t rest = st.cnt - nc;               // entries of the files the batch did not reach
+  uint64_t *fkey = nullptr, *foff = nullptr;
+  uint32_t* fcnt = nullptr;
+  uint32_t nf = 0;
+  bool nf_known = true;
+  if (st.nn && !all_touched && rest) {
+    ProfScope ps(c, "tiler_store", (uint64_t)st.nn * 21ull, 2);
+    SWZ_TRY(c->get("tl_ftab_key", (size_t)st.nn, &fkey));
+    SWZ_TRY(c->get("tl_ftab_off", (size_t)st.nn, &foff));
+    SWZ_TRY(c->get("tl_ftab_cnt", (size_t)st.nn, &fcnt));
+    SWZ_TRY(fused_scan(c, UntouchedF{touched}, TableFilterG{st.nkey[st.ncur], st.noff[st.ncur], st.ncnt[st.ncur], fkey, foff, fcnt},
+                       st.nn, counters + 1, "tl"));
+    nf_known = false;
+  }
+  if (!st.key[st.cur] || (uint64_t)st.end + nt > st.cap[st.cur]) {
+    // the side is full: the files the batch left alone move to the other side, the old versions of the rest stay behind
+    if (!nf_known) {
+      SWZ_TRY(read_u32(c, counters + 1, &nf));
+      nf_known = true;
+    }
+    ProfScope ps(c, "tiler_store", (uint64_t)rest * 24ull, 2);
+    const size_t room = (size_t)rest + nt;
+    SWZ_TRY(store_compact(c, st, lvi, foff, fcnt, nf, rest, room + room / 4));
+  }
+  const uint32_t at = st.end;
   {
     ProfScope ps(c, "tiler_store", (uint64_t)ms.m * 14ull + (uint64_t)nt * 12ull, 2);
-    SWZ_TRY(fused_scan(c, TakenF{lb.taken}, TakeG{ms.akey, ms.aidx, w.wgid, tkey, tgid}, ms.m, counters + 2, "tl"));
+    SWZ_TRY(fused_scan(c, TakenF{lb.taken},
+                       TakeStoreG{ms.akey, ms.aidx, w.wgid, pull_lo, pull_lo + nc, ng, t->pool_xyz, root_box(t), plan.level,
+                                  st.key[st.cur] + at, st.gid[st.cur] + at},
+                       ms.m, counters + 2, "tl"));
   }
-  if (ng) {  // the ghosts lead the merged range and are all taken again: they are not part of the local file
-    SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
-    hipLaunchKernelGGL(tl_count_untaken_kernel, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, lb.taken, ng, counters + 1);
+  if (ng) {  // the ghosts are not part of the local file
+    SWZ_HIP(c, hipMemsetAsync(counters, 0, 4, c->stream));
+    hipLaunchKernelGGL(tl_count_untaken_kernel, dim3(div_up(ng, 256)), dim3(256), 0, c->stream, lb.taken, ng, counters);
     SWZ_LAUNCH_CHECK(c);
     uint32_t lost = 0;
-    SWZ_TRY(read_u32(c, counters + 1, &lost));
+    SWZ_TRY(read_u32(c, counters, &lost));
     if (lost) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: " + std::to_string(lost) + " ghost points were not taken again "
                                               "(they must be what the root took on LOWER shards in this batch)");
   }
-  const int dst = st.cur ^ 1;
-  SWZ_TRY(store_reserve(c, st, plan.level + 1, dst, (size_t)nr + nt - ng));
   {
-    ProfScope ps(c, "tiler_store", ((uint64_t)nr + nt - ng) * 24ull, 2);
-    SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey + ng, tgid + ng, nt - ng, nsh, 0u, st.key[dst], st.gid[dst]));
+    ProfScope ps(c, "tiler_store", (uint64_t)nt * 8ull + (uint64_t)st.nn * 20ull, 2);
+    uint32_t* hp = nullptr;
+    uint64_t* hk = nullptr;
+    uint32_t heads = 0;
+    if (nt) {
+      SWZ_TRY(c->get("tl_head_pos", (size_t)nt, &hp));
+      SWZ_TRY(c->get("tl_head_key", (size_t)nt, &hk));
+      SWZ_TRY(fused_scan(c, HeadF{st.key[st.cur] + at, nsh}, HeadG{st.key[st.cur] + at, nsh, hp, hk}, nt, counters + 3, "tl"));
+    }
+    uint32_t h4[4] = {0, 0, 0, 0};
+    if (nt || !nf_known) {  // both counts with one round trip
+      SWZ_HIP(c, hipMemcpyAsync(h4, counters, 16, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (!nf_known) nf = h4[1];
+    if (nt) heads = h4[3];
+    const int nd = st.ncur ^ 1;
+    SWZ_TRY(table_reserve(c, st, lvi, nd, (size_t)nf + heads));
+    if (nf + heads) {
+      hipLaunchKernelGGL(tl_table_merge_kernel, dim3(div_up(nf + heads, 256)), dim3(256), 0, c->stream, fkey, foff, fcnt, nf, hk, hp,
+                         heads, nt, (uint64_t)at, st.nkey[nd], st.noff[nd], st.ncnt[nd]);
+      SWZ_LAUNCH_CHECK(c);
+    }
+    st.ncur = nd;
+    st.nn = nf + heads;
   }
-  st.cur = dst;
-  st.cnt = nr + nt - ng;
+  st.end = at + nt;
+  st.cnt = rest + nt;
+  st.linear = at == 0;  // (nothing in front of the new files: they are the level)
+  if (rest == 0) st.rekeyed = true;
 
   as = ActiveSet{w.surv_key[w.which], w.surv_idx[w.which], res->remaining};
   w.which ^= 1;
@@ -751,8 +1086,7 @@ static int rr_store_node(swz_tiler* t, int level, const uint64_t* rkey, const ui
   const int dst = st.cur ^ 1;
   SWZ_TRY(store_reserve(c, st, level + 1, dst, (size_t)nr + nt));
   SWZ_TRY(merge_pairs(c, rkey, rgid, nr, tkey, tgid, nt, level < 0 ? 63u : level_shift(level), 0u, st.key[dst], st.gid[dst]));
-  st.cur = dst;
-  st.cnt = nr + nt;
+  store_written_linear(st, dst, nr + nt, false);
   return SWZ_OK;
 }
 
@@ -766,6 +1100,7 @@ static int rr_node(swz_tiler* t, BatchWork& w, const RrNode& node, double root_e
   SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
   // ---- the node's file (read_pnts_from_disk; the re-keying is irrelevant: everything is re-indexed or appended)
   StoreLevel& st = t->lv[node.level + 1];
+  SWZ_TRY(store_linearize(c, st, node.level + 1));
   uint64_t *ckey = nullptr, *rkey = nullptr;
   uint32_t *cgid = nullptr, *rgid = nullptr;
   uint32_t nc = 0, nr = 0;
@@ -1074,6 +1409,7 @@ static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats, int lowest_childr
     StoreLevel& dst = t->lv[lv];
     const uint32_t m = src.cnt;
     if (m == 0) continue;
+    SWZ_TRY(store_linearize(c, src, lv + 1));
     uint64_t* keys = nullptr;
     uint32_t *gid = nullptr, *wgid = nullptr;
     double *wx = nullptr, *wy = nullptr, *wz = nullptr;
@@ -1119,8 +1455,7 @@ static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats, int lowest_childr
     SWZ_TRY(store_reserve(c, dst, lv, w, nt));
     SWZ_HIP(c, hipMemcpyAsync(dst.key[w], tkey, (size_t)nt * 8, hipMemcpyDeviceToDevice, c->stream));
     SWZ_HIP(c, hipMemcpyAsync(dst.gid[w], tgid, (size_t)nt * 4, hipMemcpyDeviceToDevice, c->stream));
-    dst.cur = w;
-    dst.cnt = nt;
+    store_written_linear(dst, w, nt, false);
     nodes += r.num_nodes;
     rounds += r.md_rounds;
   }
@@ -1141,8 +1476,14 @@ static int tiler_node_table(swz_tiler* t, std::vector<int8_t>* nl, std::vector<u
   uint32_t* counters = nullptr;
   SWZ_TRY(c->get("tl_counters", (size_t)4, &counters));
   for (int l = 0; l < 22; ++l) {
-    const StoreLevel& s = t->lv[l];
+    StoreLevel& s = t->lv[l];
     if (!s.cnt) continue;
+    if (!nl && s.table_valid) {  // only the count is asked for
+      nn += s.nn;
+      offset += s.cnt;
+      continue;
+    }
+    SWZ_TRY(store_linearize(c, s, l));
     const int level = l - 1;
     const uint32_t nsh = level < 0 ? 63u : level_shift(level);
     uint32_t* hp = nullptr;
@@ -1379,6 +1720,7 @@ int swz_tiler_shard_fast_set_root(swz_tiler* t, const uint8_t* d_taken) {
   if (m == 0) return SWZ_OK;
   if (!d_taken) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_fast_set_root: NULL flags");
   auto body = [&]() -> int {
+    SWZ_TRY(store_linearize(c, src, 1));
     uint64_t *keys = nullptr, *tkey = nullptr;
     uint32_t *tgid = nullptr, *counters = nullptr;
     SWZ_TRY(c->get("tl_keys", (size_t)m, &keys));
@@ -1394,8 +1736,7 @@ int swz_tiler_shard_fast_set_root(swz_tiler* t, const uint8_t* d_taken) {
     SWZ_TRY(store_reserve(c, dst, 0, w, nt));
     SWZ_HIP(c, hipMemcpyAsync(dst.key[w], tkey, (size_t)nt * 8, hipMemcpyDeviceToDevice, c->stream));
     SWZ_HIP(c, hipMemcpyAsync(dst.gid[w], tgid, (size_t)nt * 4, hipMemcpyDeviceToDevice, c->stream));
-    dst.cur = w;
-    dst.cnt = nt;
+    store_written_linear(dst, w, nt, false);
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
     return SWZ_OK;
   };
@@ -1424,9 +1765,10 @@ int swz_tiler_level_positions_device(swz_tiler* t, int level, double* d_xyz_out)
   swz_ctx* c = t->c;
   SWZ_HIP(c, hipSetDevice(c->device));
   SWZ_TRY(tiler_guard(t));
-  const StoreLevel& s = t->lv[level + 1];
+  StoreLevel& s = t->lv[level + 1];
   if (!s.cnt) return SWZ_OK;
   if (!d_xyz_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_level_positions_device: NULL buffer");
+  SWZ_TRY(store_linearize(c, s, level + 1));
   hipLaunchKernelGGL(tl_rows_kernel, dim3(div_up(s.cnt, 256)), dim3(256), 0, c->stream, s.gid[s.cur], s.cnt, t->pool_xyz, d_xyz_out);
   SWZ_LAUNCH_CHECK(c);
   SWZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -1590,8 +1932,9 @@ int swz_tiler_export_device(swz_tiler* t, uint64_t* d_keys_out, uint32_t* d_ids_
   SWZ_TRY(tiler_guard(t));
   size_t off = 0;
   for (int l = 0; l < 22; ++l) {
-    const StoreLevel& s = t->lv[l];
+    StoreLevel& s = t->lv[l];
     if (!s.cnt) continue;
+    SWZ_TRY(store_linearize(c, s, l));
     if (d_keys_out) SWZ_HIP(c, hipMemcpyAsync(d_keys_out + off, s.key[s.cur], (size_t)s.cnt * 8, hipMemcpyDeviceToDevice, c->stream));
     if (d_ids_out) SWZ_HIP(c, hipMemcpyAsync(d_ids_out + off, s.gid[s.cur], (size_t)s.cnt * 4, hipMemcpyDeviceToDevice, c->stream));
     if (d_level_out) {

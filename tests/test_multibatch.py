@@ -172,6 +172,48 @@ def test_gpu_multibatch_d250_large_nodes(ctx, sampler):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sampler", SAMPLERS)
+@pytest.mark.parametrize("strategy", [O.ACCURATE, O.FAST])
+def test_gpu_multibatch_spatially_coherent_batches(ctx, sampler, strategy):
+    """Batches that arrive the way LAS tiles do: each reaches a few subtrees and leaves the files of all other nodes
+    alone.  The node store then appends the rewritten files behind the untouched ones and gathers the live files into its
+    other side when a side is full -- 24 batches so that this happens several times per level --, and a call between two
+    batches (info: the node table) must not disturb it."""
+    import schwarzwald_amd as swz
+    import torch
+    rng = np.random.default_rng(41 + 10 * sampler + strategy)
+    n, k = 240000, 24
+    xyz = _points(rng, n, UNIT, clustered=False)
+    # strips along x, every third strip a second time around (a tile visited again later)
+    xyz = xyz[np.argsort(xyz[:, 0], kind="stable")]
+    parts = np.array_split(xyz, k)
+    order = [i for i in range(k) if i % 3] + [i for i in range(k) if i % 3 == 0]
+    xyz = np.vstack([parts[i] for i in order])
+    sp = O.spacing_from_diagonal(*UNIT, 64)
+    ex, c = _oracle_files(UNIT, xyz, k, sampler, 500, sp, strategy, 2)
+    g = _gpu_files(ctx, UNIT, xyz, k, sampler, 500, sp, strategy, 2, staged=False)
+    assert g["info"]["rekey_inversions"] == 0 and c["unsorted_cached_nodes"] == 0
+    _compare(g, ex, c)
+    # the same with the node table read in the middle of the data set
+    params = swz.TileParams(sampler=sampler, max_points_per_node=500, spacing_at_root=sp, strategy=strategy, fast_concurrency=2)
+    with swz.Tiler(ctx, UNIT[0], UNIT[1], params) as t:
+        for i, p in enumerate(np.array_split(xyz, k)):
+            d = torch.from_numpy(np.ascontiguousarray(p)).cuda()
+            torch.cuda.synchronize()
+            t.add_batch_device(d.data_ptr(), p.shape[0])
+            if i in (5, 6, 17):
+                mid = t.node_table()
+                assert int(mid["count"].sum()) == int(t.info()["num_stored"])
+        t.finalize()
+        tb = t.node_table()
+        ns = int(t.info()["num_stored"])
+        d_ids = torch.empty(ns, dtype=torch.int32, device="cuda")
+        t.export_device(None, d_ids.data_ptr(), None)
+        assert np.array_equal(tb["count"], ex["count"]) and np.array_equal(tb["key"], ex["key"])
+        assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ex["ids"])
+
+
+@pytest.mark.gpu
 def test_gpu_multibatch_terminal_nodes(ctx):
     """max_depth = 2 makes level 2 terminal: its nodes append new ++ cached without sampling
     (tile_node :421-442, merge_node_data_unsorted)."""
