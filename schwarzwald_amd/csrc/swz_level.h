@@ -37,6 +37,11 @@ struct ActiveSet {
   // SamplingBehaviour::AlwaysAdhereToMinSpacing (tile_internal_node, TilingAlgorithms.cpp:272-275).
   const uint64_t* ckey = nullptr;
   uint32_t nc = 0;
+  // the nodes of the level above (LevelResult::node_prefix of the step whose survivors these are), when the caller has
+  // them: every node of this level is a child of one of them, so its first point is found by searching the sorted keys
+  // instead of by a scan over all points (level_step; null: scan)
+  const uint64_t* parent_prefix = nullptr;
+  uint32_t parents = 0;
 };
 
 struct SortedPoints {
@@ -94,6 +99,9 @@ struct LevelResult {
   uint32_t remaining = 0;
   uint32_t num_nodes = 0;
   uint32_t md_rounds = 0;
+  // the key prefixes of the level's nodes, ascending (device; only when the step compacted survivors: for the next
+  // level's ActiveSet::parent_prefix).  Valid until the step after the next one on this context.
+  const uint64_t* node_prefix = nullptr;
 };
 
 // What the host decides for the nodes of one level (tiler_rules: the terminal / re-root tests of tile_node,

@@ -42,6 +42,96 @@ struct NodeAssignG {
     if (i == m - 1) nstart[id + 1] = m;
   }
 };
+// ---- segmentation by search: the nodes of a level are children of the nodes of the level above, and the active set is
+// sorted by node prefix, so child o of parent P starts at the lower bound of (P, o) among the keys.  Nine searches per
+// parent node instead of two passes over the keys of every point (20 bytes per point: the segmentation was as expensive
+// as the sort's histogram passes); the node id per point, which the samplers look up, is then filled from the node starts.
+__global__ __launch_bounds__(256) void node_child_bounds_kernel(const uint64_t* __restrict__ akey, uint32_t m, uint32_t nsh,
+                                                                const uint64_t* __restrict__ pprefix, uint32_t parents,
+                                                                uint32_t* __restrict__ cb) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t j = t >> 4, o = t & 15u;
+  if (j >= parents || o > 8u) return;
+  const uint64_t target = (pprefix[j] >> nsh) + o;
+  uint32_t lo = 0, hi = m;
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if ((akey[mid] >> nsh) < target) lo = mid + 1; else hi = mid;
+  }
+  cb[j * 9u + o] = lo;
+}
+struct ChildExistsF {
+  const uint32_t* cb;
+  uint32_t parents, m;
+  uint32_t* counters;
+  __device__ uint32_t operator()(uint32_t e) const {
+    const uint32_t j = e >> 3, o = e & 7u;
+    if (o == 0) {  // the parents' ranges must tile the active set: a point under none of them would belong to no node
+      const uint32_t b = cb[j * 9u], en = cb[j * 9u + 8u];
+      const bool ok = (j == 0 ? b == 0u : b == cb[(j - 1u) * 9u + 8u]) && (j + 1u < parents || en == m);
+      if (!ok) atomicMax(&counters[CTR_ERROR], (uint32_t)SWZ_ERR_INTERNAL);
+    }
+    return cb[j * 9u + o + 1u] > cb[j * 9u + o] ? 1u : 0u;
+  }
+};
+struct ChildStartG {
+  const uint32_t* cb;
+  uint32_t* nstart;
+  __device__ void operator()(uint32_t e, uint32_t excl, uint32_t exists) const {
+    if (!exists) return;
+    const uint32_t j = e >> 3, o = e & 7u;
+    nstart[excl] = cb[j * 9u + o];
+    nstart[excl + 1u] = cb[j * 9u + o + 1u];  // (the next child writes the same value; the last one closes the table)
+  }
+};
+constexpr uint32_t NF_TILE = 1024;  // points per workgroup: four per thread, one 16-byte store
+__global__ __launch_bounds__(256) void node_fill_kernel(const uint32_t* __restrict__ nstart, const uint32_t* __restrict__ counters,
+                                                        uint32_t m, uint32_t* __restrict__ nid) {
+  __shared__ uint32_t s_lo, s_hi;
+  __shared__ uint32_t ss[NF_TILE + 1];
+  const uint32_t nn = counters[CTR_NUM_NODES];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t i0 = blockIdx.x * NF_TILE;
+  const uint32_t last = (m - i0) > NF_TILE ? i0 + NF_TILE - 1u : m - 1u;
+  auto node_of = [&](uint32_t i) {  // the last node that starts at or before i
+    uint32_t lo = 0, hi = nn;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (nstart[mid] <= i) lo = mid + 1; else hi = mid;
+    }
+    return lo - 1u;
+  };
+  if (tid == 0) s_lo = node_of(i0);
+  if (tid == 64) s_hi = node_of(last);
+  __syncthreads();
+  const uint32_t lo = s_lo, span = s_hi - s_lo + 1u;  // (at most one node starts per point: span <= NF_TILE)
+  for (uint32_t k = tid; k <= span; k += 256u) ss[k] = (lo + k < nn) ? nstart[lo + k] : 0xFFFFFFFFu;  // ss[k]: start of node lo + k
+  __syncthreads();
+  const uint32_t i = i0 + tid * 4u;
+  if (i >= m) return;
+  uint32_t a = 0, b = span;  // the last k < span with ss[k] <= i
+  while (a < b) {
+    const uint32_t mid = a + (b - a) / 2;
+    if (ss[mid] <= i) a = mid + 1; else b = mid;
+  }
+  uint32_t k = a - 1u;
+  uint32_t v[4];
+#pragma unroll
+  for (uint32_t q = 0; q < 4u; ++q) {
+    while (ss[k + 1u] <= i + q) ++k;
+    v[q] = lo + k;
+  }
+  if (i + 4u <= m) {
+    *reinterpret_cast<uint4*>(nid + i) = make_uint4(v[0], v[1], v[2], v[3]);
+  } else {
+    for (uint32_t q = 0; i + q < m; ++q) nid[i + q] = v[q];
+  }
+}
+__global__ __launch_bounds__(256) void node_prefix_kernel(const uint32_t* __restrict__ nstart, const uint64_t* __restrict__ akey,
+                                                          uint32_t nsh, uint32_t nn, uint64_t* __restrict__ out) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < nn) out[j] = nsh >= 63u ? 0ull : ((akey[nstart[j]] >> nsh) << nsh);
+}
 __global__ void single_node_kernel(uint32_t* __restrict__ nstart, uint32_t* __restrict__ num_nodes, uint32_t m) {
   nstart[0] = 0;
   nstart[1] = m;
@@ -1095,6 +1185,16 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
       SWZ_HIP(c, hipMemsetAsync(lb.nid, 0, (size_t)m * sizeof(uint32_t), c->stream));
       hipLaunchKernelGGL(single_node_kernel, dim3(1), dim3(1), 0, c->stream, lb.nstart, lb.counters + CTR_NUM_NODES, m);
       SWZ_LAUNCH_CHECK(c);
+    } else if (as.parent_prefix && as.parents && m > 0 && !c->opt("SWZ_LEVEL_NODES_SCAN")) {
+      uint32_t* cb = nullptr;
+      SWZ_TRY(c->get("lvl_child_bounds", (size_t)as.parents * 9u, &cb));
+      hipLaunchKernelGGL(node_child_bounds_kernel, dim3(div_up(as.parents * 16u, 256u)), dim3(256), 0, c->stream, as.akey, m,
+                         plan.node_shift, as.parent_prefix, as.parents, cb);
+      SWZ_LAUNCH_CHECK(c);
+      SWZ_TRY(fused_scan(c, ChildExistsF{cb, as.parents, m, lb.counters}, ChildStartG{cb, lb.nstart}, as.parents * 8u,
+                         lb.counters + CTR_NUM_NODES, "lvl"));
+      hipLaunchKernelGGL(node_fill_kernel, dim3(div_up(m, NF_TILE)), dim3(256), 0, c->stream, lb.nstart, lb.counters, m, lb.nid);
+      SWZ_LAUNCH_CHECK(c);
     } else {
       SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
                          lb.counters + CTR_NUM_NODES, "lvl"));
@@ -1222,6 +1322,15 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
   }
   res->remaining = h[CTR_REMAINING];
   res->num_nodes = h[CTR_NUM_NODES];
+  res->node_prefix = nullptr;
+  if (okey && res->remaining && res->num_nodes) {  // for the next level's segmentation (two buffers: the one of the level above is still read)
+    uint64_t* np = nullptr;
+    SWZ_TRY(c->get((plan.level & 1) ? "lvl_node_prefix_1" : "lvl_node_prefix_0", (size_t)res->num_nodes, &np));
+    hipLaunchKernelGGL(node_prefix_kernel, dim3(div_up(res->num_nodes, 256)), dim3(256), 0, c->stream, lb.nstart, as.akey,
+                       plan.node_shift, res->num_nodes, np);
+    SWZ_LAUNCH_CHECK(c);
+    res->node_prefix = np;
+  }
   return SWZ_OK;
 }
 
@@ -1353,6 +1462,8 @@ static int session_prepare(swz_ctx* c, TileSession& t, double* d_xyz, uint32_t n
 // root_mode: -1 = decide per node from its count; 0/1 force take-all/sample for the FIRST level run
 // (sharded batches decide the root from the global point count).
 static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int first_mode) {
+  const uint64_t* pprefix = nullptr;
+  uint32_t parents = 0;
   for (int level = t.next_level; t.as.m > 0 && level <= last_level; ++level) {
     if (level > 20) return c->fail(SWZ_ERR_INTERNAL, "level loop ran past level 20");
     if (!t.key_buf[t.which]) {
@@ -1374,6 +1485,8 @@ static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int fi
     }
     SWZ_TRY(session_need_positions(c, t, plan));
     LevelResult r;
+    t.as.parent_prefix = pprefix;
+    t.as.parents = pprefix ? parents : 0u;
     SWZ_TRY(level_step(c, plan, t.as, t.sp, t.lb, t.level, t.key_buf[t.which], t.idx_buf[t.which], &r));
     t.visited += t.as.m;
     t.nodes += r.num_nodes;
@@ -1381,6 +1494,10 @@ static int session_run_levels(swz_ctx* c, TileSession& t, int last_level, int fi
     t.max_level = level;
     ++t.nlevels;
     t.as = ActiveSet{t.key_buf[t.which], t.idx_buf[t.which], r.remaining};
+    // (the nodes of this level for the next one's segmentation -- inside this call only: between two calls of a sharded
+    // batch other work of the context may reuse the buffer)
+    pprefix = r.node_prefix;
+    parents = r.num_nodes;
     t.which ^= 1;
     t.next_level = level + 1;
   }

@@ -1055,6 +1055,8 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   if (rest == 0) st.rekeyed = true;
 
   as = ActiveSet{w.surv_key[w.which], w.surv_idx[w.which], res->remaining};
+  as.parent_prefix = res->node_prefix;
+  as.parents = res->node_prefix ? res->num_nodes : 0u;
   w.which ^= 1;
   return SWZ_OK;
 }
@@ -1326,6 +1328,8 @@ static int tiler_batch_run(swz_tiler* t, int last_level, const ShardRoot* sr) {
   swz_ctx* c = t->c;
   BatchWork& w = t->bw;
   ActiveSet& as = t->as;
+  as.parent_prefix = nullptr;  // (known inside one call only, see session_run_levels)
+  as.parents = 0;
   for (int level = t->next_level; level <= last_level; ++level) {
     const bool shard_root = sr && sr->active && level == -1;
     if (as.m == 0 && !shard_root) break;
