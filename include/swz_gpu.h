@@ -108,6 +108,12 @@ int swz_sample_points(swz_ctx* ctx, int sampler, uint64_t max_points_per_node, c
                       uint64_t node_key, int32_t node_level, const double root_min[3],
                       const double root_max[3], float spacing_at_root, int behaviour,
                       uint8_t* taken_out, uint64_t* num_taken_out);
+/* The same on device buffers (d_xyz: num_points x 3); the flags stay on the device. */
+int swz_sample_points_device(swz_ctx* ctx, int sampler, uint64_t max_points_per_node, const uint64_t* d_keys,
+                             const uint32_t* d_idx, uint64_t n, const double* d_xyz, uint64_t num_points,
+                             uint64_t node_key, int32_t node_level, const double root_min[3],
+                             const double root_max[3], float spacing_at_root, int behaviour,
+                             uint8_t* d_taken_out, uint64_t* num_taken_out);
 
 /* required_morton_index_depth (core/tiling/Sampling.cpp:29-62 with get_node_level_to_sample_from /
  * first_node_level_obeying_spacing, core/tiling/Node.cpp:37-57): the depth of key bits a sampler needs at a node of
@@ -342,6 +348,28 @@ int swz_shard_begin_device(swz_ctx* ctx, const double* d_xyz_local, uint64_t n, 
 int swz_shard_root_taken_device(swz_ctx* ctx, double* d_xyz_out);
 int swz_shard_finish_device(swz_ctx* ctx, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
                             swz_tile_stats* stats);
+/* FAST (TilingAlgorithmV3, the reference's default: executable/main.cpp:299-301) on a sharded batch.  The start level comes
+ * from the distribution of the WHOLE batch (estimate_start_node_level_in_octree, TilingAlgorithms.cpp:1473-1535); start nodes
+ * lie at level >= 2, inside one shard's octants, so the levels from there down and the reconstruction of the skipped levels
+ * down to level 0 (reconstruct_left_out_nodes, :1717-1784) are local, and only the root is reconstructed across the shards:
+ *   swz_shard_fast_begin_device: indexes + sorts the shard's points; prefix_counts_out[8^6] (host) = its points per
+ *     6-octant prefix.  The driver sums the counts of all shards and calls swz_fast_start_level_from_counts.
+ *   swz_shard_fast_run: the levels from start_level - 1 down, then the skipped levels down to 0;
+ *     num_root_candidates_out = the points this shard's level-0 nodes hold.
+ *   swz_shard_fast_root_candidates_device: their keys and positions, in key order.  The root samples the candidates of ALL
+ *     shards, one behind the other in shard order (= octant order, the order the reference appends its children in), with
+ *     AlwaysAdhereToMinSpacing: swz_sample_points_device(..., node_level -1, SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, ...).
+ *   swz_shard_fast_set_root_device: d_taken = the flags of this shard's candidates (bit 0 of dup is set for them).
+ *   swz_shard_fast_finish_device: the outputs of swz_tile_device with the FAST strategy for the local points (d_dup_out:
+ *     bit l + 1 set = the point is also stored in its ancestor at node level l).
+ *   A shard without points takes part in every step with zero counts. */
+int swz_shard_fast_begin_device(swz_ctx* ctx, const double* d_xyz_local, uint64_t n, const double bounds_min[3],
+                                const double bounds_max[3], const swz_tile_params* params, uint32_t* prefix_counts_out);
+int swz_shard_fast_run(swz_ctx* ctx, int32_t start_level, uint64_t* num_root_candidates_out);
+int swz_shard_fast_root_candidates_device(swz_ctx* ctx, uint64_t* d_keys_out, double* d_xyz_out);
+int swz_shard_fast_set_root_device(swz_ctx* ctx, const uint8_t* d_taken);
+int swz_shard_fast_finish_device(swz_ctx* ctx, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out,
+                                 uint32_t* d_dup_out, swz_tile_stats* stats);
 
 /* ---- multi-batch tiling (BASELINE config 5's single-GPU shape).
  * The reference calls TilingAlgorithmBase::build_execution_graph once per batch of at most internal_cache_size
@@ -466,7 +494,9 @@ int swz_tiler_level_positions_device(swz_tiler* tiler, int level, double* d_xyz_
  *     MIN_DISTANCE swept by all shards at once, cells at a lower octant's face reading that shard's records through peer
  *     access -- cubic bounds, one address space; otherwise the chain of ghosts from lower to higher shards), levels.  results[s] describes what shard s
  *     ended up with, exactly as swz_shard_finish_device does: device pointers owned by the shard's context, valid
- *     until the group's next call.  ACCURATE strategy, exact samplers.
+ *     until the group's next call.  ACCURATE, or FAST (TilingAlgorithmV3: the start level from the whole batch's distribution, the
+ *     skipped levels rebuilt per shard and the root from all shards' level-0 nodes on shard 0 -- swz_shard_fast_*; d_dup then
+ *     says in which ancestors a point is stored as well); MIN_DISTANCE exact or in property mode (below the root).
  *   swz_group_ctx: the shard's context, e.g. for swz_copy_to_host, swz_build_node_lists_device or
  *     swz_gather_payload_device on that shard's results. */
 typedef struct swz_group swz_group;
@@ -478,6 +508,7 @@ typedef struct {
   swz_attribute_columns attrs; /* the attribute columns that travelled with the points (rows like d_xyz) */
   uint64_t num_points;
   swz_tile_stats stats;
+  const uint32_t* d_dup;   /* FAST: bit l + 1 set = the point is also stored in its ancestor at node level l (else NULL) */
 } swz_group_result;
 int swz_group_create(int num_shards, const int* devices, int transport, swz_group** group_out);
 int swz_group_destroy(swz_group* group);

@@ -330,6 +330,13 @@ def load_library():
     L.swz_shard_presort_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), C.c_uint64]
     L.swz_shard_root_taken_device.argtypes = [vp, vp]
     L.swz_shard_finish_device.argtypes = [vp, vp, vp, vp, C.POINTER(_TileStats)]
+    L.swz_shard_fast_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), _u32p]
+    L.swz_shard_fast_run.argtypes = [vp, C.c_int32, _u64p]
+    L.swz_shard_fast_root_candidates_device.argtypes = [vp, vp, vp]
+    L.swz_shard_fast_set_root_device.argtypes = [vp, vp]
+    L.swz_shard_fast_finish_device.argtypes = [vp, vp, vp, vp, vp, C.POINTER(_TileStats)]
+    L.swz_sample_points_device.argtypes = [vp, C.c_int, C.c_uint64, vp, vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, C.c_int32, _dp, _dp,
+                                           C.c_float, C.c_int, vp, _u64p]
     L.swz_tiler_create.argtypes = [vp, _dp, _dp, C.POINTER(_TileParams), C.c_uint64, C.POINTER(vp)]
     L.swz_tiler_destroy.argtypes = [vp]
     L.swz_tiler_add_batch_device.argtypes = [vp, vp, C.c_uint64, C.POINTER(_TileStats)]
@@ -379,7 +386,9 @@ def load_library():
                  "swz_tiler_level_positions_device", "swz_tiler_poison", "swz_tiler_pool_residency", "swz_tiler_store_residency",
                  "swz_tiler_shard_fast_histogram", "swz_fast_start_level_from_counts", "swz_tiler_shard_set_start_level",
                  "swz_tiler_shard_fast_finalize_local", "swz_tiler_shard_fast_set_root", "swz_shard_joint_root_possible",
-                 "swz_shard_joint_root_begin", "swz_shard_joint_root_probe", "swz_shard_joint_root_meet", "swz_shard_joint_root_end"):
+                 "swz_shard_joint_root_begin", "swz_shard_joint_root_probe", "swz_shard_joint_root_meet", "swz_shard_joint_root_end",
+                 "swz_shard_fast_begin_device", "swz_shard_fast_run", "swz_shard_fast_root_candidates_device",
+                 "swz_shard_fast_set_root_device", "swz_shard_fast_finish_device", "swz_sample_points_device"):
         getattr(L, name).restype = C.c_int
     _lib = L
     return L
@@ -625,6 +634,43 @@ class Context:
         self._check(self._lib.swz_shard_finish_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_perm),
                                                       C.c_void_p(d_level), C.byref(stats)))
         return _stats_dict(stats)
+
+    # -- FAST (TilingAlgorithmV3) on a sharded batch (include/swz_gpu.h, swz_shard_fast_*)
+    def shard_fast_begin_device(self, d_xyz_local, n, bmin, bmax, params):
+        """Indexes + sorts the shard's points.  Returns its points per 6-octant prefix (8^6 counts)."""
+        counts = np.zeros(1 << 18, dtype=np.uint32)
+        p = params._c()
+        self._check(self._lib.swz_shard_fast_begin_device(self._ctx, C.c_void_p(d_xyz_local), int(n), _vec3(bmin), _vec3(bmax),
+                                                          C.byref(p), counts.ctypes.data_as(_u32p)))
+        return counts
+
+    def shard_fast_run(self, start_level):
+        """The levels from the start level down and the local reconstruction.  Returns the points of this shard's level-0 nodes."""
+        out = C.c_uint64()
+        self._check(self._lib.swz_shard_fast_run(self._ctx, int(start_level), C.byref(out)))
+        return int(out.value)
+
+    def shard_fast_root_candidates_device(self, d_keys, d_xyz):
+        self._check(self._lib.swz_shard_fast_root_candidates_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_xyz)))
+
+    def shard_fast_set_root_device(self, d_taken):
+        self._check(self._lib.swz_shard_fast_set_root_device(self._ctx, C.c_void_p(d_taken)))
+
+    def shard_fast_finish_device(self, d_keys, d_perm, d_level, d_dup):
+        stats = _TileStats()
+        self._check(self._lib.swz_shard_fast_finish_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_perm), C.c_void_p(d_level),
+                                                           C.c_void_p(d_dup), C.byref(stats)))
+        return _stats_dict(stats)
+
+    def sample_points_device(self, sampler, max_points_per_node, d_keys, d_idx, n, d_xyz, num_points, node_key, node_level, root_min,
+                             root_max, spacing_at_root, behaviour, d_taken):
+        """swz_sample_points on device buffers.  Returns the number of taken points."""
+        num = C.c_uint64()
+        self._check(self._lib.swz_sample_points_device(self._ctx, int(sampler), int(max_points_per_node), C.c_void_p(d_keys),
+                                                       C.c_void_p(d_idx), int(n), C.c_void_p(d_xyz), int(num_points), int(node_key),
+                                                       int(node_level), _vec3(root_min), _vec3(root_max), C.c_float(spacing_at_root),
+                                                       int(behaviour), C.c_void_p(d_taken), C.byref(num)))
+        return int(num.value)
 
     # -- the MIN_DISTANCE root of a sharded batch swept by all ranks at once (one process per GPU; include/swz_gpu.h)
     def shard_joint_root_possible(self, bmin, bmax, params):

@@ -535,6 +535,52 @@ int swz_shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_o
   return st != SWZ_OK ? st : st2;
 }
 
+// ---- FAST (TilingAlgorithmV3) on a sharded batch
+int swz_shard_fast_begin_device(swz_ctx* c, const double* d_xyz_local, uint64_t n, const double bmin[3], const double bmax[3],
+                                const swz_tile_params* params, uint32_t* prefix_counts_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_bounds(c, bmin, bmax));
+  SWZ_TRY(check_params(c, params));
+  if ((n && !d_xyz_local) || !prefix_counts_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_begin_device: NULL buffer");
+  int st = swz::shard_fast_begin_device(c, d_xyz_local, (uint32_t)n, bmin, bmax, *params, prefix_counts_out);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
+}
+int swz_shard_fast_run(swz_ctx* c, int32_t start_level, uint64_t* num_root_candidates_out) {
+  if (!c || !num_root_candidates_out) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  int st = swz::shard_fast_run_device(c, start_level, num_root_candidates_out);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
+}
+int swz_shard_fast_root_candidates_device(swz_ctx* c, uint64_t* d_keys_out, double* d_xyz_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(swz::shard_fast_root_candidates_device(c, d_keys_out, d_xyz_out));
+  return sync(c);
+}
+int swz_shard_fast_set_root_device(swz_ctx* c, const uint8_t* d_taken) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(swz::shard_fast_set_root_device(c, d_taken));
+  return sync(c);
+}
+int swz_shard_fast_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out, uint32_t* d_dup_out,
+                                 swz_tile_stats* stats) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  if (stats) {
+    std::memset(stats, 0, sizeof(*stats));
+    stats->max_level = -1;
+    stats->fast_start_levels = -1;
+  }
+  int st = swz::shard_fast_finish_device(c, d_keys_out, d_perm_out, d_level_out, d_dup_out, stats);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
+}
+
 // ------------------------------------------------------------------------------ sample_points
 int swz_sample_points(swz_ctx* c, int sampler, uint64_t max_points_per_node, const uint64_t* keys,
                       const uint32_t* idx, uint64_t n, const double* xyz, uint64_t num_points, uint64_t node_key,
@@ -570,6 +616,27 @@ int swz_sample_points(swz_ctx* c, int sampler, uint64_t max_points_per_node, con
   }
   SWZ_TRY(download(c, taken_out, d_taken, (size_t)n));
   return sync(c);
+}
+
+// the same on device buffers (d_xyz: num_points x 3; results stay on the device)
+int swz_sample_points_device(swz_ctx* c, int sampler, uint64_t max_points_per_node, const uint64_t* d_keys, const uint32_t* d_idx,
+                             uint64_t n, const double* d_xyz, uint64_t num_points, uint64_t node_key, int32_t node_level,
+                             const double root_min[3], const double root_max[3], float spacing_at_root, int behaviour,
+                             uint8_t* d_taken_out, uint64_t* num_taken_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(check_n(c, n));
+  SWZ_TRY(check_n(c, num_points));
+  SWZ_TRY(check_bounds(c, root_min, root_max));
+  if (sampler < SWZ_RANDOM_GRID || sampler > SWZ_JITTERED) return c->fail(SWZ_ERR_BAD_ARG, "unknown sampler");
+  if (node_level < -1 || node_level > 20) return c->fail(SWZ_ERR_BAD_ARG, "node_level out of range");
+  if (num_taken_out) *num_taken_out = 0;
+  if (n == 0) return SWZ_OK;
+  if (!d_keys || !d_idx || !d_xyz || !d_taken_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_sample_points_device: NULL buffer");
+  int st = swz::sample_points_device(c, sampler, max_points_per_node, d_keys, d_idx, (uint32_t)n, d_xyz, node_key, node_level, root_min,
+                                     root_max, spacing_at_root, behaviour, d_taken_out, num_taken_out);
+  int st2 = sync(c);
+  return st != SWZ_OK ? st : st2;
 }
 
 // ------------------------------------------------------------------------------ node lists

@@ -117,6 +117,12 @@ struct swz_group {
   int fast_start = -1;                       // FAST: the start level, known after the first batch
   bool peer_access = true;                   // kernels of one shard may read the memory of every other (the joint MIN_DISTANCE root does)
   std::vector<std::vector<uint32_t>> hist;   // FAST, first batch: every shard's points per 6-octant prefix
+  // FAST in swz_group_tile: what every shard's level-0 nodes hold (the root is reconstructed from all of them on shard 0)
+  int fast_tile_start = -1;
+  std::vector<uint64_t*> cand_keys;
+  std::vector<double*> cand_xyz;
+  std::vector<uint64_t> cand_count;
+  uint8_t* cand_flags = nullptr;
   // batches staged from pinned host memory: two device buffers per shard, filled on a copy stream of their own
   struct Staged {
     std::vector<uint64_t> n;  // per shard
@@ -151,6 +157,11 @@ bool joint_root_possible(const swz_ctx* c, const swz_tile_params& p, const doubl
   sp.xyz = &dummy_xyz;
   sp.perm = &dummy_perm;
   return swz::key_metric(c, plan, sp).ok && plan.cell_levels_geo >= 1 && !plan.terminal && !plan.reroot;
+}
+
+__global__ __launch_bounds__(256) void grp_iota_kernel(uint32_t* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = i;
 }
 
 struct ShardCall {
@@ -318,7 +329,107 @@ void shard_thread(ShardCall a) {
   if (!all_ok(g)) ok = false;
   const bool proceed = ok || a.batch;  // a batch keeps every shard's tiler in step with the collective decisions below
 
-  if (!a.batch) {
+  if (!a.batch && a.params->strategy == SWZ_FAST) {
+    // 3F. TilingAlgorithmV3: no root step.  The start level from the distribution of the whole batch, the levels from
+    // there down and the skipped levels down to 0 on every shard by itself, the root from the level-0 nodes of all shards
+    // on shard 0 (swz_shard_fast_*).
+    stamp(1);
+    g->hist[r].assign(1u << 18, 0u);
+    if (ok && global_points < a.params->fast_concurrency) ok = fail(g, r, SWZ_ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points");
+    GRP_TRY(swz_shard_fast_begin_device(c, recv, m, a.bmin, a.bmax, a.params, g->hist[r].data()));
+    g->barrier.wait();
+    if (r == 0) {
+      std::vector<uint64_t> sum(1u << 18, 0);
+      for (int s = 0; s < N; ++s)
+        for (uint32_t b = 0; b < (1u << 18); ++b) sum[b] += g->hist[s][b];
+      int32_t S = -1;
+      (void)swz_fast_start_level_from_counts(sum.data(), a.params->fast_concurrency, &S);
+      g->fast_tile_start = S;
+    }
+    g->barrier.wait();
+    if (!all_ok(g)) ok = false;
+    uint64_t ncand = 0;
+    GRP_TRY(swz_shard_fast_run(c, g->fast_tile_start, &ncand));
+    uint64_t* ck = nullptr;
+    double* cx = nullptr;
+    if (ok && c->get("grp_cand_keys", (size_t)std::max<uint64_t>(ncand, 1), &ck) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    if (ok && c->get("grp_cand_xyz", (size_t)std::max<uint64_t>(ncand, 1) * 3, &cx) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    if (ncand) GRP_TRY(swz_shard_fast_root_candidates_device(c, ck, cx));
+    GRP_HIP(hipStreamSynchronize(c->stream));
+    g->cand_keys[r] = ck;
+    g->cand_xyz[r] = cx;
+    g->cand_count[r] = ok ? ncand : 0;
+    stamp(2);
+    g->barrier.wait();  // ---- every shard's candidates are in place
+    const bool go_root = all_ok(g);
+    if (!go_root) ok = false;
+    std::vector<uint64_t> off(N + 1, 0);
+    for (int s = 0; s < N; ++s) off[s + 1] = off[s] + g->cand_count[s];
+    if (r == 0 && go_root) {
+      const uint64_t total = off[N];
+      g->cand_flags = nullptr;
+      if (total > 0xFFFF0000ull) ok = fail(g, r, SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points in the level-0 nodes");
+      if (ok && total) {
+        uint64_t* keys = nullptr;
+        double* all = nullptr;
+        uint32_t* iota = nullptr;
+        uint8_t* taken = nullptr;
+        if (c->get("grp_root_skeys", (size_t)total, &keys) != SWZ_OK || c->get("grp_root_xyz", (size_t)total * 3, &all) != SWZ_OK ||
+            c->get("grp_root_perm", (size_t)total, &iota) != SWZ_OK || c->get("grp_root_taken", (size_t)total, &taken) != SWZ_OK)
+          ok = fail(g, r, SWZ_ERR_HIP, c->err);
+        GRP_HIP(hipStreamSynchronize(c->stream));  // (the peer copies are not ordered with this shard's stream)
+        for (int s = 0; s < N && ok; ++s) {
+          if (!g->cand_count[s]) continue;
+          GRP_HIP(hipMemcpyPeer(keys + off[s], g->devices[0], g->cand_keys[s], g->devices[s], (size_t)g->cand_count[s] * 8));
+          GRP_HIP(hipMemcpyPeer(all + off[s] * 3, g->devices[0], g->cand_xyz[s], g->devices[s], (size_t)g->cand_count[s] * 24));
+        }
+        GRP_HIP(hipDeviceSynchronize());  // (a device-to-device hipMemcpyPeer may return before it is done; this shard's stream does not wait for it)
+        if (ok) {
+          hipLaunchKernelGGL(grp_iota_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, c->stream, iota, (uint32_t)total);
+          // the candidates of the shards one behind the other are in key order: the shards own ascending octants
+          GRP_TRY(swz::sample_points_device(c, a.params->sampler, a.params->max_points_per_node, keys, iota, (uint32_t)total, all, 0, -1, a.bmin,
+                                            a.bmax, a.params->spacing_at_root, SWZ_ALWAYS_ADHERE_TO_MIN_SPACING, taken, nullptr));
+          GRP_HIP(hipStreamSynchronize(c->stream));
+        }
+        g->cand_flags = taken;
+      }
+    }
+    g->barrier.wait();  // ---- the root is sampled (or shard 0 has failed)
+    if (!all_ok(g)) ok = false;
+    if (ok && ncand) {
+      uint8_t* mine = nullptr;
+      if (r == 0) {
+        mine = g->cand_flags;
+      } else {
+        if (c->get("grp_cand_flags", (size_t)ncand, &mine) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+        GRP_HIP(hipStreamSynchronize(c->stream));
+        GRP_HIP(hipMemcpyPeer(mine, g->devices[r], g->cand_flags + off[r], g->devices[0], (size_t)ncand));
+        GRP_HIP(hipDeviceSynchronize());
+      }
+      GRP_TRY(swz_shard_fast_set_root_device(c, mine));
+    }
+    uint64_t* okeys = nullptr;
+    uint32_t *operm = nullptr, *odup = nullptr;
+    int8_t* olevel = nullptr;
+    if (ok && c->get("grp_out_keys", (size_t)m, &okeys) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    if (ok && c->get("grp_out_perm", (size_t)m, &operm) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    if (ok && c->get("grp_out_level", (size_t)m, &olevel) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    if (ok && c->get("grp_out_dup", (size_t)m, &odup) != SWZ_OK) ok = fail(g, r, SWZ_ERR_HIP, c->err);
+    swz_tile_stats stats{};
+    GRP_TRY(swz_shard_fast_finish_device(c, okeys, operm, olevel, odup, &stats));
+    GRP_HIP(hipStreamSynchronize(c->stream));
+    stamp(3);
+    if (a.result) {
+      a.result->d_xyz = recv;
+      a.result->d_keys = okeys;
+      a.result->d_perm = operm;
+      a.result->d_level = olevel;
+      a.result->attrs = recv_attr;
+      a.result->num_points = ok ? m : 0;
+      a.result->stats = stats;
+      a.result->d_dup = odup;
+    }
+  } else if (!a.batch) {
   // 3. the root node
   stamp(1);
   const bool sequential_root = a.params->sampler == SWZ_MIN_DISTANCE && global_points > a.params->max_points_per_node;
@@ -401,6 +512,7 @@ void shard_thread(ShardCall a) {
     a.result->attrs = recv_attr;
     a.result->num_points = ok ? m : 0;
     a.result->stats = stats;
+    a.result->d_dup = nullptr;
   }
   } else if (proceed) {
     // 3'. one batch of the shard's tiler (swz_tiler_shard_*): the root's take-all / sample decision uses the counts of
@@ -574,6 +686,10 @@ int swz_group_create(int num_shards, const int* devices, int transport, swz_grou
   g->root_taken.assign(num_shards, nullptr);
   g->root_taken_count.assign(num_shards, 0);
   g->views.assign(num_shards, swz::MdPeerView{});
+  g->hist.assign(num_shards, std::vector<uint32_t>());
+  g->cand_keys.assign(num_shards, nullptr);
+  g->cand_xyz.assign(num_shards, nullptr);
+  g->cand_count.assign(num_shards, 0);
   g->timing.assign(num_shards, std::array<double, 4>{{0, 0, 0, 0}});
   g->status.assign(num_shards, SWZ_OK);
   g->status_msg.assign(num_shards, "");
@@ -633,8 +749,8 @@ swz_ctx* swz_group_ctx(swz_group* g, int shard) { return (g && shard >= 0 && sha
 int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_columns* d_attrs, const uint64_t* n, const double bmin[3],
                    const double bmax[3], const swz_tile_params* params, swz_group_result* results) {
   if (!g || !d_xyz || !n || !bmin || !bmax || !params) return SWZ_ERR_BAD_ARG;
-  if (params->strategy != SWZ_ACCURATE || (params->flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY)) {
-    g->err = "sharded batches support the ACCURATE strategy and exact MIN_DISTANCE";
+  if (params->strategy != SWZ_ACCURATE && params->strategy != SWZ_FAST) {
+    g->err = "unknown strategy";
     return SWZ_ERR_BAD_ARG;
   }
   if (d_attrs)
@@ -903,6 +1019,7 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
       }
     }
     (void)hipSetDevice(g->devices[0]);
+    (void)hipDeviceSynchronize();  // (a device-to-device hipMemcpyPeer may return before it is done; shard 0's stream does not wait for it)
     int rc = swz_morton_encode_device(c0, all, total, g->tbmin, g->tbmax, keys);
     if (rc == SWZ_OK) rc = swz_sort_by_key_device(c0, keys, total, perm, skeys);
     if (rc == SWZ_OK)
@@ -929,6 +1046,7 @@ int swz_group_finalize(swz_group* g, swz_tile_stats* stats) {
           c->err = "copy of the root flags failed";
           return shard_fail(r, SWZ_ERR_HIP);
         }
+        (void)hipDeviceSynchronize();
       }
     }
     const int rc = swz_tiler_shard_fast_set_root(g->tiler[r], mine);

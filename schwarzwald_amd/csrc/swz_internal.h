@@ -189,6 +189,14 @@ int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, 
                         swz_tile_stats* stats);
 int shard_begin_empty(swz_ctx* c);
 void shard_free(swz_ctx* c);
+// FAST on a sharded batch (swz_shard_fast_*)
+int shard_fast_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
+                            const swz_tile_params& p, uint32_t* counts_host);
+int shard_fast_run_device(swz_ctx* c, int start_level, uint64_t* num_root_candidates);
+int shard_fast_root_candidates_device(swz_ctx* c, uint64_t* d_keys_out, double* d_xyz_out);
+int shard_fast_set_root_device(swz_ctx* c, const uint8_t* d_taken);
+int shard_fast_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out, uint32_t* d_dup_out,
+                             swz_tile_stats* stats);
 // One radix pass on the top key digit: perm groups the points by octant (stable); octants (host)
 // receives the eight counts.
 int partition_top_digit(swz_ctx* c, const uint64_t* d_keys, uint32_t n, uint32_t* d_perm_out, uint64_t octants[8]);

@@ -1626,32 +1626,19 @@ int fast_start_level(swz_ctx* c, const uint64_t* d_keys_sorted, uint32_t n, uint
   return SWZ_OK;
 }
 
-int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
-                const swz_tile_params& p, const TileDeviceOut& out_in, swz_tile_stats* stats) {
-  TileDeviceOut out = out_in;
-  if (p.strategy == SWZ_FAST && !out.dup) SWZ_TRY(c->get("fast_dup", (size_t)n, &out.dup));
-  TileSession t;
-  SWZ_TRY(session_prepare(c, t, d_xyz, n, bmin, bmax, p, out));
-  if (p.strategy == SWZ_ACCURATE) {
-    SWZ_TRY(session_run_levels(c, t, 20, -1));
-    session_stats(t, stats);
-    return SWZ_OK;
-  }
-  // ---- FAST: TilingAlgorithmV3 first iteration (:1250-1360) + finalize (:1717-1784)
-  int S = 0;
-  SWZ_TRY(fast_start_level(c, t.keys, n, p.fast_concurrency, &S));
-  t.fast_start = S;
-  // every point starts in the node made of its first S octants (split_indexed_points_into_subranges)
-  t.next_level = S - 1;
-  SWZ_TRY(session_run_levels(c, t, 20, -1));
-  // reconstruct the skipped levels, deepest first: a node with lv octants samples the points persisted
-  // by its (up to) 8 children with AlwaysAdhereToMinSpacing (reconstruct_single_node :1661-1715)
+// FAST: reconstruct the skipped levels S-1 .. lowest_lv, deepest first: a node with lv octants samples the points
+// persisted by its (up to) 8 children with AlwaysAdhereToMinSpacing (reconstruct_single_node :1661-1715).
+// lowest_lv = 0 includes the root; a shard of a sharded batch stops at 1 (the root's children lie on several shards).
+static int session_fast_reconstruct(swz_ctx* c, TileSession& t, const swz_tile_params& p, int S, int lowest_lv) {
+  const uint32_t n = t.n;
+  const double* bmin = t.bmin;
+  const double* bmax = t.bmax;
   uint64_t* rkey = nullptr;
   uint32_t* ridx = nullptr;
   SWZ_TRY(c->get("recon_keys", (size_t)n, &rkey));
   SWZ_TRY(c->get("recon_idx", (size_t)n, &ridx));
   const uint32_t nb = div_up(n, 256);
-  for (int lv = S - 1; lv >= 0; --lv) {
+  for (int lv = S - 1; lv >= lowest_lv; --lv) {
     const uint32_t child_bit = (lv + 1 == S) ? 0u : (1u << (lv + 1));
     hipLaunchKernelGGL(recon_select_kernel, dim3(nb), dim3(256), 0, c->stream, t.level, t.dup, n, S - 1, child_bit,
                        t.lb.flags);
@@ -1678,6 +1665,28 @@ int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], con
     t.nodes += r.num_nodes;
     t.rounds += r.md_rounds;
   }
+  return SWZ_OK;
+}
+
+int tile_device(swz_ctx* c, double* d_xyz, uint32_t n, const double bmin[3], const double bmax[3],
+                const swz_tile_params& p, const TileDeviceOut& out_in, swz_tile_stats* stats) {
+  TileDeviceOut out = out_in;
+  if (p.strategy == SWZ_FAST && !out.dup) SWZ_TRY(c->get("fast_dup", (size_t)n, &out.dup));
+  TileSession t;
+  SWZ_TRY(session_prepare(c, t, d_xyz, n, bmin, bmax, p, out));
+  if (p.strategy == SWZ_ACCURATE) {
+    SWZ_TRY(session_run_levels(c, t, 20, -1));
+    session_stats(t, stats);
+    return SWZ_OK;
+  }
+  // ---- FAST: TilingAlgorithmV3 first iteration (:1250-1360) + finalize (:1717-1784)
+  int S = 0;
+  SWZ_TRY(fast_start_level(c, t.keys, n, p.fast_concurrency, &S));
+  t.fast_start = S;
+  // every point starts in the node made of its first S octants (split_indexed_points_into_subranges)
+  t.next_level = S - 1;
+  SWZ_TRY(session_run_levels(c, t, 20, -1));
+  SWZ_TRY(session_fast_reconstruct(c, t, p, S, 0));
   session_stats(t, stats);
   return SWZ_OK;
 }
@@ -1693,6 +1702,8 @@ struct ShardState {
   const double* xyz_local = nullptr;
   bool perm_local = false;  // perm of the local points counts from the first LOCAL point
   bool empty = false;       // the open batch has no local points
+  bool fast = false;        // the open batch runs the FAST strategy (swz_shard_fast_*)
+  uint32_t fast_candidates = 0;  // points of this shard's level-0 nodes: what the root is reconstructed from
 };
 
 static ShardState* shard_state(swz_ctx* c) {
@@ -1702,6 +1713,7 @@ static ShardState* shard_state(swz_ctx* c) {
 int shard_begin_empty(swz_ctx* c) {
   ShardState* s = shard_state(c);
   s->presorted = false;
+  s->fast = false;
   s->t = TileSession{};
   s->n_local = 0;
   s->empty = true;
@@ -1753,11 +1765,12 @@ __global__ __launch_bounds__(256) void shard_strip_kernel(const uint64_t* __rest
 // same time, so that only the root node itself is left in the chain that passes the ghosts from shard to shard.
 int shard_presort_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
                          const swz_tile_params& p, uint32_t ghost_capacity) {
-  if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "this call runs the ACCURATE strategy of a sharded batch (FAST: swz_shard_fast_*)");
   if ((uint64_t)n + ghost_capacity > 0xFFFFFFFEull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "shard + ghosts exceed 2^32-2 points");
   ShardState* s = shard_state(c);
   s->open = false;
   s->presorted = false;
+  s->fast = false;
   TileDeviceOut out{};
   const size_t cap = (size_t)n + ghost_capacity;
   SWZ_TRY(c->get("shard_keys", cap, &out.keys));
@@ -1818,10 +1831,11 @@ static int shard_attach_ghosts(swz_ctx* c, ShardState* s, const double* d_ghost_
 int shard_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3],
                        const double bmax[3], const swz_tile_params& p, uint64_t global_points,
                        const double* d_ghost_xyz, uint32_t ghosts, uint64_t* num_root_taken) {
-  if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "sharded batches support the ACCURATE strategy");
+  if (p.strategy != SWZ_ACCURATE) return c->fail(SWZ_ERR_BAD_ARG, "this call runs the ACCURATE strategy of a sharded batch (FAST: swz_shard_fast_*)");
   ShardState* s = shard_state(c);
   s->open = false;
   s->empty = false;
+  s->fast = false;
   const uint32_t total = n + ghosts;
   const bool fast = s->presorted && s->xyz_local == d_xyz_local && s->n_local == n && ghosts <= s->front;
   s->presorted = false;
@@ -1896,6 +1910,153 @@ int shard_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, 
   hipLaunchKernelGGL(shard_strip_kernel, dim3(div_up(s->n_local, 256)), dim3(256), 0, c->stream, s->t.keys, s->t.perm,
                      s->t.level, s->t.ghosts, s->perm_local ? 0u : s->t.ghosts, s->n_local, d_keys_out, d_perm_out, d_level_out);
   SWZ_LAUNCH_CHECK(c);
+  session_stats(s->t, stats);
+  return SWZ_OK;
+}
+
+// ---- FAST (TilingAlgorithmV3, the reference's default) on a sharded batch.  The start level comes from the distribution
+// of the WHOLE batch (:1473-1535): every shard reports the counts of its part per 6-octant prefix, the driver sums them
+// and tells every shard the level.  Start nodes lie at level >= 2, inside one shard's octants, so the levels from there
+// down and the reconstruction of the skipped levels down to level 0 (:1717-1784) are local; the root is reconstructed
+// from what the level-0 nodes of ALL shards hold -- in octant order, which is shard order --, so the driver collects
+// those candidates (swz_shard_fast_root_candidates_device), samples them in one place (swz_sample_points_device with
+// AlwaysAdhereToMinSpacing at node level -1) and hands every shard the flags of its part.
+__global__ __launch_bounds__(256) void shard_fast_cand_kernel(const uint64_t* __restrict__ keys, uint32_t n, const uint32_t* __restrict__ pos,
+                                                              const int8_t* __restrict__ level, const uint32_t* __restrict__ dup,
+                                                              int start_node_level, uint32_t child_bit, SortedPoints sp,
+                                                              uint64_t* __restrict__ okeys, double* __restrict__ oxyz) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool sel = child_bit ? ((dup[i] & child_bit) != 0) : (level[i] == (int8_t)start_node_level);
+  if (!sel) return;
+  const uint64_t o = pos[i];
+  okeys[o] = keys[i];
+  if (sp.X) {
+    oxyz[3 * o] = sp.X[i];
+    oxyz[3 * o + 1] = sp.Y[i];
+    oxyz[3 * o + 2] = sp.Z[i];
+  } else {
+    const double* q = sorted_point_xyz(sp.xyz, sp.perm, sp.ghost_xyz, sp.ghosts, i);
+    oxyz[3 * o] = q[0];
+    oxyz[3 * o + 1] = q[1];
+    oxyz[3 * o + 2] = q[2];
+  }
+}
+__global__ __launch_bounds__(256) void shard_fast_mark_root_kernel(uint32_t n, const uint32_t* __restrict__ pos, const int8_t* __restrict__ level,
+                                                                   uint32_t* __restrict__ dup, int start_node_level, uint32_t child_bit,
+                                                                   const uint8_t* __restrict__ taken) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool sel = child_bit ? ((dup[i] & child_bit) != 0) : (level[i] == (int8_t)start_node_level);
+  if (sel && taken[pos[i]]) dup[i] |= 1u;
+}
+__global__ __launch_bounds__(256) void shard_fast_strip_kernel(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                                               const int8_t* __restrict__ level, const uint32_t* __restrict__ dup, uint32_t n,
+                                                               uint64_t* __restrict__ okeys, uint32_t* __restrict__ operm,
+                                                               int8_t* __restrict__ olevel, uint32_t* __restrict__ odup) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  okeys[i] = keys[i];
+  operm[i] = perm[i];
+  olevel[i] = level[i];
+  odup[i] = dup[i];
+}
+
+int shard_fast_begin_device(swz_ctx* c, const double* d_xyz_local, uint32_t n, const double bmin[3], const double bmax[3],
+                            const swz_tile_params& p, uint32_t* counts_host) {
+  if (p.strategy != SWZ_FAST) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_begin_device: not the FAST strategy");
+  ShardState* s = shard_state(c);
+  s->open = false;
+  s->presorted = false;
+  s->fast = true;
+  s->fast_candidates = 0;
+  s->empty = n == 0;
+  s->n_local = n;
+  if (n == 0) {
+    s->t = TileSession{};
+    s->t.params = p;
+    for (uint32_t b = 0; b < (1u << 18); ++b) counts_host[b] = 0;
+    s->open = true;
+    return SWZ_OK;
+  }
+  TileDeviceOut out{};
+  SWZ_TRY(c->get("shard_keys", (size_t)n, &out.keys));
+  SWZ_TRY(c->get("shard_perm", (size_t)n, &out.perm));
+  SWZ_TRY(c->get("shard_level", (size_t)n, &out.level));
+  SWZ_TRY(c->get("shard_dup", (size_t)n, &out.dup));
+  SWZ_TRY(session_prepare(c, s->t, const_cast<double*>(d_xyz_local), n, bmin, bmax, p, out));
+  s->perm_local = true;
+  SWZ_TRY(fast_prefix_counts(c, s->t.keys, n, counts_host));
+  s->open = true;
+  return SWZ_OK;
+}
+
+// the levels from the start level down, the local reconstruction, and how many points this shard's level-0 nodes hold
+int shard_fast_run_device(swz_ctx* c, int start_level, uint64_t* num_root_candidates) {
+  ShardState* s = shard_state(c);
+  if (!s->open || !s->fast) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_run: no FAST sharded batch is open");
+  if (start_level < 1 || start_level > 6) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_run: start levels 1..6");
+  *num_root_candidates = 0;
+  TileSession& t = s->t;
+  t.fast_start = start_level;
+  if (s->empty) return SWZ_OK;
+  t.next_level = start_level - 1;
+  SWZ_TRY(session_run_levels(c, t, 20, -1));
+  SWZ_TRY(session_fast_reconstruct(c, t, t.params, start_level, 1));
+  // what the root's children hold (the selection of reconstruct level 0)
+  const uint32_t child_bit = (1 == start_level) ? 0u : 2u;
+  uint32_t* pos = nullptr;
+  SWZ_TRY(c->get("shard_fast_pos", (size_t)t.n, &pos));
+  hipLaunchKernelGGL(recon_select_kernel, dim3(div_up(t.n, 256)), dim3(256), 0, c->stream, t.level, t.dup, t.n, start_level - 1, child_bit, pos);
+  SWZ_LAUNCH_CHECK(c);
+  SWZ_HIP(c, hipMemsetAsync(t.lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
+  SWZ_TRY(scan_exclusive_u32(c, pos, pos, t.n, t.lb.counters + CTR_REMAINING, "rec"));
+  uint32_t m = 0;
+  SWZ_HIP(c, hipMemcpyAsync(&m, t.lb.counters + CTR_REMAINING, 4, hipMemcpyDeviceToHost, c->stream));
+  SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  s->fast_candidates = m;
+  *num_root_candidates = m;
+  return SWZ_OK;
+}
+
+int shard_fast_root_candidates_device(swz_ctx* c, uint64_t* d_keys_out, double* d_xyz_out) {
+  ShardState* s = shard_state(c);
+  if (!s->open || !s->fast) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_root_candidates_device: no FAST sharded batch is open");
+  if (s->empty || !s->fast_candidates) return SWZ_OK;
+  TileSession& t = s->t;
+  uint32_t* pos = nullptr;
+  SWZ_TRY(c->get("shard_fast_pos", (size_t)t.n, &pos));
+  hipLaunchKernelGGL(shard_fast_cand_kernel, dim3(div_up(t.n, 256)), dim3(256), 0, c->stream, t.keys, t.n, pos, t.level, t.dup,
+                     t.fast_start - 1, (1 == t.fast_start) ? 0u : 2u, t.sp, d_keys_out, d_xyz_out);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}
+
+int shard_fast_set_root_device(swz_ctx* c, const uint8_t* d_taken) {
+  ShardState* s = shard_state(c);
+  if (!s->open || !s->fast) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_set_root_device: no FAST sharded batch is open");
+  if (s->empty || !s->fast_candidates) return SWZ_OK;
+  TileSession& t = s->t;
+  uint32_t* pos = nullptr;
+  SWZ_TRY(c->get("shard_fast_pos", (size_t)t.n, &pos));
+  hipLaunchKernelGGL(shard_fast_mark_root_kernel, dim3(div_up(t.n, 256)), dim3(256), 0, c->stream, t.n, pos, t.level, t.dup,
+                     t.fast_start - 1, (1 == t.fast_start) ? 0u : 2u, d_taken);
+  SWZ_LAUNCH_CHECK(c);
+  return SWZ_OK;
+}
+
+int shard_fast_finish_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_perm_out, int8_t* d_level_out, uint32_t* d_dup_out,
+                             swz_tile_stats* stats) {
+  ShardState* s = shard_state(c);
+  if (!s->open || !s->fast) return c->fail(SWZ_ERR_BAD_ARG, "swz_shard_fast_finish_device: no FAST sharded batch is open");
+  s->open = false;
+  s->fast = false;
+  if (!s->empty) {
+    hipLaunchKernelGGL(shard_fast_strip_kernel, dim3(div_up(s->n_local, 256)), dim3(256), 0, c->stream, s->t.keys, s->t.perm, s->t.level,
+                       s->t.dup, s->n_local, d_keys_out, d_perm_out, d_level_out, d_dup_out);
+    SWZ_LAUNCH_CHECK(c);
+  }
+  s->empty = false;
   session_stats(s->t, stats);
   return SWZ_OK;
 }

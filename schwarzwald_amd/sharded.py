@@ -300,7 +300,8 @@ class ShardedTiler:
         total = torch.tensor([n], dtype=torch.int64, device=dev if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(total, group=self.group)
         global_points = int(total.item())
-        sequential_root = self.params.sampler == api.MIN_DISTANCE and global_points > self.params.max_points_per_node
+        sequential_root = (self.params.strategy != api.FAST and self.params.sampler == api.MIN_DISTANCE and
+                           global_points > self.params.max_points_per_node)
         headroom = GHOST_HEADROOM if (sequential_root and self.rank > 0) else 0
         buf, recv_counts = exchange_rows(send, send_counts, self.group, headroom)
         recv_counts_total = sum(recv_counts)
@@ -330,6 +331,8 @@ class ShardedTiler:
                 failure.append(e)
                 return default
 
+        if self.params.strategy == api.FAST:
+            return self._tile_fast(buf, recv, m, global_points, failure, guarded, stages, t0)
         # 3. root node.  m == 0 (this rank's octants are empty, e.g. the upper half of a cubic box around flat
         # terrain) is an ordinary shard: the library takes nothing of the root and reports zero points.
         possible = (sequential_root and world > 1 and self.joint_root and dev.type == "cuda" and
@@ -401,6 +404,109 @@ class ShardedTiler:
             raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
         self.result = (recv, okeys, operm, olevel)
         self._keepalive = buf  # the context reads the points until shard_finish returned
+        stats["shard_points"] = m
+        stats["root_mode"] = self.root_mode
+        return stats
+
+    def _tile_fast(self, buf, recv, m, global_points, failure, guarded, stages, t0):
+        """FAST (TilingAlgorithmV3, the reference's default, executable/main.cpp:299-301) on this batch: no root step.  The start
+        level comes from the distribution of the whole batch (TilingAlgorithms.cpp:1473-1535: the ranks' prefix histograms
+        summed), the levels from there down and the skipped levels down to 0 are local, and the root (reconstruct_single_node,
+        :1661-1715) samples what the level-0 nodes of ALL ranks hold -- one behind the other in rank order = octant order --
+        on rank 0 with AlwaysAdhereToMinSpacing; every rank gets the flags of its candidates back.  self.result holds
+        (recv_xyz, keys, perm, level, dup)."""
+        ctx, dev, world = self.ctx, self.device, self.world
+        on_gpu = dist.get_backend(self.group) == "nccl"
+        wire_dev = dev if on_gpu else "cpu"
+        wire = (lambda t: t) if on_gpu else (lambda t: t.cpu())
+        self.root_mode = "reconstructed on rank 0"
+
+        def vote():
+            flag = torch.tensor([1 if failure else 0], dtype=torch.int64, device=wire_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if int(flag.item()):
+                if failure:
+                    raise failure[0]
+                raise api.SwzError(api.ERR_PEER_FAILED, "another rank failed to tile its shard of this batch")
+
+        if global_points < self.params.fast_concurrency:
+            failure.append(api.SwzError(api.ERR_BAD_ARG, "FAST: a batch needs at least fast_concurrency points"))
+        hist = guarded(lambda: ctx.shard_fast_begin_device(recv.data_ptr(), m, self.bmin, self.bmax, self.params),
+                       np.zeros(1 << 18, dtype=np.uint32))
+        vote()
+        h = torch.from_numpy(hist.astype(np.int64)).to(wire_dev)
+        dist.all_reduce(h, group=self.group)
+        start = api.fast_start_level_from_counts(h.cpu().numpy().astype(np.uint64), self.params.fast_concurrency)
+        ncand = guarded(lambda: ctx.shard_fast_run(start), 0)
+        ckeys = torch.empty(max(ncand, 1), dtype=torch.int64, device=dev)
+        cxyz = torch.empty((max(ncand, 1), 3), dtype=torch.float64, device=dev)
+        if ncand:
+            guarded(lambda: ctx.shard_fast_root_candidates_device(ckeys.data_ptr(), cxyz.data_ptr()), None)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        stages.mark("levels_ms")
+        vote()
+        counts = torch.zeros(world, dtype=torch.int64, device=wire_dev)
+        counts[self.rank] = ncand
+        dist.all_reduce(counts, group=self.group)
+        counts = [int(c) for c in counts.cpu()]
+        ckeys, cxyz = ckeys[:ncand], cxyz[:ncand]
+        flags = None
+        taken_all = None
+        if self.rank == 0:
+            kparts, xparts = [ckeys], [cxyz]
+            for r in range(1, world):
+                kb = torch.empty(counts[r], dtype=torch.int64, device=wire_dev)
+                xb = torch.empty((counts[r], 3), dtype=torch.float64, device=wire_dev)
+                if counts[r]:
+                    dist.recv(kb, src=r, group=self.group)
+                    dist.recv(xb, src=r, group=self.group)
+                kparts.append(kb.to(dev))
+                xparts.append(xb.to(dev))
+            allk, allx = torch.cat(kparts), torch.cat(xparts).contiguous()
+            total = allk.shape[0]
+            taken_all = torch.zeros(max(total, 1), dtype=torch.uint8, device=dev)
+            if total:
+                # (the ranks own ascending octants: their candidates one behind the other are in key order)
+                idx = torch.arange(total, dtype=torch.int32, device=dev)
+                guarded(lambda: ctx.sample_points_device(self.params.sampler, self.params.max_points_per_node, allk.data_ptr(),
+                                                         idx.data_ptr(), total, allx.data_ptr(), total, 0, -1, self.bmin, self.bmax,
+                                                         self.params.spacing_at_root, api.ALWAYS_ADHERE_TO_MIN_SPACING,
+                                                         taken_all.data_ptr()), 0)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+        elif ncand:
+            dist.send(wire(ckeys), dst=0, group=self.group)
+            dist.send(wire(cxyz), dst=0, group=self.group)
+        vote()  # (rank 0 has sampled the root, or failed to: the others learn which before they wait for their flags)
+        if self.rank == 0:
+            off = 0
+            for r in range(world):
+                part = taken_all[off:off + counts[r]]
+                off += counts[r]
+                if r == 0:
+                    flags = part.contiguous()
+                elif counts[r]:
+                    dist.send(wire(part.contiguous()), dst=r, group=self.group)
+        elif ncand:
+            fb = torch.empty(ncand, dtype=torch.uint8, device=wire_dev)
+            dist.recv(fb, src=0, group=self.group)
+            flags = fb.to(dev)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        if ncand:
+            guarded(lambda: ctx.shard_fast_set_root_device(flags.data_ptr()), None)
+        stages.mark("root_ms")
+        okeys = torch.empty(m, dtype=torch.int64, device=dev)
+        operm = torch.empty(m, dtype=torch.int32, device=dev)
+        olevel = torch.empty(m, dtype=torch.int8, device=dev)
+        odup = torch.empty(m, dtype=torch.int32, device=dev)
+        zero = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
+        stats = guarded(lambda: ctx.shard_fast_finish_device(okeys.data_ptr(), operm.data_ptr(), olevel.data_ptr(), odup.data_ptr()), zero)
+        self._stages = stages
+        vote()
+        self.result = (recv, okeys, operm, olevel, odup)
+        self._keepalive = buf
         stats["shard_points"] = m
         stats["root_mode"] = self.root_mode
         return stats

@@ -84,6 +84,9 @@ int main(int argc, char** argv) {
     std::vector<size_t> cut(shards + 1, 0);
     for (int s = 1; s <= shards; ++s) cut[s] = (s == 2 && shards > 2) ? cut[1] : std::min(n, (size_t)((double)n * s * s / ((double)shards * shards)));
     cut[shards] = n;
+    // (FAST: TilingAlgorithmV3 through the same call -- start level from the shards' summed prefix counts, the skipped levels
+    // rebuilt per shard, the root from all shards' level-0 nodes on shard 0; the rows then carry the dup mask as well)
+    for (int strategy : {SWZ_ACCURATE, SWZ_FAST})
     for (int sampler = 0; sampler < 4; ++sampler) {
       std::vector<double*> d_xyz(shards, nullptr);
       std::vector<swz_attribute_columns> d_attrs(shards);
@@ -107,7 +110,7 @@ int main(int argc, char** argv) {
       p.max_points_per_node = 2000;
       p.spacing_at_root = spacing;
       p.max_depth = 100;
-      p.strategy = SWZ_ACCURATE;
+      p.strategy = strategy;
       p.fast_concurrency = 8;
       std::vector<swz_group_result> res(shards);
       if (swz_group_tile(g, d_xyz.data(), d_attrs.data(), cnt.data(), mn, mx, &p, res.data()) != SWZ_OK) return fail("swz_group_tile", swz_group_last_error(g));
@@ -119,6 +122,7 @@ int main(int argc, char** argv) {
         std::vector<uint64_t> k(m);
         std::vector<uint32_t> perm(m);
         std::vector<int8_t> lv(m);
+        std::vector<uint32_t> dup(m, 0u);
         std::vector<double> got_gps(m);
         std::vector<uint8_t> got_rgb(m * 3);
         swz_ctx* c = swz_group_ctx(g, s);
@@ -130,6 +134,8 @@ int main(int argc, char** argv) {
           if (swz_copy_to_host(c, px.data(), res[s].d_xyz, m * 24) || swz_copy_to_host(c, k.data(), res[s].d_keys, m * 8) ||
               swz_copy_to_host(c, perm.data(), res[s].d_perm, m * 4) || swz_copy_to_host(c, lv.data(), res[s].d_level, m))
             return fail("download");
+          if ((strategy == SWZ_FAST) != (res[s].d_dup != nullptr)) return fail("d_dup must be set for FAST and only then");
+          if (res[s].d_dup && swz_copy_to_host(c, dup.data(), res[s].d_dup, m * 4)) return fail("download of the dup mask");
         }
         for (uint64_t i = 0; i < m; ++i) {
           if (i && k[i] < k[i - 1]) return fail("keys of a shard do not ascend");
@@ -142,7 +148,7 @@ int main(int argc, char** argv) {
             return fail("GPS time column did not travel with its point");
           if (got_rgb[3 * q] != (uint8_t)src || got_rgb[3 * q + 1] != (uint8_t)(src >> 8) || got_rgb[3 * q + 2] != (uint8_t)(src >> 16))
             return fail("RGB column did not travel with its point");
-          got.emplace_back(k[i], px[3 * q], px[3 * q + 1], px[3 * q + 2], (int)lv[i]);
+          got.emplace_back(k[i], px[3 * q], px[3 * q + 1], px[3 * q + 2], (int)(lv[i] & 0xFF) + (int)(dup[i] << 8));
         }
       }
       if (got.size() != n) return fail("points lost or duplicated in the exchange");
@@ -151,14 +157,16 @@ int main(int argc, char** argv) {
       std::vector<uint64_t> ok(n);
       std::vector<uint32_t> operm(n);
       std::vector<int8_t> olv(n);
-      orc_tile_params op{sampler, 2000, spacing, 100, ORC_ACCURATE, 8};
+      std::vector<uint32_t> odup(n, 0u);
+      orc_tile_params op{sampler, 2000, spacing, 100, strategy == SWZ_FAST ? ORC_FAST : ORC_ACCURATE, 8};
       orc_tile_stats ost;
-      if (orc_tile(copy.data(), n, mn, mx, &op, ok.data(), operm.data(), olv.data(), nullptr, &ost) != 0) return fail("oracle");
+      if (orc_tile(copy.data(), n, mn, mx, &op, ok.data(), operm.data(), olv.data(), strategy == SWZ_FAST ? odup.data() : nullptr, &ost) != 0)
+        return fail("oracle");
       std::vector<Row> want;
       want.reserve(n);
       for (size_t i = 0; i < n; ++i) {
         const uint32_t q = operm[i];
-        want.emplace_back(ok[i], copy[3 * q], copy[3 * q + 1], copy[3 * q + 2], (int)olv[i]);
+        want.emplace_back(ok[i], copy[3 * q], copy[3 * q + 1], copy[3 * q + 2], (int)(olv[i] & 0xFF) + (int)(odup[i] << 8));
       }
       std::sort(got.begin(), got.end());
       std::sort(want.begin(), want.end());
@@ -169,11 +177,19 @@ int main(int argc, char** argv) {
             ++bad;
             if (first == n) first = i;
           }
-        std::fprintf(stderr, "%s, %d shards: %zu rows differ, first at %zu (level %d vs %d)\n", names[sampler], shards, bad, first,
-                     std::get<4>(got[first]), std::get<4>(want[first]));
+        std::fprintf(stderr, "%s%s, %d shards: %zu rows differ, first at %zu (level | dup << 8: %d vs %d)\n", strategy == SWZ_FAST ? "FAST " : "",
+                     names[sampler], shards, bad, first, std::get<4>(got[first]), std::get<4>(want[first]));
+        if (strategy == SWZ_FAST) {  // which octants' points the two roots hold
+          size_t g8[8] = {0}, w8[8] = {0};
+          for (size_t i = 0; i < n; ++i) {
+            if ((std::get<4>(got[i]) >> 8) & 1) ++g8[std::get<0>(got[i]) >> 60];
+            if ((std::get<4>(want[i]) >> 8) & 1) ++w8[std::get<0>(want[i]) >> 60];
+          }
+          for (int o = 0; o < 8; ++o) std::fprintf(stderr, "  root points of octant %d: %zu, oracle %zu\n", o, g8[o], w8[o]);
+        }
         return fail("sharded result differs from the oracle");
       }
-      std::printf("%-12s %d shard(s) ok\n", names[sampler], shards);
+      std::printf("%s%-12s %d shard(s) ok\n", strategy == SWZ_FAST ? "FAST " : "", names[sampler], shards);
       for (int s = 0; s < shards; ++s) {
         swz_device_free(d_xyz[s]);
         swz_device_free(d_attrs[s].column[SWZ_ATTR_GPS_TIME]);

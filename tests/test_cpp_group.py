@@ -32,7 +32,7 @@ def test_group_peer_copies_match_the_oracle(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     # per shard count: 4 samplers x (one batch + class) and x {ACCURATE, FAST} x {1, 3} batches through swz_group_add_batch;
     # plus the lopsided MIN_DISTANCE cloud (nearly everything on shard 0) with 2, 4 and 8 shards
-    assert r.stdout.count(" ok") == 99
+    assert r.stdout.count(" ok") == 115
     assert r.stdout.count("lopsided cloud") == 3
 
 
@@ -44,7 +44,7 @@ def test_group_with_the_root_taken_in_turns(tmp_path):
     exe = _build(str(tmp_path))
     r = subprocess.run([exe, "0"], capture_output=True, text=True, timeout=900, env=dict(os.environ, SWZ_GROUP_JOINT_ROOT="0"))
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count(" ok") == 99
+    assert r.stdout.count(" ok") == 115
 
 
 @pytest.mark.gpu

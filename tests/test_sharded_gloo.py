@@ -340,6 +340,67 @@ def test_sharded_tile_with_empty_shards(sampler, world):
     assert np.array_equal(rec(got[0][1], got[0][3], pos), rec(ref["keys"], ref["level"], ref_xyz))
 
 
+def _fast_tile_worker(rank, world, port, n, sampler, max_pts, spacing, concurrency, q, corner):
+    import schwarzwald_amd as swz
+    from schwarzwald_amd import sharded
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    _init(rank, world, port, "gloo")
+    ctx = swz.Context(0)
+    params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing, strategy=swz.FAST,
+                            fast_concurrency=concurrency)
+    xyz = torch.from_numpy(_corner_cloud(n, 300 + rank, world) if corner else _cloud(n, 300 + rank)).to(dev)
+    tiler = sharded.ShardedTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
+    stats = tiler.tile(xyz)
+    recv, keys, perm, level, dup = tiler.result
+    q.put((rank, recv.cpu().numpy(), keys.cpu().numpy().view(np.uint64), perm.cpu().numpy().view(np.uint32),
+           level.cpu().numpy(), dup.cpu().numpy().view(np.uint32), stats))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED])
+@pytest.mark.parametrize("world,corner", [(2, False), (4, False), (4, True)])
+def test_sharded_single_batch_fast_strategy_matches_oracle(sampler, world, corner):
+    """FAST (TilingAlgorithmV3, the reference's default) through ShardedTiler.tile: the start level from the ranks' summed
+    prefix histograms, the skipped levels rebuilt per rank, the root from all ranks' level-0 nodes on rank 0.  Level and
+    the ancestors a point is stored in as well (dup) must be the single-process oracle's, also with ranks that own nothing."""
+    n, max_pts, concurrency = 60000, 300, 2
+    spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 60 if sampler == O.MIN_DISTANCE else 250)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fast_tile_worker, args=(r, world, port, n, sampler, max_pts, spacing, concurrency, q, corner))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        item = q.get(timeout=_QUEUE_TIMEOUT)
+        got[item[0]] = item[1:]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    union = np.vstack([(_corner_cloud(n, 300 + r, world) if corner else _cloud(n, 300 + r)) for r in range(world)])
+    ref = O.tile(union, [0, 0, 0], [1, 1, 1], sampler, max_pts, spacing, strategy=O.FAST, fast_concurrency=concurrency)
+    assert ref["status"] == 0 and ref["stats"]["fast_start_levels"] >= 1
+    ref_xyz = ref["xyz_clamped"][ref["perm"]]
+    keys = np.concatenate([got[r][1] for r in range(world)])
+    level = np.concatenate([got[r][3] for r in range(world)])
+    dup = np.concatenate([got[r][4] for r in range(world)])
+    pos = np.vstack([got[r][0][got[r][2]] for r in range(world)])
+    assert np.array_equal(keys, ref["keys"])
+    assert all(got[r][5]["fast_start_levels"] == ref["stats"]["fast_start_levels"] for r in range(world))
+
+    def canon(k, lv, du, p):
+        rec = np.rec.fromarrays([k, lv, du, p[:, 0], p[:, 1], p[:, 2]], names="k,l,d,x,y,z")
+        return np.sort(rec, order=["k", "x", "y", "z", "l", "d"])
+
+    assert np.array_equal(canon(keys, level, dup, pos), canon(ref["keys"], ref["level"], ref["dup"], ref_xyz))
+    assert int((dup & 1).sum()) > 0  # the reconstructed root holds points
+
+
 # ------------------------------------------------------------------ GPU: sharded AND multi-batch (BASELINE config 5's shape)
 def _mb_cloud(n, batch, rank, corner_world=0):
     xyz = _cloud(n, 500 + 10 * batch + rank)
