@@ -250,6 +250,30 @@ int main(int argc, char** argv) {
       std::sort(want.begin(), want.end());
       if (got != want) return fail("lopsided cloud: sharded MIN_DISTANCE differs from the oracle");
       std::printf("MIN_DISTANCE %d shard(s), lopsided cloud (smallest shard with points: %llu) ok\n", shards, (unsigned long long)smallest);
+      // the same batch with SWZ_FLAG_MIN_DISTANCE_PROPERTY: the root spans the shards and stays the exact one, the levels
+      // below run in property mode (checked on one context in tests/test_min_distance_property.py): every point gets a level
+      p.flags = SWZ_FLAG_MIN_DISTANCE_PROPERTY;
+      if (swz_group_tile(g, d_xyz.data(), d_attrs.data(), cnt.data(), mn, mx, &p, res.data()) != SWZ_OK) return fail("swz_group_tile (property mode)", swz_group_last_error(g));
+      std::vector<uint64_t> root_got, root_want;
+      uint64_t total_p = 0;
+      for (int s = 0; s < shards; ++s) {
+        const uint64_t m = res[s].num_points;
+        std::vector<uint64_t> k(m);
+        std::vector<int8_t> lv(m);
+        swz_ctx* c = swz_group_ctx(g, s);
+        if (m && (swz_copy_to_host(c, k.data(), res[s].d_keys, m * 8) || swz_copy_to_host(c, lv.data(), res[s].d_level, m))) return fail("download");
+        for (uint64_t i = 0; i < m; ++i) {
+          if (lv[i] < -1 || lv[i] > 20) return fail("property mode: a point without a level");
+          if (lv[i] == -1) root_got.push_back(k[i]);
+        }
+        total_p += m;
+      }
+      for (size_t i = 0; i < n; ++i)
+        if (olv[i] == -1) root_want.push_back(ok[i]);
+      std::sort(root_got.begin(), root_got.end());
+      std::sort(root_want.begin(), root_want.end());
+      if (total_p != n || root_got != root_want) return fail("property mode: the root of a sharded batch must be the exact one");
+      std::printf("MIN_DISTANCE %d shard(s), property mode below the exact root: fine\n", shards);
       for (int s = 0; s < shards; ++s) swz_device_free(d_xyz[s]);
     }
 
