@@ -876,7 +876,13 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     const PullCntF pf{hk, st.nkey[st.ncur], st.ncnt[st.ncur], st.nn};
     SWZ_TRY(fused_scan(c, pf, PullSegG{pf, st.noff[st.ncur], poff, psrc, touched}, heads, counters, "tl"));
     SWZ_TRY(read_u32(c, counters, &nc));
-    if (nc) {
+    if (nc == st.cnt && st.linear) {
+      // the batch reaches every node of the level and the side holds the files in node order (a batch cut out of the whole
+      // cloud): what would be copied out is the side itself.  Everything on it is rewritten by this batch -- behind its end
+      // or on the other side --, so the merge may read it in place (and a re-sort after an inversion may reorder it).
+      ckey = st.key[st.cur];
+      cgid = st.gid[st.cur];
+    } else if (nc) {
       ProfScope ps(c, "tiler_pull", (uint64_t)nc * 24ull, 1);
       SWZ_TRY(c->get("tl_ckey", (size_t)nc, &ckey));
       SWZ_TRY(c->get("tl_cgid", (size_t)nc, &cgid));
