@@ -270,6 +270,14 @@ __global__ __launch_bounds__(256) void take_all_kernel(uint32_t m, const uint32_
 constexpr int GA_THREADS = SWZ_GA_THREADS;
 constexpr int GA_IPT = SWZ_GA_IPT;
 constexpr int GA_TILE = GA_THREADS * GA_IPT;
+// the kernel that decides on keys (grid_argmin_keys_kernel) takes four points per thread: its loads are the keys alone, and
+// the segmented scan across the lanes -- a third of its instructions -- is paid per thread (measured at 1 B points,
+// GRID_CENTER / JITTERED sampling per step: 26.0 / 27.9 ms with two, 24.0 / 23.5 ms with four)
+#ifndef SWZ_GAK_IPT
+#define SWZ_GAK_IPT 4
+#endif
+constexpr int GAK_IPT = SWZ_GAK_IPT;
+constexpr int GAK_TILE = GA_THREADS * GAK_IPT;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
 struct Agg {
@@ -750,6 +758,9 @@ struct KTileSummary {
 struct GridKeys {
   float w[3];   // key cell width per axis relative to the widest one
   double hk;    // half a key cell plus the slack (see above)
+  // the same for the kernel's single-precision bounds, rounded to the safe side: hk up, the widths down for the lower and
+  // up for the upper bound (grid_argmin_keys_kernel)
+  float hk_f, w_lo[3], w_hi[3];
   uint2* amb;   // runs the keys cannot decide: {first, end} active index
   uint32_t* amb_count;
 };
@@ -770,14 +781,14 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
   GridKeys gk, uint32_t node_shift, uint8_t* __restrict__ taken, KTileSummary* __restrict__ summaries, uint32_t* __restrict__ counters) {
   __shared__ KAgg wave_tot[GA_THREADS / WAVE];
   const uint32_t tid = threadIdx.x, w = tid / WAVE, l = lane_id();
-  const uint32_t tile_base = blockIdx.x * GA_TILE;
-  const uint32_t tile_end = (m - tile_base) < (uint32_t)GA_TILE ? m : tile_base + GA_TILE;
+  const uint32_t tile_base = blockIdx.x * GAK_TILE;
+  const uint32_t tile_end = (m - tile_base) < (uint32_t)GAK_TILE ? m : tile_base + GAK_TILE;
   const uint32_t last_valid = tile_end - 1;
-  const uint32_t first = tile_base + tid * GA_IPT;
+  const uint32_t first = tile_base + tid * GAK_IPT;
   const bool all_sampled = counters[CTR_SAMPLE_NODES] == counters[CTR_NUM_NODES];
 
-  uint64_t key[GA_IPT];
-  bool sample[GA_IPT];
+  uint64_t key[GAK_IPT];
+  bool sample[GAK_IPT];
   uint64_t prev_key = 0;
   bool have_prev = false;
   if (first < tile_end && first > 0) {
@@ -785,40 +796,40 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
     have_prev = true;
   }
 #pragma unroll
-  for (int j = 0; j < GA_IPT; ++j) {
+  for (int j = 0; j < GAK_IPT; ++j) {
     const uint32_t gc = first + j < tile_end ? first + j : last_valid;
     key[j] = akey[gc];
     sample[j] = all_sampled || nmode[nid[gc]] == MODE_SAMPLE;
   }
-  JitNode jn[GA_IPT];
+  JitNode jn[GAK_IPT];
   if (g.sampler != SWZ_GRID_CENTER) {  // what JITTERED derives from the node's box: grid size, levels, error (as above)
     if (g.jit_table) {
       const uint32_t tsh = g.level < 0 ? 63u : level_shift(g.level);
 #pragma unroll
-      for (int j = 0; j < GA_IPT; ++j) jn[j] = g.jit_table[key[j] >> tsh];
+      for (int j = 0; j < GAK_IPT; ++j) jn[j] = g.jit_table[key[j] >> tsh];
     } else {
-      Box kb[GA_IPT];
+      Box kb[GAK_IPT];
       if (g.table_depth > 0) {
         const uint32_t tsh = level_shift(g.table_depth - 1);
 #pragma unroll
-        for (int j = 0; j < GA_IPT; ++j) kb[j] = g.box_table[key[j] >> tsh];
+        for (int j = 0; j < GAK_IPT; ++j) kb[j] = g.box_table[key[j] >> tsh];
       } else {
 #pragma unroll
-        for (int j = 0; j < GA_IPT; ++j) kb[j] = g.root;
+        for (int j = 0; j < GAK_IPT; ++j) kb[j] = g.root;
       }
-      bounds_from_keys<GA_IPT>(key, g.table_depth, g.level + 1, kb);
+      bounds_from_keys<GAK_IPT>(key, g.table_depth, g.level + 1, kb);
 #pragma unroll
-      for (int j = 0; j < GA_IPT; ++j) jn[j] = jitter_node(kb[j], g.spacing_node, g.level);
+      for (int j = 0; j < GAK_IPT; ++j) jn[j] = jitter_node(kb[j], g.spacing_node, g.level);
     }
   }
 
-  float ub[GA_IPT], lb[GA_IPT];
-  bool head[GA_IPT];
+  float ub[GAK_IPT], lb[GAK_IPT];
+  bool head[GAK_IPT];
   uint32_t last_csh = node_shift;
   uint64_t last_key = 0;
   bool any_head = false;
 #pragma unroll
-  for (int j = 0; j < GA_IPT; ++j) {
+  for (int j = 0; j < GAK_IPT; ++j) {
     const uint32_t gi = first + j;
     ub[j] = __builtin_inff();
     lb[j] = __builtin_inff();
@@ -827,17 +838,24 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
       uint32_t csh = node_shift;
       if (sample[j]) {
         int err = 0;
-        // offset of the point's key cell centre from the target, per axis, in key cells
-        double ox = 0, oy = 0, oz = 0;
-        const uint32_t ix = (uint32_t)contract_bits_by_3(key[j] >> 2), iy = (uint32_t)contract_bits_by_3(key[j] >> 1),
-                       iz = (uint32_t)contract_bits_by_3(key[j]);
+        // Offset of the point's key cell centre from the target, per axis, in key cells -- in single precision, exactly:
+        // a half-integer below 2^21 (GRID_CENTER), or a multiple of the permutation step 2^(sbits - levels) >= 2^-6 below
+        // 2^sbits with levels <= 6 (JITTERED): at most 22 significant bits either way.
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        uint32_t ix, iy, iz;
+        {  // (the key's coordinates with 32-bit arithmetic: a third of the instructions of the 64-bit bit trick)
+          const uint32_t klo = (uint32_t)key[j], khi = (uint32_t)(key[j] >> 32);
+          ix = contract_bits_by_3_u32(klo >> 2) | (contract_bits_by_3_u32(khi) << 10);
+          iy = contract_bits_by_3_u32(klo >> 1) | (contract_bits_by_3_u32(khi >> 2) << 11);
+          iz = contract_bits_by_3_u32(klo) | (contract_bits_by_3_u32(khi >> 1) << 11);
+        }
         if (g.sampler == SWZ_GRID_CENTER) {
           csh = level_shift(g.cand);
           const uint32_t sbits = csh / 3u, mask = (1u << sbits) - 1u;
-          const double half = ldexp(1.0, (int)sbits - 1);  // (0.5 for a cell one key cell wide)
-          ox = (double)(ix & mask) + 0.5 - half;
-          oy = (double)(iy & mask) + 0.5 - half;
-          oz = (double)(iz & mask) + 0.5 - half;
+          const float half = ldexpf(1.0f, (int)sbits - 1);  // (0.5 for a cell one key cell wide)
+          ox = (float)(ix & mask) + 0.5f - half;
+          oy = (float)(iy & mask) + 0.5f - half;
+          oz = (float)(iz & mask) + 0.5f - half;
         } else {
           err = jn[j].err;
           if (!err) {
@@ -862,22 +880,26 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
             const uint32_t px = (uint32_t)table[s0 * width + ((gy + gz) & plen_mask)] - 1u;
             const uint32_t py = (uint32_t)table[s1 * width + ((gx + gz) & plen_mask)] - 1u;
             const uint32_t pz = (uint32_t)table[s2 * width + ((gx + gy) & plen_mask)] - 1u;
-            const double perm = ldexp(1.0, (int)sbits - (int)levels);  // perm_size = cell_size / cells, in key cells
-            ox = (double)(ix & mask) + 0.5 - (double)px * perm;
-            oy = (double)(iy & mask) + 0.5 - (double)py * perm;
-            oz = (double)(iz & mask) + 0.5 - (double)pz * perm;
+            const float perm = ldexpf(1.0f, (int)sbits - (int)levels);  // perm_size = cell_size / cells, in key cells
+            ox = (float)(ix & mask) + 0.5f - (float)px * perm;
+            oy = (float)(iy & mask) + 0.5f - (float)py * perm;
+            oz = (float)(iz & mask) + 0.5f - (float)pz * perm;
           }
         }
         if (err) {
           atomicMax(&counters[CTR_ERROR], (uint32_t)err);
           csh = node_shift;
         } else {
-          const double ax = fabs(ox), ay = fabs(oy), az = fabs(oz);
-          const double lx = fmax(ax - gk.hk, 0.0) * gk.w[0], ly = fmax(ay - gk.hk, 0.0) * gk.w[1], lz = fmax(az - gk.hk, 0.0) * gk.w[2];
-          const double ux = (ax + gk.hk) * gk.w[0], uy = (ay + gk.hk) * gk.w[1], uz = (az + gk.hk) * gk.w[2];
-          // (rounded outwards: the conversions to float are off by 6e-8 relative at most)
-          lb[j] = (float)((lx * lx + ly * ly + lz * lz) * (1.0 - 0x1.0p-22));
-          ub[j] = (float)((ux * ux + uy * uy + uz * uz) * (1.0 + 0x1.0p-22));
+          // Bounds of the squared distance, rounded outwards.  hk_f >= hk and w_lo <= w <= w_hi are rounded to the safe side
+          // already; what is left are the roundings of this arithmetic on non-negative terms -- the sum / difference with
+          // hk_f, the product with the width, the square, two additions: five at 2^-24 relative each along any path --, which
+          // the factors 1 -+ 2^-20 cover several times over.  (Until round 4 this ran in double: half the rate and twice the
+          // registers for bounds that end up as floats.)
+          const float ax = fabsf(ox), ay = fabsf(oy), az = fabsf(oz);
+          const float lx = fmaxf(ax - gk.hk_f, 0.f) * gk.w_lo[0], ly = fmaxf(ay - gk.hk_f, 0.f) * gk.w_lo[1], lz = fmaxf(az - gk.hk_f, 0.f) * gk.w_lo[2];
+          const float ux = (ax + gk.hk_f) * gk.w_hi[0], uy = (ay + gk.hk_f) * gk.w_hi[1], uz = (az + gk.hk_f) * gk.w_hi[2];
+          lb[j] = (lx * lx + ly * ly + lz * lz) * (1.0f - 0x1.0p-20f);
+          ub[j] = (ux * ux + uy * uy + uz * uz) * (1.0f + 0x1.0p-20f);
         }
       } else {
         taken[gi] = 1;  // take-all node
@@ -894,7 +916,7 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
   // thread aggregate over its items, then block-wide exclusive segmented scan
   KAgg a = kagg_identity();
 #pragma unroll
-  for (int j = 0; j < GA_IPT; ++j) {
+  for (int j = 0; j < GAK_IPT; ++j) {
     const uint32_t gi = first + j;
     if (gi < tile_end) {
       KAgg it{ub[j], lb[j], __builtin_inff(), gi, head[j] ? gi : NONE, head[j] ? 1u : 0u};
@@ -924,7 +946,7 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
   KAgg run = carry;
   KTileSummary* sum = &summaries[blockIdx.x];
 #pragma unroll
-  for (int j = 0; j < GA_IPT; ++j) {
+  for (int j = 0; j < GAK_IPT; ++j) {
     const uint32_t gi = first + j;
     if (gi < tile_end) {
       if (head[j] && gi != tile_base) {  // the run ending at gi - 1 closes inside this tile
@@ -1155,8 +1177,18 @@ bool grid_level_uses_keys(const swz_ctx* c, const LevelPlan& plan, const SortedP
   if (const char* e = c->opt("SWZ_GRID_KEYS_SLACK")) slack += atof(e);
   if (!(slack < 0.25) && !c->opt("SWZ_GRID_KEYS_SLACK")) return false;  // bounds far from the origin relative to their size
   if (out) {
-    for (int a = 0; a < 3; ++a) out->w[a] = (float)(ext[a] / wmax);
+    for (int a = 0; a < 3; ++a) {
+      out->w[a] = (float)(ext[a] / wmax);
+      const double wd = ext[a] / wmax;
+      float lo = (float)wd, hi = (float)wd;
+      if ((double)lo > wd) lo = std::nextafterf(lo, 0.f);
+      if ((double)hi < wd) hi = std::nextafterf(hi, INFINITY);
+      out->w_lo[a] = lo;
+      out->w_hi[a] = hi;
+    }
     out->hk = 0.5 + slack;
+    out->hk_f = (float)out->hk;
+    if ((double)out->hk_f < out->hk) out->hk_f = std::nextafterf(out->hk_f, INFINITY);
     out->amb = nullptr;
     out->amb_count = nullptr;
   }
@@ -1263,13 +1295,14 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     if (grid_level_uses_keys(c, plan, sp, &gk)) {
       // decided on the key coordinates; the runs they cannot decide repeated on the original positions
       KTileSummary* d_ksum = nullptr;
-      SWZ_TRY(c->get("grid_key_summaries", (size_t)ntiles, &d_ksum));
+      const uint32_t nktiles = div_up(m, GAK_TILE);
+      SWZ_TRY(c->get("grid_key_summaries", (size_t)nktiles, &d_ksum));
       SWZ_TRY(c->get("grid_key_undecided", (size_t)m / 2 + 1024, &gk.amb));  // (a run of one point is always decided)
       gk.amb_count = lb.counters + CTR_NUM_CELLS;
-      hipLaunchKernelGGL(grid_argmin_keys_kernel, dim3(ntiles), dim3(GA_THREADS), 0, c->stream, as.akey, m, lb.nid, lb.nmode, g, gk,
+      hipLaunchKernelGGL(grid_argmin_keys_kernel, dim3(nktiles), dim3(GA_THREADS), 0, c->stream, as.akey, m, lb.nid, lb.nmode, g, gk,
                          plan.node_shift, lb.taken, d_ksum, lb.counters);
       SWZ_LAUNCH_CHECK(c);
-      hipLaunchKernelGGL(grid_resolve_keys_kernel, dim3(div_up(ntiles, 256)), dim3(256), 0, c->stream, d_ksum, ntiles, gk, lb.taken);
+      hipLaunchKernelGGL(grid_resolve_keys_kernel, dim3(div_up(nktiles, 256)), dim3(256), 0, c->stream, d_ksum, nktiles, gk, lb.taken);
       SWZ_LAUNCH_CHECK(c);
       hipLaunchKernelGGL(grid_exact_runs_kernel, dim3(std::min<uint32_t>(div_up(m, 2048u), 4096u)), dim3(256), 0, c->stream, as.akey, as.aidx,
                          sp, g, gk, lb.taken);
