@@ -79,6 +79,16 @@ __device__ __host__ __forceinline__ uint32_t contract_bits_by_3_u32(uint32_t v) 
   return v;
 }
 
+// The three 21-bit coordinates of a 63-bit Morton key (bit 3j+2 of the key is bit j of x, 3j+1 of y, 3j of z,
+// MortonIndex.h:62-79) with 32-bit arithmetic -- a third of the instructions of three 64-bit contract_bits_by_3.  The low
+// word holds x bits 0-9, y bits 0-10, z bits 0-10; the high word (bit 32 on) the rest.
+__device__ __host__ __forceinline__ void key_coords_u32(uint64_t key, uint32_t& x, uint32_t& y, uint32_t& z) {
+  const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+  x = contract_bits_by_3_u32(lo >> 2) | (contract_bits_by_3_u32(hi) << 10);
+  y = contract_bits_by_3_u32(lo >> 1) | (contract_bits_by_3_u32(hi >> 2) << 11);
+  z = contract_bits_by_3_u32(lo) | (contract_bits_by_3_u32(hi >> 1) << 11);
+}
+
 struct Box {  // AABB, core/math/AABB.h
   double minx, miny, minz, maxx, maxy, maxz;
 };

@@ -843,12 +843,7 @@ __global__ __launch_bounds__(GA_THREADS) void grid_argmin_keys_kernel(
         // 2^sbits with levels <= 6 (JITTERED): at most 22 significant bits either way.
         float ox = 0.f, oy = 0.f, oz = 0.f;
         uint32_t ix, iy, iz;
-        {  // (the key's coordinates with 32-bit arithmetic: a third of the instructions of the 64-bit bit trick)
-          const uint32_t klo = (uint32_t)key[j], khi = (uint32_t)(key[j] >> 32);
-          ix = contract_bits_by_3_u32(klo >> 2) | (contract_bits_by_3_u32(khi) << 10);
-          iy = contract_bits_by_3_u32(klo >> 1) | (contract_bits_by_3_u32(khi >> 2) << 11);
-          iz = contract_bits_by_3_u32(klo) | (contract_bits_by_3_u32(khi >> 1) << 11);
-        }
+        key_coords_u32(key[j], ix, iy, iz);
         if (g.sampler == SWZ_GRID_CENTER) {
           csh = level_shift(g.cand);
           const uint32_t sbits = csh / 3u, mask = (1u << sbits) - 1u;

@@ -217,7 +217,9 @@ struct MqMin {
 
 __device__ __forceinline__ uint64_t mq_pack(uint64_t key) {
   // octant = x << 2 | y << 1 | z (MortonIndex.h:62-79): bit 3j+2 of the key is bit j of x
-  return contract_bits_by_3(key >> 2) | (contract_bits_by_3(key >> 1) << 21) | (contract_bits_by_3(key) << 42);
+  uint32_t x, y, z;
+  key_coords_u32(key, x, y, z);
+  return (uint64_t)x | ((uint64_t)y << 21) | ((uint64_t)z << 42);
 }
 __device__ __forceinline__ void mq_unpack(uint64_t v, float& x, float& y, float& z) {
   const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);

@@ -133,7 +133,9 @@ __global__ __launch_bounds__(256) void sp_key_records_kernel(const uint64_t* __r
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= m) return;
   const uint64_t k = akey[i];
-  rec[i] = make_float4((float)contract_bits_by_3(k >> 2), (float)contract_bits_by_3(k >> 1), (float)contract_bits_by_3(k), 0.f);
+  uint32_t x, y, z;
+  key_coords_u32(k, x, y, z);
+  rec[i] = make_float4((float)x, (float)y, (float)z, 0.f);
 }
 
 // the exact compare of the reference on the original positions (GridCell.cpp:52)
