@@ -231,7 +231,8 @@ int swz_gather_payload_device(swz_ctx* ctx, const uint32_t* d_perm, const uint32
  *   swz_bin_read_header / swz_bin_read_node: retrieve_points; read_node fills xyz_out (count x 3) and
  *     every non-NULL column whose bit is set in the file.
  *   swz_bin_persist_nodes: one file per node of a node table, named "r" + octant digits
- *     (TilingAlgorithms.cpp:139) in directory dir; xyz / columns are the gathered payload of the batch. */
+ *     (TilingAlgorithms.cpp:139) in directory dir; xyz / columns are the gathered payload of the batch.  The files are
+ *     written by several host threads (option SWZ_BIN_WRITER_THREADS; default: the host's, at most 32). */
 int swz_bin_write_node(swz_ctx* ctx, const char* path, uint64_t count, const double* xyz,
                        const swz_attribute_columns* columns, int compressed);
 int swz_bin_read_header(swz_ctx* ctx, const char* path, int compressed, uint32_t* bitmask_out, uint64_t* count_out);
