@@ -101,8 +101,10 @@ __global__ __launch_bounds__(256) void node_fill_kernel(const uint32_t* __restri
     }
     return lo - 1u;
   };
-  if (tid == 0) s_lo = node_of(i0);
-  if (tid == 64) s_hi = node_of(last);
+  if (tid < 2) {  // (two lanes of one wavefront: see tl_merge_rank_kernel, swz_tiler.hip)
+    const uint32_t r = node_of(tid ? last : i0);
+    if (tid) s_hi = r; else s_lo = r;
+  }
   __syncthreads();
   const uint32_t lo = s_lo, span = s_hi - s_lo + 1u;  // (at most one node starts per point: span <= NF_TILE)
   for (uint32_t k = tid; k <= span; k += 256u) ss[k] = (lo + k < nn) ? nstart[lo + k] : 0xFFFFFFFFu;  // ss[k]: start of node lo + k

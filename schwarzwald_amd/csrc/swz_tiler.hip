@@ -160,8 +160,10 @@ __global__ __launch_bounds__(256) void tl_touch_kernel(const uint64_t* __restric
     }
     return lo;
   };
-  if (threadIdx.x == 0) s_lo = lower(0u, m, skey[j0] >> nsh);
-  if (threadIdx.x == 64) s_hi = lower(0u, m, skey[last] >> nsh);
+  if (threadIdx.x < 2) {  // (two lanes of one wavefront: see tl_merge_rank_kernel)
+    const uint32_t r = lower(0u, m, skey[threadIdx.x ? last : j0] >> nsh);
+    if (threadIdx.x) s_hi = r; else s_lo = r;
+  }
   __syncthreads();
   if (j >= cnt) return;
   const uint64_t prefix = skey[j] >> nsh;
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(256) void tl_fill_kernel(const uint32_t* __restrict
 // all others: two searches over the whole other run per workgroup, then every thread searches that bracket only -- out of
 // LDS when it holds at most 1024 keys (runs of similar length interleave: a few hundred), instead of ~25 dependent probes
 // all over a run of tens of millions of keys per element.
-constexpr uint32_t TL_MERGE_LDS = 1024;
+constexpr uint32_t TL_MERGE_LDS = 2048;
+constexpr uint32_t TL_MERGE_IPT = 4;                    // elements per thread: the two searches over the whole other run that
+constexpr uint32_t TL_MERGE_TILE = 256 * TL_MERGE_IPT;  // open a workgroup (~23 dependent loads each) serve 1024 elements
 template <bool UPPER>
 __device__ __forceinline__ uint32_t tl_rank(const uint64_t* __restrict__ k, uint32_t lo, uint32_t hi, uint64_t ks, uint32_t sh) {
   while (lo < hi) {
@@ -299,25 +303,33 @@ __global__ __launch_bounds__(256) void tl_merge_rank_kernel(const uint64_t* __re
   __shared__ uint32_t s_lo, s_hi;
   __shared__ uint64_t sk[TL_MERGE_LDS];
   const uint32_t tid = threadIdx.x;
-  const uint32_t i0 = blockIdx.x * 256u;
-  const uint32_t i = i0 + tid;
-  const uint32_t last = (na - i0) > 256u ? i0 + 255u : na - 1u;
-  if (tid == 0) s_lo = tl_rank<UPPER>(kb, 0u, nb, ka[i0] >> sh, sh);
-  if (tid == 64) s_hi = tl_rank<UPPER>(kb, 0u, nb, ka[last] >> sh, sh);
+  const uint32_t i0 = blockIdx.x * TL_MERGE_TILE;
+  const uint32_t last = (na - i0) > TL_MERGE_TILE ? i0 + TL_MERGE_TILE - 1u : na - 1u;
+  // (both searches by two lanes of the first wavefront.  With the second one on thread 64 -- alone in its wavefront, so
+  // hipcc 7.2 turns its search into scalar loads -- and more than one element per thread, the shift count of the loops
+  // below came out of a register that only some wavefronts had set: wrong ranks for threads 128-255.  Found with a
+  // stand-alone copy of this kernel against std::merge.)
+  if (tid < 2) {
+    const uint32_t r = tl_rank<UPPER>(kb, 0u, nb, ka[tid ? last : i0] >> sh, sh);
+    if (tid) s_hi = r; else s_lo = r;
+  }
   __syncthreads();
   const uint32_t lo = s_lo, hi = s_hi;
   const bool in_lds = hi - lo <= TL_MERGE_LDS;
   if (in_lds)
     for (uint32_t j = tid; j < hi - lo; j += 256u) sk[j] = kb[lo + j] >> sh;
   __syncthreads();
-  if (i >= na) return;
-  const uint64_t k = ka[i];
-  const uint64_t ks = k >> sh;
-  uint32_t r;
-  if (in_lds) r = lo + tl_rank<UPPER>(sk, 0u, hi - lo, ks, 0u);
-  else r = tl_rank<UPPER>(kb, lo, hi, ks, sh);
-  ok[i + r] = k;
-  ov[i + r] = va ? va[i] : base + i;
+  for (uint32_t q = 0; q < TL_MERGE_IPT; ++q) {
+    const uint32_t i = i0 + q * 256u + tid;
+    if (i >= na) break;
+    const uint64_t k = ka[i];
+    const uint64_t ks = k >> sh;
+    uint32_t r;
+    if (in_lds) r = lo + tl_rank<UPPER>(sk, 0u, hi - lo, ks, 0u);
+    else r = tl_rank<UPPER>(kb, lo, hi, ks, sh);
+    ok[i + r] = k;
+    ov[i + r] = va ? va[i] : base + i;
+  }
 }
 
 struct TakenF {
@@ -448,8 +460,10 @@ __global__ __launch_bounds__(256) void tl_gather_files_kernel(const uint32_t* __
   const uint32_t tid = threadIdx.x;
   const uint32_t e0 = blockIdx.x * 256u, e = e0 + tid;
   const uint32_t last = (total - e0) > 256u ? e0 + 255u : total - 1u;
-  if (tid == 0) s_lo = tl_upper_u32(poff, 0u, segs, e0) - 1u;
-  if (tid == 64) s_hi = tl_upper_u32(poff, 0u, segs, last) - 1u;
+  if (tid < 2) {  // (two lanes of one wavefront: see tl_merge_rank_kernel)
+    const uint32_t r = tl_upper_u32(poff, 0u, segs, tid ? last : e0) - 1u;
+    if (tid) s_hi = r; else s_lo = r;
+  }
   __syncthreads();
   const uint32_t lo = s_lo, span = s_hi - s_lo + 1u;
   const bool in_lds = span <= TL_SEG_LDS;
@@ -751,11 +765,11 @@ static int pool_reserve(swz_tiler* t, size_t points) {
 static int merge_pairs(swz_ctx* c, const uint64_t* k1, const uint32_t* v1, uint32_t n1, const uint64_t* k2,
                        const uint32_t* v2, uint32_t n2, uint32_t sh, uint32_t base2, uint64_t* ok, uint32_t* ov) {
   if (n1) {
-    hipLaunchKernelGGL(tl_merge_rank_kernel<false>, dim3(div_up(n1, 256)), dim3(256), 0, c->stream, k1, v1, n1, k2, n2, sh, 0u, ok, ov);
+    hipLaunchKernelGGL(tl_merge_rank_kernel<false>, dim3(div_up(n1, TL_MERGE_TILE)), dim3(256), 0, c->stream, k1, v1, n1, k2, n2, sh, 0u, ok, ov);
     SWZ_LAUNCH_CHECK(c);
   }
   if (n2) {
-    hipLaunchKernelGGL(tl_merge_rank_kernel<true>, dim3(div_up(n2, 256)), dim3(256), 0, c->stream, k2, v2, n2, k1, n1, sh, base2, ok, ov);
+    hipLaunchKernelGGL(tl_merge_rank_kernel<true>, dim3(div_up(n2, TL_MERGE_TILE)), dim3(256), 0, c->stream, k2, v2, n2, k1, n1, sh, base2, ok, ov);
     SWZ_LAUNCH_CHECK(c);
   }
   return SWZ_OK;
