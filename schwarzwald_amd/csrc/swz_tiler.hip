@@ -382,7 +382,10 @@ struct TakeStoreG {
   int level;
   uint64_t* okey;
   uint32_t* ogid;
+  uint32_t nsh;
+  uint32_t* texcl;  // [i]: taken entries in front of merged entry i, written where a node starts (-> the heads of the new files)
   __device__ void operator()(uint32_t i, uint32_t excl, uint32_t t) const {
+    if (i == 0 || (mkey[i] >> nsh) != (mkey[i - 1] >> nsh)) texcl[i] = excl;
     if (!t || excl < ghosts) return;
     const uint32_t w = midx ? midx[i] : i;
     const uint32_t g = wgid[w];
@@ -508,6 +511,18 @@ struct SegMoveG {  // the files of a table, gathered one behind the other: where
     off[i] = excl;
   }
 };
+// the heads of the files a level step has just written: node j of the merged range starts at merged entry nstart[j], its
+// file at the number of taken entries in front of that (texcl, TakeStoreG) -- no scan over the new files
+__global__ __launch_bounds__(256) void tl_new_heads_kernel(const uint64_t* __restrict__ mkey, const uint32_t* __restrict__ nstart,
+                                                           const uint32_t* __restrict__ texcl, uint32_t nodes, uint32_t nsh, uint32_t ghosts,
+                                                           uint64_t* __restrict__ hk, uint32_t* __restrict__ hp) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nodes) return;
+  const uint32_t i = nstart[j];
+  hk[j] = nsh >= 63u ? 0ull : ((mkey[i] >> nsh) << nsh);
+  const uint32_t e = texcl[i];
+  hp[j] = e > ghosts ? e - ghosts : 0u;
+}
 // two node tables with disjoint keys, both ascending, into one: the entries the batch left alone (f*) and the heads of
 // the files it wrote (keys hk at positions hp of the `added` entries appended at `base`)
 __global__ __launch_bounds__(256) void tl_table_merge_kernel(const uint64_t* __restrict__ fkey, const uint64_t* __restrict__ foff,
@@ -1026,11 +1041,13 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     SWZ_TRY(store_compact(c, st, lvi, foff, fcnt, nf, rest, room + room / 4));
   }
   const uint32_t at = st.end;
+  uint32_t* texcl = nullptr;
+  SWZ_TRY(c->get("tl_texcl", (size_t)ms.m, &texcl));
   {
     ProfScope ps(c, "tiler_store", (uint64_t)ms.m * 14ull + (uint64_t)nt * 12ull, 2);
     SWZ_TRY(fused_scan(c, TakenF{lb.taken},
                        TakeStoreG{ms.akey, ms.aidx, w.wgid, pull_lo, pull_lo + nc, ng, t->pool_xyz, root_box(t), plan.level,
-                                  st.key[st.cur] + at, st.gid[st.cur] + at},
+                                  st.key[st.cur] + at, st.gid[st.cur] + at, nsh, texcl},
                        ms.m, counters + 2, "tl"));
   }
   if (ng) {  // the ghosts are not part of the local file
@@ -1044,21 +1061,18 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   }
   {
     ProfScope ps(c, "tiler_store", (uint64_t)nt * 8ull + (uint64_t)st.nn * 20ull, 2);
+    // the nodes of the merged range are the nodes of the new files (every node takes at least one point; only a sharded
+    // root whose local points all fell to the ghosts writes nothing): their number is the level step's, no read-back
     uint32_t* hp = nullptr;
     uint64_t* hk = nullptr;
-    uint32_t heads = 0;
-    if (nt) {
-      SWZ_TRY(c->get("tl_head_pos", (size_t)nt, &hp));
-      SWZ_TRY(c->get("tl_head_key", (size_t)nt, &hk));
-      SWZ_TRY(fused_scan(c, HeadF{st.key[st.cur] + at, nsh}, HeadG{st.key[st.cur] + at, nsh, hp, hk}, nt, counters + 3, "tl"));
+    const uint32_t heads = nt ? res->num_nodes : 0u;
+    if (heads) {
+      SWZ_TRY(c->get("tl_head_pos", (size_t)heads, &hp));
+      SWZ_TRY(c->get("tl_head_key", (size_t)heads, &hk));
+      hipLaunchKernelGGL(tl_new_heads_kernel, dim3(div_up(heads, 256)), dim3(256), 0, c->stream, ms.akey, lb.nstart, texcl, heads, nsh, ng, hk, hp);
+      SWZ_LAUNCH_CHECK(c);
     }
-    uint32_t h4[4] = {0, 0, 0, 0};
-    if (nt || !nf_known) {  // both counts with one round trip
-      SWZ_HIP(c, hipMemcpyAsync(h4, counters, 16, hipMemcpyDeviceToHost, c->stream));
-      SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    }
-    if (!nf_known) nf = h4[1];
-    if (nt) heads = h4[3];
+    if (!nf_known) SWZ_TRY(read_u32(c, counters + 1, &nf));
     const int nd = st.ncur ^ 1;
     SWZ_TRY(table_reserve(c, st, lvi, nd, (size_t)nf + heads));
     if (nf + heads) {
