@@ -284,8 +284,10 @@ constexpr int OS_BATCH = 1;  // tiles per ticket: batches serialise the workgrou
 __device__ __forceinline__ uint32_t div_up_dev(uint32_t a, uint32_t b) { return (a + b - 1u) / b; }
 constexpr uint32_t OS_FLAG_LOCAL = 1u << 30, OS_FLAG_INCL = 2u << 30, OS_VALUE_MASK = (1u << 30) - 1u;
 
+// (first: the lowest digit anybody will ask for -- a sort that runs passes over the top four digits only spends half the
+// LDS atomics, which are what this kernel takes its time for: 2.5 ms per 1 B keys with eight digits)
 __global__ __launch_bounds__(RS_THREADS) void radix_ghist_kernel(const uint64_t* __restrict__ keys, uint32_t n,
-                                                                 uint32_t* __restrict__ ghist /*[8][256]*/) {
+                                                                 uint32_t* __restrict__ ghist /*[8][256]*/, int first) {
   __shared__ uint32_t h[RADIX_PASSES][RADIX];
   for (uint32_t i = threadIdx.x; i < RADIX_PASSES * RADIX; i += RS_THREADS) (&h[0][0])[i] = 0;
   __syncthreads();
@@ -296,7 +298,8 @@ __global__ __launch_bounds__(RS_THREADS) void radix_ghist_kernel(const uint64_t*
       if (i < n) {
         const uint64_t key = keys[i];
 #pragma unroll
-        for (int p = 0; p < RADIX_PASSES; ++p) atomicAdd(&h[p][(uint32_t)(key >> (p * RADIX_BITS)) & (RADIX - 1)], 1u);
+        for (int p = 0; p < RADIX_PASSES; ++p)
+          if (p >= first) atomicAdd(&h[p][(uint32_t)(key >> (p * RADIX_BITS)) & (RADIX - 1)], 1u);
       }
     }
   }
@@ -623,13 +626,15 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
     SWZ_TRY(c->get("radix_ghist", (size_t)RADIX_PASSES * RADIX, &d_ghist));
     SWZ_TRY(c->get("radix_status", (size_t)ntiles * RADIX, &d_status));
     SWZ_TRY(c->get("radix_ticket", (size_t)RADIX_PASSES, &d_ticket));
-    {
+    // the digit histograms of the whole input, for the digits from `first` up
+    auto global_histograms = [&](int first) -> int {
       ProfScope ps(c, "radix_hist", (uint64_t)n * 8ull);
       SWZ_HIP(c, hipMemsetAsync(d_ghist, 0, sizeof(uint32_t) * RADIX_PASSES * RADIX, c->stream));
-      hipLaunchKernelGGL(radix_ghist_kernel, dim3(std::min<uint32_t>(ntiles, 256u * 8u)), dim3(RS_THREADS), 0, c->stream, kin, n, d_ghist);
+      hipLaunchKernelGGL(radix_ghist_kernel, dim3(std::min<uint32_t>(ntiles, 256u * 8u)), dim3(RS_THREADS), 0, c->stream, kin, n, d_ghist, first);
       hipLaunchKernelGGL(radix_gscan_kernel, dim3(RADIX_PASSES), dim3(RADIX), 0, c->stream, d_ghist);
       SWZ_LAUNCH_CHECK(c);
-    }
+      return SWZ_OK;
+    };
     // how many top digits: from a sorted sample of the keys
     int top = RADIX_PASSES;
     uint32_t min_n = 1u << 24, short_max = FIX_SHORT, long_max = FIX_LONG;
@@ -650,7 +655,7 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
       SWZ_TRY(c->get("radix_sample_ghist", (size_t)RADIX_PASSES * RADIX, &d_sghist));
       hipLaunchKernelGGL(radix_sample_kernel, dim3(div_up(samples, 256)), dim3(256), 0, c->stream, kin, n, samples, d_sk);
       SWZ_HIP(c, hipMemsetAsync(d_sghist, 0, sizeof(uint32_t) * RADIX_PASSES * RADIX, c->stream));
-      hipLaunchKernelGGL(radix_ghist_kernel, dim3(div_up(samples, RS_TILE)), dim3(RS_THREADS), 0, c->stream, d_sk, samples, d_sghist);
+      hipLaunchKernelGGL(radix_ghist_kernel, dim3(div_up(samples, RS_TILE)), dim3(RS_THREADS), 0, c->stream, d_sk, samples, d_sghist, 0);
       hipLaunchKernelGGL(radix_gscan_kernel, dim3(RADIX_PASSES), dim3(RADIX), 0, c->stream, d_sghist);
       SWZ_LAUNCH_CHECK(c);
       uint64_t *a = d_sk, *b = d_sk2;
@@ -669,6 +674,7 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
     if (c->opt("SWZ_DEBUG") && n >= min_n) fprintf(stderr, "[swz] sort: %u keys, passes over the top %d digits\n", n, top);
     if (top < RADIX_PASSES) {
       const int first_pass = RADIX_PASSES - top;
+      SWZ_TRY(global_histograms(first_pass));
       SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, first_pass, RADIX_PASSES - 1, vals_identity, d_ghist, d_status, d_ticket));
       // an even number of passes: the data is back in the first pair; the run pass writes the second
       uint32_t* d_long = nullptr;
@@ -689,9 +695,11 @@ int radix_sort_pairs(swz_ctx* c, uint64_t* d_keys_in, uint32_t* d_vals_tmp, uint
       // runs of equal top bits too long to rank: all eight passes over what the top passes left in the first pair
       // (equal keys are still in input order there, so the result is the same stable order)
       if (c->opt("SWZ_DEBUG")) fprintf(stderr, "[swz] sort: %u runs of equal top %d bits longer than %u, falling back to eight passes\n", h[1], 8 * top - 1, long_max);
+      SWZ_TRY(global_histograms(0));  // (of what the top passes left in the first pair: the same multiset of keys)
       SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, 0, RADIX_PASSES - 1, false, d_ghist, d_status, d_ticket));
       return radix_copy_pairs(c, kin, vin, kout, vout, n);
     }
+    SWZ_TRY(global_histograms(0));
     SWZ_TRY(radix_lsd_passes(c, kin, vin, kout, vout, n, 0, RADIX_PASSES - 1, vals_identity, d_ghist, d_status, d_ticket));
     return radix_copy_pairs(c, kin, vin, kout, vout, n);
   }
