@@ -85,11 +85,14 @@ struct ChildStartG {
   }
 };
 constexpr uint32_t NF_TILE = 1024;  // points per workgroup: four per thread, one 16-byte store
+// (lazy: the grid samplers look a point's node up only on levels that have take-all nodes -- the counters node_mode_kernel
+// has just written say so --, and most levels of a large batch have none)
 __global__ __launch_bounds__(256) void node_fill_kernel(const uint32_t* __restrict__ nstart, const uint32_t* __restrict__ counters,
-                                                        uint32_t m, uint32_t* __restrict__ nid) {
+                                                        uint32_t m, uint32_t* __restrict__ nid, int lazy) {
   __shared__ uint32_t s_lo, s_hi;
   __shared__ uint32_t ss[NF_TILE + 1];
   const uint32_t nn = counters[CTR_NUM_NODES];
+  if (lazy && counters[CTR_SAMPLE_NODES] == nn) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t i0 = blockIdx.x * NF_TILE;
   const uint32_t last = (m - i0) > NF_TILE ? i0 + NF_TILE - 1u : m - 1u;
@@ -1209,9 +1212,14 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
   SWZ_HIP(c, hipMemsetAsync(lb.counters, 0, CTR_COUNT * sizeof(uint32_t), c->stream));
   {
     ProfScope ps(c, "level_nodes", (uint64_t)m * 8ull, 3);
+    bool fill_after_modes = false;
     if (plan.node_shift >= 63u && m > 0) {
       // the root (Morton keys have 63 bits): one node, nothing to segment -- two passes over the keys saved
-      SWZ_HIP(c, hipMemsetAsync(lb.nid, 0, (size_t)m * sizeof(uint32_t), c->stream));
+      // (node ids: zeros -- unless the one node is going to be sampled and the sampler is one that then never looks, see
+      // node_fill_kernel)
+      const bool sampled_for_sure = !plan.terminal && (plan.force_sample || (uint64_t)m > plan.max_points);
+      if (plan.sampler == SWZ_MIN_DISTANCE || !sampled_for_sure)
+        SWZ_HIP(c, hipMemsetAsync(lb.nid, 0, (size_t)m * sizeof(uint32_t), c->stream));
       hipLaunchKernelGGL(single_node_kernel, dim3(1), dim3(1), 0, c->stream, lb.nstart, lb.counters + CTR_NUM_NODES, m);
       SWZ_LAUNCH_CHECK(c);
     } else if (as.parent_prefix && as.parents && m > 0 && !c->opt("SWZ_LEVEL_NODES_SCAN")) {
@@ -1222,8 +1230,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
       SWZ_LAUNCH_CHECK(c);
       SWZ_TRY(fused_scan(c, ChildExistsF{cb, as.parents, m, lb.counters}, ChildStartG{cb, lb.nstart}, as.parents * 8u,
                          lb.counters + CTR_NUM_NODES, "lvl"));
-      hipLaunchKernelGGL(node_fill_kernel, dim3(div_up(m, NF_TILE)), dim3(256), 0, c->stream, lb.nstart, lb.counters, m, lb.nid);
-      SWZ_LAUNCH_CHECK(c);
+      fill_after_modes = true;
     } else {
       SWZ_TRY(fused_scan(c, NodeHeadF{as.akey, plan.node_shift}, NodeAssignG{lb.nid, lb.nstart, m}, m,
                          lb.counters + CTR_NUM_NODES, "lvl"));
@@ -1232,6 +1239,11 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
                        plan.max_points, plan.force_sample ? 1 : 0, plan.terminal ? 1 : 0, plan.reroot ? 1 : 0, as.akey,
                        plan.node_shift, as.ckey, as.nc);
     SWZ_LAUNCH_CHECK(c);
+    if (fill_after_modes) {  // the node id per point, from the node starts (MIN_DISTANCE reads it on every level)
+      hipLaunchKernelGGL(node_fill_kernel, dim3(div_up(m, NF_TILE)), dim3(256), 0, c->stream, lb.nstart, lb.counters, m, lb.nid,
+                         plan.sampler == SWZ_MIN_DISTANCE ? 0 : 1);
+      SWZ_LAUNCH_CHECK(c);
+    }
   }
 
   const bool first_only = (plan.sampler == SWZ_RANDOM_GRID || plan.sampler == SWZ_GRID_CENTER) && plan.cand < 0;
