@@ -98,6 +98,44 @@ def test_oracle_layout_and_library_writer_agree(tmp_path, names):
             assert np.array_equal(reader_attrs[k], attrs[k][refs])
 
 
+def test_node_files_of_a_batch_written_by_several_threads(tmp_path):
+    """swz_bin_persist_nodes hands the nodes of a table to a few host threads (no context needed: the error text is all a
+    context carries for it).  Every file must hold its node's rows byte for byte, an empty node no file, and a directory
+    that cannot be written an error instead of a crash."""
+    import ctypes as C
+    import schwarzwald_amd as swz
+    from schwarzwald_amd import api
+    rng = np.random.default_rng(9)
+    counts = np.array([0, 1, 5000, 3, 0, 777] + list(rng.integers(1, 400, 60)), dtype=np.uint64)
+    n = int(counts.sum())
+    offsets = np.concatenate([[0], np.cumsum(counts)[:-1]]).astype(np.uint64)
+    xyz = rng.random((n, 3))
+    attrs = _attributes(rng, n, ["rgb", "intensity", "gps_time"])
+    level = np.full(len(counts), 2, dtype=np.int8)
+    keys = (np.arange(len(counts), dtype=np.uint64) << np.uint64(54))   # distinct level-2 nodes: octant triples 000 .. 101
+    cols, keep = api._host_columns(attrs, n)
+    L = swz.load_library()
+    L.swz_bin_persist_nodes.argtypes = [C.c_void_p, C.c_char_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+
+    def run(directory):
+        return L.swz_bin_persist_nodes(None, str(directory).encode(), len(counts), level.ctypes.data, keys.ctypes.data,
+                                       offsets.ctypes.data, counts.ctypes.data, xyz.ctypes.data, C.byref(cols), 0)
+
+    out = tmp_path / "nodes"
+    out.mkdir()
+    assert run(out) == 0
+    for k in range(len(counts)):
+        f = out / (swz.node_name(2, int(keys[k])) + ".bin")
+        if counts[k] == 0:
+            assert not f.exists()
+            continue
+        refs = np.arange(int(offsets[k]), int(offsets[k] + counts[k]))
+        assert f.read_bytes() == _expected_bytes(refs, xyz, attrs)
+    assert len(list(out.iterdir())) == int((counts > 0).sum())
+    assert run(tmp_path / "does" / "not" / "exist") != 0
+
+
 def test_empty_node_writes_no_file_and_names(tmp_path):
     import schwarzwald_amd as swz
     swz.bin_write_node(str(tmp_path / "none.bin"), np.empty((0, 3)))
