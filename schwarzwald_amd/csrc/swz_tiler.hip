@@ -744,6 +744,17 @@ static int grow_preserving(swz_ctx* c, const char* name, size_t bytes, size_t ke
     }
     if (e != hipSuccess) return c->fail(SWZ_ERR_HIP, std::string("hipMalloc(") + name + "): " + hipGetErrorString(e));
     if (b.ptr && keep) SWZ_HIP(c, hipMemcpy(np, b.ptr, keep, hipMemcpyDefault));
+    if (const char* e = c->opt("SWZ_POISON")) {  // (like swz_ctx::get: what nobody has written yet must not read as zeros)
+      const char* only = c->opt("SWZ_POISON_ONLY");
+      if (!only || strstr(name, only)) {
+        if (host) {
+          memset((char*)np + keep, atoi(e), want - keep);
+        } else {  // (complete before anybody's stream writes into the buffer: hipMemset may return early)
+          SWZ_HIP(c, hipMemset((char*)np + keep, atoi(e), want - keep));
+          SWZ_HIP(c, hipDeviceSynchronize());
+        }
+      }
+    }
     c->free_buf(b);
     b.ptr = np;
     b.cap = want;
