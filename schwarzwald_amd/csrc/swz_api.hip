@@ -47,7 +47,9 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
         // ("..._sr": the root level of a sharded batch -- the other shards read those arrays through peer access / IPC
         // mappings until the batch ends, long after this shard has gone on to its own levels: never evicted here)
         const bool shared_root = md_shard_root_published && nm.size() >= 3 && nm.compare(nm.size() - 3, 3, "_sr") == 0;
-        if (level_scratch && !shared_root && kv.second.ptr && kv.second.epoch < scratch_epoch && &kv.second != &b) free_buf(kv.second);
+        const bool tiler_scratch = tiler_scratch_dead && nm.compare(0, 3, "tl_") == 0;
+        if ((level_scratch || tiler_scratch) && !shared_root && kv.second.ptr && kv.second.epoch < scratch_epoch && &kv.second != &b)
+          free_buf(kv.second);
       }
       e = hipMalloc(&b.ptr, want);
       if (e == hipErrorOutOfMemory && want > minimal) {  // without the growth head-room, then

@@ -121,7 +121,12 @@ struct swz_tiler {
 };
 
 static int tiler_guard(swz_tiler* t) {
-  if (!t->failed) return SWZ_OK;
+  // (every call of the tiler's API starts a scratch epoch: what earlier calls asked for and nothing holds on to -- level
+  // scratch, and the per-batch "tl_*" buffers once no batch is open -- may be freed when the device runs out of memory)
+  if (!t->failed) {
+    t->c->next_scratch_epoch();
+    return SWZ_OK;
+  }
   return t->c->fail(SWZ_ERR_TILER_FAILED, "swz_tiler: an earlier batch failed part-way (" + t->failed_why +
                                             "); the node store is incomplete -- destroy the tiler");
 }
@@ -855,6 +860,11 @@ __global__ __launch_bounds__(256) void tl_count_untaken_kernel(const uint8_t* __
 static int work_need_positions(swz_tiler* t, BatchWork& w) {
   if (w.have_pos) return SWZ_OK;
   swz_ctx* c = t->c;
+  // (24 bytes per working-pool entry -- batch + everything stored -- that most data sets never touch: allocated here, not
+  // with the batch.  At 2.4 B stored points the three arrays were 78 of the 286 GB that ran the device out of memory.)
+  SWZ_TRY(c->get("tl_wx", (size_t)w.wcap, &w.wx));
+  SWZ_TRY(c->get("tl_wy", (size_t)w.wcap, &w.wy));
+  SWZ_TRY(c->get("tl_wz", (size_t)w.wcap, &w.wz));
   if (w.wused) {
     hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(w.wused, 256)), dim3(256), 0, c->stream, w.wgid, w.wused, t->pool_xyz, w.wx, w.wy, w.wz,
                        (uint32_t*)nullptr);
@@ -935,6 +945,7 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   }
   const uint32_t pull_lo = w.wused;  // working indices of the pulled entries, below
   ActiveSet ms = as;
+  if (ng) SWZ_TRY(work_need_positions(t, w));  // (the ghosts bring their positions: the working pool holds them from here on)
   if (nc || ng) {
     if (nc && !st.rekeyed) {
       // ("tiler_rekey": the pulled points' keys against their NODE's bounds -- a random 24-byte read per point from the
@@ -958,7 +969,8 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     if (w.wused + nc + ng > w.wcap) return c->fail(SWZ_ERR_INTERNAL, "working pool overflow");
     if (nc) {
       hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, cgid, nc, t->pool_xyz,
-                         w.have_pos ? w.wx + w.wused : nullptr, w.wy + w.wused, w.wz + w.wused, w.wgid + w.wused);
+                         w.have_pos ? w.wx + w.wused : nullptr, w.have_pos ? w.wy + w.wused : nullptr,
+                         w.have_pos ? w.wz + w.wused : nullptr, w.wgid + w.wused);
       SWZ_LAUNCH_CHECK(c);
     }
     uint64_t* mkey = nullptr;
@@ -1311,6 +1323,7 @@ static uint64_t stored_total(const swz_tiler* t) {
 // Index + sort + positions into Morton order (K1, K2, gather), exactly like a single batch; leaves the batch open.
 static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t extra_pool) {
   swz_ctx* c = t->c;
+  c->tiler_scratch_dead = false;  // (the batch's scratch lives until tiler_batch_close)
   if (t->finalized) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: batches cannot be added after finalize");
   if (t->batch_open) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler: the previous batch is still open (swz_tiler_shard_finish)");
   // parallel::scatter throws for a batch with fewer points than indexing threads (util/threading/Parallel.h:181-186)
@@ -1344,9 +1357,6 @@ static int tiler_batch_prepare(swz_tiler* t, double* d_xyz, uint32_t n, uint32_t
   const uint64_t wcap64 = (uint64_t)n + stored_total(t) + extra_pool;
   if (wcap64 > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "batch + stored points exceed 2^32-65536");
   w.wcap = (uint32_t)wcap64;
-  SWZ_TRY(c->get("tl_wx", (size_t)w.wcap, &w.wx));
-  SWZ_TRY(c->get("tl_wy", (size_t)w.wcap, &w.wy));
-  SWZ_TRY(c->get("tl_wz", (size_t)w.wcap, &w.wz));
   SWZ_TRY(c->get("tl_wlevel", (size_t)w.wcap, &w.wlevel));
   SWZ_TRY(c->get("tl_wgid", (size_t)w.wcap, &w.wgid));
   if (n) {  // (positions: on demand, work_need_positions)
@@ -1407,6 +1417,7 @@ static int tiler_batch_run(swz_tiler* t, int last_level, const ShardRoot* sr) {
 }
 
 static void tiler_batch_close(swz_tiler* t, swz_tile_stats* stats) {
+  t->c->tiler_scratch_dead = true;
   t->total += t->bw.n;
   if (t->staged_total < t->total) t->staged_total = t->total;
   ++t->batches;
