@@ -165,6 +165,30 @@ _QUEUE_TIMEOUT = int(os.environ.get("SWZ_TEST_QUEUE_TIMEOUT", "300"))  # seconds
 
 
 # ------------------------------------------------------------------ GPU: full sharded tiler, 2 ranks on one GPU
+@pytest.mark.parametrize("n,concurrency,clustered", [(3000, 2, False), (200000, 2, False), (200000, 8, True), (50000, 32, True)])
+def test_fast_start_level_from_summed_prefix_counts(n, concurrency, clustered):
+    """FAST on a sharded batch takes its start level from the ranks' summed 6-octant prefix histograms
+    (swz_fast_start_level_from_counts, a host function): it must be the level the single-process oracle derives from the
+    whole batch (estimate_start_node_level_in_octree, TilingAlgorithms.cpp:1473-1535), however the points are dealt out."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(n + concurrency)
+    xyz = _cloud(n, 77)
+    if clustered:
+        xyz[: n // 2] = 0.4 + 0.01 * rng.standard_normal((n // 2, 3))
+        xyz = np.clip(xyz, 0.0, 1.0)
+    keys, _ = O.index_points(xyz, [0, 0, 0], [1, 1, 1])
+    parts = np.array_split(rng.permutation(n), 4)            # four "ranks", any points each
+    counts = np.zeros(1 << 18, dtype=np.uint64)
+    for part in parts:
+        counts += np.bincount((keys[part] >> np.uint64(45)).astype(np.int64), minlength=1 << 18).astype(np.uint64)
+    assert int(counts.sum()) == n
+    got = swz.api.fast_start_level_from_counts(counts, concurrency)
+    ref = O.tile(xyz, [0, 0, 0], [1, 1, 1], O.RANDOM_GRID, 300, O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 64), strategy=O.FAST,
+                 fast_concurrency=concurrency)
+    assert ref["status"] == 0
+    assert got == ref["stats"]["fast_start_levels"]
+
+
 def _corner_cloud(n, seed, world):
     """Points in the octants of rank 0 only: every other rank's shard is empty (flat terrain in a cubic
     root box leaves whole octants, i.e. whole ranks, without points)."""
