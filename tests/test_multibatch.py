@@ -196,13 +196,24 @@ def test_gpu_multibatch_spatially_coherent_batches(ctx, sampler, strategy):
     _compare(g, ex, c)
     # the same with the node table read in the middle of the data set
     params = swz.TileParams(sampler=sampler, max_points_per_node=500, spacing_at_root=sp, strategy=strategy, fast_concurrency=2)
-    with swz.Tiler(ctx, UNIT[0], UNIT[1], params) as t:
+    ctx2 = swz.Context(0)  # (a workspace of its own: what the calls below allocate is then known)
+    with swz.Tiler(ctx2, UNIT[0], UNIT[1], params) as t:
         for i, p in enumerate(np.array_split(xyz, k)):
             d = torch.from_numpy(np.ascontiguousarray(p)).cuda()
             torch.cuda.synchronize()
             t.add_batch_device(d.data_ptr(), p.shape[0])
             if i in (5, 6, 17):
-                mid = t.node_table()
+                # (once with the first allocation of the call pretending to run out of memory: the workspace then frees the
+                # scratch of the batches -- nobody holds on to it between two batches -- and the next batch allocates again)
+                held = ctx2.workspace_bytes()
+                if i == 6:
+                    ctx2.set_option("SWZ_FAIL_ALLOC", "tl_head_pos")
+                try:
+                    mid = t.node_table()
+                finally:
+                    ctx2.set_option("SWZ_FAIL_ALLOC", None)
+                if i == 6:
+                    assert ctx2.workspace_bytes() < held, "the batches' scratch should have been given back"
                 assert int(mid["count"].sum()) == int(t.info()["num_stored"])
         t.finalize()
         tb = t.node_table()
@@ -211,6 +222,7 @@ def test_gpu_multibatch_spatially_coherent_batches(ctx, sampler, strategy):
         t.export_device(None, d_ids.data_ptr(), None)
         assert np.array_equal(tb["count"], ex["count"]) and np.array_equal(tb["key"], ex["key"])
         assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ex["ids"])
+    ctx2.close()
 
 
 @pytest.mark.gpu
