@@ -432,6 +432,11 @@ int swz_tiler_get_info(swz_tiler* tiler, swz_tiler_info* info);
  * SWZ_ERR_HIP as before).  Replaces nothing in the reference, whose node files live on disk between batches
  * (core/tiling/TilingAlgorithms.cpp:50-109); this is what bounds the size of a data set per GPU here. */
 int swz_tiler_pool_residency(swz_tiler* tiler, uint64_t* device_bytes_out, uint64_t* host_bytes_out);
+/* Makes room in the pools for `total_points` points of the data set NOW (what the next batch would do on its own).  A
+ * driver that must know where the pools will live while a batch is tiled -- the joint MIN_DISTANCE root of one process per
+ * GPU exports them as IPC handles, which page-locked host memory does not have -- reserves first and asks
+ * swz_tiler_pool_residency afterwards. */
+int swz_tiler_reserve(swz_tiler* tiler, uint64_t total_points);
 /* The same for the node store (the files' {key, point id} entries, two sides per octree level): a side that finds no device
  * memory, or would push the workspace over SWZ_TILER_DEVICE_BUDGET_MB, is placed in mapped pinned host memory like a pool
  * and the merges stream through it over the host link. */

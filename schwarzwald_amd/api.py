@@ -765,6 +765,11 @@ class Tiler:
         self._ctx._check(self._lib.swz_tiler_pool_residency(self._t, C.byref(dev), C.byref(host)))
         return int(dev.value), int(host.value)
 
+    def reserve(self, total_points):
+        """room in the pools for total_points points of the data set, now (swz_tiler_reserve)"""
+        self._lib.swz_tiler_reserve.argtypes = [C.c_void_p, C.c_uint64]
+        self._ctx._check(self._lib.swz_tiler_reserve(self._t, int(total_points)))
+
     def store_residency(self):
         """(bytes of the node store in device memory, bytes placed in mapped page-locked host memory)"""
         dev, host = C.c_uint64(), C.c_uint64()

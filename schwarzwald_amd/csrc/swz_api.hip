@@ -32,12 +32,16 @@ int swz_ctx::get(const char* name, size_t bytes, void** out) {
     want = (want + 255) & ~size_t(255);
     hipError_t e = hipMalloc(&b.ptr, want);
     // SWZ_FAIL_ALLOC=<name>: treat every first attempt to allocate that buffer as out of memory (tests of the path below)
-    if (const char* fa = opt("SWZ_FAIL_ALLOC"))
-      if (e == hipSuccess && strcmp(fa, name) == 0) {
+    // ("md_*": any buffer whose name starts with what stands in front of the star)
+    if (const char* fa = opt("SWZ_FAIL_ALLOC")) {
+      const size_t fl = strlen(fa);
+      const bool hit = fl && fa[fl - 1] == '*' ? strncmp(fa, name, fl - 1) == 0 : strcmp(fa, name) == 0;
+      if (e == hipSuccess && hit) {
         (void)hipFree(b.ptr);
         b.ptr = nullptr;
         e = hipErrorOutOfMemory;
       }
+    }
     if (e == hipErrorOutOfMemory) {  // give back the level scratch nobody has asked for since an earlier level
       (void)hipGetLastError();
       SWZ_HIP(this, hipStreamSynchronize(stream));

@@ -343,8 +343,10 @@ void shard_thread(ShardCall a) {
       for (int s = 0; s < N; ++s)
         for (uint32_t b = 0; b < (1u << 18); ++b) sum[b] += g->hist[s][b];
       int32_t S = -1;
-      (void)swz_fast_start_level_from_counts(sum.data(), a.params->fast_concurrency, &S);
+      const int rc = swz_fast_start_level_from_counts(sum.data(), a.params->fast_concurrency, &S);
       g->fast_tile_start = S;
+      if (ok && (rc != SWZ_OK || S < 0))  // (raised before the barrier: all_ok() then stops every shard with the real cause)
+        ok = fail(g, 0, rc != SWZ_OK ? rc : SWZ_ERR_INTERNAL, "FAST: no start level from the summed prefix histograms of the batch");
     }
     g->barrier.wait();
     if (!all_ok(g)) ok = false;
@@ -761,6 +763,8 @@ int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_colum
           return SWZ_ERR_BAD_ARG;
         }
   g->turn = 0;
+  g->fast_tile_start = -1;  // (group state shard 0 writes: nothing of an earlier call, failed or not, may be seen by this one)
+  g->cand_flags = nullptr;
   g->t_call = std::chrono::steady_clock::now();
   std::fill(g->status.begin(), g->status.end(), SWZ_OK);
   std::vector<std::thread> threads;

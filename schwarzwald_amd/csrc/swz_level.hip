@@ -93,6 +93,8 @@ __global__ __launch_bounds__(256) void node_fill_kernel(const uint32_t* __restri
   __shared__ uint32_t ss[NF_TILE + 1];
   const uint32_t nn = counters[CTR_NUM_NODES];
   if (lazy && counters[CTR_SAMPLE_NODES] == nn) return;
+  // (an inconsistent segmentation -- ChildExistsF raises CTR_ERROR -- must not be walked: the host reads the counter later)
+  if (counters[CTR_ERROR] != 0u || nn == 0u) return;
   const uint32_t tid = threadIdx.x;
   const uint32_t i0 = blockIdx.x * NF_TILE;
   const uint32_t last = (m - i0) > NF_TILE ? i0 + NF_TILE - 1u : m - 1u;
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void node_fill_kernel(const uint32_t* __restri
     if (tid) s_hi = r; else s_lo = r;
   }
   __syncthreads();
-  const uint32_t lo = s_lo, span = s_hi - s_lo + 1u;  // (at most one node starts per point: span <= NF_TILE)
+  const uint32_t lo = s_lo, span = min(s_hi - s_lo + 1u, (uint32_t)NF_TILE);  // (at most one node starts per point: span <= NF_TILE)
   for (uint32_t k = tid; k <= span; k += 256u) ss[k] = (lo + k < nn) ? nstart[lo + k] : 0xFFFFFFFFu;  // ss[k]: start of node lo + k
   __syncthreads();
   const uint32_t i = i0 + tid * 4u;
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void node_fill_kernel(const uint32_t* __restri
   uint32_t v[4];
 #pragma unroll
   for (uint32_t q = 0; q < 4u; ++q) {
-    while (ss[k + 1u] <= i + q) ++k;
+    while (k + 1u <= span && ss[k + 1u] <= i + q) ++k;
     v[q] = lo + k;
   }
   if (i + 4u <= m) {
@@ -1201,6 +1203,17 @@ bool level_decides_on_keys(const swz_ctx* c, const LevelPlan& plan, const Sorted
   return grid_level_uses_keys(c, plan, sp, nullptr);
 }
 
+// what a kernel of the level raised in CTR_ERROR, in words
+static const char* level_error_message(int code) {
+  switch (code) {
+    case SWZ_ERR_JITTER_GRID_TOO_SMALL: return "Grids smaller than 16x16 are not supported currently!";
+    case SWZ_ERR_JITTER_NODE_TOO_DEEP: return "node is too small to be sampled with JITTERED";
+    case SWZ_ERR_REROOT_UNSUPPORTED: return "node needs Morton re-rooting (unsupported)";
+    case SWZ_ERR_INTERNAL: return "level segmentation inconsistent, or a MIN_DISTANCE sweep / a peer shard failed";
+    default: return "a kernel of the level raised an error";
+  }
+}
+
 // ----------------------------------------------------------------------------- one level
 // Samples every node of the level.  When okey/oidx are given the survivors are compacted into them
 // and level_out receives plan.level for the taken points; otherwise only lb.taken is produced.
@@ -1330,7 +1343,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
     uint32_t h[CTR_COUNT];
     SWZ_HIP(c, hipMemcpyAsync(h, lb.counters, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
-    if (h[CTR_ERROR]) return c->fail((int)h[CTR_ERROR], "node needs Morton re-rooting (unsupported)");
+    if (h[CTR_ERROR]) return c->fail((int)h[CTR_ERROR], level_error_message((int)h[CTR_ERROR]));
     if (h[CTR_SAMPLE_NODES] < h[CTR_NUM_NODES]) {  // only levels that have take-all nodes pay for the pass
       hipLaunchKernelGGL(take_all_kernel, dim3(nb), dim3(256), 0, c->stream, m, lb.nid, lb.nmode, lb.taken);
       SWZ_LAUNCH_CHECK(c);
@@ -1356,11 +1369,7 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
   c->prof_collect();
   if (h[CTR_ERROR]) {
     const int code = (int)h[CTR_ERROR];
-    const char* msg = code == SWZ_ERR_JITTER_GRID_TOO_SMALL
-                        ? "Grids smaller than 16x16 are not supported currently!"
-                        : code == SWZ_ERR_JITTER_NODE_TOO_DEEP ? "node is too small to be sampled with JITTERED"
-                                                               : "node needs Morton re-rooting (unsupported)";
-    return c->fail(code, msg);
+    return c->fail(code, level_error_message(code));
   }
   res->remaining = h[CTR_REMAINING];
   res->num_nodes = h[CTR_NUM_NODES];

@@ -1557,6 +1557,29 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   }
   // a level is done when a round starts with an empty queue: only running cells wake sleeping ones
   std::vector<uint32_t> gleft(groups, 1);
+  // The grid of a round follows its queue.  The workgroups of a segment draw its entries by ticket, so any multiple of the
+  // segment count works; a round of a small level -- a 10 M batch of the multi-batch tiler holds a few hundred cells per
+  // round -- then starts a few hundred single-wavefront workgroups instead of the ~6000 that are resident at once, all but
+  // a few of which would find their segment empty (an empty launch of the full grid costs ~15 us, and such a level runs
+  // ~2000 rounds).  The host knows the size of the last queue it looked at; the queue of a round grows slowly (a front
+  // moving through the cells), so four times that size, at least eight workgroups per segment, covers the rounds until
+  // the next look -- a grid that turns out small only makes its workgroups draw more tickets.
+  const bool adapt_grid = !(c->opt("SWZ_MD_ADAPT_GRID") && atoi(c->opt("SWZ_MD_ADAPT_GRID")) == 0) && !c->opt("SWZ_MD_GRID");
+  std::vector<uint32_t> ggrid(groups, sweep_grid);
+  auto grid_for = [&](uint32_t queued) {
+    const uint64_t want = std::max<uint64_t>(8ull * a.nseg, 4ull * queued);
+    return (uint32_t)std::min<uint64_t>(sweep_grid, (want + a.nseg - 1u) / a.nseg * a.nseg);
+  };
+  if (adapt_grid) {  // the first rounds: what mq_nbr_build_kernel has queued
+    std::vector<uint32_t> h((size_t)a.nseg * 32u);
+    for (uint32_t g = 0; g < groups; ++g) {
+      SWZ_HIP(c, hipMemcpyAsync(h.data(), ga[g].qctr, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      uint64_t queued = 0;
+      for (uint32_t sgm = 0; sgm < a.nseg; ++sgm) queued += std::min(h[(size_t)sgm * 32u], a.segcap);
+      ggrid[g] = grid_for((uint32_t)std::min<uint64_t>(queued, 0xFFFFFFFFull));
+    }
+  }
   uint32_t round = MQ_FIRST_ROUND;
   bool running = true;
   while (running) {
@@ -1565,14 +1588,14 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
         if (sharded) {
           hipLaunchKernelGGL(mq_round_word_kernel, dim3(1), dim3(1), 0, gs[g], a.round_word, round);
           if (big_cells)
-            hipLaunchKernelGGL((mq_sweep_kernel<4, true>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+            hipLaunchKernelGGL((mq_sweep_kernel<4, true>), dim3(ggrid[g]), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
           else
-            hipLaunchKernelGGL((mq_sweep_kernel<1, true>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+            hipLaunchKernelGGL((mq_sweep_kernel<1, true>), dim3(ggrid[g]), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
         } else if (big_cells) {
-          hipLaunchKernelGGL((mq_sweep_kernel<4, false>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+          hipLaunchKernelGGL((mq_sweep_kernel<4, false>), dim3(ggrid[g]), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
           if (ndense) hipLaunchKernelGGL(mq_dense_reject_kernel, dim3(ndense), dim3(256), 0, gs[g], ga[g], round);
         } else {
-          hipLaunchKernelGGL((mq_sweep_kernel<1, false>), dim3(sweep_grid), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
+          hipLaunchKernelGGL((mq_sweep_kernel<1, false>), dim3(ggrid[g]), dim3(WAVE), lds_bytes, gs[g], ga[g], round);
         }
       }
     }
@@ -1586,6 +1609,7 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
     for (uint32_t g = 0; g < groups; ++g) {
       SWZ_HIP(c, hipStreamSynchronize(gs[g]));
       running |= gleft[g] != 0u;
+      if (adapt_grid) ggrid[g] = grid_for(gleft[g]);
     }
     if (peer_err) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE root of a sharded batch: a lower shard's sweep failed (or a queue overflowed); this shard gives up as well");
     if (std::chrono::duration<double>(std::chrono::steady_clock::now() - wall0).count() > wall_limit) {

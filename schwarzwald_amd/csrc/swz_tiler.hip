@@ -1452,9 +1452,20 @@ static int tiler_add_batch(swz_tiler* t, double* d_xyz, uint32_t n, swz_tile_sta
 // TilingAlgorithmV3::finalize -> reconstruct_left_out_nodes (:1717-1784): every ancestor of a start node samples the
 // points its children hold (children in octant order = the store order of the level below), re-indexed against the
 // root bounds, with AlwaysAdhereToMinSpacing (reconstruct_single_node :1661-1715).
+// While a call outside a batch holds "tl_*" buffers across level_step (whose MIN_DISTANCE levels open new scratch
+// epochs and may run out of memory), the workspace must not count them as dead scratch: get() would free the very
+// arrays the level is reading.
+struct TilerScratchLive {
+  swz_ctx* c;
+  bool was;
+  explicit TilerScratchLive(swz_ctx* ctx) : c(ctx), was(ctx->tiler_scratch_dead) { c->tiler_scratch_dead = false; }
+  ~TilerScratchLive() { c->tiler_scratch_dead = was; }
+};
+
 static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats, int lowest_children = 0) {
   swz_ctx* c = t->c;
   zero_stats(stats);
+  TilerScratchLive live(c);
   if (t->finalized) return SWZ_OK;
   if (!t->staged_sizes.empty()) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_finalize: staged batches have not been tiled");
   t->finalized = lowest_children == 0;  // (a shard stops below the root: swz_tiler_shard_fast_set_root ends the data set)
@@ -1779,6 +1790,7 @@ int swz_tiler_shard_fast_set_root(swz_tiler* t, const uint8_t* d_taken) {
   t->finalized = true;
   if (m == 0) return SWZ_OK;
   if (!d_taken) return c->fail(SWZ_ERR_BAD_ARG, "swz_tiler_shard_fast_set_root: NULL flags");
+  TilerScratchLive live(c);
   auto body = [&]() -> int {
     SWZ_TRY(store_linearize(c, src, 1));
     uint64_t *keys = nullptr, *tkey = nullptr;
@@ -1952,6 +1964,16 @@ int swz_tiler_pool_residency(swz_tiler* t, uint64_t* device_bytes_out, uint64_t*
   if (device_bytes_out) *device_bytes_out = dev;
   if (host_bytes_out) *host_bytes_out = host;
   return SWZ_OK;
+}
+
+int swz_tiler_reserve(swz_tiler* t, uint64_t total_points) {
+  if (!t) return SWZ_ERR_BAD_ARG;
+  swz_ctx* c = t->c;
+  SWZ_HIP(c, hipSetDevice(c->device));
+  SWZ_TRY(tiler_guard(t));
+  if (total_points > 0xFFFF0000ull) return c->fail(SWZ_ERR_TOO_MANY_POINTS, "more than 2^32-65536 points per tiler");
+  if (total_points <= t->pool_cap && t->pool_xyz) return SWZ_OK;
+  return pool_reserve(t, (size_t)total_points);
 }
 
 int swz_tiler_store_residency(swz_tiler* t, uint64_t* device_bytes_out, uint64_t* host_bytes_out) {

@@ -604,7 +604,20 @@ class ShardedBatchTiler:
         if possible and self._joint_usable is None:
             self._joint_usable = _joint_root_usable(ctx, self.rank, world, gather)
         joint = bool(possible and self._joint_usable)
-        self.root_mode = "local" if not sequential_root else ("joint" if joint else ("chain (no IPC mapping)" if possible else "chain"))
+        why_chain = "no IPC mapping"
+        if joint:
+            # The probe exported a small hipMalloc buffer; the real thing exports the tiler's position pool, and a pool that
+            # has spilled to page-locked host memory (SWZ_TILER_SPILL, a device budget, out of memory) has no IPC handle
+            # (ADVICE r4): reserve this batch's room first, then every rank says where its pool lives -- one vote per batch.
+            exportable = 1
+            try:
+                self.tiler.reserve(int(self.tiler.info()["num_points"]) + m)
+                exportable = int(self.tiler.pool_residency()[1] == 0)
+            except api.SwzError:
+                exportable = 0  # (the batch fails on its own below; the others must not wait for this rank's export)
+            if self._all_sum(exportable) != world:
+                joint, why_chain = False, "a pool lives in host memory"
+        self.root_mode = "local" if not sequential_root else ("joint" if joint else ("chain (%s)" % why_chain if possible else "chain"))
         if not sequential_root:
             guarded(lambda: self.tiler.shard_begin_device(recv.data_ptr(), m, ptrs, global_new, root_stored), 0)
         elif joint:

@@ -92,7 +92,8 @@ def ctx():
     c.close()
 
 
-def _gpu_files(ctx, bounds, xyz, k, sampler, max_points, spacing, strategy, concurrency, staged, max_depth=100):
+def _gpu_files(ctx, bounds, xyz, k, sampler, max_points, spacing, strategy, concurrency, staged, max_depth=100,
+               fail_alloc_in_finalize=None):
     import schwarzwald_amd as swz
     import torch
     params = swz.TileParams(sampler=sampler, max_points_per_node=max_points, spacing_at_root=spacing, max_depth=max_depth,
@@ -116,7 +117,13 @@ def _gpu_files(ctx, bounds, xyz, k, sampler, max_points, spacing, strategy, conc
                 d = torch.from_numpy(np.ascontiguousarray(p)).cuda()
                 torch.cuda.synchronize()
                 visited += t.add_batch_device(d.data_ptr(), p.shape[0])["points_visited"]
-        t.finalize()
+        if fail_alloc_in_finalize:
+            ctx.set_option("SWZ_FAIL_ALLOC", fail_alloc_in_finalize)
+        try:
+            t.finalize()
+        finally:
+            if fail_alloc_in_finalize:
+                ctx.set_option("SWZ_FAIL_ALLOC", None)
         info = t.info()
         table = t.node_table()
         ns = int(info["num_stored"])
@@ -223,6 +230,30 @@ def test_gpu_multibatch_spatially_coherent_batches(ctx, sampler, strategy):
         assert np.array_equal(tb["count"], ex["count"]) and np.array_equal(tb["key"], ex["key"])
         assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ex["ids"])
     ctx2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [0, 1])
+def test_gpu_fast_finalize_survives_out_of_memory_inside_its_levels(flags):
+    """FAST + MIN_DISTANCE: finalize rebuilds the skipped levels from ALL stored points, so its levels are larger than any
+    batch's and the sampler scratch grows there.  When such an allocation runs out of memory the workspace frees scratch
+    of earlier epochs -- but not the arrays finalize itself holds across the level ("tl_keys", "tl_wx", ...), although no
+    batch is open (they were freed and read afterwards).  SWZ_FAIL_ALLOC="md_*" makes the first attempt of every
+    growing MIN_DISTANCE buffer fail."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(77)
+    n, k = 150000, 3
+    xyz = _points(rng, n, UNIT, clustered=False)
+    sp = O.spacing_from_diagonal(*UNIT, 64)
+    ex, c = _oracle_files(UNIT, xyz, k, O.MIN_DISTANCE, 500, sp, O.FAST, 2)
+    ctx2 = swz.Context(0)
+    try:
+        if flags:
+            ctx2.set_option("SWZ_POISON", "205")  # freed-and-reallocated arrays then never hold the old bytes by luck
+        g = _gpu_files(ctx2, UNIT, xyz, k, O.MIN_DISTANCE, 500, sp, O.FAST, 2, staged=False, fail_alloc_in_finalize="md_*")
+    finally:
+        ctx2.close()
+    _compare(g, ex, c)
 
 
 @pytest.mark.gpu

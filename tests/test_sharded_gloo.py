@@ -437,6 +437,8 @@ def _mb_cloud(n, batch, rank, corner_world=0):
 
 def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, strategy=0, concurrency=8, root="default"):
     # the MIN_DISTANCE root of every batch: swept by all ranks at once (the default, after the IPC probe) or in turns
+    # ("spilled": rank 0 -- whose root arrays the higher ranks map -- keeps its pools in page-locked host memory, which has
+    # no IPC handle: the per-batch vote must then take the chain on EVERY rank)
     if root == "chain":
         os.environ["SWZ_SHARD_JOINT_ROOT"] = "0"
     else:
@@ -447,6 +449,8 @@ def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, st
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     ctx = swz.Context(0)
+    if root == "spilled" and rank == 0:
+        ctx.set_option("SWZ_TILER_SPILL", "host")
     params = swz.TileParams(sampler=sampler, max_points_per_node=max_pts, spacing_at_root=spacing, strategy=strategy,
                             fast_concurrency=concurrency)
     st = sharded.ShardedBatchTiler(ctx, dev, [0, 0, 0], [1, 1, 1], params)
@@ -456,7 +460,8 @@ def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, st
         attrs = {"intensity": (ids & 0xFFFF).to(torch.int16).to(dev), "point_source_id": (ids >> 16).to(torch.int16).to(dev)}
         bstats = st.add_batch(xyz, attrs)
         if sampler == swz.MIN_DISTANCE and strategy == 0 and bstats["root_mode"] != "local":
-            assert bstats["root_mode"] == ("chain" if root == "chain" else "joint"), bstats["root_mode"]
+            want_mode = {"chain": "chain", "spilled": "chain (a pool lives in host memory)"}.get(root, "joint")
+            assert bstats["root_mode"] == want_mode, bstats["root_mode"]
     st.finalize()
     info = st.tiler.info()
     table = st.tiler.node_table()
@@ -476,14 +481,15 @@ def _mb_worker(rank, world, port, n, k, sampler, max_pts, spacing, q, corner, st
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED, "MIN_DISTANCE+chain"])
+@pytest.mark.parametrize("sampler", [O.RANDOM_GRID, O.GRID_CENTER, O.MIN_DISTANCE, O.JITTERED, "MIN_DISTANCE+chain",
+                                     "MIN_DISTANCE+spilled"])
 @pytest.mark.parametrize("corner", [False, True])
 def test_sharded_multibatch_matches_the_multibatch_oracle(sampler, corner):
     """Two ranks (sharing cuda:0, collectives over gloo), three batches each: the union of the shards' node files must
     be the single-process multi-batch oracle's, file by file and in file order; the root's file is the concatenation of
     the shards' parts in rank order.  corner: rank 1 never owns a point."""
-    root = "chain" if sampler == "MIN_DISTANCE+chain" else "default"   # (MIN_DISTANCE alone: every batch's root swept jointly)
-    sampler = O.MIN_DISTANCE if root == "chain" else sampler
+    root = sampler.split("+")[1] if isinstance(sampler, str) else "default"   # (MIN_DISTANCE alone: every batch's root swept jointly)
+    sampler = O.MIN_DISTANCE if root != "default" else sampler
     world, n, k, max_pts = 2, 20000, 3, 400
     spacing = O.spacing_from_diagonal([0, 0, 0], [1, 1, 1], 250 if sampler != O.MIN_DISTANCE else 60)
     mpctx = mp.get_context("spawn")

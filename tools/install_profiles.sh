@@ -1,18 +1,27 @@
-# Copies the summaries of the last tools/profile_round.sh run (gpurun_out/profile/) into profiles/$1 (default r04) and derives
-# traffic.json; files other tools left there (las_decode_*.txt, bin_backend_*.txt) are kept.
-R=${1:-r04}
+# Copies the summaries of the last tools/profile_round.sh run (gpurun_out/profile/) into profiles/$1 (default r05) and derives
+# traffic.json.  Nothing already in profiles/$1 is deleted: the new set is assembled in a temporary directory first and only
+# then copied over what is there (files other tools left -- las_decode_*.txt, bin_backend_*.txt, extra probes -- stay).
+set -euo pipefail
+R=${1:-r05}
 P=gpurun_out/profile
 D=profiles/$R
-mkdir -p /tmp/keep_$R && cp $D/las_decode_*.txt $D/bin_backend_*.txt /tmp/keep_$R/ 2>/dev/null
-rm -rf $D && mkdir -p $D && cp /tmp/keep_$R/* $D/ 2>/dev/null
-cp $P/bench_100M_*.json $P/bench_1B_100batches_*_tiles.json $P/bench_1B_100batches_*_uniform.json $P/bench_1B_GRID_CENTER.json \
-   $P/bench_1B_JITTERED.json $P/bench_1B_RANDOM_GRID.json $P/bench_1B_min_distance*.json $P/bench_500M_*.json $P/bench_group_driver_*.json \
-   $P/clustered_100M.txt $P/fullsize_pytest.txt $P/fullsize_verification_1B.log $P/group_joint_root_vs_turns.txt $P/pmc_*_by_kernel*.csv \
-   $P/source_sha16.txt $D/
-cp $P/stats_run.json $D/bench_under_rocprofv3.json
-cp $P/stats/bench_kernel_stats.csv $D/rocprofv3_kernel_stats_bench_default.csv
-cp $P/stats_gc/bench_kernel_stats.csv $D/rocprofv3_kernel_stats_GRID_CENTER.csv
-cp $P/stats_prop/bench_kernel_stats.csv $D/rocprofv3_kernel_stats_property_mode.csv
-cp $P/stats_mb/bench_kernel_stats.csv $D/rocprofv3_kernel_stats_1B_100batches_RANDOM_GRID.csv
-python tools/make_traffic.py $D
-echo "run on sources $(cat $D/source_sha16.txt), tree has $(python -c 'import bench; print(bench.library_source_sha16())')"
+[ -d "$P" ] || { echo "install_profiles: $P does not exist (run tools/profile_round.sh through gpurun first)" >&2; exit 1; }
+[ -s "$P/source_sha16.txt" ] || { echo "install_profiles: $P/source_sha16.txt is missing -- the profile run did not finish" >&2; exit 1; }
+T=$(mktemp -d)
+trap 'rm -rf "$T"' EXIT
+shopt -s nullglob
+for f in "$P"/bench_*.json "$P"/clustered_*.txt "$P"/fullsize_pytest.txt "$P"/fullsize_verification_1B.log \
+         "$P"/group_joint_root_vs_turns.txt "$P"/pmc_*_by_kernel*.csv "$P"/source_sha16.txt "$P"/*.txt; do
+  cp "$f" "$T"/
+done
+[ -f "$P/stats_run.json" ] && cp "$P/stats_run.json" "$T/bench_under_rocprofv3.json"
+for pair in stats:bench_default stats_gc:GRID_CENTER stats_prop:property_mode stats_mb:1B_100batches_RANDOM_GRID \
+            stats_mbmd:100batches_MIN_DISTANCE_FAST; do
+  src=${pair%%:*}; name=${pair##*:}
+  [ -f "$P/$src/bench_kernel_stats.csv" ] && cp "$P/$src/bench_kernel_stats.csv" "$T/rocprofv3_kernel_stats_$name.csv"
+done
+[ -n "$(ls -A "$T")" ] || { echo "install_profiles: nothing to install" >&2; exit 1; }
+mkdir -p "$D"
+cp "$T"/* "$D"/
+python tools/make_traffic.py "$D"
+echo "run on sources $(cat "$D/source_sha16.txt"), tree has $(python -c 'import bench; print(bench.library_source_sha16())')"
