@@ -32,6 +32,7 @@
 namespace swz {
 
 constexpr uint32_t PR_NONE = 0xFFFFFFFFu;
+constexpr uint32_t PR_WL_ENTRIES = 28;  // winners around a cell written side by side for the first kill passes (pr_kill_wlist_kernel): 27 + one of padding
 enum : uint8_t { PR_ALIVE = 0, PR_DEAD = 1 };
 enum { PRC_ALIVE = CTR_DBG_HIST, PRC_LIST = CTR_DBG_HIST + 1, PRC_BAND = CTR_DBG_HIST + 2, PRC_WON = CTR_DBG_HIST + 3 };
 
@@ -42,7 +43,10 @@ struct PrArgs {
   const uint8_t* nmode;
   const uint32_t* snode_of;
   uint32_t all_sampled;
-  const uint32_t* ids;   // caller's index of active point i: exact positions at xyz[3 * ids[i]]
+  // exact position of active point i: xyz[3 * perm[aidx ? aidx[i] : i]] -- looked up for the pairs inside the band only (a
+  // few in ten thousand), so the composed index is not materialised (2.7 ms per level and 1 B points, round 5)
+  const uint32_t* aidx;
+  const uint32_t* perm;
   const double* xyz;
   uint8_t* taken;
   uint8_t* state;        // [m] PR_*
@@ -86,8 +90,8 @@ __device__ __forceinline__ float pr_d2(float ax, float ay, float az, float bx, f
 }
 // the reference's compare on the exact positions (GridCell.cpp:52) for active points i and j
 __device__ __forceinline__ bool pr_exact_near(const PrArgs& a, uint32_t i, uint32_t j) {
-  const double* p = a.xyz + (size_t)a.ids[i] * 3;
-  const double* q = a.xyz + (size_t)a.ids[j] * 3;
+  const double* p = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[i] : i] * 3;
+  const double* q = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[j] : j] * 3;
   return sq_dist(p[0], p[1], p[2], q[0], q[1], q[2]) < a.sq_spacing;
 }
 __device__ __forceinline__ bool pr_sampled(const PrArgs& a, uint32_t i) { return a.all_sampled || a.nmode[a.nid[i]] == MODE_SAMPLE; }
@@ -137,65 +141,45 @@ __global__ __launch_bounds__(256) void pr_candidates_kernel(PrArgs a, uint32_t c
 }
 
 // (2) a candidate wins unless a conflicting candidate of an adjacent cell has the better priority
+__device__ __forceinline__ uint64_t pr_winner_of(const PrArgs& a, uint32_t cur, uint64_t c);
 __global__ __launch_bounds__(256) void pr_winners_kernel(PrArgs a, uint32_t cur) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= a.ncells) return;
-  const uint64_t mine = a.candq[c];
-  uint64_t won = 0ull;
-  if (mine) {
-    const uint32_t i = a.cand[cur][c];
-    float x, y, z;
-    pr_unpack(mine, x, y, z);
-    const uint64_t base = c & ~(a.cells_per_node - 1ull);
-    const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
-    const uint32_t my_prio = pr_prio(c);
-    bool lose = false;
-    uint32_t nband = 0;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) {
-      if (k == 13) continue;
-      const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
-      if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE || lose) continue;
-      const uint64_t nc = base + (X | Y | Z);
-      const uint64_t q = a.candq[nc];
-      if (!q || pr_prio(nc) > my_prio) continue;
-      float qx, qy, qz;
-      pr_unpack(q, qx, qy, qz);
-      const float d2 = pr_d2(x, y, z, qx, qy, qz);
-      if (d2 < a.f_lo) lose = true;
-      else if (d2 < a.f_hi) {
-        ++nband;
-        lose = pr_exact_near(a, i, a.cand[cur][nc]);
-      }
-    }
-    if (nband) atomicAdd(&a.counters[PRC_BAND], nband);
-    if (!lose) {
-      won = mine;
-      a.woni[c] = i;
-      a.taken[i] = 1;
-      a.state[i] = PR_DEAD;
-    }
-  }
-  a.wonq[c] = won;
+  a.wonq[c] = pr_winner_of(a, cur, c);
 }
 
 // (2b) per cell that still has alive points: which of the 27 cells around it hold a winner of this round -- 27 lookups per
 // cell instead of 27 per alive point in (3)
-__global__ __launch_bounds__(256) void pr_mask_kernel(PrArgs a) {
+template <bool LIST>
+__global__ __launch_bounds__(256) void pr_mask_kernel(PrArgs a, float4* __restrict__ wlist, uint8_t* __restrict__ wcount) {
   const uint64_t c = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= a.ncells) return;
-  uint32_t mask = 0;
+  uint32_t mask = 0, cnt = 0;
   if (a.candq[c]) {  // (a cell without a candidate has no alive point: nobody reads its mask)
     const uint64_t base = c & ~(a.cells_per_node - 1ull);
     const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
+    float4* e = LIST ? wlist + c * PR_WL_ENTRIES : nullptr;
+    // the cell itself first, then the cells across a face, an edge, a corner: the closer winners kill most of the points
+    constexpr int ORDER[27] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25, 0, 2, 6, 8, 18, 20, 24, 26};
 #pragma unroll
-    for (int k = 0; k < 27; ++k) {
+    for (int kk = 0; kk < 27; ++kk) {
+      const int k = LIST ? ORDER[kk] : kk;
       const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
       if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE) continue;
-      if (a.wonq[base + (X | Y | Z)]) mask |= 1u << k;
+      const uint64_t nc = base + (X | Y | Z);
+      const uint64_t q = a.wonq[nc];
+      if (!q) continue;
+      mask |= 1u << k;
+      if (LIST) {
+        float qx, qy, qz;
+        pr_unpack(q, qx, qy, qz);
+        e[cnt] = make_float4(qx, qy, qz, __uint_as_float(a.woni[nc]));
+        ++cnt;
+      }
     }
   }
   a.wmask[c] = mask;
+  if (LIST) wcount[c] = (uint8_t)cnt;
 }
 
 // (3) alive points closer than the spacing to a winner around them die; the first survivor of every cell is the next
@@ -264,6 +248,154 @@ __global__ __launch_bounds__(256) void pr_kill_kernel(PrArgs a, uint32_t cur, ui
     const bool head = alive && (before == 0ull || (((uint64_t)phi << 32) | plo) != cell);
     if (head) atomicMin(&a.cand[cur ^ 1u][cell], i);
   }
+}
+
+// (2c) + (3'): the first rounds of a level, while every point is still looked at (no list of alive points yet).  The kill
+// pass above is bound by the instructions it issues (rocprofv3 and the ISA agree: ~830 per wavefront -- 160 to find the
+// adjacent cells of the point's cell, then ~60 per winner around it for as many winners as the wavefront's unluckiest lane
+// has to try -- 21 ms per 1 B points whatever the cell size), and nearly all of that is per-CELL work done per point.  So
+// the cell does it: next to the mask, pr_mask_kernel<true> writes the winners around the cell side by side as ready-made
+// {x, y, z, index} entries (own cell first), and a point loads them four at a time and spends ten instructions per winner.
+// (Measured with SQ_INSTS_VALU per dispatch: 913 vector instructions per wavefront in the first round at the root for the
+// loop over the mask.)  448 bytes per cell: levels of dozens of points per cell only.
+constexpr uint32_t PR_WL = PR_WL_ENTRIES;  // (every cell around may hold a winner -- at the root nearly all do in the first round: the first points of
+                                           // adjacent cells, their candidates, sit a cell apart -- so a record has room for all 27)
+
+__global__ __launch_bounds__(256) void pr_kill_wlist_kernel(PrArgs a, uint32_t cur, const float4* __restrict__ wlist, const uint8_t* __restrict__ wcount) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  bool alive = i < a.m && a.state[i] == PR_ALIVE;
+  uint64_t cell = 0;
+  if (alive) {
+    cell = pr_cell_of(a, i);
+    float x, y, z;
+    {
+      uint32_t ux, uy, uz;
+      pr_coords_u(a.akey[i], ux, uy, uz);
+      x = (float)ux;
+      y = (float)uy;
+      z = (float)uz;
+    }
+    const uint32_t cnt = wcount[cell];
+    bool dead = false;
+    uint32_t nband = 0;
+    {
+      const float4* __restrict__ e = wlist + cell * PR_WL;
+      for (uint32_t j0 = 0; j0 < PR_WL; j0 += 4u) {
+        if (j0 >= cnt || dead) break;
+        const float4 e0 = e[j0], e1 = e[j0 + 1u], e2 = e[j0 + 2u], e3 = e[j0 + 3u];  // (allocated for every cell; entries >= cnt are not looked at)
+        const float4 en[4] = {e0, e1, e2, e3};
+#pragma unroll
+        for (uint32_t t = 0; t < 4u; ++t) {
+          if (j0 + t < cnt && !dead) {
+            const float d2 = pr_d2(x, y, z, en[t].x, en[t].y, en[t].z);
+            if (d2 < a.f_lo) dead = true;
+            else if (d2 < a.f_hi) {
+              ++nband;
+              dead = pr_exact_near(a, i, __float_as_uint(en[t].w));
+            }
+          }
+        }
+      }
+    }
+    if (nband) atomicAdd(&a.counters[PRC_BAND], nband);
+    if (dead) {
+      a.state[i] = PR_DEAD;
+      alive = false;
+    }
+  }
+  const uint64_t am = __ballot(alive);
+  if (!am) return;
+  {
+    const uint64_t before = am & lanemask_lt();
+    const int prev = before ? 63 - __clzll((unsigned long long)before) : 0;
+    const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)cell, prev, WAVE), phi = (uint32_t)__shfl((int)(uint32_t)(cell >> 32), prev, WAVE);
+    const bool head = alive && (before == 0ull || (((uint64_t)phi << 32) | plo) != cell);
+    if (head) atomicMin(&a.cand[cur ^ 1u][cell], i);
+  }
+}
+
+// ---- the per-cell steps over a LIST of alive points.  Once the alive points are listed (in order: a cell's points are
+// consecutive in the list) the cells that still matter are the cells of the list's entries -- a tenth of the grid after one
+// round, a hundredth after two -- and the first entry of every cell (its head in the list) does the cell's work; the
+// kernels over the whole cell grid cost 4.5 ms per round at level 1 of the 1 B run (134 M cells), seven rounds per level.
+__device__ __forceinline__ bool pr_list_head(const PrArgs& a, const uint32_t* __restrict__ list, uint32_t t, uint32_t& i, uint64_t& cell) {
+  i = list[t];
+  cell = pr_cell_of(a, i);
+  return t == 0u || pr_cell_of(a, list[t - 1u]) != cell;
+}
+// (1) over the list of the round BEFORE (the cells that had a candidate then): the new candidate's coordinates, or none --
+// a cell whose last alive point has died must not keep its old candidate, the cells around it would lose against a dead
+// point for ever --, the slot of the round after emptied, last round's winner forgotten (its kills are done)
+__global__ __launch_bounds__(256) void pr_candidates_list_kernel(PrArgs a, uint32_t cur, const uint32_t* __restrict__ prev_list, uint32_t nprev) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nprev) return;
+  uint32_t i;
+  uint64_t c;
+  if (!pr_list_head(a, prev_list, t, i, c)) return;
+  const uint32_t ci = a.cand[cur][c];
+  a.candq[c] = ci != PR_NONE ? (pr_pack(a.akey[ci]) | (1ull << 63)) : 0ull;
+  a.cand[cur ^ 1u][c] = PR_NONE;
+  a.wonq[c] = 0ull;
+}
+__device__ __forceinline__ uint64_t pr_winner_of(const PrArgs& a, uint32_t cur, uint64_t c) {
+  const uint64_t mine = a.candq[c];
+  if (!mine) return 0ull;
+  const uint32_t i = a.cand[cur][c];
+  float x, y, z;
+  pr_unpack(mine, x, y, z);
+  const uint64_t base = c & ~(a.cells_per_node - 1ull);
+  const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
+  const uint32_t my_prio = pr_prio(c);
+  bool lose = false;
+  uint32_t nband = 0;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    if (k == 13) continue;
+    const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
+    if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE || lose) continue;
+    const uint64_t nc = base + (X | Y | Z);
+    const uint64_t q = a.candq[nc];
+    if (!q || pr_prio(nc) > my_prio) continue;
+    float qx, qy, qz;
+    pr_unpack(q, qx, qy, qz);
+    const float d2 = pr_d2(x, y, z, qx, qy, qz);
+    if (d2 < a.f_lo) lose = true;
+    else if (d2 < a.f_hi) {
+      ++nband;
+      lose = pr_exact_near(a, i, a.cand[cur][nc]);
+    }
+  }
+  if (nband) atomicAdd(&a.counters[PRC_BAND], nband);
+  if (lose) return 0ull;
+  a.woni[c] = i;
+  a.taken[i] = 1;
+  a.state[i] = PR_DEAD;
+  return mine;
+}
+__global__ __launch_bounds__(256) void pr_winners_list_kernel(PrArgs a, uint32_t cur, const uint32_t* __restrict__ list, uint32_t nlist) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nlist) return;
+  uint32_t i;
+  uint64_t c;
+  if (!pr_list_head(a, list, t, i, c)) return;
+  a.wonq[c] = pr_winner_of(a, cur, c);
+}
+__global__ __launch_bounds__(256) void pr_mask_list_kernel(PrArgs a, const uint32_t* __restrict__ list, uint32_t nlist) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= nlist) return;
+  uint32_t i;
+  uint64_t c;
+  if (!pr_list_head(a, list, t, i, c)) return;
+  uint32_t mask = 0;
+  const uint64_t base = c & ~(a.cells_per_node - 1ull);
+  const PrNbr n = pr_nbr(a, (uint32_t)(c & (a.cells_per_node - 1ull)));
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const uint32_t X = n.dx[k % 3], Y = n.dy[(k / 3) % 3], Z = n.dz[k / 9];
+    if (X == PR_NONE || Y == PR_NONE || Z == PR_NONE) continue;
+    if (a.wonq[base + (X | Y | Z)]) mask |= 1u << k;
+  }
+  a.wmask[c] = mask;
 }
 
 // The alive points after a round, counted and -- once they are few -- listed in their order by a scan (no atomics: a
@@ -338,7 +470,8 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.sq_spacing = plan.sq_spacing;
   // a cell must be at least one spacing wide on the key grid, band included (cell_levels_geo guarantees it geometrically)
   if (std::ldexp(1.0, (int)(a.cell_shift / 3u)) < km.T + 4.0) return SWZ_OK;
-  SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
+  a.aidx = as.aidx;  // (no ghosts here: checked above)
+  a.perm = sp.perm;
 
   ProfScope ps(c, "sample_min_distance_property", (uint64_t)sample_points * 33ull, 1);
   const auto wall0 = std::chrono::steady_clock::now();
@@ -360,29 +493,65 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   const bool lists = !(c->opt("SWZ_MD_ROUNDS_LIST") && atoi(c->opt("SWZ_MD_ROUNDS_LIST")) == 0);
   std::string trace;
   uint32_t* d_total = lb.counters + PRC_ALIVE;
+  // the first kill passes (no list yet) read the winners around their cell from per-cell records (pr_kill_wlist_kernel) when
+  // the records are affordable (448 bytes per cell: levels of dozens of points per cell)
+  double wl_min_pop = 24.0;
+  if (const char* e = c->opt("SWZ_MD_ROUNDS_WLIST_MIN_POP")) wl_min_pop = atof(e);
+  const bool wl = (double)sample_points / (double)a.ncells >= wl_min_pop;
+  float4* wlist = nullptr;
+  uint8_t* wcount = nullptr;
+  if (wl) {
+    SWZ_TRY(c->get("md_pr_wlist", (size_t)a.ncells * PR_WL, &wlist));
+    SWZ_TRY(c->get("md_pr_wcount", (size_t)a.ncells, &wcount));
+  }
+  const bool cell_lists = !(c->opt("SWZ_MD_ROUNDS_CELL_LISTS") && atoi(c->opt("SWZ_MD_ROUNDS_CELL_LISTS")) == 0);
+  bool prev_list = false;   // the round before ran over a list (list[cur ^ 1], nprev entries: still intact)
+  uint32_t nprev = 0;
   for (;;) {
     ++rounds;
-    hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
-    hipLaunchKernelGGL(pr_winners_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
-    hipLaunchKernelGGL(pr_mask_kernel, dim3(cblocks), dim3(256), 0, c->stream, a);
-    const uint32_t threads = use_list ? nlist : m;
-    if (threads) hipLaunchKernelGGL(pr_kill_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, use_list ? 1u : 0u, nlist);
-    SWZ_LAUNCH_CHECK(c);
-    // who is alive now: a count while they are many, a list (in order) once they are few
-    const bool make_list = lists && (use_list || alive < m / 4u);
-    if (make_list && !a.list[0]) {
-      SWZ_TRY(c->get("md_pr_list0", (size_t)alive + 64, &a.list[0]));
-      SWZ_TRY(c->get("md_pr_list1", (size_t)alive + 64, &a.list[1]));
+    if (use_list && cell_lists) {
+      if (prev_list) hipLaunchKernelGGL(pr_candidates_list_kernel, dim3(div_up(std::max(nprev, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur ^ 1u], nprev);
+      else hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+      hipLaunchKernelGGL(pr_winners_list_kernel, dim3(div_up(std::max(nlist, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur], nlist);
+      hipLaunchKernelGGL(pr_mask_list_kernel, dim3(div_up(std::max(nlist, 1u), 256)), dim3(256), 0, c->stream, a, a.list[cur], nlist);
+    } else {
+      hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+      hipLaunchKernelGGL(pr_winners_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+      if (wl && !use_list) hipLaunchKernelGGL(pr_mask_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, a, wlist, wcount);
+      else hipLaunchKernelGGL(pr_mask_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, a, (float4*)nullptr, (uint8_t*)nullptr);
     }
-    if (use_list) SWZ_TRY(fused_scan(c, PrAliveOfListF{a.state, a.list[cur]}, PrListOfListG{a.list[cur], a.list[cur ^ 1u]}, nlist, d_total, "mdpr"));
-    else if (make_list) SWZ_TRY(fused_scan(c, PrAliveF{a.state}, PrListG{a.list[cur ^ 1u]}, m, d_total, "mdpr"));
-    else {
+    const uint32_t threads = use_list ? nlist : m;
+    if (threads) {
+      if (!use_list && wl)
+        hipLaunchKernelGGL(pr_kill_wlist_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, wlist, wcount);
+      else
+        hipLaunchKernelGGL(pr_kill_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, use_list ? 1u : 0u, nlist);
+    }
+    SWZ_LAUNCH_CHECK(c);
+    prev_list = use_list && cell_lists;
+    nprev = nlist;
+    // who is alive now: a count while they are many, a list (in order) once they are few -- decided on the count this round
+    // leaves, not the one it started with: the first round of a level kills nine points in ten, and the second one must
+    // not look at all of them again
+    uint32_t now = 0;
+    bool make_list = false;
+    if (use_list) {
+      make_list = true;
+      SWZ_TRY(fused_scan(c, PrAliveOfListF{a.state, a.list[cur]}, PrListOfListG{a.list[cur], a.list[cur ^ 1u]}, nlist, d_total, "mdpr"));
+      SWZ_HIP(c, hipMemcpyAsync(&now, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    } else {
       uint32_t* d_partial = nullptr;
       SWZ_TRY(fused_scan_sums(c, PrAliveF{a.state}, m, d_total, "mdpr", &d_partial));
+      SWZ_HIP(c, hipMemcpyAsync(&now, d_total, 4, hipMemcpyDeviceToHost, c->stream));
+      SWZ_HIP(c, hipStreamSynchronize(c->stream));
+      make_list = lists && now < m / 4u && now > 0u;
+      if (make_list) {
+        SWZ_TRY(c->get("md_pr_list0", (size_t)now + 64, &a.list[0]));
+        SWZ_TRY(c->get("md_pr_list1", (size_t)now + 64, &a.list[1]));
+        SWZ_TRY(fused_scan_apply(c, PrAliveF{a.state}, PrListG{a.list[cur ^ 1u]}, m, d_partial));
+      }
     }
-    uint32_t now = 0;
-    SWZ_HIP(c, hipMemcpyAsync(&now, d_total, 4, hipMemcpyDeviceToHost, c->stream));
-    SWZ_HIP(c, hipStreamSynchronize(c->stream));
     if (dbg && rounds <= 24) trace += " " + std::to_string(now);
     if (now >= alive && rounds > 1)
       return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE property rounds: a round without progress at level " + std::to_string(plan.level));

@@ -52,8 +52,8 @@ struct SpArgs {
   const double* X;
   const double* Y;
   const double* Z;
-  const double* xyz;         // on keys: exact position of active point i = xyz[3 * ids[i]]
-  const uint32_t* ids;
+  const double* xyz;         // on keys: exact position of active point i = xyz[3 * perm[aidx ? aidx[i] : i]] (local points
+  const uint32_t* perm;      // only, see below) -- composed on the fly: only the pairs inside the band look it up
   float f_lo, f_hi;          // float squared distance < f_lo: closer than the spacing for sure, >= f_hi: farther for sure
   uint32_t m;
   uint32_t cell_shift;      // key >> cell_shift = node prefix + cell code
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256) void sp_key_records_kernel(const uint64_t* __r
 // the exact compare of the reference on the original positions (GridCell.cpp:52)
 __device__ __forceinline__ bool sp_exact_near(const SpArgs& a, uint32_t p, uint32_t q) {
   if (a.xyz) {
-    const double* u = a.xyz + (size_t)a.ids[p] * 3;
-    const double* v = a.xyz + (size_t)a.ids[q] * 3;
+    const double* u = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[p] : p] * 3;
+    const double* v = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[q] : q] * 3;
     return sq_dist(u[0], u[1], u[2], v[0], v[1], v[2]) < a.sq_spacing;
   }
   const uint32_t sp = a.aidx ? a.aidx[p] : p, sq = a.aidx ? a.aidx[q] : q;
@@ -504,8 +504,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     // (A sharded batch: the ghosts in front of the sorted order have their own position array and ids below sp.ghosts,
     // local point p has id ghosts + p, see key_point_ids.  Ghosts are accepted again at the root and never reach a level
     // below it, and the root level of a batch with ghosts is left to the sweep -- above --, so only local ids occur here.)
-    a.xyz = sp.xyz - (size_t)sp.ghosts * 3;
-    SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
+    a.xyz = sp.xyz;
+    a.perm = sp.perm;
     a.f_lo = km.f_lo;
     a.f_hi = km.f_hi;
     if (const char* e = c->opt("SWZ_SP_FILTER_EPS"))  // tests: 1e30 sends every compare within reach to the exact path
