@@ -74,7 +74,30 @@ def parse_args():
                     "ncclSend / ncclRecv or by hipMemcpyPeerAsync (peer copies also work with all shards on ONE device)")
     ap.add_argument("--group-devices", type=int, default=0, help="--driver group: devices the shards are dealt to (0 = as "
                     "many as there are shards; 1 = all shards share device 0, the only way to run it on a one-GPU box)")
-    return ap.parse_args()
+    ap.add_argument("--config", type=int, default=0, choices=[0, 4, 5], help="BASELINE.json's multi-GPU configurations as one "
+                    "command each: 4 = 1 B points IN TOTAL, JITTERED, sharded over --gpus ranks by the top Morton bits (strong "
+                    "scaling); 5 = 4 B points in total with RGB + intensity, MIN_DISTANCE, every rank's share staged from pinned "
+                    "host memory in batches of about 50 M points (strong scaling).  --total-points scales either down for a dry "
+                    "run; --driver group runs the same shape from ONE C++ process")
+    ap.add_argument("--total-points", type=int, default=0, help="points of the whole job, split evenly over the ranks (strong "
+                    "scaling: `scaling` says so); overrides --points")
+    ap.add_argument("--one-device", action="store_true", help="dry run of an N-rank configuration on ONE GPU: all ranks share "
+                    "cuda:0 and talk over gloo (RCCL does not put two ranks on one device); the line is labelled a dry run")
+    args = ap.parse_args()
+    if args.config == 4:
+        args.sampler, args.strategy, args.batches = "JITTERED", "ACCURATE", 1
+        args.total_points = args.total_points or 1_000_000_000
+    elif args.config == 5:
+        args.sampler, args.staged = "MIN_DISTANCE", True
+        args.payload = args.payload or "rgb,intensity"
+        args.total_points = args.total_points or 4_000_000_000
+        if args.md_mode == "both":
+            args.md_mode = "exact"
+    if args.total_points:
+        args.points = args.total_points // max(args.gpus, 1)
+    if args.config == 5 and args.batches <= 1:
+        args.batches = max(2, (args.points + 49_999_999) // 50_000_000)  # (2 at least: the path under test is the batch tiler)
+    return args
 
 
 def visible_gpus():
@@ -107,8 +130,8 @@ def launch_ranks(args):
     import socket
     import subprocess
     have = visible_gpus()
-    if have is not None and have < args.gpus:
-        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (args.gpus, have))
+    if have is not None and have < args.gpus and not args.one_device:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (--one-device: a dry run with all ranks on one)\n" % (args.gpus, have))
         return 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -142,7 +165,7 @@ def run_group_driver(args):
                     "-lswz_gpu", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     sampler = ["RANDOM_GRID", "GRID_CENTER", "MIN_DISTANCE", "JITTERED"].index(args.sampler)
     cmd = [exe, str(shards), str(args.points), str(args.warmup + args.steps), str(devices), str(transport), str(args.batches),
-           str(sampler), "1" if args.strategy == "FAST" else "0", str(args.warmup)]
+           str(sampler), "1" if args.strategy == "FAST" else "0", str(args.warmup), "1" if (args.staged and args.batches > 1) else "0"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     sys.stderr.write(r.stderr)
     if r.returncode != 0:
@@ -179,9 +202,16 @@ def run_group_driver(args):
     line = {
         "metric": "Mpoints/s end-to-end tile (Morton+sort+sample)", "value": round(shards * args.points * args.steps / total_ms / 1e3, 3),
         "unit": "Mpoints/s", "n_gpus": shards, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 keys / f64 positions", "data": "synthetic",
-        "config": {"workload": "%d uniform points per shard in the unit cube, %s sampling, spacing = diagonal/250, "
-                               "max_points_per_node=20000, %s strategy, %d batch(es)" % (args.points, args.sampler, args.strategy, args.batches),
+        "higher_is_better": True, "scaling": "strong" if args.total_points else "weak", "vs_baseline": None, "dtype": "u64 keys / f64 positions", "data": "synthetic",
+        "config": {"workload": "%s%d uniform points per shard in the unit cube, %s sampling, spacing = diagonal/250, "
+                               "max_points_per_node=20000, %s strategy, %d batch(es)%s" % (
+                                   ("BASELINE config %d%s: %d points in total, " % (args.config, " (scaled down)" if args.total_points != {
+                                       4: 1_000_000_000, 5: 4_000_000_000}[args.config] else "", args.total_points)) if args.config else "",
+                                   args.points, args.sampler, args.strategy, args.batches,
+                                   " staged from pinned host memory with RGB + intensity (29 B/pt; the wall time includes the host link)"
+                                   if (args.staged and args.batches > 1) else ""),
+                   "baseline_config": args.config or None, "total_points": args.total_points or None,
+                   "staged_from_pinned_host": bool(args.staged and args.batches > 1) or None,
                    "points_per_gpu": args.points, "sampler": args.sampler, "strategy": args.strategy, "batches": args.batches,
                    "parallelism": "%d shards on %d device(s), ONE C++ process (swz_group_%s), exchange by %s" % (
                        shards, devices, "add_batch" if args.batches > 1 else "tile", "RCCL send/recv" if transport else "peer copies")},
@@ -189,7 +219,9 @@ def run_group_driver(args):
                                            "sort, root, levels (inputs resident on the shards' devices)",
         "steps_ms": [round(x, 3) for x in timed], "roofline": roofline,
         "kernels_ms_per_step_shard0": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
-        "shards": shard_rows, "cpu_baseline": None,
+        "shards": shard_rows, "cpu_baseline": None, "cpu_baseline_reference": committed_cpu_baseline(),
+        "ranks_in_process_group": 1, "root_mode": os.environ.get("SWZ_GROUP_JOINT_ROOT", "1") not in ("", "0") and "joint" or "chain",
+        "exchange_ms": max((r["exchange_done_ms"] for r in shard_rows), default=None),
         "driver_output": r.stdout.splitlines()[-min(len(ms), 3):],
     }
     print(json.dumps(line))
@@ -252,6 +284,19 @@ def measured_traffic(kernel_class, n, sampler):
                 rnd, t.get("source_sha16", "(unstamped)"), sha)
         return t.get("bytes_per_launch", {}).get(kernel_class), "profiles/%s/traffic.json (rocprofv3 --pmc, kernel sources %s)" % (rnd, sha)
     return None, "no committed profile"
+
+
+def committed_cpu_baseline():
+    """N > 1 lines carry no CPU timing of their own (rank 0 at N = 1 measures it): the newest committed N = 1 line's."""
+    for rnd in ("r05", "r04", "r03"):
+        path = os.path.join(ROOT, "profiles", rnd, "bench_1B_min_distance.json")
+        try:
+            cb = json.load(open(path)).get("cpu_baseline")
+        except Exception:
+            continue
+        if cb:
+            return dict(cb, source="profiles/%s/bench_1B_min_distance.json" % rnd)
+    return None
 
 
 def cpu_baseline(args, spacing):
@@ -386,13 +431,17 @@ def main():
             sock.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sock.getsockname()[1])
             sock.close()
-    if distributed:
+    if distributed and args.one_device:
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="gloo")
+    elif distributed:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if distributed else 0)
+    dev = torch.device("cuda", local_rank if (distributed and not args.one_device) else 0)
 
     n = args.points
     bmin, bmax = [0.0, 0.0, 0.0], [args.bounds_scale] * 3
@@ -458,8 +507,11 @@ def main():
                 ev.record(copy_stream)
             return bx, bc, ev
 
+        last = {}
+
         def step():
             runner = sharded.ShardedBatchTiler(ctx, dev, bmin, bmax, params, capacity_hint=int(1.3 * n) + 1024)
+            last["runner"] = runner
             tot = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
             nxt = fetch(0)
             for i in range(k):
@@ -474,6 +526,9 @@ def main():
                 tot["max_level"] = max(tot["max_level"], st["max_level"])
             runner.finalize()
             tot["num_nodes"] = int(runner.tiler.info()["num_nodes"])
+            tot["shard_points"] = int(runner.tiler.info()["num_points"])
+            last["stage_ms"] = runner.stage_timings()
+            last["root_mode"] = runner.root_mode
             runner.close()
             return tot
     elif distributed:
@@ -504,6 +559,7 @@ def main():
 
     def barrier():
         if distributed:
+            torch.cuda.synchronize(dev)
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -520,7 +576,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -528,10 +584,11 @@ def main():
     # the sharded single-batch driver: what every rank's last step spent where (events on the launch stream), which way the
     # MIN_DISTANCE root went, how many points the rank ended up owning
     shard_report = None
-    if distributed and args.batches <= 1 and hasattr(runner, "stage_timings"):
-        mine = {"rank": rank, "root_mode": getattr(runner, "root_mode", None),
+    if distributed:
+        batch_path = args.batches > 1 or args.strategy == "FAST"
+        mine = {"rank": rank, "root_mode": last.get("root_mode") if batch_path else getattr(runner, "root_mode", None),
                 "shard_points": int(stats.get("shard_points", 0)) if stats else 0}
-        mine.update(runner.stage_timings())
+        mine.update(last.get("stage_ms", {}) if batch_path else runner.stage_timings())  # (batch path: summed over the batches of the last step)
         gathered = [None] * dist.get_world_size()
         dist.all_gather_object(gathered, mine)
         shard_report = gathered
@@ -556,10 +613,13 @@ def main():
         out = {
             "metric": "Mpoints/s end-to-end tile (Morton+sort+sample)", "value": round(value, 3),
             "unit": "Mpoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.total_points else "weak", "vs_baseline": None,
             "dtype": "u64 keys / f64 positions", "data": "synthetic",
-            "config": {"workload": "%d uniform points per GPU in the unit cube, %s sampling, spacing = diagonal/%g, "
+            "config": {"workload": "%s%d uniform points per GPU in the unit cube, %s sampling, spacing = diagonal/%g, "
                                    "max_points_per_node=%d, %s strategy, %s" % (
+                                       ("BASELINE config %d%s: %d points in total, " % (args.config, " (scaled down)" if (
+                                           args.total_points != {4: 1_000_000_000, 5: 4_000_000_000}[args.config]) else "", args.total_points))
+                                       if args.config else ("%d points in total, " % args.total_points if args.total_points else ""),
                                        n, args.sampler, args.diagonal_fraction, args.max_points_per_node, args.strategy,
                                        "one batch" if args.batches <= 1 else "%d batches through the multi-batch tiler (%s)" % (
                                            args.batches, "cut out of the whole cloud" if args.batch_order == "uniform" else "one x-y tile each")),
@@ -568,9 +628,12 @@ def main():
                        "batches": args.batches, "batch_order": args.batch_order if args.batches > 1 else None,
                        "staged_from_pinned_host": bool(args.staged and distributed and args.batches > 1) or None,
                        "payload_columns": [a for a in args.payload.split(",") if a] if (distributed and args.batches > 1) else None,
-                       "parallelism": "1 GPU" if world == 1 else "%d GPUs sharded by top Morton bits, one all-to-all" % world},
+                       "baseline_config": args.config or None, "total_points": args.total_points or None,
+                       "parallelism": "1 GPU" if world == 1 else ("%d ranks sharded by top Morton bits, one all-to-all%s" % (
+                           world, " -- DRY RUN: all ranks on ONE GPU over gloo" if args.one_device else ""))},
             "ranks_in_process_group": dist.get_world_size() if distributed else 1,
             "root_mode": shard_report[0]["root_mode"] if shard_report else None,
+            "exchange_ms": max((r.get("exchange_ms", 0.0) for r in shard_report), default=None) if shard_report else None,
             "shards": shard_report,
             "visit_factor": round(visit, 4),
             "hbm_frac_end_to_end": round(alg * total_points / world / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
@@ -624,6 +687,8 @@ def main():
             out["payload"] = payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n)
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args, spacing)
+        elif world > 1:
+            out["cpu_baseline_reference"] = committed_cpu_baseline()
         print(json.dumps(out))
     if distributed:
         dist.destroy_process_group()

@@ -857,6 +857,7 @@ int swz_group_add_batch(swz_group* g, double* const* d_xyz, const swz_attribute_
     }
   }
   g->turn = 0;
+  g->t_call = std::chrono::steady_clock::now();  // (swz_group_shard_timing: milliseconds since this batch's call began)
   std::fill(g->status.begin(), g->status.end(), SWZ_OK);
   std::fill(g->root_taken_count.begin(), g->root_taken_count.end(), 0);
   std::vector<std::thread> threads;

@@ -542,6 +542,19 @@ class ShardedBatchTiler:
     def close(self):
         self.tiler.close()
 
+    def _fold_stages(self):
+        # the stage times of the batches of a data set add up (read by bench.py after the last one)
+        self._pending_stages = getattr(self, "_pending_stages", [])
+        self._pending_stages.append(self._batch_stages)
+
+    def stage_timings(self):
+        """Milliseconds per stage summed over the batches added so far on this rank (synchronises the device)."""
+        tot = {}
+        for st in getattr(self, "_pending_stages", []):
+            for k, v in st.ms().items():
+                tot[k] = round(tot.get(k, 0.0) + v, 3)
+        return tot
+
     def _all_sum(self, value):
         t = torch.tensor([int(value)], dtype=torch.int64,
                          device=self.device if dist.get_backend(self.group) == "nccl" else "cpu")
@@ -563,6 +576,7 @@ class ShardedBatchTiler:
         ctx, dev, world = self.ctx, self.device, self.world
         attrs = attrs or {}
         n = xyz.shape[0]
+        stages = self._batch_stages = _Stages(dev)
         keys = torch.empty(n, dtype=torch.int64, device=dev)
         ctx.morton_encode_device(xyz.data_ptr(), n, self.bmin, self.bmax, keys.data_ptr())
         perm = torch.empty(n, dtype=torch.int32, device=dev)
@@ -572,7 +586,10 @@ class ShardedBatchTiler:
         order = perm.long()
         del perm
         global_new = self._all_sum(n)
-        recv, recv_counts = exchange_rows(xyz.index_select(0, order), send_counts, self.group)
+        send = xyz.index_select(0, order)
+        stages.mark("encode_partition_group_ms")
+        recv, recv_counts = exchange_rows(send, send_counts, self.group)
+        del send
         m = recv.shape[0]
         cols = {}
         for name, t in attrs.items():  # the same exchange, column by column
@@ -581,8 +598,12 @@ class ShardedBatchTiler:
             assert rc == recv_counts
             cols[name] = got.contiguous()
         del order
+        stages.mark("exchange_ms")
         if self.params.strategy == api.FAST:
-            return self._add_batch_fast(recv, m, cols, global_new)
+            st = self._add_batch_fast(recv, m, cols, global_new)
+            stages.mark("levels_ms")
+            self._fold_stages()
+            return st
         root_stored = self._all_sum(self.tiler.level_count(-1))
         sample = root_stored > 0 or global_new + root_stored > self.params.max_points_per_node
         sequential_root = self.params.sampler == api.MIN_DISTANCE and sample and global_new > 0
@@ -646,8 +667,11 @@ class ShardedBatchTiler:
                     self._bcast(b, r)
                 if self.rank > r:
                     ghosts.append(b)
+        stages.mark("root_ms")
         zero = dict(num_nodes=0, points_visited=0, max_level=-1, fast_start_levels=-1, num_levels=0, min_distance_rounds=0)
         stats = guarded(lambda: self.tiler.shard_finish(), zero)
+        stages.mark("levels_ms")
+        self._fold_stages()
         if self._all_sum(1 if failure else 0):
             # the ranks that did not fail have committed this batch and the failing one has not: no rank may go on
             try:

@@ -32,3 +32,28 @@ def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path, mon
     assert value is None or "profiles/" in source
     if value is None:
         assert "stale" in source or "no " in source or source
+
+
+def _args(argv):
+    import sys
+    old = sys.argv
+    sys.argv = ["bench.py"] + argv
+    try:
+        return bench.parse_args()
+    finally:
+        sys.argv = old
+
+
+def test_baseline_config_presets():
+    """--config 4 / 5 are BASELINE.json's multi-GPU configurations as one command each: total sizes split over the ranks
+    (strong scaling), sampler / payload / staging set; --total-points scales them down for a dry run."""
+    a = _args(["--config", "4", "--gpus", "8"])
+    assert (a.sampler, a.strategy, a.batches, a.total_points, a.points) == ("JITTERED", "ACCURATE", 1, 1_000_000_000, 125_000_000)
+    a = _args(["--config", "5", "--gpus", "8"])
+    assert (a.sampler, a.total_points, a.points, a.staged, a.payload, a.md_mode) == ("MIN_DISTANCE", 4_000_000_000, 500_000_000, True,
+                                                                                     "rgb,intensity", "exact")
+    assert a.batches == 10  # about 50 M points per batch and rank
+    a = _args(["--config", "5", "--gpus", "8", "--total-points", "200000000", "--one-device"])
+    assert a.points == 25_000_000 and a.batches == 2 and a.one_device
+    a = _args(["--gpus", "2", "--total-points", "1000"])
+    assert a.points == 500 and a.config == 0

@@ -2,7 +2,10 @@
 // when the box has fewer -- each starting with P uniform points of the unit cube, exact MIN_DISTANCE, d = 250.
 // Prints the wall time of the call and every shard's root interval, with the root swept by all shards at once
 // (SWZ_GROUP_JOINT_ROOT unset) and in turns (SWZ_GROUP_JOINT_ROOT=0).
-//   group_bench SHARDS POINTS_PER_SHARD REPS DEVICES [TRANSPORT 0 = peer copies | 1 = RCCL] [BATCHES] [SAMPLER 0..3] [STRATEGY 0 | 1]
+//   group_bench SHARDS POINTS_PER_SHARD REPS DEVICES [TRANSPORT 0 = peer copies | 1 = RCCL] [BATCHES] [SAMPLER 0..3] [STRATEGY 0 | 1] [WARMUP] [STAGED 0 | 1]
+// STAGED = 1 (with BATCHES > 1; BASELINE config 5's shape): every shard's batches come from PINNED HOST memory with RGB +
+// intensity columns along (29 B per point), batch k + 1 copied on the shards' copy streams under the kernels of batch k
+// (swz_group_stage_batch / swz_group_tile_staged); the wall time then includes the host link.
 // BATCHES > 1: the shard's points in that many batches through swz_group_add_batch (one swz_tiler per shard) and
 // swz_group_finalize.  `bench.py --driver group` runs this program and reports its timings.
 //   g++ -std=c++17 -O2 tools/group_bench.cpp -o /tmp/group_bench -Lschwarzwald_amd/lib -lswz_gpu -Wl,-rpath,$PWD/schwarzwald_amd/lib
@@ -25,6 +28,7 @@ int main(int argc, char** argv) {
   const int sampler = argc > 7 ? std::atoi(argv[7]) : (int)SWZ_MIN_DISTANCE;
   const int strategy = argc > 8 ? std::atoi(argv[8]) : (int)SWZ_ACCURATE;
   const int warmup = argc > 9 ? std::atoi(argv[9]) : 0;  // reps before the kernel classes of shard 0 are timed (HIP events)
+  const bool staged = argc > 10 && std::atoi(argv[10]) != 0 && batches > 1;
   const double mn[3] = {0, 0, 0}, mx[3] = {1, 1, 1};
   std::vector<int> dev(shards);
   for (int s = 0; s < shards; ++s) dev[s] = s % ndev;
@@ -39,6 +43,20 @@ int main(int argc, char** argv) {
     swz_ctx* c = swz_group_ctx(g, s);
     if (swz_device_alloc_on(c, per * 24, (void**)&d_xyz[s]) != SWZ_OK) return 2;
   }
+  // staged: the shards' points and attribute columns in pinned host memory (filled once from the device-generated points)
+  std::vector<double*> h_xyz(shards, nullptr);
+  std::vector<uint8_t*> h_rgb(shards, nullptr);
+  std::vector<uint16_t*> h_int(shards, nullptr);
+  if (staged)
+    for (int s = 0; s < shards; ++s) {
+      if (swz_host_alloc_pinned(per * 24, (void**)&h_xyz[s]) != SWZ_OK || swz_host_alloc_pinned(per * 3, (void**)&h_rgb[s]) != SWZ_OK ||
+          swz_host_alloc_pinned(per * 2, (void**)&h_int[s]) != SWZ_OK)
+        return 2;
+      for (uint64_t i = 0; i < per; ++i) {
+        h_rgb[s][3 * i] = (uint8_t)i, h_rgb[s][3 * i + 1] = (uint8_t)(i >> 8), h_rgb[s][3 * i + 2] = (uint8_t)(i >> 16);
+        h_int[s][i] = (uint16_t)(i * 7u);
+      }
+    }
   swz_tile_params p{};
   p.sampler = sampler;
   p.max_points_per_node = 20000;
@@ -54,13 +72,41 @@ int main(int argc, char** argv) {
     }
     for (int s = 0; s < shards; ++s)
       if (swz_generate_uniform_device(swz_group_ctx(g, s), 0x5C4A72A1Dull + 3, (uint64_t)s * per, per, d_xyz[s]) != SWZ_OK) return 3;
+    if (staged && rep == 0)
+      for (int s = 0; s < shards; ++s)
+        if (swz_copy_to_host(swz_group_ctx(g, s), h_xyz[s], d_xyz[s], per * 24) != SWZ_OK) return 3;
     const auto t0 = std::chrono::steady_clock::now();
     if (batches > 1) {
       if (swz_group_tiler_open(g, mn, mx, &p, per) != SWZ_OK) {
         std::fprintf(stderr, "swz_group_tiler_open: %s\n", swz_group_last_error(g));
         return 4;
       }
-      for (int b = 0; b < batches; ++b) {
+      auto stage = [&](int b) {
+        const uint64_t lo = per * b / batches, hi = per * (b + 1) / batches;
+        std::vector<const double*> hx(shards);
+        std::vector<swz_attribute_columns> ha(shards);
+        std::vector<uint64_t> bn(shards, hi - lo);
+        for (int s = 0; s < shards; ++s) {
+          hx[s] = h_xyz[s] + lo * 3;
+          ha[s] = swz_attribute_columns{};
+          ha[s].column[SWZ_ATTR_RGB] = h_rgb[s] + lo * 3;
+          ha[s].column[SWZ_ATTR_INTENSITY] = h_int[s] + lo;
+        }
+        return swz_group_stage_batch(g, hx.data(), ha.data(), bn.data());
+      };
+      if (staged) {
+        if (stage(0) != SWZ_OK) {
+          std::fprintf(stderr, "swz_group_stage_batch: %s\n", swz_group_last_error(g));
+          return 4;
+        }
+        for (int b = 0; b < batches; ++b) {
+          if ((b + 1 < batches && stage(b + 1) != SWZ_OK) || swz_group_tile_staged(g, nullptr) != SWZ_OK) {
+            std::fprintf(stderr, "swz_group_tile_staged: %s\n", swz_group_last_error(g));
+            return 4;
+          }
+        }
+      }
+      for (int b = 0; b < batches && !staged; ++b) {
         const uint64_t lo = per * b / batches, hi = per * (b + 1) / batches;
         std::vector<double*> bx(shards);
         std::vector<uint64_t> bn(shards, hi - lo);
