@@ -509,7 +509,10 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   uint32_t nprev = 0;
   for (;;) {
     ++rounds;
-    if (use_list && cell_lists) {
+    // (a list of more entries than a quarter of the cells: the kernels over the cell grid are the cheaper ones -- a list entry
+    // costs its head test, two keys and two node ids, before its cell's work)
+    const bool by_list = use_list && cell_lists && (uint64_t)nlist * 4u < a.ncells;
+    if (by_list) {
       if (prev_list) hipLaunchKernelGGL(pr_candidates_list_kernel, dim3(div_up(std::max(nprev, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur ^ 1u], nprev);
       else hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
       hipLaunchKernelGGL(pr_winners_list_kernel, dim3(div_up(std::max(nlist, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur], nlist);
@@ -528,7 +531,7 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
         hipLaunchKernelGGL(pr_kill_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, use_list ? 1u : 0u, nlist);
     }
     SWZ_LAUNCH_CHECK(c);
-    prev_list = use_list && cell_lists;
+    prev_list = by_list;
     nprev = nlist;
     // who is alive now: a count while they are many, a list (in order) once they are few -- decided on the count this round
     // leaves, not the one it started with: the first round of a level kills nine points in ten, and the second one must
