@@ -265,13 +265,13 @@ def library_source_sha16():
     return h.hexdigest()[:16]
 
 
-def measured_traffic(kernel_class, n, sampler):
+def measured_traffic(kernel_class, n, sampler, table="bytes_per_launch"):
     """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
     (profiles/rNN/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
     command, corrected as MI355X_MICROARCH.md prescribes) -- only when that profile was taken on the kernel sources this
     run uses (traffic.json carries their hash).  Returns (bytes or None, where the number comes from / why there is none)."""
     sha = library_source_sha16()
-    for rnd in ("r04", "r03", "r02", "r01"):  # the newest committed profile of this configuration
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):  # the newest committed profile of this configuration
         path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         try:
             t = json.load(open(path))
@@ -282,7 +282,7 @@ def measured_traffic(kernel_class, n, sampler):
         if t.get("source_sha16") != sha:
             return None, "stale: profiles/%s/traffic.json was measured on kernel sources %s, this run uses %s" % (
                 rnd, t.get("source_sha16", "(unstamped)"), sha)
-        return t.get("bytes_per_launch", {}).get(kernel_class), "profiles/%s/traffic.json (rocprofv3 --pmc, kernel sources %s)" % (rnd, sha)
+        return t.get(table, {}).get(kernel_class), "profiles/%s/traffic.json (rocprofv3 --pmc, kernel sources %s)" % (rnd, sha)
     return None, "no committed profile"
 
 
@@ -661,7 +661,17 @@ def main():
             pprof = ctx.profile_get()
             pvisit = pstats["points_visited"] / float(n)
             palg = algorithmic_bytes_per_point(args.sampler, pvisit)
+            proof = None
+            if pprof:  # the roofline object of the property-mode run: its own dominant kernel class
+                pname, pk = max(pprof.items(), key=lambda kv: kv[1]["total_ms"])
+                pavg = pk["total_ms"] / max(pk["launches"], 1)
+                pach = pk["algorithmic_bytes"] / max(pk["launches"], 1) / (pavg * 1e-3) / 1e9 if pavg > 0 else 0.0
+                ptraffic = measured_traffic(pname, n, args.sampler, "bytes_per_launch_property_mode")
+                proof = {"bound": "hbm", "kernel": pname, "achieved": round(pach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(pach / HBM_PEAK_GBS, 5), "traffic": ptraffic[0], "traffic_source": ptraffic[1],
+                         "launches": pk["launches"], "avg_launch_ms": round(pavg, 4)}
             out["min_distance_property"] = {
+                "roofline": proof,
                 "ms_per_step": round(pdt * 1e3, 3), "Mpoints_per_s": round(n / pdt / 1e6, 3), "visit_factor": round(pvisit, 4),
                 "hbm_frac_end_to_end": round(palg * n / pdt / (HBM_PEAK_GBS * 1e9), 5), "tile_stats": pstats,
                 "steps": psteps,

@@ -12,9 +12,9 @@ trap 'rm -rf "$T"' EXIT
 shopt -s nullglob
 for f in "$P"/bench_*.json "$P"/clustered_*.txt "$P"/fullsize_pytest.txt "$P"/fullsize_verification_1B.log \
          "$P"/group_joint_root_vs_turns.txt "$P"/pmc_*_by_kernel*.csv "$P"/source_sha16.txt "$P"/*.txt; do
-  cp "$f" "$T"/
+  [ -f "$f" ] && cp "$f" "$T"/
 done
-[ -f "$P/stats_run.json" ] && cp "$P/stats_run.json" "$T/bench_under_rocprofv3.json"
+if [ -f "$P/stats_run.json" ]; then cp "$P/stats_run.json" "$T/bench_under_rocprofv3.json"; fi
 for pair in stats:bench_default stats_gc:GRID_CENTER stats_prop:property_mode stats_mb:1B_100batches_RANDOM_GRID \
             stats_mbmd:100batches_MIN_DISTANCE_FAST; do
   src=${pair%%:*}; name=${pair##*:}
@@ -23,5 +23,5 @@ done
 [ -n "$(ls -A "$T")" ] || { echo "install_profiles: nothing to install" >&2; exit 1; }
 mkdir -p "$D"
 cp "$T"/* "$D"/
-python tools/make_traffic.py "$D"
+if [ -f "$D/pmc_FETCH_SIZE_by_kernel.csv" ] && [ -f "$D/pmc_WRITE_SIZE_by_kernel.csv" ]; then python tools/make_traffic.py "$D"; else echo "(no PMC summaries yet: traffic.json not written)"; fi
 echo "run on sources $(cat "$D/source_sha16.txt"), tree has $(python -c 'import bench; print(bench.library_source_sha16())')"

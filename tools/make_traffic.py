@@ -66,5 +66,17 @@ out = {
         "radix_scatter": {"kernels": rs_k, "launches_per_step": rs_launches, "bytes_per_step": rs_b},
     },
 }
+# the property-mode run of the same workload (its own two --pmc passes): the rounds on the dense levels (pr_* kernels and
+# their alive scans: class sample_min_distance_property, one launch per dense level) and the exact sparse levels below
+try:
+    fetch, write = load("pmc_FETCH_SIZE_by_kernel_property_mode.csv"), load("pmc_WRITE_SIZE_by_kernel_property_mode.csv")
+    pr_k, pr_b = bytes_of(lambda k: "swz::pr_" in k or "swz::PrAlive" in k or "swz::PrList" in k)
+    sp_k, sp_b = bytes_of(lambda k: "swz::sp_" in k)
+    dense_levels = max(1, levels - 2)
+    out["bytes_per_launch_property_mode"] = {"sample_min_distance_property": pr_b / dense_levels, "sample_min_distance": sp_b / 2.0}
+    out["detail"]["property_mode"] = {"sample_min_distance_property": {"kernels": pr_k, "launches_per_step": dense_levels, "bytes_per_step": pr_b},
+                                      "sample_min_distance": {"kernels": sp_k, "launches_per_step": 2, "bytes_per_step": sp_b}}
+except FileNotFoundError:
+    pass
 json.dump(out, open(os.path.join(d, "traffic.json"), "w"), indent=1)
 print(json.dumps(out["bytes_per_launch"]), "calibration", calib)

@@ -5,8 +5,12 @@
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/profile
 PARTS=${PARTS:-lines stats pmc fullsize}
+# (nothing of an earlier run or round may survive next to this run's stamp: the lines part starts from an empty directory)
+if [[ $PARTS == *lines* ]]; then rm -rf $OUT; fi
 mkdir -p $OUT
-python -c "import bench; print(bench.library_source_sha16())" > $OUT/source_sha16.txt
+sha=$(python -c "import bench; print(bench.library_source_sha16())")
+if [ -f $OUT/source_sha16.txt ] && [ "$(cat $OUT/source_sha16.txt)" != "$sha" ]; then echo "profile_round: $OUT holds results of other kernel sources ($(cat $OUT/source_sha16.txt) vs $sha): run PARTS=lines first" >&2; exit 1; fi
+echo $sha > $OUT/source_sha16.txt
 B() { tag=$1; shift; timeout 1200 python bench.py "$@" 2>> $OUT/bench.err | grep '^{' | tail -1 > $OUT/bench_$tag.json; echo "$tag: $(grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$tag.json | head -1)"; }
 if [[ $PARTS == *lines* ]]; then
   : > $OUT/bench.err
