@@ -1564,7 +1564,10 @@ int min_distance_keys_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& 
   // ~2000 rounds).  The host knows the size of the last queue it looked at; the queue of a round grows slowly (a front
   // moving through the cells), so four times that size, at least eight workgroups per segment, covers the rounds until
   // the next look -- a grid that turns out small only makes its workgroups draw more tickets.
-  const bool adapt_grid = !(c->opt("SWZ_MD_ADAPT_GRID") && atoi(c->opt("SWZ_MD_ADAPT_GRID")) == 0) && !c->opt("SWZ_MD_GRID");
+  // (Measured, round 5: no gain where it was meant to help -- 100 M points in 10 batches 372 vs 374 ms: a small round's 32 us
+  // are the latency of its activations, not the launch of empty workgroups -- and 3 ms lost at level 1 of the 1 B run.  Off
+  // unless SWZ_MD_ADAPT_GRID=1.)
+  const bool adapt_grid = c->opt("SWZ_MD_ADAPT_GRID") && atoi(c->opt("SWZ_MD_ADAPT_GRID")) != 0 && !c->opt("SWZ_MD_GRID");
   std::vector<uint32_t> ggrid(groups, sweep_grid);
   auto grid_for = [&](uint32_t queued) {
     const uint64_t want = std::max<uint64_t>(8ull * a.nseg, 4ull * queued);

@@ -37,6 +37,9 @@ constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 // then needs 62 registers and runs 8 wavefronts per SIMD; nine (all a point usually has) need 91 -> 5 per SIMD and are
 // 25 % slower at 1 B points (level 2: 110 against 88 ms), 5-6 cells 72 registers and 92 ms.
 constexpr int SP_BATCH = SWZ_SP_BATCH;
+#ifndef SWZ_SP_DEFER
+#define SWZ_SP_DEFER 1
+#endif
 constexpr int SP_K = 8;  // recorded neighbours per point (32 B); more -> the point re-searches every round
 enum : uint8_t { SP_U = 0, SP_A = 1, SP_R = 2 };
 
@@ -52,8 +55,8 @@ struct SpArgs {
   const double* X;
   const double* Y;
   const double* Z;
-  const double* xyz;         // on keys: exact position of active point i = xyz[3 * perm[aidx ? aidx[i] : i]] (local points
-  const uint32_t* perm;      // only, see below) -- composed on the fly: only the pairs inside the band look it up
+  const double* xyz;         // on keys: exact position of active point i = xyz[3 * ids[i]]
+  const uint32_t* ids;
   float f_lo, f_hi;          // float squared distance < f_lo: closer than the spacing for sure, >= f_hi: farther for sure
   uint32_t m;
   uint32_t cell_shift;      // key >> cell_shift = node prefix + cell code
@@ -141,8 +144,8 @@ __global__ __launch_bounds__(256) void sp_key_records_kernel(const uint64_t* __r
 // the exact compare of the reference on the original positions (GridCell.cpp:52)
 __device__ __forceinline__ bool sp_exact_near(const SpArgs& a, uint32_t p, uint32_t q) {
   if (a.xyz) {
-    const double* u = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[p] : p] * 3;
-    const double* v = a.xyz + (size_t)a.perm[a.aidx ? a.aidx[q] : q] * 3;
+    const double* u = a.xyz + (size_t)a.ids[p] * 3;
+    const double* v = a.xyz + (size_t)a.ids[q] * 3;
     return sq_dist(u[0], u[1], u[2], v[0], v[1], v[2]) < a.sq_spacing;
   }
   const uint32_t sp = a.aidx ? a.aidx[p] : p, sq = a.aidx ? a.aidx[q] : q;
@@ -150,8 +153,14 @@ __device__ __forceinline__ bool sp_exact_near(const SpArgs& a, uint32_t p, uint3
 }
 
 // Visits every EARLIER point closer than the spacing to point p.  f(q) returns false to stop.
-template <typename F>
-__device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F f) {
+// DEFER: no exact compare inside the search loops at all -- the first TWO in-band pairs of a point are put aside and
+// evaluated after the search, a third one (one point in ten million) raises *over and the caller treats the point like one
+// with too many neighbours to record (the rounds search again, with DEFER = false).  The search kernel is bound by the
+// latency of its dependent loads at the eight wavefronts per SIMD that 64 registers allow, and it is touchy about what
+// sits in its loops: composing the position index there (one more dependent load in this rare path) cost level 2 of the
+// 1 B run 9 ms (82 -> 91), measured in round 5.
+template <bool DEFER, typename F>
+__device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F f, bool* over = nullptr) {
   const float4 me = a.rec[p];
   const uint64_t mykey = a.akey[p];
   const uint64_t pre = mykey >> a.cell_shift;
@@ -199,7 +208,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   // Pairs inside the band of the float compare need the exact positions: a chain of dependent scattered loads that the
   // whole wavefront waits for.  The first one of a point is put aside and evaluated after the search, all lanes together
   // (a second one is rare and evaluated on the spot).
-  uint32_t pend0 = SP_NONE;
+  uint32_t pend0 = SP_NONE, pend1 = SP_NONE;
   const uint2* __restrict__ tab = a.table + base;
   while (need) {
     uint32_t q[SP_BATCH], qe[SP_BATCH];
@@ -245,6 +254,8 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
               if (!f(q[i])) return;
             } else if (pend0 == SP_NONE) {
               pend0 = q[i];
+            } else if (DEFER) {
+              if (pend1 == SP_NONE) pend1 = q[i]; else *over = true;
             } else if (sp_exact_near(a, p, q[i])) {
               if (!f(q[i])) return;
             }
@@ -279,6 +290,8 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
           if (!f(cq)) return;
         } else if (pend0 == SP_NONE) {
           pend0 = cq;
+        } else if (DEFER) {
+          if (pend1 == SP_NONE) pend1 = cq; else *over = true;
         } else if (sp_exact_near(a, p, cq)) {
           if (!f(cq)) return;
         }
@@ -288,6 +301,9 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   }
   if (pend0 != SP_NONE && sp_exact_near(a, p, pend0)) {
     if (!f(pend0)) return;
+  }
+  if (DEFER && pend1 != SP_NONE && sp_exact_near(a, p, pend1)) {
+    if (!f(pend1)) return;
   }
 }
 
@@ -302,11 +318,13 @@ __global__ __launch_bounds__(SP_NB_THREADS, 8) void sp_neighbours_kernel(SpArgs 
   uint32_t cnt = 0;
   if (sp_sampled(a, p)) {
     uint32_t* mine = a.nbr + (size_t)p * SP_K;
-    sp_visit_earlier(a, p, [&](uint32_t q) {
+    bool over = false;
+    sp_visit_earlier<SWZ_SP_DEFER != 0>(a, p, [&](uint32_t q) {
       if (cnt < (uint32_t)SP_K) mine[cnt] = q;
       ++cnt;
       return cnt <= (uint32_t)SP_K;  // one past the capacity marks the overflow, then stop
-    });
+    }, &over);
+    if (over) cnt = (uint32_t)SP_K + 1u;  // (more in-band pairs than are put aside: the rounds search this point again, exactly)
     if (cnt > (uint32_t)SP_K) atomicAdd(overflow, 1u);
     if (cnt == 0) {
       sp_store(a.state, p, SP_A);
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(256) void sp_round_kernel(SpArgs a, const uint32_t*
         for (int it = 0; it < 4 && r == SP_U; ++it) r = sp_eval(a.state, mine, cnt);
       } else {  // too many neighbours to record: search again
         bool rej = false, wait = false;
-        sp_visit_earlier(a, p, [&](uint32_t q) {
+        sp_visit_earlier<false>(a, p, [&](uint32_t q) {
           const uint8_t s = sp_load(a.state, q);
           rej |= s == SP_A;
           wait |= s == SP_U;
@@ -504,8 +522,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     // (A sharded batch: the ghosts in front of the sorted order have their own position array and ids below sp.ghosts,
     // local point p has id ghosts + p, see key_point_ids.  Ghosts are accepted again at the root and never reach a level
     // below it, and the root level of a batch with ghosts is left to the sweep -- above --, so only local ids occur here.)
-    a.xyz = sp.xyz;
-    a.perm = sp.perm;
+    a.xyz = sp.xyz - (size_t)sp.ghosts * 3;
+    SWZ_TRY(key_point_ids(c, as, sp, &a.ids));
     a.f_lo = km.f_lo;
     a.f_hi = km.f_hi;
     if (const char* e = c->opt("SWZ_SP_FILTER_EPS"))  // tests: 1e30 sends every compare within reach to the exact path
