@@ -74,6 +74,10 @@ def parse_args():
                     "ncclSend / ncclRecv or by hipMemcpyPeerAsync (peer copies also work with all shards on ONE device)")
     ap.add_argument("--group-devices", type=int, default=0, help="--driver group: devices the shards are dealt to (0 = as "
                     "many as there are shards; 1 = all shards share device 0, the only way to run it on a one-GPU box)")
+    ap.add_argument("--also", default="GRID_CENTER,MIN_DISTANCE_FAST", help="N = 1, one batch, headline workload only: short extra legs "
+                    "after the timed region, reported under \"also\" and never part of `value` -- a sampler name runs the same points "
+                    "through that sampler (GRID_CENTER: BASELINE configs[1]'s sampler at the headline size), <sampler>_FAST through the "
+                    "FAST strategy (the reference's default, executable/main.cpp:299-301); \"\" = none")
     ap.add_argument("--config", type=int, default=0, choices=[0, 4, 5], help="BASELINE.json's multi-GPU configurations as one "
                     "command each: 4 = 1 B points IN TOTAL, JITTERED, sharded over --gpus ranks by the top Morton bits (strong "
                     "scaling); 5 = 4 B points in total with RGB + intensity, MIN_DISTANCE, every rank's share staged from pinned "
@@ -678,6 +682,46 @@ def main():
                 "kernels_ms_per_step": {k: round(v["total_ms"] / psteps, 3) for k, v in sorted(pprof.items())},
                 "note": "same workload with SWZ_FLAG_MIN_DISTANCE_PROPERTY: spacing and maximality guaranteed "
                         "(tests/test_min_distance_property.py), taken set differs from the reference's"}
+        if (args.also and world == 1 and not distributed and mb is None and args.md_mode != "property" and args.sampler == "MIN_DISTANCE"
+                and args.strategy == "ACCURATE" and not args.payload):
+            import dataclasses
+            out["also"] = {}
+            for leg in [x for x in args.also.split(",") if x]:
+                fast = leg.endswith("_FAST")
+                sname = leg[:-5] if fast else leg
+                if sname not in swz.SAMPLERS or (sname == args.sampler and (args.strategy == "FAST") == fast):
+                    continue
+                lp = dataclasses.replace(params, sampler=swz.SAMPLERS[sname], strategy=swz.FAST if fast else swz.ACCURATE, flags=0)
+
+                def lstep():
+                    return ctx.tile_device(xyz.data_ptr(), n, bmin, bmax, lp, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+                lstep()
+                ctx.profile_reset()
+                torch.cuda.synchronize(dev)
+                lsteps = max(1, min(args.steps, 3))
+                t0 = time.perf_counter()
+                for _ in range(lsteps):
+                    lstats = lstep()
+                torch.cuda.synchronize(dev)
+                ldt = (time.perf_counter() - t0) / lsteps
+                lprof = ctx.profile_get()
+                lvisit = lstats["points_visited"] / float(n)
+                lalg = algorithmic_bytes_per_point(sname, lvisit)
+                lroof = None
+                if lprof:
+                    lname, lk = max(lprof.items(), key=lambda kv: kv[1]["total_ms"])
+                    lavg = lk["total_ms"] / max(lk["launches"], 1)
+                    lach = lk["algorithmic_bytes"] / max(lk["launches"], 1) / (lavg * 1e-3) / 1e9 if lavg > 0 else 0.0
+                    lroof = {"bound": "hbm", "kernel": lname, "achieved": round(lach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(lach / HBM_PEAK_GBS, 5), "launches": lk["launches"], "avg_launch_ms": round(lavg, 4)}
+                largs = argparse.Namespace(steps=lsteps, sampler=sname)
+                out["also"][leg] = {
+                    "workload": "the same %d points, %s sampling, %s strategy" % (n, sname, "FAST" if fast else "ACCURATE"),
+                    "ms_per_step": round(ldt * 1e3, 3), "Mpoints_per_s": round(n / ldt / 1e6, 3), "visit_factor": round(lvisit, 4),
+                    "hbm_frac_end_to_end": round(lalg * n / ldt / (HBM_PEAK_GBS * 1e9), 5),
+                    "hbm_frac_end_to_end_implemented_sort": implemented_sort_frac(lprof, largs, lvisit, n, ldt),
+                    "roofline": lroof, "steps": lsteps,
+                    "kernels_ms_per_step": {k: round(v["total_ms"] / lsteps, 3) for k, v in sorted(lprof.items())}}
         if mb is not None and "run_staged" in mb:
             mb["run_staged"]()  # warm-up: pools and workspace sized
             torch.cuda.synchronize(dev)

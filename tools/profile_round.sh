@@ -39,8 +39,8 @@ if [[ $PARTS == *fullsize* ]]; then
   tail -3 $OUT/fullsize_pytest.txt
 fi
 cd /tmp && export TMPDIR=/tmp
-S() { dir=$1; shift; rm -rf $OUT/$dir; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$dir -o bench -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/$dir.json 2>/dev/null; find $OUT/$dir -name "*kernel_trace*" -delete; f=$(find $OUT/$dir -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/$dir/bench_kernel_stats.csv; }
-P() { ctr=$1; dir=$2; shift 2; rm -rf $OUT/$dir; timeout 1200 rocprofv3 --pmc $ctr --output-format csv -d $OUT/$dir -o p -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > /dev/null 2>&1; }
+S() { dir=$1; shift; rm -rf $OUT/$dir; timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$dir -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --also "" "$@" > $OUT/$dir.json 2>/dev/null; find $OUT/$dir -name "*kernel_trace*" -delete; f=$(find $OUT/$dir -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $OUT/$dir/bench_kernel_stats.csv; }
+P() { ctr=$1; dir=$2; shift 2; rm -rf $OUT/$dir; timeout 1200 rocprofv3 --pmc $ctr --output-format csv -d $OUT/$dir -o p -- python3 $GRAFT_REPO_ROOT/bench.py --also "" "$@" > /dev/null 2>&1; }
 if [[ $PARTS == *stats* ]]; then
   S stats --cpu-sample 0 --md-mode exact
   cp $OUT/stats.json $OUT/stats_run.json
