@@ -1486,10 +1486,24 @@ static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats, int lowest_childr
     double *wx = nullptr, *wy = nullptr, *wz = nullptr;
     SWZ_TRY(c->get("tl_keys", (size_t)m, &keys));
     SWZ_TRY(c->get("tl_perm", (size_t)m, &gid));
-    SWZ_TRY(c->get("tl_wx", (size_t)m, &wx));
-    SWZ_TRY(c->get("tl_wy", (size_t)m, &wy));
-    SWZ_TRY(c->get("tl_wz", (size_t)m, &wz));
     SWZ_TRY(c->get("tl_wgid", (size_t)m, &wgid));
+    LevelPlan plan = make_plan(lv - 1, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
+                               t->bmin, t->bmax, true, false);
+    plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
+    // Like the levels of a batch (tiler_level), the rebuilt levels are decided on key coordinates with the exact positions
+    // looked up in the pool through the point ids (round 5: they gathered the positions and ran the sweep on positions --
+    // 253 of the 1 073 ms of the default operating point's data set, 1 B points in 100 tile batches); positions in
+    // Morton order only for what cannot be decided on keys.
+    SortedPoints sp{nullptr, nullptr, nullptr, t->pool_xyz, wgid};
+    const bool on_keys = level_decides_on_keys(c, plan, sp);
+    if (!on_keys) {
+      SWZ_TRY(c->get("tl_wx", (size_t)m, &wx));
+      SWZ_TRY(c->get("tl_wy", (size_t)m, &wy));
+      SWZ_TRY(c->get("tl_wz", (size_t)m, &wz));
+      sp.X = wx;
+      sp.Y = wy;
+      sp.Z = wz;
+    }
     SWZ_HIP(c, hipMemcpyAsync(gid, src.gid[src.cur], (size_t)m * 4, hipMemcpyDeviceToDevice, c->stream));
     hipLaunchKernelGGL(tl_reencode_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, gid, m, t->pool_xyz, root_box(t), keys);
     SWZ_LAUNCH_CHECK(c);
@@ -1506,14 +1520,11 @@ static int tiler_finalize(swz_tiler* t, swz_tile_stats* stats, int lowest_childr
     }
     hipLaunchKernelGGL(tl_fill_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, gid, m, t->pool_xyz, wx, wy, wz, wgid);
     SWZ_LAUNCH_CHECK(c);
-    LevelPlan plan = make_plan(lv - 1, t->p.sampler, t->p.max_points_per_node, t->p.spacing_at_root, t->p.max_depth,
-                               t->bmin, t->bmax, true, false);
-    plan.md_property = (t->p.flags & SWZ_FLAG_MIN_DISTANCE_PROPERTY) != 0;
     LevelBuffers lb;
     SWZ_TRY(alloc_level_buffers(c, m, &lb));
     ActiveSet as{keys, nullptr, m};
     LevelResult r;
-    SWZ_TRY(level_step(c, plan, as, SortedPoints{wx, wy, wz}, lb, nullptr, nullptr, nullptr, &r));
+    SWZ_TRY(level_step(c, plan, as, sp, lb, nullptr, nullptr, nullptr, &r));
     // count the taken points, then write them as the parents' files
     uint64_t* tkey = nullptr;
     uint32_t* tgid = nullptr;
