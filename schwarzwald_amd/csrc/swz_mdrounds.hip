@@ -497,12 +497,17 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   // the records are affordable (448 bytes per cell: levels of dozens of points per cell)
   double wl_min_pop = 24.0;
   if (const char* e = c->opt("SWZ_MD_ROUNDS_WLIST_MIN_POP")) wl_min_pop = atof(e);
-  const bool wl = (double)sample_points / (double)a.ncells >= wl_min_pop;
+  bool wl = (double)sample_points / (double)a.ncells >= wl_min_pop;
   float4* wlist = nullptr;
   uint8_t* wcount = nullptr;
   if (wl) {
-    SWZ_TRY(c->get("md_pr_wlist", (size_t)a.ncells * PR_WL, &wlist));
-    SWZ_TRY(c->get("md_pr_wcount", (size_t)a.ncells, &wcount));
+    // (an accelerator only: when the records do not fit -- 448 bytes per cell -- the loop over the mask does the same job)
+    if (c->get("md_pr_wlist", (size_t)a.ncells * PR_WL, &wlist) != SWZ_OK || c->get("md_pr_wcount", (size_t)a.ncells, &wcount) != SWZ_OK) {
+      (void)hipGetLastError();
+      wl = false;
+      wlist = nullptr;
+      wcount = nullptr;
+    }
   }
   const bool cell_lists = !(c->opt("SWZ_MD_ROUNDS_CELL_LISTS") && atoi(c->opt("SWZ_MD_ROUNDS_CELL_LISTS")) == 0);
   bool prev_list = false;   // the round before ran over a list (list[cur ^ 1], nprev entries: still intact)

@@ -119,6 +119,29 @@ def test_property_mode_small(ctx, kind, d, max_points):
     assert 0.85 < tp / te < 1.15, (te, tp)
 
 
+def test_property_mode_kill_paths_agree(ctx):
+    """Round 5: the first kill passes of levels with dozens of points per cell read the winners around their cell from
+    per-cell records, the per-cell steps run over the list of alive points once it is short.  Both are accelerators: with
+    either switched off (the loop over the mask everywhere / the cell grid in every round) the set must be the same, bit
+    for bit -- and it must have the properties."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(55)
+    n = 3000000
+    xyz = rng.random((n, 3))
+    sp = O.spacing_from_diagonal(*UNIT, 40)  # root cells of ~700 points, level 0 ~90: records; level 1 ~11: the mask loop
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=2000, spacing_at_root=sp, flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+    base = ctx.tile(xyz, *UNIT, params)
+    for opt, val in (("SWZ_MD_ROUNDS_WLIST_MIN_POP", "1e9"), ("SWZ_MD_ROUNDS_CELL_LISTS", "0"), ("SWZ_MD_ROUNDS_LIST", "0")):
+        ctx.set_option(opt, val)
+        try:
+            other = ctx.tile(xyz, *UNIT, params)
+        finally:
+            ctx.set_option(opt, None)
+        assert np.array_equal(other.level, base.level), opt
+    a, b = _check_property(base.keys, base.level, base.xyz_clamped[base.perm], sp, 2000, base.stats["max_level"])
+    assert a > 0 and b > 0
+
+
 def test_property_mode_fast_strategy_and_multibatch(ctx):
     """The flag travels through FAST's reconstruction and the multi-batch tiler (AlwaysAdhereToMinSpacing nodes)."""
     import schwarzwald_amd as swz
