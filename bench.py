@@ -567,8 +567,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    extra_warmups = 0
     for _ in range(args.warmup):
         step()
+    if mb is not None:
+        # The multi-batch tiler's workspace (node store sides, merge buffers) is sized by what the data sets before have asked
+        # for and may still grow in the second or third one (the store's compaction points move with the capacities it
+        # finds); a multi-GB hipMalloc in the middle of a data set stalls it for 0.25-2 s (tools/default_op_probe.py).  The
+        # timed steps are the steady state: warm up until a whole data set leaves the workspace as it found it -- at most two
+        # more (in repeated data sets on one context the workspace keeps creeping up by ~0.5 GB per data set: the
+        # log-structured store's compaction points move with the capacities it finds).
+        held = ctx.workspace_bytes()
+        while extra_warmups < 2:
+            step()
+            extra_warmups += 1
+            now = ctx.workspace_bytes()
+            grew = now > held
+            held = now
+            if not grew:
+                break
     if not args.no_profile:
         ctx.profile_enable(True)
         ctx.profile_reset()
@@ -635,6 +652,7 @@ def main():
                        "baseline_config": args.config or None, "total_points": args.total_points or None,
                        "parallelism": "1 GPU" if world == 1 else ("%d ranks sharded by top Morton bits, one all-to-all%s" % (
                            world, " -- DRY RUN: all ranks on ONE GPU over gloo" if args.one_device else ""))},
+            "extra_warmup_data_sets": extra_warmups if mb is not None else None,
             "ranks_in_process_group": dist.get_world_size() if distributed else 1,
             "root_mode": shard_report[0]["root_mode"] if shard_report else None,
             "exchange_ms": max((r.get("exchange_ms", 0.0) for r in shard_report), default=None) if shard_report else None,
