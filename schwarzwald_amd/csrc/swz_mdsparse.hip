@@ -132,13 +132,25 @@ __global__ __launch_bounds__(256) void sp_gather_kernel(const uint32_t* __restri
 
 // Key coordinates as records (swz_level.h, KeyMetric): the differences of integers below 2^21 are exact in float, and
 // the band [f_lo, f_hi) around the spacing holds every pair the quantisation cannot decide.
-__global__ __launch_bounds__(256) void sp_key_records_kernel(const uint64_t* __restrict__ akey, uint32_t m, float4* __restrict__ rec) {
+// Both in one pass over the keys (round 5: the two kernels above read every key once each, and a memset wrote the state
+// bytes: 15 ms per 1 B-point step for the two sparse levels): record, state byte, and the table entries of the run's ends.
+__global__ __launch_bounds__(256) void sp_prepare_keys_kernel(SpArgs a, float4* __restrict__ rec) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  const uint64_t k = akey[i];
+  if (i >= a.m) return;
+  const uint64_t k = a.akey[i];
   uint32_t x, y, z;
   key_coords_u32(k, x, y, z);
   rec[i] = make_float4((float)x, (float)y, (float)z, 0.f);
+  a.state[i] = SP_U;
+  if (!sp_sampled(a, i)) return;
+  const uint64_t pre = k >> a.cell_shift;
+  const bool head = i == 0 || (a.akey[i - 1] >> a.cell_shift) != pre;
+  const bool tail = i + 1 == a.m || (a.akey[i + 1] >> a.cell_shift) != pre;
+  if (!head && !tail) return;
+  const uint64_t code = pre & (a.cells_per_node - 1ull);
+  uint2* e = a.table + ((uint64_t)sp_snode(a, i) * a.cells_per_node + code);
+  if (head) e->x = i;
+  if (tail) e->y = i + 1u;
 }
 
 // the exact compare of the reference on the original positions (GridCell.cpp:52)
@@ -560,16 +572,18 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
   SWZ_HIP(c, memset_large(a.table, 0xFF, (size_t)entries * sizeof(uint2), c->stream));
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
-  SWZ_HIP(c, memset_large(a.state, SP_U, (size_t)m, c->stream));
   const uint32_t nb = div_up(m, 256);
-  if (km.ok)
-    hipLaunchKernelGGL(sp_key_records_kernel, dim3(nb), dim3(256), 0, c->stream, as.akey, m, rec);
-  else
+  if (km.ok) {
+    hipLaunchKernelGGL(sp_prepare_keys_kernel, dim3(nb), dim3(256), 0, c->stream, a, rec);
+    SWZ_LAUNCH_CHECK(c);
+  } else {
+    SWZ_HIP(c, memset_large(a.state, SP_U, (size_t)m, c->stream));
     hipLaunchKernelGGL(sp_gather_kernel, dim3(nb), dim3(256), 0, c->stream, as.aidx, as.akey, m, sp.X, sp.Y, sp.Z, plan.root,
                        plan.level + 1, rec);
-  SWZ_LAUNCH_CHECK(c);
-  hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
-  SWZ_LAUNCH_CHECK(c);
+    SWZ_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(sp_table_kernel, dim3(nb), dim3(256), 0, c->stream, a);
+    SWZ_LAUNCH_CHECK(c);
+  }
   const uint32_t xcd = c->opt("SWZ_MD_XCD") ? ((uint32_t)atoi(c->opt("SWZ_MD_XCD")) >> 1) & 1u : 1u;
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
