@@ -37,6 +37,9 @@ constexpr uint32_t SP_NONE = 0xFFFFFFFFu;
 // then needs 62 registers and runs 8 wavefronts per SIMD; nine (all a point usually has) need 91 -> 5 per SIMD and are
 // 25 % slower at 1 B points (level 2: 110 against 88 ms), 5-6 cells 72 registers and 92 ms.
 constexpr int SP_BATCH = SWZ_SP_BATCH;
+#ifndef SWZ_SP_TABLE4
+#define SWZ_SP_TABLE4 1
+#endif
 #ifndef SWZ_SP_DEFER
 #define SWZ_SP_DEFER 1
 #endif
@@ -67,6 +70,8 @@ struct SpArgs {
   float usq_f[3];           // squared slab width per axis, rounded down
   float cull_f;             // squared spacing with a margin: adjacent cells farther than this are skipped
   uint2* table;             // [sample node][cell code] -> {first, end} active index of the cell's run
+  uint32_t* table4;         // on keys (SWZ_SP_TABLE4): [sample node][cell code] -> first only, 4 bytes per cell; the run's
+                            // length travels in the w field of its FIRST record, which the search loads anyway
   uint32_t* nbr;            // [point][SP_K]
   uint8_t* ncount;          // recorded neighbours, SP_K + 1 = overflow
   uint8_t* state;
@@ -140,11 +145,23 @@ __global__ __launch_bounds__(256) void sp_prepare_keys_kernel(SpArgs a, float4* 
   const uint64_t k = a.akey[i];
   uint32_t x, y, z;
   key_coords_u32(k, x, y, z);
-  rec[i] = make_float4((float)x, (float)y, (float)z, 0.f);
   a.state[i] = SP_U;
-  if (!sp_sampled(a, i)) return;
   const uint64_t pre = k >> a.cell_shift;
-  const bool head = i == 0 || (a.akey[i - 1] >> a.cell_shift) != pre;
+  const bool sampled = sp_sampled(a, i);
+  const bool head = sampled && (i == 0 || (a.akey[i - 1] >> a.cell_shift) != pre);
+  if (a.table4) {
+    // the head of a run walks to its end (runs are short on the levels this path takes) and leaves the length in its record
+    uint32_t len = 0;
+    if (head) {
+      len = 1;
+      while (i + len < a.m && (a.akey[i + len] >> a.cell_shift) == pre) ++len;
+      a.table4[(uint64_t)sp_snode(a, i) * a.cells_per_node + (pre & (a.cells_per_node - 1ull))] = i;
+    }
+    rec[i] = make_float4((float)x, (float)y, (float)z, __uint_as_float(len));
+    return;
+  }
+  rec[i] = make_float4((float)x, (float)y, (float)z, 0.f);
+  if (!sampled) return;
   const bool tail = i + 1 == a.m || (a.akey[i + 1] >> a.cell_shift) != pre;
   if (!head && !tail) return;
   const uint64_t code = pre & (a.cells_per_node - 1ull);
@@ -171,7 +188,7 @@ __device__ __forceinline__ bool sp_exact_near(const SpArgs& a, uint32_t p, uint3
 // latency of its dependent loads at the eight wavefronts per SIMD that 64 registers allow, and it is touchy about what
 // sits in its loops: composing the position index there (one more dependent load in this rare path) cost level 2 of the
 // 1 B run 9 ms (82 -> 91), measured in round 5.
-template <bool DEFER, typename F>
+template <bool DEFER, bool T4, typename F>
 __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F f, bool* over = nullptr) {
   const float4 me = a.rec[p];
   const uint64_t mykey = a.akey[p];
@@ -222,6 +239,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
   // (a second one is rare and evaluated on the spot).
   uint32_t pend0 = SP_NONE, pend1 = SP_NONE;
   const uint2* __restrict__ tab = a.table + base;
+  const uint32_t* __restrict__ tab4 = a.table4 + base;
   while (need) {
     uint32_t q[SP_BATCH], qe[SP_BATCH];
 #pragma unroll
@@ -234,10 +252,18 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
         const uint32_t kx = k % 3u, ky = (k / 3u) % 3u, kz = k / 9u;
         const uint32_t ncode = (kx == 0u ? dx[0] : (kx == 1u ? dx[1] : dx[2])) | (ky == 0u ? dy[0] : (ky == 1u ? dy[1] : dy[2])) |
                                (kz == 0u ? dz[0] : (kz == 1u ? dz[1] : dz[2]));
-        const uint2 e = tab[ncode];
-        if (e.x != SP_NONE) {  // empty cells are {NONE, NONE}
-          q[i] = e.x;
-          qe[i] = min(e.y, p);  // own cell: earlier points only
+        if (T4) {
+          const uint32_t e = tab4[ncode];
+          if (e < p) {  // (empty cells are NONE; own cell: earlier points only)
+            q[i] = e;
+            qe[i] = e + 1u;  // (the run's end comes with its first record, below)
+          }
+        } else {
+          const uint2 e = tab[ncode];
+          if (e.x != SP_NONE) {  // empty cells are {NONE, NONE}
+            q[i] = e.x;
+            qe[i] = min(e.y, p);  // own cell: earlier points only
+          }
         }
       }
     }
@@ -252,6 +278,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
           rx[i] = r.x;
           ry[i] = r.y;
           rz[i] = r.z;
+          if (T4) qe[i] = min(q[i] + __float_as_uint(r.w), p);
           any = true;
         }
       }
@@ -321,6 +348,7 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
 
 // phase 1: record the earlier neighbours; points without any are accepted right away
 constexpr int SP_NB_THREADS = 256;
+template <bool T4>
 __global__ __launch_bounds__(SP_NB_THREADS, 8) void sp_neighbours_kernel(SpArgs a, uint32_t* __restrict__ overflow, uint32_t xcd) {
   // workgroups go round-robin over the 8 XCDs: XCD x takes the x-th contiguous eighth of the points, so the
   // neighbourhoods a workgroup reads were mostly fetched into the same L2 by the workgroups just before it
@@ -331,7 +359,7 @@ __global__ __launch_bounds__(SP_NB_THREADS, 8) void sp_neighbours_kernel(SpArgs 
   if (sp_sampled(a, p)) {
     uint32_t* mine = a.nbr + (size_t)p * SP_K;
     bool over = false;
-    sp_visit_earlier<SWZ_SP_DEFER != 0>(a, p, [&](uint32_t q) {
+    sp_visit_earlier<SWZ_SP_DEFER != 0, T4>(a, p, [&](uint32_t q) {
       if (cnt < (uint32_t)SP_K) mine[cnt] = q;
       ++cnt;
       return cnt <= (uint32_t)SP_K;  // one past the capacity marks the overflow, then stop
@@ -434,6 +462,7 @@ __global__ __launch_bounds__(256) void sp_resolve_kernel(SpArgs a, uint32_t max_
 }
 
 // phase 2: one fixpoint round over the undecided points
+template <bool T4>
 __global__ __launch_bounds__(256) void sp_round_kernel(SpArgs a, const uint32_t* __restrict__ uin, const uint32_t* __restrict__ nin,
                                                        uint32_t* __restrict__ uout, uint32_t* __restrict__ nout) {
   const uint32_t n = *nin;
@@ -450,7 +479,7 @@ __global__ __launch_bounds__(256) void sp_round_kernel(SpArgs a, const uint32_t*
         for (int it = 0; it < 4 && r == SP_U; ++it) r = sp_eval(a.state, mine, cnt);
       } else {  // too many neighbours to record: search again
         bool rej = false, wait = false;
-        sp_visit_earlier<false>(a, p, [&](uint32_t q) {
+        sp_visit_earlier<false, T4>(a, p, [&](uint32_t q) {
           const uint8_t s = sp_load(a.state, q);
           rej |= s == SP_A;
           wait |= s == SP_U;
@@ -570,7 +599,12 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_TRY(c->get("sp_ulist1", (size_t)m, &u1));
   SWZ_TRY(c->get("sp_counts", (size_t)4, &cnt));
   ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
-  SWZ_HIP(c, memset_large(a.table, 0xFF, (size_t)entries * sizeof(uint2), c->stream));
+  const bool t4 = km.ok && SWZ_SP_TABLE4 != 0;
+  if (t4) {
+    a.table4 = reinterpret_cast<uint32_t*>(a.table);
+    a.table = nullptr;
+  }
+  SWZ_HIP(c, memset_large(t4 ? (void*)a.table4 : (void*)a.table, 0xFF, (size_t)entries * (t4 ? sizeof(uint32_t) : sizeof(uint2)), c->stream));
   SWZ_HIP(c, hipMemsetAsync(cnt, 0, 16, c->stream));
   const uint32_t nb = div_up(m, 256);
   if (km.ok) {
@@ -594,7 +628,10 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     (void)hipEventRecord(ev0, c->stream);
   }
   const uint32_t nbn = div_up(m, SP_NB_THREADS);
-  hipLaunchKernelGGL(sp_neighbours_kernel, dim3(xcd ? div_up(nbn, 8) * 8 : nbn), dim3(SP_NB_THREADS), 0, c->stream, a, cnt + 2, xcd);
+  if (t4)
+    hipLaunchKernelGGL(sp_neighbours_kernel<true>, dim3(xcd ? div_up(nbn, 8) * 8 : nbn), dim3(SP_NB_THREADS), 0, c->stream, a, cnt + 2, xcd);
+  else
+    hipLaunchKernelGGL(sp_neighbours_kernel<false>, dim3(xcd ? div_up(nbn, 8) * 8 : nbn), dim3(SP_NB_THREADS), 0, c->stream, a, cnt + 2, xcd);
   SWZ_LAUNCH_CHECK(c);
   {
     const uint32_t max_polls = c->opt("SWZ_SP_POLLS") ? (uint32_t)atoi(c->opt("SWZ_SP_POLLS")) : 16u;
@@ -624,8 +661,12 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     // a few rounds per host look; an empty list makes the remaining launches no-ops
     for (int r = 0; r < 4; ++r, ++rounds) {
       hipLaunchKernelGGL(sp_zero_kernel, dim3(1), dim3(1), 0, c->stream, cnt + (cur ^ 1));
-      hipLaunchKernelGGL(sp_round_kernel, dim3(std::min<uint32_t>(4096u, std::max(1u, div_up(left, 256)))), dim3(256), 0,
-                         c->stream, a, uin, cnt + cur, uout, cnt + (cur ^ 1));
+      if (t4)
+        hipLaunchKernelGGL(sp_round_kernel<true>, dim3(std::min<uint32_t>(4096u, std::max(1u, div_up(left, 256)))), dim3(256), 0,
+                           c->stream, a, uin, cnt + cur, uout, cnt + (cur ^ 1));
+      else
+        hipLaunchKernelGGL(sp_round_kernel<false>, dim3(std::min<uint32_t>(4096u, std::max(1u, div_up(left, 256)))), dim3(256), 0,
+                           c->stream, a, uin, cnt + cur, uout, cnt + (cur ^ 1));
       SWZ_LAUNCH_CHECK(c);
       std::swap(uin, uout);
       cur ^= 1;
