@@ -202,4 +202,10 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
                               const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes,
                               uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used);
 
+// The same set by blocks of 8^3 cells staged in LDS, blocks in Morton order, decisions in the same launch
+// (swz_mdblock.hip, round 6); *done = false: the level does not qualify or a block did not fit, nothing is lost.
+int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+                             const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes, uint32_t sample_points,
+                             const uint32_t occupied[12], const KeyMetric& km, bool* done);
+
 }  // namespace swz

@@ -524,6 +524,18 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   // the root of a sharded batch with ghosts in front, decided on keys: the sweep looks up two position arrays, this path one
   if (sp.ghosts && plan.level == -1 && !sp.X) return SWZ_OK;
   const uint32_t m = as.m;
+  const KeyMetric km = key_metric(c, plan, sp);
+  {
+    // round 6: blocks of cells out of LDS, decisions in the same launch (swz_mdblock.hip); levels it cannot take --
+    // no key metric, a block that does not fit its LDS capacity -- go on below as before
+    bool done = false;
+    SWZ_TRY(min_distance_block_level(c, plan, as, sp, lb, snode_of, all_sampled, sample_nodes, sample_points, occupied, km, &done));
+    if (done) {
+      if (rounds_out) *rounds_out += 1;
+      *used = true;
+      return SWZ_OK;
+    }
+  }
 
   SpArgs a{};
   a.akey = as.akey;
@@ -557,7 +569,6 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   a.X = sp.X;
   a.Y = sp.Y;
   a.Z = sp.Z;
-  const KeyMetric km = key_metric(c, plan, sp);
   if (!km.ok && !sp.X) return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE: this level needs the positions in Morton order and they were not gathered");
   if (km.ok) {
     // (A sharded batch: the ghosts in front of the sorted order have their own position array and ids below sp.ghosts,
