@@ -38,6 +38,9 @@
 
 namespace swz {
 
+#ifndef SB_MINW
+#define SB_MINW 6   // wavefronts per SIMD the kernel is compiled for (80 registers; measured against 5: level 2 of the 1 B run 69 -> 64 ms)
+#endif
 constexpr int SB_THREADS = 256;
 constexpr int SB_K = 4;               // undecided earlier neighbours recorded per point (0.73 expected at level 2 of the 1 B run); more: the point searches again
 constexpr int SB_PEND = 63;            // in-band pairs a wavefront puts aside per block (more: compared on the spot)
@@ -48,7 +51,7 @@ constexpr uint32_t SB_NONE = 0xFFFFFFFFu;
 enum : uint32_t { SB_U = 0, SB_A = 1, SB_R = 2 };
 enum : uint32_t { SB_ABORT_NONE = 0, SB_ABORT_CAPACITY = 1, SB_ABORT_TIMEOUT = 2 };
 // words behind the ticket counters
-enum : uint32_t { SBW_ABORT = 0, SBW_MAX_OWN = 1, SBW_MAX_HALO = 2, SBW_ITER = 3, SBW_BLOCKS = 4, SBW_WAITS = 5, SBW_RESEARCH = 6,
+enum : uint32_t { SBW_ABORT = 0, SBW_MAX_OWN = 1, SBW_MAX_HALO = 2, SBW_ITER = 3, SBW_BLOCKS = 4, SBW_WAITS = 5, SBW_RESEARCH = 6, SBW_STEPS = 7,
                   SBW_T0 = 8 /* -DSWZ_SB_STATS: ticks (10 ns) of thread 0 per phase: ticket, granules, stage, index, search, decide, tail */, SBW_COUNT = 16 };
 #ifdef SWZ_SB_STATS
 #define SB_T(i) do { if (tid == 0) { const uint64_t now_ = wall_clock64(); tacc[i] += (uint32_t)(now_ - tlast); tlast = now_; } } while (0)
@@ -124,7 +127,6 @@ struct SbLds {
   uint32_t* occ;    // [128] (iz, iy) -> bit ix: the region cell holds staged points
   uint32_t* soff;   // [224] halo slot (region granule 0..215) -> LDS offset of its run; [216] = total
   uint32_t* sfirst; // [224] ... -> active index of its first point
-  uint32_t* gidx;   // [halo_cap] active index of a halo point
   uint32_t* pub;    // own state bits to publish, by word of st2
   uint32_t* misc;   // SBM_*
   uint32_t* scan;   // [8] block scan scratch
@@ -137,7 +139,6 @@ __host__ __device__ inline size_t sb_lds_bytes(uint32_t own_cap, uint32_t halo_c
   const size_t tot = (size_t)own_cap + halo_cap;
   size_t b = tot * 8;                                            // pts
   b += 1024 * 4 + 128 * 4 + 224 * 4 + 224 * 4;                   // cse, occ, soff, sfirst
-  b += (size_t)halo_cap * 4;                                     // gidx
   b += (((size_t)own_cap / 16 + 5) & ~(size_t)1) * 4 + SBM_COUNT * 4 + 8 * 4;   // pub (even: what follows stays 8-byte aligned), misc, scan
   b += std::max((size_t)own_cap * SB_K, tot) * 2;                // nbr / rc
   b += ((tot + 3) & ~(size_t)3) + own_cap + 4 * (SB_PEND + 1) * 4; // st, cnt4, pend
@@ -151,8 +152,7 @@ __device__ __forceinline__ SbLds sb_carve(unsigned char* smem, uint32_t own_cap,
   l.occ = l.cse + 1024;
   l.soff = l.occ + 128;
   l.sfirst = l.soff + 224;
-  l.gidx = l.sfirst + 224;
-  l.pub = l.gidx + halo_cap;
+  l.pub = l.sfirst + 224;
   l.misc = l.pub + ((own_cap / 16 + 5u) & ~1u);
   l.scan = l.misc + SBM_COUNT;
   l.nbr = reinterpret_cast<uint16_t*>(l.scan + 8);
@@ -187,7 +187,20 @@ __device__ __forceinline__ uint64_t sb_make_point(const SbArgs& a, const SbBlock
                  zr = (z & nmask) - ((k.bz8 - 1u) << a.cell_bits);
   return (uint64_t)((xr & 0xFFFFu) | (yr << 16)) | ((uint64_t)((zr & 0xFFFFu) | (c << 16)) << 32);
 }
-__device__ __forceinline__ uint32_t sb_active_index(const SbLds& l, const SbBlock& k, uint32_t q) { return q < k.n_own ? k.first + q : l.gidx[q - k.n_own]; }
+// the halo run that holds staged point j >= n_own: soff ascends, [216] = total (branch-free: eight steps for every lane)
+__device__ __forceinline__ uint32_t sb_halo_slot(const SbLds& l, uint32_t j) {
+  uint32_t lo = 0;
+#pragma unroll
+  for (uint32_t step = 128u; step; step >>= 1)
+    if (lo + step <= 216u && l.soff[lo + step] <= j) lo += step;
+  return lo;
+}
+// active index of staged point q (a halo point's is looked up: only polls and compares on the original positions want it)
+__device__ __forceinline__ uint32_t sb_active_index(const SbLds& l, const SbBlock& k, uint32_t q) {
+  if (q < k.n_own) return k.first + q;
+  const uint32_t slot = sb_halo_slot(l, q);
+  return l.sfirst[slot] + (q - l.soff[slot]);
+}
 
 // Which of the 27 cells around own cell (ix, iy, iz) -- 1..8 each -- can hold EARLIER points.  Bit 9 * zi + 3 * yi + xi,
 // xi = 0 / 1 / 2 for the cell at x - 1 / x / x + 1.  Cells outside the block were staged only when their granule precedes
@@ -221,27 +234,35 @@ __device__ __forceinline__ uint32_t sb_earlier_mask(uint32_t ix, uint32_t iy, ui
   return m | hx * 0x1249249u | hy * 0x40201u | hz;
 }
 
-// Visits every EARLIER staged point closer than the spacing to own point j.  f(q) returns false to stop.
-// One loop over all candidates of the point: a lane either fetches its next cell or tests its next candidate, so the
-// wavefront runs as long as its busiest lane has candidates -- not 27 x the fullest cell.
-// g(q): a pair inside the quantisation band; returns true when the caller has put it aside (else it is compared here).
-template <bool WIDE, typename F, typename G>
-__device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t j, F f, G g) {
+// An own point as the search loops want it: coordinates, the corner of its 3 x 3 x 3 cells in the cell index, and which
+// of those cells hold points that can matter -- occupied (nine rows of occupancy bits), not later in Morton order, and,
+// in the narrow format, within reach: the squared gap between the point and the cell, exact in integers (the region's
+// corner is a cell corner, so the low bits of a relative coordinate are the offset inside the cell).
+struct SbOwn {
+  uint32_t ux, uy, uz;
+  float fx, fy, fz;
+  uint32_t corner;
+  uint32_t mask;
+};
+template <bool WIDE>
+__device__ __forceinline__ SbOwn sb_own_point(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t j) {
+  SbOwn p;
   const uint64_t me = l.pts[j];
-  uint32_t ux, uy, uz, cell;
+  uint32_t cell;
   if (WIDE) {
-    sb_unpack(me, ux, uy, uz);
-    cell = sb_region_cell(a, k, ux, uy, uz);
+    sb_unpack(me, p.ux, p.uy, p.uz);
+    cell = sb_region_cell(a, k, p.ux, p.uy, p.uz);
   } else {
     const uint32_t lo = (uint32_t)me, hi = (uint32_t)(me >> 32);
-    ux = lo & 0xFFFFu;
-    uy = lo >> 16;
-    uz = hi & 0xFFFFu;
+    p.ux = lo & 0xFFFFu;
+    p.uy = lo >> 16;
+    p.uz = hi & 0xFFFFu;
     cell = hi >> 16;
   }
-  const float mx = (float)ux, my = (float)uy, mz = (float)uz;
+  p.fx = (float)p.ux;
+  p.fy = (float)p.uy;
+  p.fz = (float)p.uz;
   const uint32_t ix = cell & 15u, iy = (cell >> 4) & 15u, iz = cell >> 8;  // 1..8: an own point
-  // which of the 27 cells around the point hold anything: nine rows of occupancy bits
   uint32_t mask = 0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -250,10 +271,8 @@ __device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const 
   }
   if (!(a.dbg & 4u)) mask &= sb_earlier_mask(ix, iy, iz);
   if (!WIDE && !(a.dbg & 2u)) {
-    // ... and are within reach: the squared gap between the point and the cell, exact in integers (the region's corner is
-    // a cell corner, so the low bits of a relative coordinate are the offset inside the cell)
     const uint32_t cs = 1u << a.cell_bits;
-    const int ox = (int)(ux & (cs - 1u)), oy = (int)(uy & (cs - 1u)), oz = (int)(uz & (cs - 1u));
+    const int ox = (int)(p.ux & (cs - 1u)), oy = (int)(p.uy & (cs - 1u)), oz = (int)(p.uz & (cs - 1u));
     const uint32_t gx[3] = {(uint32_t)__mul24(ox, ox), 0u, (uint32_t)__mul24((int)cs - ox, (int)cs - ox)};
     const uint32_t gy[3] = {(uint32_t)__mul24(oy, oy), 0u, (uint32_t)__mul24((int)cs - oy, (int)cs - oy)};
     const uint32_t gz[3] = {(uint32_t)__mul24(oz, oz), 0u, (uint32_t)__mul24((int)cs - oz, (int)cs - oz)};
@@ -270,38 +289,55 @@ __device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const 
     mask &= reach;
   }
   if (a.dbg & 1u) mask = 0;
-  const uint32_t corner = (ix - 1u) + 10u * (iy - 1u) + 100u * (iz - 1u);
+  p.mask = mask;
+  p.corner = (ix - 1u) + 10u * (iy - 1u) + 100u * (iz - 1u);
+  return p;
+}
+// squared distance of own point p to staged point word o: closer than the spacing for sure / possibly
+template <bool WIDE>
+__device__ __forceinline__ void sb_compare(const SbArgs& a, const SbOwn& p, uint64_t o, bool& sure, bool& maybe) {
+  if (WIDE) {
+    uint32_t vx, vy, vz;
+    sb_unpack(o, vx, vy, vz);
+    const float ddx = p.fx - (float)vx, ddy = p.fy - (float)vy, ddz = p.fz - (float)vz;
+    const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+    sure = d2 < a.f_lo;
+    maybe = d2 < a.f_hi;
+  } else {
+    const uint32_t lo = (uint32_t)o, hi = (uint32_t)(o >> 32);
+    const int ddx = (int)p.ux - (int)(lo & 0xFFFFu), ddy = (int)p.uy - (int)(lo >> 16), ddz = (int)p.uz - (int)(hi & 0xFFFFu);
+    const uint32_t d2 = (uint32_t)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz));  // < 3 * 2^26: adjacent cells
+    sure = d2 < a.i_lo;
+    maybe = d2 < a.i_hi;
+  }
+}
+__device__ __forceinline__ uint32_t sb_cell_offset(uint32_t b) {  // bit of the 27-cell mask -> offset in the cell index
+  const uint32_t dz = (b * 57u) >> 9, rem = b - 9u * dz, dy = (rem * 11u) >> 5, dx = rem - 3u * dy;
+  return dx + 10u * dy + 100u * dz;
+}
+
+// Visits every EARLIER staged point closer than the spacing to own point j.  f(q) returns false to stop.  (The general
+// form, for the rare point that has to search again; the search proper is sb_search below.)
+template <bool WIDE, typename F>
+__device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t j, F f) {
+  const SbOwn p = sb_own_point<WIDE>(a, l, k, j);
+  uint32_t mask = p.mask;
   uint32_t q = 0, e = 0;
   for (;;) {
     if (q >= e) {
       if (!mask) break;
       const uint32_t b = (uint32_t)__ffs((int)mask) - 1u;
       mask &= mask - 1u;
-      const uint32_t dz = (b * 57u) >> 9, rem = b - 9u * dz, dy = (rem * 11u) >> 5, dx = rem - 3u * dy;
-      const uint32_t e2 = l.cse[corner + dx + 10u * dy + 100u * dz];
+      const uint32_t e2 = l.cse[p.corner + sb_cell_offset(b)];
       q = e2 & 0xFFFFu;
       e = e2 >> 16;
       if (q < k.n_own) e = min(e, j);  // a cell of the block itself: earlier points only (own points are staged in Morton order)
       if (q >= e) continue;
     }
-    const uint64_t o = l.pts[q];
     bool sure, maybe;
-    if (WIDE) {
-      uint32_t vx, vy, vz;
-      sb_unpack(o, vx, vy, vz);
-      const float ddx = mx - (float)vx, ddy = my - (float)vy, ddz = mz - (float)vz;
-      const float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-      sure = d2 < a.f_lo;
-      maybe = d2 < a.f_hi;
-    } else {
-      const uint32_t lo = (uint32_t)o, hi = (uint32_t)(o >> 32);
-      const int ddx = (int)ux - (int)(lo & 0xFFFFu), ddy = (int)uy - (int)(lo >> 16), ddz = (int)uz - (int)(hi & 0xFFFFu);
-      const uint32_t d2 = (uint32_t)(__mul24(ddx, ddx) + __mul24(ddy, ddy) + __mul24(ddz, ddz));  // < 3 * 2^26: adjacent cells
-      sure = d2 < a.i_lo;
-      maybe = d2 < a.i_hi;
-    }
+    sb_compare<WIDE>(a, p, l.pts[q], sure, maybe);
     if (maybe) {
-      if (sure || (!g(q) && sb_exact_near(a, k.first + j, sb_active_index(l, k, q)))) {
+      if (sure || sb_exact_near(a, k.first + j, sb_active_index(l, k, q))) {
         if (!f(q)) return;
       }
     }
@@ -309,11 +345,66 @@ __device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const 
   }
 }
 
+// The search of own point j (lanes without a point: active = false): its earlier neighbours go to mine[] (the first
+// SB_K), *cnt counts them -- whatever their state: the states are looked at after the loop.  One loop over all candidates
+// of the point -- a lane either takes its next cell or tests its next candidate, so the wavefront runs as long as its
+// busiest lane has candidates, not 27 x the fullest cell -- written without divergent branches: every lane executes every
+// step on clamped indices and the outcome is selected.  (With branches the loop spent a third of its instructions on the
+// execution mask: 2 300 scalar instructions per wavefront and block, and the scalar unit -- one per CU -- was the kernel's
+// bound.)  A wavefront issues an instruction every four cycles at best and every LDS read it waits for costs ~100 more, so
+// a step is kept short and has ONE read on its critical path: the candidate; the entry of the lane's next cell is requested
+// a step ahead and the neighbours' states are not read here at all.
+// Pairs inside the quantisation band go to the wavefront's pending list.
+template <bool WIDE>
+__device__ __forceinline__ void sb_search(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t j, bool active, uint16_t* mine,
+                                          uint32_t* pend, uint32_t* cnt_out, uint32_t* steps) {
+  const SbOwn p = sb_own_point<WIDE>(a, l, k, active ? j : 0u);
+  uint32_t mask = active ? p.mask : 0u;
+  uint32_t q = 0, e = 0, cnt = 0;
+  uint32_t ne2 = l.cse[mask ? p.corner + sb_cell_offset((uint32_t)__ffs((int)mask) - 1u) : 0u];  // the first cell's entry
+  while (__ballot(active)) {
+    ++*steps;
+    // lanes whose cell is used up take their next one (its entry is here already) and ask for the one after it
+    const bool need = active && q >= e;
+    const bool fetch = need && mask != 0u;
+    const uint32_t s2 = ne2 & 0xFFFFu, t2 = ne2 >> 16;
+    const uint32_t t3 = s2 < k.n_own ? min(t2, j) : t2;  // a cell of the block itself: earlier points only
+    mask = fetch ? (mask & (mask - 1u)) : mask;
+    q = fetch ? s2 : q;
+    e = fetch ? t3 : e;
+    active = active && !(need && !fetch);
+    if (__ballot(fetch)) {
+      const uint32_t nxt = l.cse[(fetch && mask) ? p.corner + sb_cell_offset((uint32_t)__ffs((int)mask) - 1u) : 0u];
+      ne2 = fetch ? nxt : ne2;
+    }
+    // lanes that have a candidate test it
+    const bool valid = active && q < e;
+    bool sure, maybe;
+    sb_compare<WIDE>(a, p, l.pts[valid ? q : 0u], sure, maybe);
+    maybe = maybe && valid;
+    if (__ballot(maybe)) {
+      const bool band = maybe && !sure;
+      bool near = maybe && sure;
+      if (__ballot(band)) {
+        if (band) {
+          const uint32_t slot = atomicAdd(&pend[SB_PEND], 1u);
+          if (slot < (uint32_t)SB_PEND) pend[slot] = (j << 16) | q;
+          else near = sb_exact_near(a, k.first + j, sb_active_index(l, k, q));
+        }
+      }
+      if (near && cnt < (uint32_t)SB_K) mine[cnt] = (uint16_t)q;
+      cnt += near ? 1u : 0u;
+    }
+    q += valid ? 1u : 0u;
+  }
+  *cnt_out = cnt;
+}
+
 // state of staged point q as far as anybody knows: halo points still undecided are looked up again
 __device__ __forceinline__ uint32_t sb_state_of(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t q, bool poll) {
   uint32_t s = sb_lds_state(l.st, q);
   if (poll && s == SB_U && q >= k.n_own) {
-    const uint32_t gi = l.gidx[q - k.n_own];
+    const uint32_t gi = sb_active_index(l, k, q);
     s = (sb_load_word(a.st2 + (gi >> 4)) >> ((gi & 15u) * 2u)) & 3u;
     if (s != SB_U) sb_lds_set(l.st, q, s);
   }
@@ -321,7 +412,7 @@ __device__ __forceinline__ uint32_t sb_state_of(const SbArgs& a, const SbLds& l,
 }
 
 template <bool WIDE>
-__global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
+__global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
   extern __shared__ __align__(16) unsigned char sb_smem[];
   const SbLds l = sb_carve(sb_smem, a.own_cap, a.halo_cap);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -333,7 +424,7 @@ __global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
   // XCD, whose L2 holds the keys the blocks before it have read)
   uint32_t kc = (blockIdx.x & 7u) + 8u * ((blockIdx.x >> 3) % (SB_NC / 8u));
   uint32_t tried = 0;
-  uint32_t my_blocks = 0, my_iters = 0, my_waits = 0, my_research = 0;
+  uint32_t my_blocks = 0, my_iters = 0, my_waits = 0, my_research = 0, my_steps = 0;
   uint16_t* rc = l.nbr;  // (alias: region cells while staging, neighbour lists afterwards)
 #ifdef SWZ_SB_STATS
   uint32_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -439,10 +530,7 @@ __global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
           gi[p] = k.first + j;  // the block is one run of the sorted keys
         } else if (j < total) {
           // the halo run that holds staged point j: soff ascends, [216] = total (branch-free: eight steps for every lane)
-          uint32_t lo = 0;
-#pragma unroll
-          for (uint32_t step = 128u; step; step >>= 1)
-            if (lo + step <= 216u && l.soff[lo + step] <= j) lo += step;
+          const uint32_t lo = sb_halo_slot(l, j);
           gi[p] = l.sfirst[lo] + (j - l.soff[lo]);
         }
       }
@@ -467,7 +555,6 @@ __global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
         l.pts[j] = sb_make_point<WIDE>(a, k, x, y, z, &cell);
         rc[j] = (uint16_t)cell;
         l.st[j] = (uint8_t)((sw[p] >> ((gi[p] & 15u) * 2u)) & 3u);
-        if (j >= n_own) l.gidx[j - n_own] = gi[p];
       }
     }
     __syncthreads();
@@ -499,58 +586,66 @@ __global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
     if (lane == 0) pend[SB_PEND] = 0u;
     for (uint32_t base = ja; base < jb; base += 64u) {
       const uint32_t j = base + lane;
-      if (j >= jb) continue;
+      const bool have = j < jb;
       uint32_t cnt = 0;
-      bool rejected = false;
-      uint16_t* mine = l.nbr + (size_t)j * SB_K;
-      sb_visit<WIDE>(a, l, k, j, [&](uint32_t q) {
-        const uint32_t s = sb_lds_state(l.st, q);
-        if (s == SB_A) {
-          rejected = true;
-          return false;
-        }
-        if (s == SB_U) {
-          if (cnt < (uint32_t)SB_K) mine[cnt] = (uint16_t)q;
-          ++cnt;
-        }
-        return true;
-      }, [&](uint32_t q) {
-        const uint32_t slot = atomicAdd(&pend[SB_PEND], 1u);
-        if (slot >= (uint32_t)SB_PEND) return false;
-        pend[slot] = (j << 16) | q;
-        return true;
-      });
-      cnt1[j] = (uint8_t)min(cnt, 200u);
-      if (rejected) {
-        sb_lds_set(l.st, j, SB_R);
-        const uint32_t gi = k.first + j;
-        atomicOr(&l.pub[(gi >> 4) - w0], (uint32_t)SB_R << ((gi & 15u) * 2u));
-      }
+      sb_search<WIDE>(a, l, k, j, have, l.nbr + (size_t)(have ? j : 0u) * SB_K, pend, &cnt, &my_steps);
+      if (have) cnt1[j] = (uint8_t)min(cnt, 200u);
     }
     {
       const uint32_t np = min(pend[SB_PEND], (uint32_t)SB_PEND);
       for (uint32_t i = lane; i < np; i += 64u) {
         const uint32_t j = pend[i] >> 16, q = pend[i] & 0xFFFFu;
-        if (sb_lds_state(l.st, j) == SB_R) continue;
         if (!sb_exact_near(a, k.first + j, sb_active_index(l, k, q))) continue;
-        const uint32_t s = sb_lds_state(l.st, q);
-        if (s == SB_A) {
-          sb_lds_set(l.st, j, SB_R);
-          const uint32_t gi = k.first + j;
-          atomicOr(&l.pub[(gi >> 4) - w0], (uint32_t)SB_R << ((gi & 15u) * 2u));
-        } else if (s == SB_U) {  // one more undecided neighbour of j: a byte of a counter word, bumped atomically
-          const uint32_t slot = (atomicAdd(&l.cnt4[j >> 2], 1u << (8u * (j & 3u))) >> (8u * (j & 3u))) & 0xFFu;
-          if (slot < (uint32_t)SB_K) l.nbr[(size_t)j * SB_K + slot] = (uint16_t)q;
-        }
+        // one more neighbour of j: a byte of a counter word, bumped atomically
+        const uint32_t slot = (atomicAdd(&l.cnt4[j >> 2], 1u << (8u * (j & 3u))) >> (8u * (j & 3u))) & 0xFFu;
+        if (slot < (uint32_t)SB_K) l.nbr[(size_t)j * SB_K + slot] = (uint16_t)q;
       }
     }
-    // what has no undecided earlier neighbour (and was not rejected) is taken
+    // The neighbours' states as far as they are known now: an accepted one rejects the point, rejected ones are dropped
+    // from the list, a point that keeps none is taken.  (A list that could not hold all neighbours stays as it is: the
+    // decisions below search again once its entries are all rejected.)
     for (uint32_t base = ja; base < jb; base += 64u) {
       const uint32_t j = base + lane;
-      if (j >= jb || sb_lds_state(l.st, j) != SB_U || cnt1[j] != 0) continue;
-      sb_lds_set(l.st, j, SB_A);
-      const uint32_t gi = k.first + j;
-      atomicOr(&l.pub[(gi >> 4) - w0], (uint32_t)SB_A << ((gi & 15u) * 2u));
+      if (j >= jb) continue;
+      const uint32_t cnt = cnt1[j];
+      uint32_t dec = SB_U;
+      if (cnt == 0u) {
+        dec = SB_A;
+      } else {
+        static_assert(SB_K == 4, "four two-byte entries = one eight-byte load");
+        uint64_t* slot = reinterpret_cast<uint64_t*>(l.nbr + (size_t)j * SB_K);
+        const uint64_t n4 = *slot;
+        const uint32_t c4 = min(cnt, (uint32_t)SB_K);
+        uint32_t st[SB_K];
+#pragma unroll
+        for (int i = 0; i < SB_K; ++i) st[i] = (uint32_t)i < c4 ? sb_lds_state(l.st, (uint32_t)(n4 >> (16 * i)) & 0xFFFFu) : (uint32_t)SB_R;
+        uint64_t kept = 0;
+        uint32_t nk = 0;
+        bool any_a = false;
+#pragma unroll
+        for (int i = 0; i < SB_K; ++i) {
+          any_a |= st[i] == SB_A;
+          if (st[i] == SB_U) {
+            kept |= ((n4 >> (16 * i)) & 0xFFFFull) << (16u * nk);
+            ++nk;
+          }
+        }
+        if (any_a) {
+          dec = SB_R;
+        } else if (cnt <= (uint32_t)SB_K) {
+          if (nk == 0u) {
+            dec = SB_A;
+          } else if (nk != cnt) {
+            *slot = kept;
+            cnt1[j] = (uint8_t)nk;
+          }
+        }
+      }
+      if (dec != SB_U) {
+        sb_lds_set(l.st, j, dec);
+        const uint32_t gi = k.first + j;
+        atomicOr(&l.pub[(gi >> 4) - w0], dec << ((gi & 15u) * 2u));
+      }
     }
     SB_T(4);
     // decisions: passes over the wavefront's undecided points until every one is final.  A pass reads the LDS states (other
@@ -593,7 +688,7 @@ __global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
             any_a |= s == SB_A;
             any_u |= s == SB_U;
             return !any_a;
-          }, [](uint32_t) { return false; });
+          });
         }
         const uint32_t dec = any_a ? SB_R : (any_u ? SB_U : SB_A);
         if (dec != SB_U) {
@@ -668,6 +763,7 @@ __global__ __launch_bounds__(SB_THREADS, 5) void sb_block_kernel(SbArgs a) {
     if (my_blocks) atomicAdd(words + SBW_BLOCKS, my_blocks);
     if (my_iters) atomicAdd(words + SBW_ITER, my_iters);
     if (my_waits) atomicAdd(words + SBW_WAITS, my_waits);
+    if (my_steps) atomicAdd(words + SBW_STEPS, my_steps);
   }
   if (my_research) atomicAdd(words + SBW_RESEARCH, my_research);
 }
@@ -815,8 +911,8 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
     c->event_pool.insert(c->event_pool.end(), {ev0, ev1});
     fprintf(stderr,
             "[swz] MIN_DISTANCE level %d block path: %u pts in %u nodes, cell_levels %d (geo %d), %.0f pts/block, caps %u / %u, LDS %zu B, grid %u, "
-            "%u blocks, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
-            plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS], h[SBW_ITER],
+            "%u blocks, %u search steps, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
+            plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS], h[SBW_STEPS], h[SBW_ITER],
             h[SBW_WAITS], h[SBW_RESEARCH], h[SBW_ABORT], h[SBW_MAX_OWN], h[SBW_MAX_HALO], ms);
   }
 #ifdef SWZ_SB_STATS
