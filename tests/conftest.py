@@ -27,7 +27,7 @@ FULLSIZE_RECORDS = []
 def pytest_terminal_summary(terminalreporter, exitstatus, config):
     if not FULLSIZE_RECORDS:
         return
-    terminalreporter.write_sep("=", "full-size verification (tests/test_gpu_fullsize.py)")
+    terminalreporter.write_sep("=", "full-size verification (tests/test_gpu_fullsize.py, tests/test_min_distance_property.py)")
     for r in FULLSIZE_RECORDS:
         terminalreporter.write_line("FULLSIZE %s cloud, N = %d: %s -- %d levels, %d points checked" % (
             r["cloud"], r["points"], r["check"], r["levels"], r["points_checked"]))

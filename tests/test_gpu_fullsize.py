@@ -66,21 +66,15 @@ def _log(msg):
         pass
 
 
-@pytest.fixture(scope="module", params=["uniform", "clustered"])
-def tiled(request):
-    import torch
-    import schwarzwald_amd as swz
-    dev = torch.device("cuda:0")
-    torch.cuda.empty_cache()  # the library allocates with hipMalloc: hand back what earlier tests left in torch's cache
-    # the surface-like cloud makes levels of hundreds of millions of cells (per-cell tables): half the points there
-    N = _points() if request.param == "uniform" else max(_points() // 2, min(_points(), 100_000_000))
-    ctx = swz.Context(0)
-    # the context has its own non-blocking stream: run it on torch's, or the tile could start while the torch
-    # kernels below are still writing the points (that race once made this fixture look like a hang)
-    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+def cloud_points(kind):
+    """the surface-like cloud makes levels of hundreds of millions of cells (per-cell tables): half the points there"""
+    return _points() if kind == "uniform" else max(_points() // 2, min(_points(), 100_000_000))
+
+
+def make_cloud(torch, ctx, dev, N, kind):
     xyz = torch.empty((N, 3), dtype=torch.float64, device=dev)
     ctx.generate_uniform_device(SEED, 0, N, xyz.data_ptr())
-    if request.param == "clustered":
+    if kind == "clustered":
         # surface-like data (what LAS files look like): a thin wavy sheet, a dense blob and a sparse background,
         # so that sparse and dense MIN_DISTANCE levels, the sparse path's give-up and deep nodes all occur
         g = torch.Generator(device=dev)
@@ -90,6 +84,21 @@ def tiled(request):
             + 0.0005 * torch.randn(k, dtype=torch.float64, device=dev, generator=g)
         xyz[k:2 * k] = 0.6 + 0.03 * torch.randn((k, 3), dtype=torch.float64, device=dev, generator=g)
         xyz.clamp_(0.0, 1.0)
+    return xyz
+
+
+@pytest.fixture(scope="module", params=["uniform", "clustered"])
+def tiled(request):
+    import torch
+    import schwarzwald_amd as swz
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()  # the library allocates with hipMalloc: hand back what earlier tests left in torch's cache
+    N = cloud_points(request.param)
+    ctx = swz.Context(0)
+    # the context has its own non-blocking stream: run it on torch's, or the tile could start while the torch
+    # kernels below are still writing the points (that race once made this fixture look like a hang)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    xyz = make_cloud(torch, ctx, dev, N, request.param)
     spacing = O.spacing_from_diagonal(*UNIT, 250)
     out = {}
     for sampler in (swz.MIN_DISTANCE, swz.RANDOM_GRID):
@@ -134,31 +143,29 @@ def test_output_is_a_sorted_permutation_with_matching_keys(tiled):
     _record("sorted permutation, keys = oracle encoder on a sample", tiled["cloud"], N, stats["num_levels"], N)
 
 
-def _check_level(tiled, L, rng, target_points=1_500_000):
-    """Verifies taken(p) <=> no earlier taken point of the same node within the spacing, for all points of a random
-    box that are active at level L.  Returns (#points checked, #taken among them)."""
-    from scipy.spatial import cKDTree
-    torch, swz = tiled["torch"], tiled["swz"]
-    keys, perm, level, _ = tiled["out"][swz.MIN_DISTANCE]
-    s = np.float32(tiled["spacing"]) / np.float32(2.0 ** (L + 1))   # exact in float (power of two)
-    sq = float(np.float32(s) * np.float32(s))                        # SparseGrid.cpp:18: float product
+def box_of_level(torch, keys, perm, level, xyz, spacing, L, rng, target_points):
+    """The points of sampling nodes that are active at level L inside a random box (plus a margin of one spacing): their
+    positions, sorted indices, node prefixes and taken flags on the host, the box, the spacing and its float square.
+    None when no node of the level samples."""
+    s = np.float32(spacing) / np.float32(2.0 ** (L + 1))   # exact in float (power of two)
+    sq = float(np.float32(s) * np.float32(s))                # SparseGrid.cpp:18: float product
     active = level >= L
     n_active = int(active.sum())
     if n_active == 0:
-        return 0, 0
+        return None
     shift = 63 - 3 * (L + 1)
     node = (keys >> shift) if shift < 63 else torch.zeros_like(keys)
     # nodes that sample (more than MAX_POINTS arrive) -- the others take everything
     uniq, counts = torch.unique_consecutive(node[active], return_counts=True)
     sampling_nodes = uniq[counts > MAX_POINTS]
     if sampling_nodes.numel() == 0:
-        return 0, 0
+        return None
     in_sampling = active & torch.isin(node, sampling_nodes)
     # a box holding about target_points of them
     frac = min(1.0, target_points / max(1, int(in_sampling.sum())))
     h = 0.5 * frac ** (1.0 / 3.0)
     idx_all = torch.nonzero(in_sampling).squeeze(1)
-    pos = tiled["xyz"][perm[idx_all].long()]
+    pos = xyz[perm[idx_all].long()]
     # centred on a random point of the level (so that dense parts are visited in proportion to their points) and
     # shrunk until it holds about target_points
     c = pos[int(rng.integers(0, pos.shape[0]))].cpu().numpy()
@@ -171,11 +178,20 @@ def _check_level(tiled, L, rng, target_points=1_500_000):
             break
         h *= 0.75
     idx = idx_all[near]
-    P = pos[near].cpu().numpy()
-    sorted_index = idx.cpu().numpy()
-    node_h = node[idx].cpu().numpy()
-    taken = (level[idx] == L).cpu().numpy()
-    del pos, near, idx_all, in_sampling, active, node
+    return {"P": pos[near].cpu().numpy(), "sorted_index": idx.cpu().numpy(), "node": node[idx].cpu().numpy(),
+            "taken": (level[idx] == L).cpu().numpy(), "c": c, "h": h, "s": s, "sq": sq}
+
+
+def _check_level(tiled, L, rng, target_points=1_500_000):
+    """Verifies taken(p) <=> no earlier taken point of the same node within the spacing, for all points of a random
+    box that are active at level L.  Returns (#points checked, #taken among them)."""
+    from scipy.spatial import cKDTree
+    torch, swz = tiled["torch"], tiled["swz"]
+    keys, perm, level, _ = tiled["out"][swz.MIN_DISTANCE]
+    b = box_of_level(torch, keys, perm, level, tiled["xyz"], tiled["spacing"], L, rng, target_points)
+    if b is None:
+        return 0, 0
+    P, sorted_index, node_h, taken, c, h, s, sq = b["P"], b["sorted_index"], b["node"], b["taken"], b["c"], b["h"], b["s"], b["sq"]
     inner = np.all((P >= c - h) & (P <= c + h), axis=1)              # the points to verify ...
     if int(inner.sum()) > target_points:                              # ... a random subset of them in dense parts
         drop = rng.choice(np.nonzero(inner)[0], size=int(inner.sum()) - target_points, replace=False)

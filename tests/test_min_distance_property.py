@@ -17,7 +17,6 @@ import oracle_lib as O
 pytestmark = pytest.mark.gpu
 
 UNIT = ([0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
-N_FULL = int(os.environ.get("SWZ_FULLSIZE_POINTS", "100000000"))
 
 
 def _check_property(keys, level, pos, spacing_at_root, max_points, max_level, rng=None, box_points=None):
@@ -189,88 +188,78 @@ def test_property_mode_fast_strategy_and_multibatch(ctx):
     assert checked > 0
 
 
-def test_property_mode_full_size():
-    """BASELINE's MIN_DISTANCE workload at SWZ_FULLSIZE_POINTS (default 100 M) in property mode: (a) and (b) on the
-    points of random boxes on every level."""
+def _check_property_level(torch, keys, perm, level, xyz, spacing, L, rng, target_points=1_500_000):
+    """(a) and (b) on the points of a random box of level L (any level: the taken points within one spacing of the box
+    are part of the selection).  Returns (taken points checked, left-out points checked)."""
+    import test_gpu_fullsize as F
+    from scipy.spatial import cKDTree
+    b = F.box_of_level(torch, keys, perm, level, xyz, spacing, L, rng, target_points)
+    if b is None:
+        return 0, 0
+    P, node, taken, c, h, s, sq = b["P"], b["node"], b["taken"], b["c"], b["h"], b["s"], b["sq"]
+    T, Tn = P[taken], node[taken]
+    assert T.shape[0] > 0, "level %d: a box of a sampling node without a single taken point" % L
+    tree = cKDTree(T)
+    # (a) no two taken points of one node closer than the spacing
+    pairs = tree.query_pairs(float(s) * (1.0 + 1e-9), output_type="ndarray")
+    if pairs.size:
+        d = T[pairs[:, 0]] - T[pairs[:, 1]]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        bad = (d2 < sq) & (Tn[pairs[:, 0]] == Tn[pairs[:, 1]])
+        assert not bad.any(), "level %d: %d taken pairs closer than the spacing" % (L, int(bad.sum()))
+    # (b) every point of the box that was handed down has a taken point of its node within the spacing
+    rest = ~taken & np.all((P >= c - h) & (P <= c + h), axis=1)
+    if int(rest.sum()) > target_points:
+        drop = rng.choice(np.nonzero(rest)[0], size=int(rest.sum()) - target_points, replace=False)
+        rest[drop] = False
+    Q, Qn = P[rest], node[rest]
+    if Q.shape[0]:
+        m = cKDTree(Q).sparse_distance_matrix(tree, float(s) * (1.0 + 1e-9), output_type="ndarray")
+        d = Q[m["i"]] - T[m["j"]]
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        ok = (d2 < sq) & (Qn[m["i"]] == Tn[m["j"]])
+        covered = np.zeros(Q.shape[0], dtype=bool)
+        covered[m["i"][ok]] = True
+        assert covered.all(), "level %d: %d points left out although no taken point is within the spacing" % (L, int((~covered).sum()))
+    return int(T.shape[0]), int(Q.shape[0])
+
+
+@pytest.mark.parametrize("cloud", ["uniform", "clustered"])
+def test_property_mode_full_size(cloud):
+    """BASELINE's MIN_DISTANCE workload in property mode at the size bench.py reports it at -- 1 B uniform points on a
+    288 GB part, sized from the free memory exactly like tests/test_gpu_fullsize.py (and failing instead of shrinking
+    there) -- and on the 500 M surface-like cloud: spacing (a) and maximality (b) on random boxes of EVERY level, the
+    dense ones (property-mode rounds) and the sparse ones (the exact block path) alike."""
     import torch
     import schwarzwald_amd as swz
+    import test_gpu_fullsize as F
     dev = torch.device("cuda:0")
     torch.cuda.empty_cache()
+    n = F.cloud_points(cloud)
     ctx = swz.Context(0)
     ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    n = N_FULL
-    xyz = torch.empty((n, 3), dtype=torch.float64, device=dev)
-    ctx.generate_uniform_device(0x5C4A72A1D + 3, 0, n, xyz.data_ptr())
+    xyz = F.make_cloud(torch, ctx, dev, n, cloud)
     sp = O.spacing_from_diagonal(*UNIT, 250)
     keys = torch.empty(n, dtype=torch.int64, device=dev)
     perm = torch.empty(n, dtype=torch.int32, device=dev)
     level = torch.empty(n, dtype=torch.int8, device=dev)
-    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=20000, spacing_at_root=sp,
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=F.MAX_POINTS, spacing_at_root=sp,
                             flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
     stats = ctx.tile_device(xyz.data_ptr(), n, *UNIT, params, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
     torch.cuda.synchronize()
     ctx.release_workspace()
     assert int(level.min()) >= -1 and int(level.max()) == stats["max_level"]
+    assert bool((keys[1:] >= keys[:-1]).all())
     rng = np.random.default_rng(3)
-    # a slab of the Morton order (contiguous, so whole nodes of the deeper levels) plus the coarse levels' points
     total_a = total_b = 0
-    for rep in range(3):
-        # random box: select on the device, verify on the host
-        c = rng.random(3) * 0.8 + 0.1
-        h = 0.5 * (3_000_000 / n) ** (1.0 / 3.0)
-        pos_all = xyz[perm.long()]
-        lo = torch.tensor(c - 3 * h, device=dev)
-        hi = torch.tensor(c + 3 * h, device=dev)
-        sel = ((pos_all >= lo) & (pos_all <= hi)).all(dim=1)
-        del pos_all
-        idx = torch.nonzero(sel).squeeze(1)
-        k = keys[idx].cpu().numpy().view(np.uint64)
-        lv = level[idx].cpu().numpy()
-        P = xyz[perm[idx].long()].cpu().numpy()
-        # nodes cut by the selection box would look under-populated: restrict every level's check to the nodes that
-        # lie inside the selection completely, i.e. verify levels whose nodes are smaller than the margin
-        for L in range(-1, stats["max_level"] + 1):
-            node_size = 0.5 ** (L + 1)
-            if node_size > 2 * h:
-                continue
-            s = np.float32(sp) / np.float32(2.0 ** (L + 1))
-            sq = float(np.float32(s) * np.float32(s))
-            shift = 63 - 3 * (L + 1)
-            node = k >> np.uint64(shift)
-            active = lv >= L
-            # nodes whose box lies inside [c - 3h + eps, c + 3h - eps]
-            from scipy.spatial import cKDTree
-            nmin = np.floor(P / node_size) * node_size
-            inside = np.all((nmin >= c - 3 * h) & (nmin + node_size <= c + 3 * h), axis=1) & active
-            if not inside.any():
-                continue
-            uniq, inv, counts = np.unique(node[inside], return_inverse=True, return_counts=True)
-            sampled = np.zeros(P.shape[0], dtype=bool)
-            sampled[np.nonzero(inside)[0]] = (counts > 20000)[inv]
-            if not sampled.any():
-                continue
-            Pi, ni = P[sampled], node[sampled]
-            tk = lv[sampled] == L
-            T, Tn = Pi[tk], ni[tk]
-            tree = cKDTree(T)
-            pairs = tree.query_pairs(float(s) * (1.0 + 1e-9), output_type="ndarray")
-            if pairs.size:
-                d = T[pairs[:, 0]] - T[pairs[:, 1]]
-                d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
-                assert not ((d2 < sq) & (Tn[pairs[:, 0]] == Tn[pairs[:, 1]])).any(), "level %d" % L
-            Q, Qn = Pi[~tk], ni[~tk]
-            if Q.shape[0] > 400000:
-                pick = rng.choice(Q.shape[0], 400000, replace=False)
-                Q, Qn = Q[pick], Qn[pick]
-            m = cKDTree(Q).sparse_distance_matrix(tree, float(s) * (1.0 + 1e-9), output_type="ndarray")
-            d = Q[m["i"]] - T[m["j"]]
-            d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
-            ok = (d2 < sq) & (Qn[m["i"]] == Tn[m["j"]])
-            covered = np.zeros(Q.shape[0], dtype=bool)
-            covered[m["i"][ok]] = True
-            assert covered.all(), "level %d: %d uncovered" % (L, int((~covered).sum()))
-            total_a += int(T.shape[0])
-            total_b += int(Q.shape[0])
-    print("property mode, %d points: %d taken points and %d left-out points verified" % (n, total_a, total_b))
+    for L in range(-1, stats["max_level"] + 1):
+        for rep in range(2):
+            a, b = _check_property_level(torch, keys, perm, level, xyz, sp, L, rng)
+            total_a += a
+            total_b += b
+            F._log("%s cloud, %d points, property mode, level %d box %d: %d taken points at least the spacing apart, %d left-out points "
+                   "each within the spacing of a taken one" % (cloud, n, L, rep, a, b))
     assert total_a > 1000 and total_b > 100000
+    F._record("property MIN_DISTANCE: spacing + maximality, random boxes of every level (%d taken, %d left out)" % (total_a, total_b),
+              cloud, n, stats["num_levels"], total_a + total_b)
     ctx.close()
