@@ -28,6 +28,27 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 SEED = 0x5C4A72A1D
 
 
+def check_shard_stamps(rows, step_ms):
+    """Per-shard stage stamps are milliseconds inside ONE step: a value that is negative, not finite or larger than the
+    step it belongs to is a bookkeeping error (a stamp taken against an unset clock once printed 1.85e8 ms) -- the line
+    then carries the reason instead of the numbers.  Returns None when the rows are plausible."""
+    import math
+    for r in rows:
+        for k, v in r.items():
+            if k == "shard" or v is None:
+                continue
+            if not math.isfinite(v) or v < 0.0 or (step_ms > 0.0 and v > step_ms * 1.05 + 1.0):
+                return "shard %s: %s = %r ms does not fit into a step of %.3f ms" % (r.get("shard"), k, v, step_ms)
+    return None
+
+
+def shard_stamp_error(report, step_ms):
+    """the same check for the per-rank stage times of the torch driver (numeric *_ms fields of every rank's row)"""
+    rows = [{"shard": r.get("rank", i), **{k: v for k, v in r.items() if k.endswith("_ms") and isinstance(v, (int, float))}}
+            for i, r in enumerate(report or [])]
+    return check_shard_stamps(rows, step_ms)
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,10 +95,11 @@ def parse_args():
                     "ncclSend / ncclRecv or by hipMemcpyPeerAsync (peer copies also work with all shards on ONE device)")
     ap.add_argument("--group-devices", type=int, default=0, help="--driver group: devices the shards are dealt to (0 = as "
                     "many as there are shards; 1 = all shards share device 0, the only way to run it on a one-GPU box)")
-    ap.add_argument("--also", default="GRID_CENTER,MIN_DISTANCE_FAST", help="N = 1, one batch, headline workload only: short extra legs "
+    ap.add_argument("--also", default="GRID_CENTER,GRID_CENTER@100000000,JITTERED,MIN_DISTANCE_FAST", help="N = 1, one batch, headline workload only: short extra legs "
                     "after the timed region, reported under \"also\" and never part of `value` -- a sampler name runs the same points "
                     "through that sampler (GRID_CENTER: BASELINE configs[1]'s sampler at the headline size), <sampler>_FAST through the "
-                    "FAST strategy (the reference's default, executable/main.cpp:299-301); \"\" = none")
+                    "FAST strategy (the reference's default, executable/main.cpp:299-301), <leg>@POINTS on the first POINTS points of the cloud "
+                    "(GRID_CENTER@100000000 = BASELINE configs[1]); a leg that fails reports its error and costs nothing else; \"\" = none")
     ap.add_argument("--config", type=int, default=0, choices=[0, 4, 5], help="BASELINE.json's multi-GPU configurations as one "
                     "command each: 4 = 1 B points IN TOTAL, JITTERED, sharded over --gpus ranks by the top Morton bits (strong "
                     "scaling); 5 = 4 B points in total with RGB + intensity, MIN_DISTANCE, every rank's share staged from pinned "
@@ -198,11 +220,13 @@ def run_group_driver(args):
     last_rep = args.warmup + args.steps - 1
     shard_rows = []
     for ln in r.stdout.splitlines():
-        if ln.startswith("shard "):
-            f = ln.split()
-            if int(f[1]) == last_rep:
-                shard_rows.append({"shard": int(f[2]), "exchange_done_ms": float(f[3]), "root_begun_ms": float(f[4]),
-                                   "root_done_ms": float(f[5]), "levels_done_ms": float(f[6])})
+        f = ln.split()
+        if ln.startswith("shard ") and int(f[1]) == last_rep:
+            shard_rows.append({"shard": int(f[2]), "exchange_done_ms": float(f[3]), "root_begun_ms": float(f[4]),
+                               "root_done_ms": float(f[5]), "levels_done_ms": float(f[6])})
+        if ln.startswith("shardsum ") and int(f[1]) == last_rep:  # batches: per stage, summed over the batches of the last data set
+            shard_rows.append({"shard": int(f[2]), "exchange_ms": float(f[3]), "root_ms": float(f[4]), "levels_ms": float(f[5])})
+    stamp_error = check_shard_stamps(shard_rows, timed[-1] if timed else 0.0)
     line = {
         "metric": "Mpoints/s end-to-end tile (Morton+sort+sample)", "value": round(shards * args.points * args.steps / total_ms / 1e3, 3),
         "unit": "Mpoints/s", "n_gpus": shards, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(total_ms / args.steps, 3),
@@ -223,9 +247,10 @@ def run_group_driver(args):
                                            "sort, root, levels (inputs resident on the shards' devices)",
         "steps_ms": [round(x, 3) for x in timed], "roofline": roofline,
         "kernels_ms_per_step_shard0": {k: round(v["total_ms"] / args.steps, 3) for k, v in sorted(prof.items())},
-        "shards": shard_rows, "cpu_baseline": None, "cpu_baseline_reference": committed_cpu_baseline(),
+        "shards": None if stamp_error else shard_rows, "cpu_baseline": None, "cpu_baseline_reference": committed_cpu_baseline(),
         "ranks_in_process_group": 1, "root_mode": os.environ.get("SWZ_GROUP_JOINT_ROOT", "1") not in ("", "0") and "joint" or "chain",
-        "exchange_ms": max((r["exchange_done_ms"] for r in shard_rows), default=None),
+        "exchange_ms": None if stamp_error else max((r.get("exchange_done_ms", r.get("exchange_ms", 0.0)) for r in shard_rows), default=None),
+        "stamp_error": stamp_error,
         "driver_output": r.stdout.splitlines()[-min(len(ms), 3):],
     }
     print(json.dumps(line))
@@ -360,6 +385,42 @@ def payload_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n):
                "gather_Mpoints_per_s": round(n / (t2 - t1) / 1e6, 1), "algorithmic_bytes_per_point": alg,
                "gather_hbm_frac": round(alg * n / (t2 - t1) / (HBM_PEAK_GBS * 1e9), 4)}
     return res
+
+
+def also_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, n, bmin, bmax, params, sname, fast):
+    """One short leg beside the headline (after the timed region): another sampler or strategy on the first n points of the
+    same cloud, with its own roofline object.  Never part of `value`."""
+    import dataclasses
+    lp = dataclasses.replace(params, sampler=swz.SAMPLERS[sname], strategy=swz.FAST if fast else swz.ACCURATE, flags=0)
+
+    def lstep():
+        return ctx.tile_device(xyz.data_ptr(), n, bmin, bmax, lp, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
+    lstep()
+    ctx.profile_reset()
+    torch.cuda.synchronize(dev)
+    lsteps = max(1, min(args.steps, 3))
+    t0 = time.perf_counter()
+    for _ in range(lsteps):
+        lstats = lstep()
+    torch.cuda.synchronize(dev)
+    ldt = (time.perf_counter() - t0) / lsteps
+    lprof = ctx.profile_get()
+    lvisit = lstats["points_visited"] / float(n)
+    lalg = algorithmic_bytes_per_point(sname, lvisit)
+    lroof = None
+    if lprof:
+        lname, lk = max(lprof.items(), key=lambda kv: kv[1]["total_ms"])
+        lavg = lk["total_ms"] / max(lk["launches"], 1)
+        lach = lk["algorithmic_bytes"] / max(lk["launches"], 1) / (lavg * 1e-3) / 1e9 if lavg > 0 else 0.0
+        lroof = {"bound": "hbm", "kernel": lname, "achieved": round(lach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(lach / HBM_PEAK_GBS, 5), "launches": lk["launches"], "avg_launch_ms": round(lavg, 4)}
+    largs = argparse.Namespace(steps=lsteps, sampler=sname)
+    return {"workload": "the %s %d points, %s sampling, %s strategy" % ("same" if n == xyz.shape[0] else "first", n, sname, "FAST" if fast else "ACCURATE"),
+            "points": n, "ms_per_step": round(ldt * 1e3, 3), "Mpoints_per_s": round(n / ldt / 1e6, 3), "visit_factor": round(lvisit, 4),
+            "hbm_frac_end_to_end": round(lalg * n / ldt / (HBM_PEAK_GBS * 1e9), 5),
+            "hbm_frac_end_to_end_implemented_sort": implemented_sort_frac(lprof, largs, lvisit, n, ldt),
+            "roofline": lroof, "steps": lsteps,
+            "kernels_ms_per_step": {k: round(v["total_ms"] / lsteps, 3) for k, v in sorted(lprof.items())}}
 
 
 def multibatch_leg(args, ctx, swz, torch, dev, xyz, n, bmin, bmax, params):
@@ -655,7 +716,8 @@ def main():
             "extra_warmup_data_sets": extra_warmups if mb is not None else None,
             "ranks_in_process_group": dist.get_world_size() if distributed else 1,
             "root_mode": shard_report[0]["root_mode"] if shard_report else None,
-            "exchange_ms": max((r.get("exchange_ms", 0.0) for r in shard_report), default=None) if shard_report else None,
+            "exchange_ms": max((r.get("exchange_ms", 0.0) for r in shard_report), default=None) if shard_report and not shard_stamp_error(shard_report, ms_per_step) else None,
+            "stamp_error": shard_stamp_error(shard_report, ms_per_step) if shard_report else None,
             "shards": shard_report,
             "visit_factor": round(visit, 4),
             "hbm_frac_end_to_end": round(alg * total_points / world / (elapsed / args.steps) / (HBM_PEAK_GBS * 1e9), 5),
@@ -705,41 +767,18 @@ def main():
             import dataclasses
             out["also"] = {}
             for leg in [x for x in args.also.split(",") if x]:
-                fast = leg.endswith("_FAST")
-                sname = leg[:-5] if fast else leg
-                if sname not in swz.SAMPLERS or (sname == args.sampler and (args.strategy == "FAST") == fast):
+                # NAME[_FAST][@POINTS]: POINTS < n runs the leg on the first POINTS points of the same cloud (BASELINE
+                # configs[1] is GRID_CENTER at 100 M points)
+                spec, _, at = leg.partition("@")
+                fast = spec.endswith("_FAST")
+                sname = spec[:-5] if fast else spec
+                ln = min(n, int(at)) if at else n
+                if sname not in swz.SAMPLERS or (sname == args.sampler and (args.strategy == "FAST") == fast and ln == n):
                     continue
-                lp = dataclasses.replace(params, sampler=swz.SAMPLERS[sname], strategy=swz.FAST if fast else swz.ACCURATE, flags=0)
-
-                def lstep():
-                    return ctx.tile_device(xyz.data_ptr(), n, bmin, bmax, lp, keys.data_ptr(), perm.data_ptr(), level.data_ptr())
-                lstep()
-                ctx.profile_reset()
-                torch.cuda.synchronize(dev)
-                lsteps = max(1, min(args.steps, 3))
-                t0 = time.perf_counter()
-                for _ in range(lsteps):
-                    lstats = lstep()
-                torch.cuda.synchronize(dev)
-                ldt = (time.perf_counter() - t0) / lsteps
-                lprof = ctx.profile_get()
-                lvisit = lstats["points_visited"] / float(n)
-                lalg = algorithmic_bytes_per_point(sname, lvisit)
-                lroof = None
-                if lprof:
-                    lname, lk = max(lprof.items(), key=lambda kv: kv[1]["total_ms"])
-                    lavg = lk["total_ms"] / max(lk["launches"], 1)
-                    lach = lk["algorithmic_bytes"] / max(lk["launches"], 1) / (lavg * 1e-3) / 1e9 if lavg > 0 else 0.0
-                    lroof = {"bound": "hbm", "kernel": lname, "achieved": round(lach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(lach / HBM_PEAK_GBS, 5), "launches": lk["launches"], "avg_launch_ms": round(lavg, 4)}
-                largs = argparse.Namespace(steps=lsteps, sampler=sname)
-                out["also"][leg] = {
-                    "workload": "the same %d points, %s sampling, %s strategy" % (n, sname, "FAST" if fast else "ACCURATE"),
-                    "ms_per_step": round(ldt * 1e3, 3), "Mpoints_per_s": round(n / ldt / 1e6, 3), "visit_factor": round(lvisit, 4),
-                    "hbm_frac_end_to_end": round(lalg * n / ldt / (HBM_PEAK_GBS * 1e9), 5),
-                    "hbm_frac_end_to_end_implemented_sort": implemented_sort_frac(lprof, largs, lvisit, n, ldt),
-                    "roofline": lroof, "steps": lsteps,
-                    "kernels_ms_per_step": {k: round(v["total_ms"] / lsteps, 3) for k, v in sorted(lprof.items())}}
+                try:  # an optional leg must never cost the line its headline (out of memory for a grid table, ...)
+                    out["also"][leg] = also_leg(args, ctx, swz, torch, dev, xyz, keys, perm, level, ln, bmin, bmax, params, sname, fast)
+                except Exception as e:  # noqa: BLE001
+                    out["also"][leg] = {"error": "%s: %s" % (type(e).__name__, e)}
         if mb is not None and "run_staged" in mb:
             mb["run_staged"]()  # warm-up: pools and workspace sized
             torch.cuda.synchronize(dev)

@@ -525,6 +525,8 @@ void shard_thread(ShardCall a) {
     auto tiler_try = [&](int st) {
       if (ok && st != SWZ_OK) ok = fail(g, r, st, swz_last_error(c));
     };
+    stamp(1);  // (the batch path stamps like the single-batch one: root step begun / done, levels done -- for FAST, which has
+               // no root step per batch, "root" is the indexing of the batch and the vote on the start level)
     if (g->tparams.strategy == SWZ_FAST) {
       // TilingAlgorithmV3: no root step per batch.  The start level comes from the FIRST batch's distribution over all
       // shards (TilingAlgorithms.cpp:1473-1535) and is kept (:1230-1236).
@@ -548,9 +550,12 @@ void shard_thread(ShardCall a) {
         g->barrier.wait();
       }
       if (ok) tiler_try(swz_tiler_shard_set_start_level(t, g->fast_start));
+      stamp(2);
       swz_tile_stats stats{};
       if (ok) tiler_try(swz_tiler_shard_finish(t, &stats));
       if (a.stats) *a.stats = stats;
+      (void)hipStreamSynchronize(c->stream);
+      stamp(3);
     } else {
     uint64_t root_before = 0;
     for (int s = 0; s < N; ++s) root_before += g->root_stored[s];
@@ -611,9 +616,12 @@ void shard_thread(ShardCall a) {
       }
       g->turn_cv.notify_all();
     }
+    stamp(2);
     swz_tile_stats stats{};
     if (ok) tiler_try(swz_tiler_shard_finish(t, &stats));
     if (a.stats) *a.stats = stats;
+    (void)hipStreamSynchronize(c->stream);
+    stamp(3);
     }
   }
   g->barrier.wait();  // ---- nobody reads a neighbour's buffers any more
@@ -766,6 +774,7 @@ int swz_group_tile(swz_group* g, double* const* d_xyz, const swz_attribute_colum
   g->fast_tile_start = -1;  // (group state shard 0 writes: nothing of an earlier call, failed or not, may be seen by this one)
   g->cand_flags = nullptr;
   g->t_call = std::chrono::steady_clock::now();
+  for (auto& t4 : g->timing) std::fill(std::begin(t4), std::end(t4), 0.0);
   std::fill(g->status.begin(), g->status.end(), SWZ_OK);
   std::vector<std::thread> threads;
   for (int r = 0; r < g->n; ++r)
@@ -858,6 +867,7 @@ int swz_group_add_batch(swz_group* g, double* const* d_xyz, const swz_attribute_
   }
   g->turn = 0;
   g->t_call = std::chrono::steady_clock::now();  // (swz_group_shard_timing: milliseconds since this batch's call began)
+  for (auto& t4 : g->timing) std::fill(std::begin(t4), std::end(t4), 0.0);  // a stamp a path does not reach reads 0, never an older call's
   std::fill(g->status.begin(), g->status.end(), SWZ_OK);
   std::fill(g->root_taken_count.begin(), g->root_taken_count.end(), 0);
   std::vector<std::thread> threads;

@@ -518,8 +518,17 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     // costs its head test, two keys and two node ids, before its cell's work)
     const bool by_list = use_list && cell_lists && (uint64_t)nlist * 4u < a.ncells;
     if (by_list) {
-      if (prev_list) hipLaunchKernelGGL(pr_candidates_list_kernel, dim3(div_up(std::max(nprev, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur ^ 1u], nprev);
-      else hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+      if (prev_list) {
+        hipLaunchKernelGGL(pr_candidates_list_kernel, dim3(div_up(std::max(nprev, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur ^ 1u], nprev);
+      } else {
+        // The first round over the list.  Invariant of the list rounds: wonq holds winners of THIS round only --
+        // pr_winners_list_kernel writes it for the cells at a list head, pr_candidates_list_kernel clears the cells of the
+        // list before.  The rounds over the whole grid leave last round's winners in EVERY cell (they are taken points whose
+        // victims are dead already: harmless for the result, but pr_mask_list_kernel would keep pointing the kill pass at them
+        // for the rest of the level), so the switch clears them once.
+        SWZ_HIP(c, memset_large(a.wonq, 0, (size_t)a.ncells * sizeof(uint64_t), c->stream));
+        hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
+      }
       hipLaunchKernelGGL(pr_winners_list_kernel, dim3(div_up(std::max(nlist, 1u), 256)), dim3(256), 0, c->stream, a, cur, a.list[cur], nlist);
       hipLaunchKernelGGL(pr_mask_list_kernel, dim3(div_up(std::max(nlist, 1u), 256)), dim3(256), 0, c->stream, a, a.list[cur], nlist);
     } else {

@@ -278,7 +278,9 @@ __device__ __forceinline__ void sp_visit_earlier(const SpArgs& a, uint32_t p, F 
           rx[i] = r.x;
           ry[i] = r.y;
           rz[i] = r.z;
-          if (T4) qe[i] = min(q[i] + __float_as_uint(r.w), p);
+          // (only a run's FIRST record carries the length, and only the first step reads a first record: with the four-byte
+          // table this loop must stay at one step -- a later one would cut every run after two records)
+          if (T4 && step == 0) qe[i] = min(q[i] + __float_as_uint(r.w), p);
           any = true;
         }
       }

@@ -57,3 +57,15 @@ def test_baseline_config_presets():
     assert a.points == 25_000_000 and a.batches == 2 and a.one_device
     a = _args(["--gpus", "2", "--total-points", "1000"])
     assert a.points == 500 and a.config == 0
+
+
+def test_shard_stamps_that_do_not_fit_a_step_are_refused():
+    """ADVICE / VERDICT r5: a stamp taken against an unset clock printed exchange_ms = 1.85e8 into a committed line."""
+    import bench
+    ok = [{"shard": 0, "exchange_done_ms": 3.0, "root_begun_ms": 3.1, "root_done_ms": 20.0, "levels_done_ms": 41.0}]
+    assert bench.check_shard_stamps(ok, 42.0) is None
+    assert "185461977" in bench.check_shard_stamps([{"shard": 1, "exchange_done_ms": 185461977.9, "root_begun_ms": 0.0}], 820.0)
+    assert bench.check_shard_stamps([{"shard": 0, "exchange_ms": -1.0}], 10.0) is not None
+    assert bench.check_shard_stamps([{"shard": 0, "exchange_ms": float("nan")}], 10.0) is not None
+    assert bench.shard_stamp_error([{"rank": 0, "exchange_ms": 2.0, "levels_ms": 5.0, "root_mode": "joint", "points": 7}], 9.0) is None
+    assert bench.shard_stamp_error([{"rank": 0, "exchange_ms": 2.0e9, "root_mode": "joint"}], 9.0) is not None

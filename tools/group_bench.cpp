@@ -10,6 +10,7 @@
 // swz_group_finalize.  `bench.py --driver group` runs this program and reports its timings.
 //   g++ -std=c++17 -O2 tools/group_bench.cpp -o /tmp/group_bench -Lschwarzwald_amd/lib -lswz_gpu -Wl,-rpath,$PWD/schwarzwald_amd/lib
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -76,6 +77,17 @@ int main(int argc, char** argv) {
       for (int s = 0; s < shards; ++s)
         if (swz_copy_to_host(swz_group_ctx(g, s), h_xyz[s], d_xyz[s], per * 24) != SWZ_OK) return 3;
     const auto t0 = std::chrono::steady_clock::now();
+    // batches: what every shard spent per stage, summed over the batches of the data set (exchange, root step, levels)
+    std::vector<std::array<double, 3>> stage_sum(shards, std::array<double, 3>{{0, 0, 0}});
+    auto add_stamps = [&]() {
+      for (int s = 0; s < shards; ++s) {
+        double t[4];
+        swz_group_shard_timing(g, s, t);
+        stage_sum[s][0] += t[0];
+        stage_sum[s][1] += std::max(0.0, t[2] - t[1]);
+        stage_sum[s][2] += std::max(0.0, t[3] - t[2]);
+      }
+    };
     if (batches > 1) {
       if (swz_group_tiler_open(g, mn, mx, &p, per) != SWZ_OK) {
         std::fprintf(stderr, "swz_group_tiler_open: %s\n", swz_group_last_error(g));
@@ -104,6 +116,7 @@ int main(int argc, char** argv) {
             std::fprintf(stderr, "swz_group_tile_staged: %s\n", swz_group_last_error(g));
             return 4;
           }
+          add_stamps();
         }
       }
       for (int b = 0; b < batches && !staged; ++b) {
@@ -115,6 +128,7 @@ int main(int argc, char** argv) {
           std::fprintf(stderr, "swz_group_add_batch: %s\n", swz_group_last_error(g));
           return 4;
         }
+        add_stamps();
       }
       if (swz_group_finalize(g, nullptr) != SWZ_OK || swz_group_tiler_close(g) != SWZ_OK) {
         std::fprintf(stderr, "swz_group_finalize: %s\n", swz_group_last_error(g));
@@ -140,7 +154,10 @@ int main(int argc, char** argv) {
     for (int s = 0; s < shards; ++s) {
       double t[4];
       swz_group_shard_timing(g, s, t);
-      std::printf("shard %d %d %.3f %.3f %.3f %.3f\n", rep, s, t[0], t[1], t[2], t[3]);
+      if (batches > 1)  // (the last batch's stamps say little about a data set: the sums over its batches)
+        std::printf("shardsum %d %d %.3f %.3f %.3f\n", rep, s, stage_sum[s][0], stage_sum[s][1], stage_sum[s][2]);
+      else
+        std::printf("shard %d %d %.3f %.3f %.3f %.3f\n", rep, s, t[0], t[1], t[2], t[3]);
     }
   }
   {

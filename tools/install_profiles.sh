@@ -2,7 +2,7 @@
 # traffic.json.  Nothing already in profiles/$1 is deleted: the new set is assembled in a temporary directory first and only
 # then copied over what is there (files other tools left -- las_decode_*.txt, bin_backend_*.txt, extra probes -- stay).
 set -euo pipefail
-R=${1:-r05}
+R=${1:-r06}
 P=gpurun_out/profile
 D=profiles/$R
 [ -d "$P" ] || { echo "install_profiles: $P does not exist (run tools/profile_round.sh through gpurun first)" >&2; exit 1; }
@@ -22,6 +22,14 @@ for pair in stats:bench_default stats_gc:GRID_CENTER stats_prop:property_mode st
 done
 [ -n "$(ls -A "$T")" ] || { echo "install_profiles: nothing to install" >&2; exit 1; }
 mkdir -p "$D"
+# Files of another run must not end up under the new stamp: when $D was measured on other kernel sources its files are moved
+# aside (profiles/$R/superseded_<their stamp>/) unless --keep-old is given.
+if [ -s "$D/source_sha16.txt" ] && ! cmp -s "$D/source_sha16.txt" "$T/source_sha16.txt" && [ "${2:-}" != "--keep-old" ]; then
+  old=$(tr -d '[:space:]' < "$D/source_sha16.txt")
+  mkdir -p "$D/superseded_$old"
+  find "$D" -maxdepth 1 -type f -exec mv {} "$D/superseded_$old/" \;
+  echo "install_profiles: $D held a run on sources $old: moved to $D/superseded_$old/"
+fi
 cp "$T"/* "$D"/
 if [ -f "$D/pmc_FETCH_SIZE_by_kernel.csv" ] && [ -f "$D/pmc_WRITE_SIZE_by_kernel.csv" ]; then python tools/make_traffic.py "$D"; else echo "(no PMC summaries yet: traffic.json not written)"; fi
 echo "run on sources $(cat "$D/source_sha16.txt"), tree has $(python -c 'import bench; print(bench.library_source_sha16())')"
