@@ -655,7 +655,7 @@ __global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a)
     uint32_t idle = 0;
     bool gave_up = false, poll = false, to_publish = true;
     for (;;) {
-      bool remaining = false, progress = false;
+      bool remaining = false, progress = false, halo_wait = false;
       for (uint32_t base = ja; base < jb; base += 64u) {
         const uint32_t j = base + lane;
         if (j >= jb || sb_lds_state(l.st, j) != SB_U) continue;
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a)
             if (poll && v == SB_U && q[i] >= k.n_own) v = sb_state_of(a, l, k, q[i], true);
             any_a |= v == SB_A;
             any_u |= v == SB_U;
+            halo_wait |= v == SB_U && q[i] >= k.n_own;
           }
         }
         if (cnt > (uint32_t)SB_K && !any_a && !any_u) {
@@ -718,8 +719,9 @@ __global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a)
         poll = false;
         continue;
       }
-      // nothing decided in this pass: the wavefront waits for other wavefronts or for earlier blocks
-      poll = true;
+      // nothing decided in this pass: the wavefront waits for other wavefronts of its workgroup (their decisions show up in
+      // the LDS states) or for earlier blocks (the next pass asks the state array: a global round trip)
+      poll = __ballot(halo_wait) != 0;
       ++idle;
       if (lane == 0) ++my_waits;
       if (idle > 1u) __builtin_amdgcn_s_sleep(4);
