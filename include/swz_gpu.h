@@ -444,6 +444,25 @@ int swz_tiler_store_residency(swz_tiler* tiler, uint64_t* device_bytes_out, uint
 int swz_tiler_export_device(swz_tiler* tiler, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out);
 int swz_tiler_node_table(swz_tiler* tiler, uint64_t max_nodes, int8_t* node_level_out, uint64_t* node_key_out,
                          uint64_t* node_offset_out, uint64_t* node_count_out, uint64_t* num_nodes_out);
+/* ONE batch as node files -- the single-batch call for batches whose nodes may need Morton re-rooting
+ * (core/tiling/TilingAlgorithms.cpp:444-483).  swz_tile's outputs (a level per point of the sorted batch, the node being
+ * a prefix of the point's root key) cannot express a re-rooted subtree -- its children are contiguous chunks of the
+ * re-indexed points, :479-482 -- and swz_tile returns SWZ_ERR_REROOT_UNSUPPORTED there; this pair of calls returns the
+ * node table and the files' contents instead, in the form swz_tiler_node_table / swz_tiler_export_device hand out (it
+ * runs the batch through a tiler of its own: one batch, finalize).  In two steps so that the caller can size its buffers:
+ *   swz_tile_nodes_begin_device: tiles d_xyz (device, clamped in place like index_point does); *num_stored_out entries
+ *     in *num_nodes_out node files;
+ *   swz_tile_nodes_end_device: the files -- d_keys_out / d_ids_out / d_level_out (device, num_stored entries, any may be
+ *     NULL; ids are rows of d_xyz) -- and the node table (host arrays of max_nodes >= num_nodes entries: level, Morton
+ *     index, offset and count of every node, nodes ordered by (level, Morton index)); closes the call.
+ * swz_tile_nodes_end_device with every pointer NULL and max_nodes 0 just closes it.  One open call per context; a context
+ * that has a swz_tiler open cannot take it (SWZ_ERR_BAD_ARG). */
+int swz_tile_nodes_begin_device(swz_ctx* ctx, double* d_xyz, uint64_t n, const double bounds_min[3], const double bounds_max[3],
+                                const swz_tile_params* params, uint64_t* num_stored_out, uint64_t* num_nodes_out,
+                                swz_tile_stats* stats);
+int swz_tile_nodes_end_device(swz_ctx* ctx, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out, uint64_t max_nodes,
+                              int8_t* node_level_out, uint64_t* node_key_out, uint64_t* node_offset_out,
+                              uint64_t* node_count_out);
 /* the pools by point id: positions (num_points x 3, clamped) and the attribute columns staged so far */
 int swz_tiler_pools_device(swz_tiler* tiler, const double** d_xyz_out, swz_attribute_columns* d_attrs_out);
 /* ---- one tiler per GPU of a multi-GPU run (BASELINE config 5: sharded + multi-batch).  Points are owned by their

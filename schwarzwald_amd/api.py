@@ -302,6 +302,8 @@ def load_library():
                            C.POINTER(_TileStats)]
     L.swz_tile_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), vp, vp, vp, vp,
                                   C.POINTER(_TileStats)]
+    L.swz_tile_nodes_begin_device.argtypes = [vp, vp, C.c_uint64, _dp, _dp, C.POINTER(_TileParams), _u64p, _u64p, C.POINTER(_TileStats)]
+    L.swz_tile_nodes_end_device.argtypes = [vp, vp, vp, vp, C.c_uint64, _i8p, _u64p, _u64p, _u64p]
     L.swz_build_node_lists.argtypes = [vp, _u64p, _i8p, C.c_uint64, _u32p, C.c_uint64, _i8p, _u64p, _u64p, _u64p,
                                        _u64p]
     L.swz_generate_uniform_device.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
@@ -372,7 +374,7 @@ def load_library():
     L.swz_profile_get.argtypes = [vp, C.POINTER(_KernelStat), C.c_uint32, _u32p]
     for name in ("swz_create", "swz_destroy", "swz_set_stream", "swz_release_workspace", "swz_morton_encode",
                  "swz_morton_encode_device", "swz_sort_by_key", "swz_sort_by_key_device", "swz_sample_points",
-                 "swz_tile", "swz_tile_device", "swz_build_node_lists", "swz_generate_uniform_device",
+                 "swz_tile", "swz_tile_device", "swz_tile_nodes_begin_device", "swz_tile_nodes_end_device", "swz_build_node_lists", "swz_generate_uniform_device",
                  "swz_profile_enable", "swz_profile_reset", "swz_profile_get", "swz_partition_by_octant_device",
                  "swz_shard_begin_device", "swz_shard_root_taken_device", "swz_shard_finish_device",
                  "swz_build_node_lists_device", "swz_gather_payload_device", "swz_bin_write_node",
@@ -552,6 +554,31 @@ class Context:
     def sort_by_key_device(self, d_keys, n, d_perm, d_keys_sorted=None):
         self._check(self._lib.swz_sort_by_key_device(self._ctx, C.c_void_p(d_keys), int(n), C.c_void_p(d_perm),
                                                      C.c_void_p(d_keys_sorted)))
+
+    def tile_nodes_device(self, d_xyz, n, bmin, bmax, params, alloc):
+        """One batch as node files (swz_tile_nodes_begin_device / _end_device): works where tile() fails with
+        ERR_REROOT_UNSUPPORTED.  alloc(num_stored) returns the device pointers (d_keys, d_ids, d_level) for the files'
+        contents (any may be None).  Returns (stats, node table: level / key / offset / count arrays, num_stored)."""
+        p = params._c()
+        stats = _TileStats()
+        ns, nn = C.c_uint64(), C.c_uint64()
+        self._check(self._lib.swz_tile_nodes_begin_device(self._ctx, C.c_void_p(d_xyz), int(n), _vec3(bmin), _vec3(bmax), C.byref(p),
+                                                          C.byref(ns), C.byref(nn), C.byref(stats)))
+        try:
+            d_keys, d_ids, d_level = alloc(int(ns.value))
+        except BaseException:
+            self._lib.swz_tile_nodes_end_device(self._ctx, None, None, None, 0, None, None, None, None)
+            raise
+        cap = max(int(nn.value), 1)
+        nl = np.empty(cap, dtype=np.int8)
+        nk = np.empty(cap, dtype=np.uint64)
+        no = np.empty(cap, dtype=np.uint64)
+        nc = np.empty(cap, dtype=np.uint64)
+        self._check(self._lib.swz_tile_nodes_end_device(self._ctx, C.c_void_p(d_keys), C.c_void_p(d_ids), C.c_void_p(d_level), cap,
+                                                        nl.ctypes.data_as(_i8p), nk.ctypes.data_as(_u64p), no.ctypes.data_as(_u64p),
+                                                        nc.ctypes.data_as(_u64p)))
+        m = int(nn.value)
+        return _stats_dict(stats), dict(level=nl[:m].copy(), key=nk[:m].copy(), offset=no[:m].copy(), count=nc[:m].copy()), int(ns.value)
 
     def tile_device(self, d_xyz, n, bmin, bmax, params, d_keys, d_perm, d_level, d_dup=None):
         stats = _TileStats()

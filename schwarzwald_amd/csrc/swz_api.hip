@@ -249,6 +249,10 @@ int swz_set_option(swz_ctx* c, const char* name, const char* value) {
 int swz_destroy(swz_ctx* c) {
   if (!c) return SWZ_OK;
   (void)hipSetDevice(c->device);
+  if (c->nodes_tiler) {  // an swz_tile_nodes_begin_device that was never closed
+    (void)swz_tiler_destroy(c->nodes_tiler);
+    c->nodes_tiler = nullptr;
+  }
   swz::shard_free(c);
   c->release_all();
   c->prof_collect();

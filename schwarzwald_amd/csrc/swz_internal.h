@@ -87,6 +87,7 @@ struct swz_ctx {
   const void* md_shard_root = nullptr;  // swz::MdShardRoot while swz_group runs the MIN_DISTANCE root of a sharded batch on all shards at once
   bool md_shard_root_published = false;  // the "md_*_sr" arrays of this context are mapped by other shards: they stay (see get())
   bool tiler_active = false;  // a swz_tiler lives on this context: its node store is part of the workspace
+  swz_tiler* nodes_tiler = nullptr;  // the tiler of an open swz_tile_nodes_begin_device / _end_device pair
   // no batch of the tiler is open: its per-batch scratch ("tl_*") holds nothing anybody will read again, and get() may free
   // what was not asked for since the last next_scratch_epoch() when the device runs out of memory (a data set of 3 B points
   // could be tiled but not exported: 100 GB of merge and survivor buffers of the last batch stood in the way)

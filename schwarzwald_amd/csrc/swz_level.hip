@@ -1208,7 +1208,7 @@ static const char* level_error_message(int code) {
   switch (code) {
     case SWZ_ERR_JITTER_GRID_TOO_SMALL: return "Grids smaller than 16x16 are not supported currently!";
     case SWZ_ERR_JITTER_NODE_TOO_DEEP: return "node is too small to be sampled with JITTERED";
-    case SWZ_ERR_REROOT_UNSUPPORTED: return "node needs Morton re-rooting (unsupported)";
+    case SWZ_ERR_REROOT_UNSUPPORTED: return "a node needs Morton re-rooting, which this call's per-point outputs cannot express: use swz_tile_nodes_begin_device / _end_device (one batch as node files) or a swz_tiler";
     case SWZ_ERR_INTERNAL: return "level segmentation inconsistent, or a MIN_DISTANCE sweep / a peer shard failed";
     default: return "a kernel of the level raised an error";
   }
@@ -1263,14 +1263,14 @@ int level_step(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const Sor
   if (plan.sampler == SWZ_RANDOM_GRID || first_only) {
     // candidate level -1: "just take the first point" (Sampling.h:290-298, :346-348)
     const uint32_t csh = first_only ? plan.node_shift : level_shift(plan.cand);
-    if (!first_only && plan.cand >= (int)MAX_LEVELS) return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, "candidate level >= 21");
+    if (!first_only && plan.cand >= (int)MAX_LEVELS) return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, level_error_message(SWZ_ERR_REROOT_UNSUPPORTED));
     ProfScope ps(c, "sample_random_grid", (uint64_t)m * 9ull);
     hipLaunchKernelGGL(random_grid_kernel, dim3(div_up(m, 256u * RG_IPT)), dim3(256), 0, c->stream, as.akey, m, lb.nid, lb.nmode, csh,
                        lb.taken, lb.counters);
     SWZ_LAUNCH_CHECK(c);
   } else if (plan.sampler == SWZ_GRID_CENTER || plan.sampler == SWZ_JITTERED) {
     if (plan.sampler == SWZ_GRID_CENTER && plan.cand >= (int)MAX_LEVELS)
-      return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, "candidate level >= 21");
+      return c->fail(SWZ_ERR_REROOT_UNSUPPORTED, level_error_message(SWZ_ERR_REROOT_UNSUPPORTED));
     const uint32_t ntiles = div_up(m, GA_TILE);
     TileSummary* d_sum = nullptr;
     SWZ_TRY(c->get("grid_summaries", (size_t)ntiles, &d_sum));

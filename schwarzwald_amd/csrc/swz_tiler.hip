@@ -2041,6 +2041,55 @@ int swz_tiler_export_device(swz_tiler* t, uint64_t* d_keys_out, uint32_t* d_ids_
   return SWZ_OK;
 }
 
+// One batch as node files (see the header): a tiler of its own for the batch, closed by the second call.
+int swz_tile_nodes_begin_device(swz_ctx* c, double* d_xyz, uint64_t n, const double bmin[3], const double bmax[3],
+                                const swz_tile_params* params, uint64_t* num_stored_out, uint64_t* num_nodes_out, swz_tile_stats* stats) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  if (!num_stored_out || !num_nodes_out) return c->fail(SWZ_ERR_BAD_ARG, "swz_tile_nodes_begin_device: NULL argument");
+  if (c->nodes_tiler) return c->fail(SWZ_ERR_BAD_ARG, "swz_tile_nodes_begin_device: the call before has not been closed (swz_tile_nodes_end_device)");
+  swz_tiler* t = nullptr;
+  SWZ_TRY(swz_tiler_create(c, bmin, bmax, params, n, &t));
+  swz_tile_stats batch{}, fin{};
+  int st = swz_tiler_add_batch_device(t, d_xyz, n, &batch);
+  if (st == SWZ_OK) st = swz_tiler_finalize(t, &fin);
+  swz_tiler_info info{};
+  if (st == SWZ_OK) st = swz_tiler_get_info(t, &info);
+  if (st != SWZ_OK) {
+    const std::string why = c->err;  // (destroying the tiler must not lose the reason)
+    (void)swz_tiler_destroy(t);
+    return c->fail(st, why);
+  }
+  if (stats) {
+    *stats = batch;
+    stats->num_nodes = (uint32_t)info.num_nodes;
+    stats->points_visited += fin.points_visited;
+    stats->num_levels += fin.num_levels;
+    stats->min_distance_rounds += fin.min_distance_rounds;
+    stats->max_level = std::max(batch.max_level, fin.max_level);
+  }
+  *num_stored_out = info.num_stored;
+  *num_nodes_out = info.num_nodes;
+  c->nodes_tiler = t;
+  return SWZ_OK;
+}
+
+int swz_tile_nodes_end_device(swz_ctx* c, uint64_t* d_keys_out, uint32_t* d_ids_out, int8_t* d_level_out, uint64_t max_nodes,
+                              int8_t* node_level_out, uint64_t* node_key_out, uint64_t* node_offset_out, uint64_t* node_count_out) {
+  if (!c) return SWZ_ERR_BAD_ARG;
+  swz_tiler* t = c->nodes_tiler;
+  if (!t) return c->fail(SWZ_ERR_BAD_ARG, "swz_tile_nodes_end_device: no call is open (swz_tile_nodes_begin_device)");
+  int st = SWZ_OK;
+  if (d_keys_out || d_ids_out || d_level_out) st = swz_tiler_export_device(t, d_keys_out, d_ids_out, d_level_out);
+  if (st == SWZ_OK && (max_nodes || node_level_out || node_key_out || node_offset_out || node_count_out)) {
+    uint64_t nn = 0;
+    st = swz_tiler_node_table(t, max_nodes, node_level_out, node_key_out, node_offset_out, node_count_out, &nn);
+  }
+  const std::string why = c->err;
+  c->nodes_tiler = nullptr;
+  (void)swz_tiler_destroy(t);
+  return st == SWZ_OK ? SWZ_OK : c->fail(st, why);
+}
+
 int swz_tiler_pools_device(swz_tiler* t, const double** d_xyz_out, swz_attribute_columns* d_attrs_out) {
   if (!t) return SWZ_ERR_BAD_ARG;
   if (d_xyz_out) *d_xyz_out = t->pool_xyz;

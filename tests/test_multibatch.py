@@ -319,6 +319,42 @@ def test_single_batch_entry_point_reports_reroot(ctx):
     with pytest.raises(swz.SwzError) as e:
         ctx.tile(xyz, *DEEP, swz.TileParams(sampler=swz.RANDOM_GRID, max_points_per_node=200, spacing_at_root=sp))
     assert e.value.code == 5
+    assert "swz_tile_nodes_begin_device" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sampler", SAMPLERS)
+def test_single_batch_as_node_files_reroots_like_the_oracle(ctx, sampler):
+    """swz_tile_nodes_begin_device / _end_device: ONE batch comes back as node files (node table + contents), re-rooted
+    subtrees included (TilingAlgorithms.cpp:444-483) -- the oracle's files of the same batch, node for node and in file
+    order."""
+    import torch
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(70 + sampler)
+    n = 100000
+    xyz = _deep_cloud(rng, n)
+    sp = float(np.float32(1024.0 / 4096.0))
+    ex, c = _oracle_files(DEEP, xyz, 1, sampler, 200, sp, O.ACCURATE, 2)
+    assert int(ex["level"].max()) > 9
+    d = torch.from_numpy(np.ascontiguousarray(xyz)).cuda()
+    bufs = {}
+
+    def alloc(ns):
+        bufs["k"] = torch.empty(max(ns, 1), dtype=torch.int64, device="cuda")
+        bufs["i"] = torch.empty(max(ns, 1), dtype=torch.int32, device="cuda")
+        bufs["l"] = torch.empty(max(ns, 1), dtype=torch.int8, device="cuda")
+        return bufs["k"].data_ptr(), bufs["i"].data_ptr(), bufs["l"].data_ptr()
+    params = swz.TileParams(sampler=sampler, max_points_per_node=200, spacing_at_root=sp, fast_concurrency=2)
+    stats, table, ns = ctx.tile_nodes_device(d.data_ptr(), n, *DEEP, params, alloc)
+    torch.cuda.synchronize()
+    g = dict(table=table, ids=bufs["i"].cpu().numpy().view(np.uint32)[:ns], level=bufs["l"].cpu().numpy()[:ns])
+    _compare(g, ex, c)
+    assert stats["num_nodes"] == c["num_nodes"] and ns == n
+    # the context is free again: a second call and a tiler both work
+    stats2, table2, ns2 = ctx.tile_nodes_device(d.data_ptr(), n, *DEEP, params, alloc)
+    assert np.array_equal(table2["key"], table["key"]) and ns2 == ns
+    with swz.Tiler(ctx, DEEP[0], DEEP[1], params) as t:
+        assert t.info()["num_points"] == 0
 
 
 @pytest.mark.gpu
