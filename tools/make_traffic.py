@@ -39,7 +39,8 @@ if "swz::radix_ghist_kernel" in fetch:
 else:
     calib = 2.0 * fetch["swz::radix_hist_kernel"][1] * 1024.0 / (8 * 8.0 * points)
 # (templated kernels are listed as "void swz::md_sweep_kernel<1, false>"; the fused cell scan belongs to the class too)
-md_k, md_b = bytes_of(lambda k: "swz::md_" in k or "swz::sp_" in k or "swz::mq_" in k or "swz::CellHeadF" in k or "swz::MqHeadF" in k)
+# (round 6: the sparse levels run sb_block_kernel / sb_table_kernel, swz_mdblock.hip)
+md_k, md_b = bytes_of(lambda k: "swz::md_" in k or "swz::sp_" in k or "swz::sb_" in k or "swz::mq_" in k or "swz::CellHeadF" in k or "swz::MqHeadF" in k)
 rs_k, rs_b = bytes_of(lambda k: k in ("swz::radix_scatter_kernel", "swz::radix_onesweep_kernel"))
 # launches of the scatter kernel in the profiled step: the passes over the whole input (the eight tiny passes that sort
 # the sample which picks the number of top digits do not count)
@@ -71,7 +72,7 @@ out = {
 try:
     fetch, write = load("pmc_FETCH_SIZE_by_kernel_property_mode.csv"), load("pmc_WRITE_SIZE_by_kernel_property_mode.csv")
     pr_k, pr_b = bytes_of(lambda k: "swz::pr_" in k or "swz::PrAlive" in k or "swz::PrList" in k)
-    sp_k, sp_b = bytes_of(lambda k: "swz::sp_" in k)
+    sp_k, sp_b = bytes_of(lambda k: "swz::sp_" in k or "swz::sb_" in k)
     dense_levels = max(1, levels - 2)
     out["bytes_per_launch_property_mode"] = {"sample_min_distance_property": pr_b / dense_levels, "sample_min_distance": sp_b / 2.0}
     out["detail"]["property_mode"] = {"sample_min_distance_property": {"kernels": pr_k, "launches_per_step": dense_levels, "bytes_per_step": pr_b},

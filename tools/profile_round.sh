@@ -1,4 +1,4 @@
-# Round 5: collects the round's evidence into gpurun_out/profile/ (tools/install_profiles.sh copies it to profiles/r05):
+# Rounds 5-6: collects the round's evidence into gpurun_out/profile/ (tools/install_profiles.sh copies it to profiles/rNN):
 # bench lines, rocprofv3 kernel summaries and HBM traffic counters (FETCH_SIZE / WRITE_SIZE in separate --pmc passes) of
 # the headline (exact), the property mode, a grid sampler and the multi-batch tiler at the reference's default operating
 # point (MIN_DISTANCE, FAST, batches of 10 M points).  PARTS (environment) selects: lines stats pmc fullsize (default: all).
