@@ -70,7 +70,13 @@ int swz_set_stream(swz_ctx* ctx, void* hip_stream);
  * is shared) and the limits SWZ_MD_TIME_LIMIT / SWZ_MD_ROUND_LIMIT (a level that exceeds them is abandoned with an
  * error).  A NEGATIVE SWZ_MD_KEYS_BAND is the one exception to "no result changes": it narrows the band in which
  * MIN_DISTANCE repeats a compare on the exact positions below its proven width and exists so that a test can show that
- * the band is needed (tests/test_min_distance_keys.py). */
+ * the band is needed (tests/test_min_distance_keys.py).
+ * Round 6, the sparse MIN_DISTANCE levels by blocks of cells (swz_mdblock.hip): SWZ_SP_BLOCK=0 keeps them on the
+ * thread-per-point path; SWZ_SP_BLOCK_WIDE=1, _CL, _OWN, _HALO, _PER_CU, _MIN force the point format, the cell level, the
+ * LDS capacities, the workgroups per CU, the points a block should hold -- results unchanged (a block that does not fit
+ * makes the level fall back); SWZ_SP_BLOCK_TIMEOUT_MS (default 10 000) bounds how long a wavefront waits for an earlier
+ * block: when it expires the call returns SWZ_ERR_INTERNAL, nothing is restarted; SWZ_SP_BLOCK_DBG switches parts of the
+ * search off for timing experiments and DOES change the result -- never set it outside tools/r6_dbg.sh. */
 int swz_set_option(swz_ctx* ctx, const char* name, const char* value);
 /* Frees all device workspace held by the context (it regrows on demand). */
 int swz_release_workspace(swz_ctx* ctx);

@@ -1,5 +1,10 @@
 // swz_mdsparse.hip -- MIN_DISTANCE for SPARSE levels: one thread per point.
 //
+// Since round 6 the levels that can be decided on keys go to swz_mdblock.hip first (blocks of 8^3 cells staged in LDS,
+// decisions in the same launch: 107 -> 86 ms for levels 2 + 3 of the 1 B run, a tenth of the memory traffic); this file
+// is what runs when that path declines -- positions instead of keys, a block that does not fit its LDS capacity,
+// SWZ_SP_BLOCK=0 -- and the entry point that picks between the two.
+//
 // Same result as the frontier sweep of swz_mindist.hip (the lexicographically-first maximal
 // independent set in Morton order, PoissonDiskSampling / SparseGrid::add, core/tiling/Sampling.h:421-471,
 // core/datastructures/SparseGrid.cpp:116-146), computed the other way round.  When a spacing-sized cell
