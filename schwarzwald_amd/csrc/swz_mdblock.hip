@@ -80,7 +80,7 @@ struct SbArgs {
   uint32_t* ctr;           // SB_NC ticket counters (stride SB_CTR_STRIDE words), then SBW_* words
   uint32_t own_cap, halo_cap;
   uint64_t timeout_ticks;  // wall_clock64 ticks (100 MHz) a wavefront may wait without any progress
-  uint32_t dbg;            // SWZ_SP_BLOCK_DBG: timing experiments that BREAK the result (1: no candidate loop, 2: no reach test, 4: no order test)
+  uint32_t dbg;            // SWZ_SP_BLOCK_DBG: timing experiments that BREAK the result (1: no candidate loop, 2: no reach test, 4: no order test, 8: undecided halo points count as rejected)
 };
 
 __device__ __forceinline__ uint32_t sb_expand3(uint32_t v) {  // 10 bits -> every third bit
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a)
         l.pts[j] = sb_make_point<WIDE>(a, k, x, y, z, &cell);
         rc[j] = (uint16_t)cell;
         l.st[j] = (uint8_t)((sw[p] >> ((gi[p] & 15u) * 2u)) & 3u);
+        if ((a.dbg & 8u) && j >= n_own && l.st[j] == SB_U) l.st[j] = SB_R;  // (timing experiment: nobody waits for another block)
       }
     }
     __syncthreads();
@@ -658,46 +659,79 @@ __global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a)
       bool remaining = false, progress = false, halo_wait = false;
       for (uint32_t base = ja; base < jb; base += 64u) {
         const uint32_t j = base + lane;
-        if (j >= jb || sb_lds_state(l.st, j) != SB_U) continue;
-        const uint32_t cnt = cnt1[j];
-        bool any_a = false, any_u = false;
-        {
-          // the recorded neighbours and their states in two LDS round trips (one load each, all four states in flight)
-          static_assert(SB_K == 4, "four two-byte entries = one eight-byte load");
-          const uint64_t n4 = *reinterpret_cast<const uint64_t*>(l.nbr + (size_t)j * SB_K);
-          const uint32_t c4 = min(cnt, (uint32_t)SB_K);
-          uint32_t q[SB_K], st[SB_K];
+        const bool have = j < jb;
+        uint32_t cur = have ? sb_lds_state(l.st, j) : (uint32_t)SB_R;  // this lane's state as the other lanes see it
+        const bool und = have && cur == SB_U;
+        if (!__ballot(und)) continue;
+        // the recorded neighbours: those among the 64 points of this round are read from the lanes' registers (shuffles,
+        // below), the others -- earlier rounds, other wavefronts, the halo -- from the LDS states, once per pass
+        static_assert(SB_K == 4, "four two-byte entries = one eight-byte load");
+        const uint32_t cnt = und ? cnt1[j] : 0u;
+        const uint64_t n4 = und ? *reinterpret_cast<const uint64_t*>(l.nbr + (size_t)j * SB_K) : 0ull;
+        const uint32_t c4 = min(cnt, (uint32_t)SB_K);
+        uint32_t q[SB_K], st[SB_K];
+        uint32_t inround = 0;
 #pragma unroll
-          for (int i = 0; i < SB_K; ++i) {
-            q[i] = (uint32_t)(n4 >> (16 * i)) & 0xFFFFu;
-            st[i] = (uint32_t)i < c4 ? sb_lds_state(l.st, q[i]) : (uint32_t)SB_R;
-          }
-#pragma unroll
-          for (int i = 0; i < SB_K; ++i) {
-            uint32_t v = st[i];
-            if (poll && v == SB_U && q[i] >= k.n_own) v = sb_state_of(a, l, k, q[i], true);
-            any_a |= v == SB_A;
-            any_u |= v == SB_U;
-            halo_wait |= v == SB_U && q[i] >= k.n_own;
-          }
+        for (int i = 0; i < SB_K; ++i) {
+          q[i] = (uint32_t)(n4 >> (16 * i)) & 0xFFFFu;
+          const bool used = (uint32_t)i < c4;
+          const bool here = used && q[i] >= base && q[i] < base + 64u;  // (own points only: the halo is staged behind them)
+          inround |= here ? 1u << i : 0u;
+          st[i] = used && !here ? sb_lds_state(l.st, q[i]) : (uint32_t)SB_R;
         }
-        if (cnt > (uint32_t)SB_K && !any_a && !any_u) {
-          // more undecided neighbours than were recorded, and the recorded ones have all been rejected: search again (rare)
+        bool ext_a = false, ext_u = false;
+#pragma unroll
+        for (int i = 0; i < SB_K; ++i) {
+          uint32_t v = st[i];
+          if (poll && v == SB_U && q[i] >= k.n_own) v = sb_state_of(a, l, k, q[i], true);
+          ext_a |= v == SB_A;
+          ext_u |= v == SB_U;
+          halo_wait |= v == SB_U && q[i] >= k.n_own;
+        }
+        // the chains inside the round, without memory: every lane shows its state, every undecided lane looks
+        const bool listed = und && cnt <= (uint32_t)SB_K;
+        bool in_u_last = false;
+        for (;;) {
+          bool in_a = false, in_u = false;
+#pragma unroll
+          for (int i = 0; i < SB_K; ++i) {
+            const uint32_t sv = (uint32_t)__shfl((int)cur, (int)((q[i] - base) & 63u), WAVE);
+            if ((inround >> i) & 1u) {
+              in_a |= sv == SB_A;
+              in_u |= sv == SB_U;
+            }
+          }
+          in_u_last = in_u;
+          bool changed = false;
+          if (und && cur == SB_U) {
+            if (ext_a || in_a) {
+              cur = SB_R;
+              changed = true;
+            } else if (listed && !ext_u && !in_u) {
+              cur = SB_A;
+              changed = true;
+            }
+          }
+          if (!__ballot(changed)) break;
+        }
+        if (und && cur == SB_U && cnt > (uint32_t)SB_K && !ext_u && !in_u_last) {
+          // more neighbours than were recorded, and the recorded ones have all been rejected: search again (rare)
+          bool any_a = false, any_u = false;
           ++my_research;
-          sb_visit<WIDE>(a, l, k, j, [&](uint32_t q) {
-            const uint32_t s = sb_state_of(a, l, k, q, true);
-            any_a |= s == SB_A;
-            any_u |= s == SB_U;
+          sb_visit<WIDE>(a, l, k, j, [&](uint32_t qq) {
+            const uint32_t sv = sb_state_of(a, l, k, qq, true);
+            any_a |= sv == SB_A;
+            any_u |= sv == SB_U;
             return !any_a;
           });
+          if (any_a) cur = SB_R; else if (!any_u) cur = SB_A;
         }
-        const uint32_t dec = any_a ? SB_R : (any_u ? SB_U : SB_A);
-        if (dec != SB_U) {
-          sb_lds_set(l.st, j, dec);
+        if (und && cur != SB_U) {
+          sb_lds_set(l.st, j, cur);
           const uint32_t gi = k.first + j;
-          atomicOr(&l.pub[(gi >> 4) - w0], dec << ((gi & 15u) * 2u));
+          atomicOr(&l.pub[(gi >> 4) - w0], cur << ((gi & 15u) * 2u));
           progress = true;
-        } else {
+        } else if (und) {
           remaining = true;
         }
       }
