@@ -41,8 +41,10 @@ namespace swz {
 #ifndef SB_MINW
 #define SB_MINW 6   // wavefronts per SIMD the kernel is compiled for (80 registers; measured against 5: level 2 of the 1 B run 69 -> 64 ms)
 #endif
+constexpr int SB_THREADS = 256;
 constexpr int SB_K = 4;               // undecided earlier neighbours recorded per point (0.73 expected at level 2 of the 1 B run); more: the point searches again
 constexpr int SB_PEND = 63;            // in-band pairs a wavefront puts aside per block (more: compared on the spot)
+constexpr int SB_PMAX = 6;            // staged points per thread: a block and its halo hold at most SB_THREADS * SB_PMAX points
 constexpr uint32_t SB_NC = 64;        // ticket counters (one per 128-byte line): nodes sn with sn % SB_NC == k draw from counter k
 constexpr uint32_t SB_CTR_STRIDE = 32;
 constexpr uint32_t SB_NONE = 0xFFFFFFFFu;
@@ -77,12 +79,6 @@ struct SbArgs {
   uint32_t ns;             // sampled nodes
   uint32_t* ctr;           // SB_NC ticket counters (stride SB_CTR_STRIDE words), then SBW_* words
   uint32_t own_cap, halo_cap;
-  // The block: an aligned box of 2^nb cells (nb low bits of the cell's Morton code: 6 = 4 x 4 x 4, 7 = 4 x 4 x 8 (x, y, z),
-  // 8 = 4 x 8 x 8, 9 = 8 x 8 x 8), one run of the sorted keys.  Around it one cell of halo: the region, rx x ry x rz cells,
-  // covered by ggx x ggy x ggz granules of 2 x 2 x 2 cells.
-  uint32_t nb, bx, by, bz;
-  uint32_t rx, ry, rxy, rcells, nrows;  // region: cells per row, rows per slice, cells per slice, cells, (z, y) rows
-  uint32_t ggx, ggy, nrg;               // region granules per row / per slice row count, in all
   uint64_t timeout_ticks;  // wall_clock64 ticks (100 MHz) a wavefront may wait without any progress
   uint32_t dbg;            // SWZ_SP_BLOCK_DBG: timing experiments that BREAK the result (1: no candidate loop, 2: no reach test, 4: no order test, 8: undecided halo points count as rejected)
 };
@@ -127,37 +123,36 @@ __device__ __forceinline__ bool sb_exact_near(const SbArgs& a, uint32_t gp, uint
 
 struct SbLds {
   uint64_t* pts;    // [own_cap + halo_cap] packed key coordinates; the block's own points first, in Morton order
-  uint32_t* cse;    // [rcells] region cell -> first | end << 16 (LDS indices); valid where the cell's occupancy bit is set
-  uint32_t* occ;    // [nrows] (iz, iy) -> bit ix: the region cell holds staged points
-  uint32_t* soff;   // [nrg + 1] halo slot (region granule) -> LDS offset of its run; [nrg] = total
-  uint32_t* sfirst; // [nrg] ... -> active index of its first point
+  uint32_t* cse;    // [1024] region cell -> first | end << 16 (LDS indices); valid where the cell's occupancy bit is set
+  uint32_t* occ;    // [128] (iz, iy) -> bit ix: the region cell holds staged points
+  uint32_t* soff;   // [224] halo slot (region granule 0..215) -> LDS offset of its run; [216] = total
+  uint32_t* sfirst; // [224] ... -> active index of its first point
   uint32_t* pub;    // own state bits to publish, by word of st2
   uint32_t* misc;   // SBM_*
   uint32_t* scan;   // [8] block scan scratch
   uint16_t* nbr;    // [own_cap][SB_K]; while the points are staged: rc[own_cap + halo_cap], the region cell of every point
   uint8_t* st;      // [own_cap + halo_cap]
   uint32_t* cnt4;   // [own_cap / 4] undecided earlier neighbours of own point j in byte j % 4 (counted with 32-bit LDS atomics)
-  uint32_t* pend;   // [wavefronts][SB_PEND + 1]: pairs inside the quantisation band, j << 16 | q; [SB_PEND]: how many
+  uint32_t* pend;   // [4][SB_PEND + 1] per wavefront: pairs inside the quantisation band, j << 16 | q; [SB_PEND]: how many
 };
-__host__ __device__ inline uint32_t sb_even(uint32_t v) { return (v + 1u) & ~1u; }
-__host__ __device__ inline size_t sb_lds_bytes(uint32_t own_cap, uint32_t halo_cap, uint32_t rcells, uint32_t nrows, uint32_t nrg, uint32_t waves) {
+__host__ __device__ inline size_t sb_lds_bytes(uint32_t own_cap, uint32_t halo_cap) {
   const size_t tot = (size_t)own_cap + halo_cap;
   size_t b = tot * 8;                                            // pts
-  b += ((size_t)sb_even(rcells) + sb_even(nrows) + sb_even(nrg + 1u) + sb_even(nrg)) * 4;  // cse, occ, soff, sfirst
+  b += 1024 * 4 + 128 * 4 + 224 * 4 + 224 * 4;                   // cse, occ, soff, sfirst
   b += (((size_t)own_cap / 16 + 5) & ~(size_t)1) * 4 + SBM_COUNT * 4 + 8 * 4;   // pub (even: what follows stays 8-byte aligned), misc, scan
   b += std::max((size_t)own_cap * SB_K, tot) * 2;                // nbr / rc
-  b += ((tot + 3) & ~(size_t)3) + own_cap + (size_t)waves * (SB_PEND + 1) * 4; // st, cnt4, pend
+  b += ((tot + 3) & ~(size_t)3) + own_cap + 4 * (SB_PEND + 1) * 4; // st, cnt4, pend
   return (b + 15) & ~(size_t)15;
 }
-__device__ __forceinline__ SbLds sb_carve(unsigned char* smem, const SbArgs& a) {
-  const uint32_t own_cap = a.own_cap, halo_cap = a.halo_cap, tot = own_cap + halo_cap;
+__device__ __forceinline__ SbLds sb_carve(unsigned char* smem, uint32_t own_cap, uint32_t halo_cap) {
+  const uint32_t tot = own_cap + halo_cap;
   SbLds l;
   l.pts = reinterpret_cast<uint64_t*>(smem);
   l.cse = reinterpret_cast<uint32_t*>(l.pts + tot);
-  l.occ = l.cse + sb_even(a.rcells);
-  l.soff = l.occ + sb_even(a.nrows);
-  l.sfirst = l.soff + sb_even(a.nrg + 1u);
-  l.pub = l.sfirst + sb_even(a.nrg);
+  l.occ = l.cse + 1024;
+  l.soff = l.occ + 128;
+  l.sfirst = l.soff + 224;
+  l.pub = l.sfirst + 224;
   l.misc = l.pub + ((own_cap / 16 + 5u) & ~1u);
   l.scan = l.misc + SBM_COUNT;
   l.nbr = reinterpret_cast<uint16_t*>(l.scan + 8);
@@ -171,15 +166,15 @@ __device__ __forceinline__ SbLds sb_carve(unsigned char* smem, const SbArgs& a) 
 struct SbBlock {
   uint32_t first;   // active index of the block's first point
   uint32_t n_own;
-  uint32_t ox, oy, oz;  // the block's origin in cells of its node
+  uint32_t bx8, by8, bz8;  // the block's origin in cells of its node
 };
-// region cell of a point as ix | iy << 4 | iz << 8 (0 .. block size + 1 each), SB_CELL_NONE outside the region
+// region cell of a point as ix | iy << 4 | iz << 8 (0..9 each), SB_CELL_NONE outside the 10^3 cells around the block
 __device__ __forceinline__ uint32_t sb_region_cell(const SbArgs& a, const SbBlock& k, uint32_t x, uint32_t y, uint32_t z) {
   const uint32_t cmask = (1u << a.cl) - 1u;
-  const uint32_t ix = ((x >> a.cell_bits) & cmask) - k.ox + 1u, iy = ((y >> a.cell_bits) & cmask) - k.oy + 1u, iz = ((z >> a.cell_bits) & cmask) - k.oz + 1u;
-  return (ix < a.bx + 2u && iy < a.by + 2u && iz < a.bz + 2u) ? (ix | (iy << 4) | (iz << 8)) : SB_CELL_NONE;
+  const uint32_t ix = ((x >> a.cell_bits) & cmask) - k.bx8 + 1u, iy = ((y >> a.cell_bits) & cmask) - k.by8 + 1u, iz = ((z >> a.cell_bits) & cmask) - k.bz8 + 1u;
+  return (ix < 10u && iy < 10u && iz < 10u) ? (ix | (iy << 4) | (iz << 8)) : SB_CELL_NONE;
 }
-__device__ __forceinline__ uint32_t sb_cell_index(const SbArgs& a, uint32_t c) { return (c & 15u) + a.rx * ((c >> 4) & 15u) + a.rxy * (c >> 8); }
+__device__ __forceinline__ uint32_t sb_cell_index(uint32_t c) { return (c & 15u) + 10u * ((c >> 4) & 15u) + 100u * (c >> 8); }
 template <bool WIDE>
 __device__ __forceinline__ uint64_t sb_make_point(const SbArgs& a, const SbBlock& k, uint32_t x, uint32_t y, uint32_t z, uint32_t* cell) {
   const uint32_t c = sb_region_cell(a, k, x, y, z);
@@ -188,35 +183,34 @@ __device__ __forceinline__ uint64_t sb_make_point(const SbArgs& a, const SbBlock
   // relative to the region's corner (one cell below the block's origin, inside the node); points outside the region keep
   // whatever the low 16 bits say -- nobody ever looks at them
   const uint32_t nmask = (1u << (a.cell_bits + a.cl)) - 1u;
-  const uint32_t xr = (x & nmask) - ((k.ox - 1u) << a.cell_bits), yr = (y & nmask) - ((k.oy - 1u) << a.cell_bits),
-                 zr = (z & nmask) - ((k.oz - 1u) << a.cell_bits);
+  const uint32_t xr = (x & nmask) - ((k.bx8 - 1u) << a.cell_bits), yr = (y & nmask) - ((k.by8 - 1u) << a.cell_bits),
+                 zr = (z & nmask) - ((k.bz8 - 1u) << a.cell_bits);
   return (uint64_t)((xr & 0xFFFFu) | (yr << 16)) | ((uint64_t)((zr & 0xFFFFu) | (c << 16)) << 32);
 }
-// the halo run that holds staged point j >= n_own: soff ascends, [nrg] = total (branch-free: eight steps for every lane)
-__device__ __forceinline__ uint32_t sb_halo_slot(const SbArgs& a, const SbLds& l, uint32_t j) {
+// the halo run that holds staged point j >= n_own: soff ascends, [216] = total (branch-free: eight steps for every lane)
+__device__ __forceinline__ uint32_t sb_halo_slot(const SbLds& l, uint32_t j) {
   uint32_t lo = 0;
 #pragma unroll
   for (uint32_t step = 128u; step; step >>= 1)
-    if (lo + step <= a.nrg && l.soff[lo + step] <= j) lo += step;
+    if (lo + step <= 216u && l.soff[lo + step] <= j) lo += step;
   return lo;
 }
 // active index of staged point q (a halo point's is looked up: only polls and compares on the original positions want it)
-__device__ __forceinline__ uint32_t sb_active_index(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t q) {
+__device__ __forceinline__ uint32_t sb_active_index(const SbLds& l, const SbBlock& k, uint32_t q) {
   if (q < k.n_own) return k.first + q;
-  const uint32_t slot = sb_halo_slot(a, l, q);
+  const uint32_t slot = sb_halo_slot(l, q);
   return l.sfirst[slot] + (q - l.soff[slot]);
 }
 
-// Which of the 27 cells around own cell (ix, iy, iz) -- 1 .. block size each -- can hold EARLIER points.  Bit 9 * zi + 3 * yi + xi,
+// Which of the 27 cells around own cell (ix, iy, iz) -- 1..8 each -- can hold EARLIER points.  Bit 9 * zi + 3 * yi + xi,
 // xi = 0 / 1 / 2 for the cell at x - 1 / x / x + 1.  Cells outside the block were staged only when their granule precedes
 // the block in Morton order, so every one of them counts.  Inside the block the order of two adjacent cells is decided by
 // the axis whose coordinate changes at the highest bit: a step of -1 flips the bits up to the lowest set one, a step of
 // +1 up to the lowest clear one; in the interleaved code bit h of x sits at 3h + 2, of y at 3h + 1, of z at 3h.  The cell
 // is earlier when the highest flipped bit belongs to an axis that steps down.
-__device__ __forceinline__ uint32_t sb_earlier_mask(const SbArgs& a, uint32_t ix, uint32_t iy, uint32_t iz) {
+__device__ __forceinline__ uint32_t sb_earlier_mask(uint32_t ix, uint32_t iy, uint32_t iz) {
   const uint32_t lx = ix - 1u, ly = iy - 1u, lz = iz - 1u;
-  // (block sizes are powers of two: the OR keeps the count of trailing zeros of a 0 coordinate finite -- that step leaves the block)
-  const int mx = 3 * (int)__builtin_ctz(lx | a.bx) + 2, my = 3 * (int)__builtin_ctz(ly | a.by) + 1, mz = 3 * (int)__builtin_ctz(lz | a.bz);
+  const int mx = 3 * (int)__builtin_ctz(lx | 8u) + 2, my = 3 * (int)__builtin_ctz(ly | 8u) + 1, mz = 3 * (int)__builtin_ctz(lz | 8u);
   const int px = 3 * (int)__builtin_ctz(~lx) + 2, py = 3 * (int)__builtin_ctz(~ly) + 1, pz = 3 * (int)__builtin_ctz(~lz);
   uint32_t m = 0x361Bu;  // no axis steps up: bits 0, 1, 3, 4, 9, 10, 12, 13
   // two axes, one up and one down
@@ -234,9 +228,9 @@ __device__ __forceinline__ uint32_t sb_earlier_mask(const SbArgs& a, uint32_t ix
   m |= (my > max(px, pz) ? 1u : 0u) << 20;  // x+, y-, z+
   m |= (mz > max(px, py) ? 1u : 0u) << 8;   // x+, y+, z-
   // the halo
-  const uint32_t hx = (ix == 1u ? 1u : 0u) | (ix == a.bx ? 4u : 0u);
-  const uint32_t hy = (iy == 1u ? 7u : 0u) | (iy == a.by ? 7u << 6 : 0u);
-  const uint32_t hz = (iz == 1u ? 0x1FFu : 0u) | (iz == a.bz ? 0x1FFu << 18 : 0u);
+  const uint32_t hx = (ix == 1u ? 1u : 0u) | (ix == 8u ? 4u : 0u);
+  const uint32_t hy = (iy == 1u ? 7u : 0u) | (iy == 8u ? 7u << 6 : 0u);
+  const uint32_t hz = (iz == 1u ? 0x1FFu : 0u) | (iz == 8u ? 0x1FFu << 18 : 0u);
   return m | hx * 0x1249249u | hy * 0x40201u | hz;
 }
 
@@ -268,14 +262,14 @@ __device__ __forceinline__ SbOwn sb_own_point(const SbArgs& a, const SbLds& l, c
   p.fx = (float)p.ux;
   p.fy = (float)p.uy;
   p.fz = (float)p.uz;
-  const uint32_t ix = cell & 15u, iy = (cell >> 4) & 15u, iz = cell >> 8;  // 1 .. block size: an own point
+  const uint32_t ix = cell & 15u, iy = (cell >> 4) & 15u, iz = cell >> 8;  // 1..8: an own point
   uint32_t mask = 0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    const uint32_t row = l.occ[(iz + (uint32_t)(i / 3) - 1u) * a.ry + (iy + (uint32_t)(i % 3) - 1u)];
+    const uint32_t row = l.occ[(iz + (uint32_t)(i / 3) - 1u) * 10u + (iy + (uint32_t)(i % 3) - 1u)];
     mask |= ((row >> (ix - 1u)) & 7u) << (3 * i);
   }
-  if (!(a.dbg & 4u)) mask &= sb_earlier_mask(a, ix, iy, iz);
+  if (!(a.dbg & 4u)) mask &= sb_earlier_mask(ix, iy, iz);
   if (!WIDE && !(a.dbg & 2u)) {
     const uint32_t cs = 1u << a.cell_bits;
     const int ox = (int)(p.ux & (cs - 1u)), oy = (int)(p.uy & (cs - 1u)), oz = (int)(p.uz & (cs - 1u));
@@ -296,7 +290,7 @@ __device__ __forceinline__ SbOwn sb_own_point(const SbArgs& a, const SbLds& l, c
   }
   if (a.dbg & 1u) mask = 0;
   p.mask = mask;
-  p.corner = (ix - 1u) + a.rx * (iy - 1u) + a.rxy * (iz - 1u);
+  p.corner = (ix - 1u) + 10u * (iy - 1u) + 100u * (iz - 1u);
   return p;
 }
 // squared distance of own point p to staged point word o: closer than the spacing for sure / possibly
@@ -317,9 +311,9 @@ __device__ __forceinline__ void sb_compare(const SbArgs& a, const SbOwn& p, uint
     maybe = d2 < a.i_hi;
   }
 }
-__device__ __forceinline__ uint32_t sb_cell_offset(const SbArgs& a, uint32_t b) {  // bit of the 27-cell mask -> offset in the cell index
+__device__ __forceinline__ uint32_t sb_cell_offset(uint32_t b) {  // bit of the 27-cell mask -> offset in the cell index
   const uint32_t dz = (b * 57u) >> 9, rem = b - 9u * dz, dy = (rem * 11u) >> 5, dx = rem - 3u * dy;
-  return dx + a.rx * dy + a.rxy * dz;
+  return dx + 10u * dy + 100u * dz;
 }
 
 // Visits every EARLIER staged point closer than the spacing to own point j.  f(q) returns false to stop.  (The general
@@ -334,7 +328,7 @@ __device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const 
       if (!mask) break;
       const uint32_t b = (uint32_t)__ffs((int)mask) - 1u;
       mask &= mask - 1u;
-      const uint32_t e2 = l.cse[p.corner + sb_cell_offset(a, b)];
+      const uint32_t e2 = l.cse[p.corner + sb_cell_offset(b)];
       q = e2 & 0xFFFFu;
       e = e2 >> 16;
       if (q < k.n_own) e = min(e, j);  // a cell of the block itself: earlier points only (own points are staged in Morton order)
@@ -343,7 +337,7 @@ __device__ __forceinline__ void sb_visit(const SbArgs& a, const SbLds& l, const 
     bool sure, maybe;
     sb_compare<WIDE>(a, p, l.pts[q], sure, maybe);
     if (maybe) {
-      if (sure || sb_exact_near(a, k.first + j, sb_active_index(a, l, k, q))) {
+      if (sure || sb_exact_near(a, k.first + j, sb_active_index(l, k, q))) {
         if (!f(q)) return;
       }
     }
@@ -367,7 +361,7 @@ __device__ __forceinline__ void sb_search(const SbArgs& a, const SbLds& l, const
   const SbOwn p = sb_own_point<WIDE>(a, l, k, active ? j : 0u);
   uint32_t mask = active ? p.mask : 0u;
   uint32_t q = 0, e = 0, cnt = 0;
-  uint32_t ne2 = l.cse[mask ? p.corner + sb_cell_offset(a, (uint32_t)__ffs((int)mask) - 1u) : 0u];  // the first cell's entry
+  uint32_t ne2 = l.cse[mask ? p.corner + sb_cell_offset((uint32_t)__ffs((int)mask) - 1u) : 0u];  // the first cell's entry
   while (__ballot(active)) {
     ++*steps;
     // lanes whose cell is used up take their next one (its entry is here already) and ask for the one after it
@@ -380,7 +374,7 @@ __device__ __forceinline__ void sb_search(const SbArgs& a, const SbLds& l, const
     e = fetch ? t3 : e;
     active = active && !(need && !fetch);
     if (__ballot(fetch)) {
-      const uint32_t nxt = l.cse[(fetch && mask) ? p.corner + sb_cell_offset(a, (uint32_t)__ffs((int)mask) - 1u) : 0u];
+      const uint32_t nxt = l.cse[(fetch && mask) ? p.corner + sb_cell_offset((uint32_t)__ffs((int)mask) - 1u) : 0u];
       ne2 = fetch ? nxt : ne2;
     }
     // lanes that have a candidate test it
@@ -395,7 +389,7 @@ __device__ __forceinline__ void sb_search(const SbArgs& a, const SbLds& l, const
         if (band) {
           const uint32_t slot = atomicAdd(&pend[SB_PEND], 1u);
           if (slot < (uint32_t)SB_PEND) pend[slot] = (j << 16) | q;
-          else near = sb_exact_near(a, k.first + j, sb_active_index(a, l, k, q));
+          else near = sb_exact_near(a, k.first + j, sb_active_index(l, k, q));
         }
       }
       if (near && cnt < (uint32_t)SB_K) mine[cnt] = (uint16_t)q;
@@ -410,20 +404,19 @@ __device__ __forceinline__ void sb_search(const SbArgs& a, const SbLds& l, const
 __device__ __forceinline__ uint32_t sb_state_of(const SbArgs& a, const SbLds& l, const SbBlock& k, uint32_t q, bool poll) {
   uint32_t s = sb_lds_state(l.st, q);
   if (poll && s == SB_U && q >= k.n_own) {
-    const uint32_t gi = sb_active_index(a, l, k, q);
+    const uint32_t gi = sb_active_index(l, k, q);
     s = (sb_load_word(a.st2 + (gi >> 4)) >> ((gi & 15u) * 2u)) & 3u;
     if (s != SB_U) sb_lds_set(l.st, q, s);
   }
   return s;
 }
 
-template <bool WIDE, int THREADS>
-__global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
-  constexpr uint32_t NW = THREADS / 64;  // wavefronts of the workgroup: 1 (a block of ~50 points per wavefront, no barrier ever waits) or 4
+template <bool WIDE>
+__global__ __launch_bounds__(SB_THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
   extern __shared__ __align__(16) unsigned char sb_smem[];
-  const SbLds l = sb_carve(sb_smem, a);
+  const SbLds l = sb_carve(sb_smem, a.own_cap, a.halo_cap);
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t nb_per_node = 1u << (3u * a.cl - a.nb);
+  const uint32_t nb_per_node = 1u << (3u * (a.cl - 3u));
   const uint32_t gmax = 1u << (a.cl - 1u);
   const uint64_t gran_per_node = 1ull << (3u * (a.cl - 1u));
   uint32_t* words = a.ctr + SB_NC * SB_CTR_STRIDE;
@@ -463,28 +456,23 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
       l.misc[SBM_FIRST] = SB_NONE;
       l.misc[SBM_NOWN] = 0;
     }
-    for (uint32_t i = tid; i < a.nrows; i += THREADS) l.occ[i] = 0u;
+    if (tid < 128u) l.occ[tid] = 0u;
     __syncthreads();
     SB_T(0);
     const uint32_t sn = l.misc[SBM_SN], b = l.misc[SBM_B];
     if (sn == SB_NONE) break;
 
-    // ---- the granules of the block and around it: their runs.  The block's Morton code has its low nb bits clear, so its
-    // origin follows from the code like any cell's coordinates.
-    const uint32_t bcode = b << a.nb;
-    SbBlock k;
-    k.ox = contract_bits_by_3_u32(bcode >> 2);
-    k.oy = contract_bits_by_3_u32(bcode >> 1);
-    k.oz = contract_bits_by_3_u32(bcode);
+    // ---- the granules of the block (4 x 4 x 4) and around it (6 x 6 x 6): their runs
+    const uint32_t bx = contract_bits_by_3_u32(b >> 2), by = contract_bits_by_3_u32(b >> 1), bz = contract_bits_by_3_u32(b);
     const uint2* gt = a.gtab + (uint64_t)sn * gran_per_node;
-    for (uint32_t r = tid; r < a.nrg; r += THREADS) {
-      const uint32_t grx = r % a.ggx, gry = (r / a.ggx) % a.ggy, grz = r / (a.ggx * a.ggy);
-      const int gx = (int)((k.ox >> 1) + grx) - 1, gy = (int)((k.oy >> 1) + gry) - 1, gz = (int)((k.oz >> 1) + grz) - 1;
-      const bool inner = grx - 1u < (a.bx >> 1) && gry - 1u < (a.by >> 1) && grz - 1u < (a.bz >> 1);
-      uint32_t own_cnt = 0, halo_cnt = 0, run_first = 0;
+    uint32_t own_cnt = 0, halo_cnt = 0, run_first = 0;
+    if (tid < 216u) {
+      const uint32_t rx = tid % 6u, ry = (tid / 6u) % 6u, rz = tid / 36u;
+      const int gx = (int)(bx * 4u + rx) - 1, gy = (int)(by * 4u + ry) - 1, gz = (int)(bz * 4u + rz) - 1;
+      const bool inner = rx - 1u < 4u && ry - 1u < 4u && rz - 1u < 4u;
       if (gx >= 0 && gy >= 0 && gz >= 0 && gx < (int)gmax && gy < (int)gmax && gz < (int)gmax) {
         const uint32_t code = (sb_expand3((uint32_t)gx) << 2) | (sb_expand3((uint32_t)gy) << 1) | sb_expand3((uint32_t)gz);
-        if (inner || code < (bcode >> 3)) {  // around the block: only granules EARLIER in Morton order can hold earlier points
+        if (inner || code < (b << 6)) {  // around the block: only granules EARLIER in Morton order can hold earlier points
           const uint2 e = gt[code];
           if (e.y) {
             run_first = e.x;
@@ -496,31 +484,22 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
         atomicMin(&l.misc[SBM_FIRST], run_first);
         atomicAdd(&l.misc[SBM_NOWN], own_cnt);
       }
-      l.sfirst[r] = run_first;
-      l.soff[r] = min(halo_cnt, 0xFFFFFu);
+      l.sfirst[tid] = run_first;
     }
-    __syncthreads();
+    uint32_t n_halo = 0;
+    const uint32_t halo_off = block_excl_sum<SB_THREADS>(min(halo_cnt, 0xFFFFFu), l.scan, n_halo);
+    SbBlock k;
     k.n_own = l.misc[SBM_NOWN];
     k.first = l.misc[SBM_FIRST];
+    k.bx8 = bx * 8u;
+    k.by8 = by * 8u;
+    k.bz8 = bz * 8u;
     const uint32_t n_own = k.n_own;
-    if (n_own == 0) {  // (uniform: every thread reads the same word)
+    if (n_own == 0) {  // (uniform: every thread has the same totals)
       __syncthreads();
       continue;
     }
-    // where each halo run starts among the staged points: an exclusive scan of the counts, by the first wavefront
-    if (wave == 0) {
-      uint32_t carry = n_own;
-      for (uint32_t c0 = 0; c0 < a.nrg; c0 += 64u) {
-        const uint32_t v = c0 + lane < a.nrg ? l.soff[c0 + lane] : 0u;
-        const uint32_t incl = wave_incl_sum(v);
-        if (c0 + lane < a.nrg) l.soff[c0 + lane] = carry + incl - v;
-        carry += (uint32_t)__shfl((int)incl, 63, WAVE);
-      }
-      if (lane == 0) l.soff[a.nrg] = carry;
-    }
-    __syncthreads();
-    const uint32_t total = l.soff[a.nrg];
-    const uint32_t n_halo = total - n_own;
+    const uint32_t total = n_own + n_halo;
     if (n_own > a.own_cap || n_halo > a.halo_cap) {
       if (tid == 0) {
         __hip_atomic_fetch_max(words + SBW_MAX_OWN, n_own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -529,24 +508,29 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
       }
       break;
     }
+    if (tid < 216u) l.soff[tid] = n_own + halo_off;
+    if (tid == 216u) l.soff[216] = total;
     const uint32_t w0 = k.first >> 4;                                  // first word of st2 the block's points touch
     const uint32_t nw = ((k.first + n_own - 1u) >> 4) - w0 + 1u;       // ... and how many
-    for (uint32_t w = tid; w < nw; w += THREADS) l.pub[w] = 0u;
+    for (uint32_t w = tid; w < nw; w += SB_THREADS) l.pub[w] = 0u;
+    __syncthreads();
     SB_T(1);
 
-    // ---- stage the points: key coordinates, region cell, state.  Three loads of a thread in flight together (all at once:
+    // ---- stage the points: key coordinates, region cell, state.  Three loads of a thread in flight together (all six:
     // 30 registers more, a wavefront per SIMD less).
 #pragma unroll 1
-    for (uint32_t j0 = 0; j0 < total; j0 += 3u * THREADS) {
+    for (uint32_t half = 0; half < (uint32_t)SB_PMAX; half += 3u) {
+      if (half * SB_THREADS >= total) break;
       uint32_t gi[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        const uint32_t j = j0 + tid + (uint32_t)p * THREADS;
+        const uint32_t j = tid + (half + (uint32_t)p) * SB_THREADS;
         gi[p] = SB_NONE;
         if (j < n_own) {
           gi[p] = k.first + j;  // the block is one run of the sorted keys
         } else if (j < total) {
-          const uint32_t lo = sb_halo_slot(a, l, j);
+          // the halo run that holds staged point j: soff ascends, [216] = total (branch-free: eight steps for every lane)
+          const uint32_t lo = sb_halo_slot(l, j);
           gi[p] = l.sfirst[lo] + (j - l.soff[lo]);
         }
       }
@@ -554,7 +538,7 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
       uint32_t sw[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        const uint32_t j = j0 + tid + (uint32_t)p * THREADS;
+        const uint32_t j = tid + (half + (uint32_t)p) * SB_THREADS;
         key[p] = 0;
         sw[p] = 0;
         if (gi[p] != SB_NONE) {
@@ -564,7 +548,7 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
-        const uint32_t j = j0 + tid + (uint32_t)p * THREADS;
+        const uint32_t j = tid + (half + (uint32_t)p) * SB_THREADS;
         if (gi[p] == SB_NONE) continue;
         uint32_t x, y, z, cell;
         key_coords_u32(key[p], x, y, z);
@@ -577,13 +561,13 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
     __syncthreads();
     SB_T(2);
     // ---- the cell index of the region: a cell's points are one run of the staged points
-    for (uint32_t j = tid; j < total; j += THREADS) {
+    for (uint32_t j = tid; j < total; j += SB_THREADS) {
       const uint32_t r = rc[j];
       if (r == SB_CELL_NONE) continue;
-      uint16_t* e = reinterpret_cast<uint16_t*>(l.cse + sb_cell_index(a, r));
+      uint16_t* e = reinterpret_cast<uint16_t*>(l.cse + sb_cell_index(r));
       if (j == 0 || rc[j - 1] != r) {
         e[0] = (uint16_t)j;
-        atomicOr(&l.occ[(r >> 8) * a.ry + ((r >> 4) & 15u)], 1u << (r & 15u));
+        atomicOr(&l.occ[(r >> 8) * 10u + ((r >> 4) & 15u)], 1u << (r & 15u));
       }
       if (j + 1 == total || rc[j + 1] != r) e[1] = (uint16_t)(j + 1);
     }
@@ -592,7 +576,7 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
 
     // ---- from here on every wavefront works on its own share of the block's points -- whole words of the state array --
     // without a barrier: search, decisions, publication.  Other wavefronts' decisions are read from the LDS states.
-    const uint32_t wa = wave * nw / NW, wb = (wave + 1u) * nw / NW;
+    const uint32_t wa = wave * nw / 4u, wb = (wave + 1u) * nw / 4u;
     const uint32_t ja = max(k.first, (w0 + wa) << 4) - k.first;
     const uint32_t jb = wa < wb ? min(k.first + n_own, (w0 + wb) << 4) - k.first : ja;
     // search: the undecided earlier neighbours of every own point.  Pairs inside the quantisation band are put aside: their
@@ -612,7 +596,7 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
       const uint32_t np = min(pend[SB_PEND], (uint32_t)SB_PEND);
       for (uint32_t i = lane; i < np; i += 64u) {
         const uint32_t j = pend[i] >> 16, q = pend[i] & 0xFFFFu;
-        if (!sb_exact_near(a, k.first + j, sb_active_index(a, l, k, q))) continue;
+        if (!sb_exact_near(a, k.first + j, sb_active_index(l, k, q))) continue;
         // one more neighbour of j: a byte of a counter word, bumped atomically
         const uint32_t slot = (atomicAdd(&l.cnt4[j >> 2], 1u << (8u * (j & 3u))) >> (8u * (j & 3u))) & 0xFFu;
         if (slot < (uint32_t)SB_K) l.nbr[(size_t)j * SB_K + slot] = (uint16_t)q;
@@ -691,7 +675,9 @@ __global__ __launch_bounds__(THREADS, SB_MINW) void sb_block_kernel(SbArgs a) {
         for (int i = 0; i < SB_K; ++i) {
           q[i] = (uint32_t)(n4 >> (16 * i)) & 0xFFFFu;
           const bool used = (uint32_t)i < c4;
-          const bool here = used && q[i] >= base && q[i] < min(base + 64u, jb);  // (points of this round only -- the halo is staged right behind the own points)
+          // (points of THIS round only: the halo is staged right behind the own points, and a halo index below base + 64, read
+          // from a lane that holds no point, once looked rejected -- 17 wrong decisions in 400 000, found with smaller blocks)
+          const bool here = used && q[i] >= base && q[i] < min(base + 64u, jb);
           inround |= here ? 1u << i : 0u;
           st[i] = used && !here ? sb_lds_state(l.st, q[i]) : (uint32_t)SB_R;
         }
@@ -858,10 +844,7 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
     if (atoi(e) == 0) return SWZ_OK;
   if (!km.ok || !sp.xyz || !sp.perm || sp.ghosts) return SWZ_OK;
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
-  // Cells: as fine as the spacing allows while 8^3 of them still hold 128 points.  The block: 64 threads (ONE wavefront: no
-  // barrier ever waits for a sibling -- with four wavefronts per block a third of a block's time was spent waiting for the
-  // slowest one, EXPERIMENTS.md R6.1) and the smallest aligned box of 4 x 4 x 4 .. 8 x 8 x 8 cells that holds ~40 points;
-  // SWZ_SP_BLOCK_THREADS=256 keeps the block of 8^3 cells with four wavefronts.
+  // cells: as fine as the spacing allows while a block of 8^3 of them still holds a workgroup's worth of points
   int cl = plan.cell_levels_geo;
   double min_block = 128.0;
   if (const char* e = c->opt("SWZ_SP_BLOCK_MIN")) min_block = atof(e);
@@ -872,32 +855,19 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   const uint64_t gran_per_node = 1ull << (3 * (cl - 1));
   const uint64_t entries = (uint64_t)sample_nodes * gran_per_node;
   if (entries > (1ull << 30)) return SWZ_OK;  // 8 GB of table
-  const double per512 = per_block(cl);  // points per OCCUPIED box of 8^3 cells
-  int threads = 64;
-  if (const char* e = c->opt("SWZ_SP_BLOCK_THREADS")) threads = atoi(e) == 256 ? 256 : 64;
-  uint32_t nb = 9;
-  if (threads == 64) {
-    double want = 40.0;
-    if (const char* e = c->opt("SWZ_SP_BLOCK_WANT")) want = atof(e);
-    nb = 6;
-    while (nb < 9u && per512 * std::ldexp(1.0, (int)nb - 9) < want) ++nb;
-  }
-  if (const char* e = c->opt("SWZ_SP_BLOCK_BITS")) nb = (uint32_t)std::min(9, std::max(6, atoi(e)));
-  if ((uint32_t)(3 * cl) < nb) return SWZ_OK;
-  const uint32_t bz = 1u << ((nb + 2u) / 3u), by = 1u << ((nb + 1u) / 3u), bx = 1u << (nb / 3u);
-  const uint32_t ggx = bx / 2u + 2u, ggy = by / 2u + 2u, ggz = bz / 2u + 2u;
-  const uint32_t nrg = ggx * ggy * ggz, own_granules = (bx / 2u) * (by / 2u) * (bz / 2u);
-  // LDS capacity from the expected population (an estimate: blocks that do not fit make the level fall back).  Uniform data: a
-  // block's population is Poisson; its halo's -- the earlier half of the granules around it, whole granules -- likewise.
-  const double expect = per512 * std::ldexp(1.0, (int)nb - 9);
-  const double expect_halo = expect / own_granules * (nrg - own_granules) * 0.5;
-  uint32_t own_cap = (uint32_t)std::max(64.0, 16.0 * std::ceil((expect + 8.0 * std::sqrt(expect) + 16.0) / 16.0));
-  uint32_t halo_cap = (uint32_t)(16.0 * std::ceil((1.05 * expect_halo + 10.0 * std::sqrt(expect_halo) + 32.0) / 16.0));
+  // LDS capacity from the expected population (an estimate: blocks that do not fit make the level fall back)
+  const double expect = per_block(cl);
+  // (uniform data: a block's population is Poisson -- 416 +- 20 at level 2 of the 1 B run --, its halo's, counted in whole
+  // granules, about 1.2 times that)
+  uint32_t own_cap = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + 8.0 * std::sqrt(expect) + 32.0) / 32.0));
+  uint32_t halo_cap = (uint32_t)(32.0 * std::ceil((1.25 * expect + 10.0 * std::sqrt(1.25 * expect) + 64.0) / 32.0));
   if (const char* e = c->opt("SWZ_SP_BLOCK_OWN")) own_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
   if (const char* e = c->opt("SWZ_SP_BLOCK_HALO")) halo_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
-  if (own_cap + halo_cap > 60000u) return SWZ_OK;  // (LDS indices are 16 bits)
-  const uint32_t rx = bx + 2u, ry = by + 2u, rz = bz + 2u;
-  const size_t lds = sb_lds_bytes(own_cap, halo_cap, rx * ry * rz, ry * rz, nrg, (uint32_t)threads / 64u);
+  if (own_cap + halo_cap > (uint32_t)(SB_THREADS * SB_PMAX)) {  // what a workgroup stages at once
+    if (own_cap >= (uint32_t)(SB_THREADS * SB_PMAX) / 2u) return SWZ_OK;
+    halo_cap = (uint32_t)(SB_THREADS * SB_PMAX) - own_cap;
+  }
+  const size_t lds = sb_lds_bytes(own_cap, halo_cap);
   if (lds > 160u * 1024u) return SWZ_OK;
 
   SbTabArgs t{};
@@ -936,18 +906,6 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   SWZ_TRY(c->get("sb_counters", (size_t)(SB_NC * SB_CTR_STRIDE + SBW_COUNT), &a.ctr));
   a.own_cap = own_cap;
   a.halo_cap = halo_cap;
-  a.nb = nb;
-  a.bx = bx;
-  a.by = by;
-  a.bz = bz;
-  a.rx = rx;
-  a.ry = ry;
-  a.rxy = rx * ry;
-  a.rcells = rx * ry * rz;
-  a.nrows = ry * rz;
-  a.ggx = ggx;
-  a.ggy = ggy;
-  a.nrg = nrg;
   double timeout_s = 10.0;
   if (const char* e = c->opt("SWZ_SP_BLOCK_TIMEOUT_MS")) timeout_s = atof(e) * 1e-3;
   a.timeout_ticks = (uint64_t)(timeout_s * 1e8);
@@ -959,19 +917,16 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   SWZ_HIP(c, hipMemsetAsync(a.ctr, 0, (size_t)(SB_NC * SB_CTR_STRIDE + SBW_COUNT) * sizeof(uint32_t), c->stream));
   hipLaunchKernelGGL(sb_table_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, t);
   SWZ_LAUNCH_CHECK(c);
+  // (every time: the attribute belongs to the function on the CURRENT device, and a process may drive several)
   bool wide = a.cell_bits > 12u;  // a region of ten cells must fit sixteen bits
   if (const char* e = c->opt("SWZ_SP_BLOCK_WIDE")) wide = wide || atoi(e) != 0;
-  const void* fn = threads == 64 ? (wide ? (const void*)sb_block_kernel<true, 64> : (const void*)sb_block_kernel<false, 64>)
-                                 : (wide ? (const void*)sb_block_kernel<true, 256> : (const void*)sb_block_kernel<false, 256>);
-  // (every time: the attribute belongs to the function on the CURRENT device, and a process may drive several)
-  SWZ_HIP(c, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  SWZ_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(wide ? sb_block_kernel<true> : sb_block_kernel<false>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-  // workgroups per CU: what the LDS holds, at most SB_MINW wavefronts per SIMD (the registers the kernel is compiled for)
-  const uint32_t wg_regs = (uint32_t)(SB_MINW * 4 * 64 / threads);
-  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(wg_regs, (160u * 1024u) / lds));
+  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / lds));
   if (const char* e = c->opt("SWZ_SP_BLOCK_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
-  const uint64_t blocks_total = (uint64_t)sample_nodes << (3 * cl - (int)nb);
+  const uint64_t blocks_total = (uint64_t)sample_nodes << (3 * (cl - 3));
   const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)cus * per_cu, std::max<uint64_t>(1, blocks_total));
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (dbg) {
@@ -979,13 +934,10 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
     ev1 = c->take_event();
     (void)hipEventRecord(ev0, c->stream);
   }
-  if (threads == 64) {
-    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(sb_block_kernel<true, 64>), dim3(grid), dim3(64), lds, c->stream, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sb_block_kernel<false, 64>), dim3(grid), dim3(64), lds, c->stream, a);
-  } else {
-    if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(sb_block_kernel<true, 256>), dim3(grid), dim3(256), lds, c->stream, a);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(sb_block_kernel<false, 256>), dim3(grid), dim3(256), lds, c->stream, a);
-  }
+  if (wide)
+    hipLaunchKernelGGL(sb_block_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, c->stream, a);
+  else
+    hipLaunchKernelGGL(sb_block_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, c->stream, a);
   SWZ_LAUNCH_CHECK(c);
   if (dbg) (void)hipEventRecord(ev1, c->stream);
   uint32_t h[SBW_COUNT] = {0};
@@ -996,9 +948,9 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     c->event_pool.insert(c->event_pool.end(), {ev0, ev1});
     fprintf(stderr,
-            "[swz] MIN_DISTANCE level %d block path: %u pts in %u nodes, cell_levels %d (geo %d), blocks of %u x %u x %u cells, %d threads, %.0f pts/block, caps %u / %u, LDS %zu B, grid %u, "
+            "[swz] MIN_DISTANCE level %d block path: %u pts in %u nodes, cell_levels %d (geo %d), %.0f pts/block, caps %u / %u, LDS %zu B, grid %u, "
             "%u blocks, %u search steps, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
-            plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, bx, by, bz, threads, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS], h[SBW_STEPS], h[SBW_ITER],
+            plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS], h[SBW_STEPS], h[SBW_ITER],
             h[SBW_WAITS], h[SBW_RESEARCH], h[SBW_ABORT], h[SBW_MAX_OWN], h[SBW_MAX_HALO], ms);
   }
 #ifdef SWZ_SB_STATS

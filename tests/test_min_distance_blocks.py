@@ -47,11 +47,6 @@ VARIANTS = {
     "default": {},
     "thread-per-point path": {"SWZ_SP_BLOCK": "0"},
     "wide points": {"SWZ_SP_BLOCK_WIDE": "1"},
-    "four wavefronts per block of 8 x 8 x 8 cells": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_THREADS": "256"},
-    "blocks of 4 x 4 x 4 cells": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_BITS": "6"},
-    "blocks of 4 x 4 x 8 cells": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_BITS": "7"},
-    "blocks of 4 x 8 x 8 cells, wide": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_BITS": "8", "SWZ_SP_BLOCK_WIDE": "1"},
-    "one wavefront per block of 8 x 8 x 8 cells": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_BITS": "9"},
     "every level": {"SWZ_MD_SPARSE_LIMIT": "1000"},
     "every level, wide": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_WIDE": "1"},
     "coarse cells": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_CL": "4"},
