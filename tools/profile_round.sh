@@ -36,7 +36,7 @@ if [[ $PARTS == *lines* ]]; then
 fi
 if [[ $PARTS == *fullsize* ]]; then
   rm -f $GRAFT_REPO_ROOT/gpurun_out/fullsize_verification.log
-  timeout 1500 python -m pytest tests/test_gpu_fullsize.py -q > $OUT/fullsize_pytest.txt 2>&1
+  timeout 2400 python -m pytest tests/test_gpu_fullsize.py tests/test_min_distance_property.py::test_property_mode_full_size -q > $OUT/fullsize_pytest.txt 2>&1
   cp $GRAFT_REPO_ROOT/gpurun_out/fullsize_verification.log $OUT/fullsize_verification_1B.log 2>/dev/null
   tail -3 $OUT/fullsize_pytest.txt
 fi
