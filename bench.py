@@ -294,13 +294,22 @@ def library_source_sha16():
     return h.hexdigest()[:16]
 
 
+def profile_rounds():
+    """profiles/rNN, newest first"""
+    try:
+        names = [d for d in os.listdir(os.path.join(ROOT, "profiles")) if len(d) == 3 and d[0] == "r" and d[1:].isdigit()]
+    except OSError:
+        return []
+    return sorted(names, reverse=True)
+
+
 def measured_traffic(kernel_class, n, sampler, table="bytes_per_launch"):
     """HBM bytes per launch of the dominant kernel class from the committed rocprofv3 PMC passes
     (profiles/rNN/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this very
     command, corrected as MI355X_MICROARCH.md prescribes) -- only when that profile was taken on the kernel sources this
     run uses (traffic.json carries their hash).  Returns (bytes or None, where the number comes from / why there is none)."""
     sha = library_source_sha16()
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):  # the newest committed profile of this configuration
+    for rnd in profile_rounds():  # the newest committed profile of this configuration
         path = os.path.join(ROOT, "profiles", rnd, "traffic.json")
         try:
             t = json.load(open(path))
@@ -317,7 +326,7 @@ def measured_traffic(kernel_class, n, sampler, table="bytes_per_launch"):
 
 def committed_cpu_baseline():
     """N > 1 lines carry no CPU timing of their own (rank 0 at N = 1 measures it): the newest committed N = 1 line's."""
-    for rnd in ("r05", "r04", "r03"):
+    for rnd in profile_rounds():
         path = os.path.join(ROOT, "profiles", rnd, "bench_1B_min_distance.json")
         try:
             cb = json.load(open(path)).get("cpu_baseline")

@@ -37,6 +37,10 @@ struct ActiveSet {
   // SamplingBehaviour::AlwaysAdhereToMinSpacing (tile_internal_node, TilingAlgorithms.cpp:272-275).
   const uint64_t* ckey = nullptr;
   uint32_t nc = 0;
+  // ... and where they sit among the active points: aidx values in [old_lo, old_hi) are pulled entries.  The entries of a
+  // file that holds more than max_points were the OUTPUT of this sampler at this spacing, so they are pairwise at least
+  // one spacing apart, and MIN_DISTANCE only has to look at what the new points can change (swz_mdblock.hip).
+  uint32_t old_lo = 0, old_hi = 0;
   // the nodes of the level above (LevelResult::node_prefix of the step whose survivors these are), when the caller has
   // them: every node of this level is a child of one of them, so its first point is found by searching the sorted keys
   // instead of by a scan over all points (level_step; null: scan)
@@ -199,13 +203,14 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
 // Thread-per-point variant for sparse levels (swz_mdsparse.hip); *used = false when the level does not
 // qualify.  snode_of: node -> index among the sampled nodes; occupied[cl]: occupied cells at cell level cl.
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
-                              const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes,
-                              uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used);
+                              const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t num_nodes,
+                              uint32_t sample_nodes, uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out,
+                              bool* used);
 
 // The same set by blocks of 8^3 cells staged in LDS, blocks in Morton order, decisions in the same launch
 // (swz_mdblock.hip, round 6); *done = false: the level does not qualify or a block did not fit, nothing is lost.
 int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
-                             const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes, uint32_t sample_points,
-                             const uint32_t occupied[12], const KeyMetric& km, bool* done);
+                             const uint32_t* snode_of, bool all_sampled, uint32_t num_nodes, uint32_t sample_nodes,
+                             uint32_t sample_points, const uint32_t occupied[12], const KeyMetric& km, bool* done);
 
 }  // namespace swz

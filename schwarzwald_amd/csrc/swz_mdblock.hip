@@ -35,6 +35,7 @@
 #include <cstdlib>
 
 #include "swz_level.h"
+#include "swz_scan.h"
 
 namespace swz {
 
@@ -812,6 +813,7 @@ struct SbTabArgs {
   const uint32_t* nid;
   const uint8_t* nmode;
   const uint32_t* snode_of;
+  const uint32_t* sn_direct;  // the sampled node of every point (a compacted subset: nid / nmode / snode_of are not looked at)
   uint32_t all_sampled;
   uint32_t m;
   uint32_t gran_shift;       // key >> gran_shift = node prefix + granule code
@@ -819,9 +821,14 @@ struct SbTabArgs {
   uint2* gtab;
 };
 __device__ __forceinline__ uint64_t sb_granule_of(const SbTabArgs& t, uint32_t i) {  // ~0: the point's node is not sampled
-  const uint32_t node = t.nid[i];
-  if (!t.all_sampled && t.nmode[node] != MODE_SAMPLE) return ~0ull;
-  const uint32_t sn = t.all_sampled ? node : t.snode_of[node];
+  uint32_t sn;
+  if (t.sn_direct) {
+    sn = t.sn_direct[i];
+  } else {
+    const uint32_t node = t.nid[i];
+    if (!t.all_sampled && t.nmode[node] != MODE_SAMPLE) return ~0ull;
+    sn = t.all_sampled ? node : t.snode_of[node];
+  }
   return (uint64_t)sn * t.gran_per_node + ((t.akey[i] >> t.gran_shift) & (t.gran_per_node - 1ull));
 }
 __global__ __launch_bounds__(256) void sb_table_kernel(SbTabArgs t) {
@@ -835,20 +842,29 @@ __global__ __launch_bounds__(256) void sb_table_kernel(SbTabArgs t) {
   if (tail) t.gtab[g].y = i + 1u;
 }
 
-// *done = false: the level does not qualify or a block did not fit -- the caller goes on with the thread-per-point path.
-int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
-                             const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes, uint32_t sample_points,
-                             const uint32_t occupied[12], const KeyMetric& km, bool* done) {
+// What one run of the block kernel works on: the level's active points, or the subset of them that new points can change.
+struct SbInput {
+  const uint64_t* akey = nullptr;
+  uint32_t m = 0;
+  const uint32_t* aidx = nullptr;       // sorted position -> working index (null: identity)
+  const uint32_t* sn_direct = nullptr;  // see SbTabArgs
+  uint8_t* taken = nullptr;             // m bytes, cleared
+  uint32_t points = 0;                  // of sampled nodes
+  const uint32_t* occupied = nullptr;   // [12]: occupied cells per cell level
+  double spread = 1.0;                  // how much wider than Poisson a block's population scatters around the mean
+  const char* what = "";
+};
+
+// *done = false: the level does not qualify or a block did not fit -- the caller goes on with another path.
+static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, const LevelBuffers& lb, const uint32_t* snode_of,
+                  bool all_sampled, uint32_t sample_nodes, const KeyMetric& km, const SbInput& in, bool* done) {
   *done = false;
-  if (const char* e = c->opt("SWZ_SP_BLOCK"))
-    if (atoi(e) == 0) return SWZ_OK;
-  if (!km.ok || !sp.xyz || !sp.perm || sp.ghosts) return SWZ_OK;
   const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
   // cells: as fine as the spacing allows while a block of 8^3 of them still holds a workgroup's worth of points
   int cl = plan.cell_levels_geo;
   double min_block = 128.0;
   if (const char* e = c->opt("SWZ_SP_BLOCK_MIN")) min_block = atof(e);
-  auto per_block = [&](int l) { return (double)sample_points / (double)std::max(1u, occupied[std::max(0, l - 3)]); };
+  auto per_block = [&](int l) { return (double)in.points / (double)std::max(1u, in.occupied[std::max(0, l - 3)]); };
   while (cl > 3 && per_block(cl) < min_block) --cl;
   if (const char* e = c->opt("SWZ_SP_BLOCK_CL")) cl = std::min(plan.cell_levels_geo, atoi(e));
   if (cl < 3 || cl > 10) return SWZ_OK;
@@ -859,8 +875,9 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   const double expect = per_block(cl);
   // (uniform data: a block's population is Poisson -- 416 +- 20 at level 2 of the 1 B run --, its halo's, counted in whole
   // granules, about 1.2 times that)
-  uint32_t own_cap = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + 8.0 * std::sqrt(expect) + 32.0) / 32.0));
-  uint32_t halo_cap = (uint32_t)(32.0 * std::ceil((1.25 * expect + 10.0 * std::sqrt(1.25 * expect) + 64.0) / 32.0));
+  const double dev = std::sqrt(expect * in.spread);
+  uint32_t own_cap = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + 8.0 * dev + 32.0) / 32.0));
+  uint32_t halo_cap = (uint32_t)(32.0 * std::ceil((1.25 * expect + 10.0 * std::sqrt(1.25) * dev + 64.0) / 32.0));
   if (const char* e = c->opt("SWZ_SP_BLOCK_OWN")) own_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
   if (const char* e = c->opt("SWZ_SP_BLOCK_HALO")) halo_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
   if (own_cap + halo_cap > (uint32_t)(SB_THREADS * SB_PMAX)) {  // what a workgroup stages at once
@@ -871,23 +888,24 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   if (lds > 160u * 1024u) return SWZ_OK;
 
   SbTabArgs t{};
-  t.akey = as.akey;
+  t.akey = in.akey;
   t.nid = lb.nid;
   t.nmode = lb.nmode;
   t.snode_of = snode_of;
+  t.sn_direct = in.sn_direct;
   t.all_sampled = all_sampled ? 1u : 0u;
-  t.m = as.m;
+  t.m = in.m;
   const uint32_t node_shift = plan.node_shift == 63u ? 63u : plan.node_shift;
   t.gran_shift = node_shift - 3u * (uint32_t)(cl - 1);
   t.gran_per_node = gran_per_node;
   SWZ_TRY(c->get("sb_gtab", (size_t)entries, &t.gtab));
   SbArgs a{};
-  a.akey = as.akey;
-  a.m = as.m;
+  a.akey = in.akey;
+  a.m = in.m;
   a.gtab = t.gtab;
-  SWZ_TRY(c->get("sb_state", (size_t)as.m / 16 + 2, &a.st2));
-  a.taken = lb.taken;
-  a.aidx = as.aidx;
+  SWZ_TRY(c->get("sb_state", (size_t)in.m / 16 + 2, &a.st2));
+  a.taken = in.taken;
+  a.aidx = in.aidx;
   a.perm = sp.perm;
   a.xyz = sp.xyz;
   a.f_lo = km.f_lo;
@@ -911,11 +929,11 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   a.timeout_ticks = (uint64_t)(timeout_s * 1e8);
   if (const char* e = c->opt("SWZ_SP_BLOCK_DBG")) a.dbg = (uint32_t)atoi(e);
 
-  ProfScope ps(c, "sample_min_distance", (uint64_t)sample_points * 33ull, 1);
+  ProfScope ps(c, "sample_min_distance", (uint64_t)in.points * 33ull, 1);
   SWZ_HIP(c, memset_large(t.gtab, 0, (size_t)entries * sizeof(uint2), c->stream));
-  SWZ_HIP(c, hipMemsetAsync(a.st2, 0, ((size_t)as.m / 16 + 2) * sizeof(uint32_t), c->stream));
+  SWZ_HIP(c, hipMemsetAsync(a.st2, 0, ((size_t)in.m / 16 + 2) * sizeof(uint32_t), c->stream));
   SWZ_HIP(c, hipMemsetAsync(a.ctr, 0, (size_t)(SB_NC * SB_CTR_STRIDE + SBW_COUNT) * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(sb_table_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, t);
+  hipLaunchKernelGGL(sb_table_kernel, dim3(div_up(in.m, 256)), dim3(256), 0, c->stream, t);
   SWZ_LAUNCH_CHECK(c);
   // (every time: the attribute belongs to the function on the CURRENT device, and a process may drive several)
   bool wide = a.cell_bits > 12u;  // a region of ten cells must fit sixteen bits
@@ -948,10 +966,10 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
     (void)hipEventElapsedTime(&ms, ev0, ev1);
     c->event_pool.insert(c->event_pool.end(), {ev0, ev1});
     fprintf(stderr,
-            "[swz] MIN_DISTANCE level %d block path: %u pts in %u nodes, cell_levels %d (geo %d), %.0f pts/block, caps %u / %u, LDS %zu B, grid %u, "
-            "%u blocks, %u search steps, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
-            plan.level, sample_points, sample_nodes, cl, plan.cell_levels_geo, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS], h[SBW_STEPS], h[SBW_ITER],
-            h[SBW_WAITS], h[SBW_RESEARCH], h[SBW_ABORT], h[SBW_MAX_OWN], h[SBW_MAX_HALO], ms);
+            "[swz] MIN_DISTANCE level %d block path%s: %u pts in %u nodes, cell_levels %d (geo %d), %.0f pts/block, caps %u / %u, LDS %zu B, "
+            "grid %u, %u blocks, %u search steps, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
+            plan.level, in.what, in.points, sample_nodes, cl, plan.cell_levels_geo, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS],
+            h[SBW_STEPS], h[SBW_ITER], h[SBW_WAITS], h[SBW_RESEARCH], h[SBW_ABORT], h[SBW_MAX_OWN], h[SBW_MAX_HALO], ms);
   }
 #ifdef SWZ_SB_STATS
   if (dbg && h[SBW_BLOCKS])
@@ -964,6 +982,296 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   if (h[SBW_ABORT] != SB_ABORT_NONE) return SWZ_OK;  // a block did not fit: the caller's other paths take the level
   *done = true;
   return SWZ_OK;
+}
+
+// ----------------------------------------------------------------------------- multi-batch tiling: only what new points can change
+// A batch of a multi-batch tiling (swz_tiler.hip) merges its points with the files earlier batches left in the nodes it
+// touches and samples the union (tile_node, TilingAlgorithms.cpp:421-442).  The entries of a file that holds more than
+// max_points points are what THIS sampler accepted at THIS spacing in an earlier batch -- a node takes everything only
+// while it holds no file and at most max_points points (TilingAlgorithms.cpp:272-275, Sampling.h:201-208) --, so any two
+// of them are at least one spacing apart: they never reject one another.  The Morton-order greedy over the union therefore
+// decides an old point o exactly as the greedy over  S = {new points} + {old points within one spacing of a new point}
+// does (o's only possible rejectors are new points; a new point's are new points and old points of S), and old points
+// outside S are accepted.  S is found on the level's finest cells (one spacing wide or more): a new point marks the 27
+// cells around it, an old point belongs to S when its cell is marked.  With 10 M new points per batch on 390 M points of
+// files (level 2 of the 1 B run in 100 batches) S is a quarter of the level, on level 3 a thirtieth.
+// "New" also covers the entries of files with at most max_points points (they may come from a take-all).
+struct SbiArgs {
+  const uint64_t* akey;
+  const uint32_t* aidx;
+  const uint32_t* nid;
+  const uint8_t* nmode;
+  const uint32_t* snode_of;
+  const uint8_t* indep;  // per node: its file's entries are pairwise a spacing apart
+  uint32_t all_sampled;
+  uint32_t m;
+  uint32_t old_lo, old_n;
+  uint32_t cell_shift;   // key >> cell_shift: node prefix + cell code
+  uint32_t cell_mask;    // 8^cl - 1
+  uint32_t cl;
+  uint32_t* bits;        // one per (sampled node, cell)
+  uint8_t* sel;          // per point: 1 = belongs to S
+  uint8_t* taken;
+};
+__global__ __launch_bounds__(256) void sbi_indep_kernel(const uint32_t* __restrict__ nstart, const uint8_t* __restrict__ nmode,
+                                                        uint32_t nnodes, const uint64_t* __restrict__ akey, uint32_t nsh,
+                                                        const uint64_t* __restrict__ ckey, uint32_t nc, uint64_t max_points,
+                                                        uint8_t* __restrict__ indep) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= nnodes) return;
+  uint8_t r = 0;
+  if (nmode[j] == MODE_SAMPLE) {
+    const uint64_t prefix = akey[nstart[j]] >> nsh;
+    uint32_t lo = 0, hi = nc;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if ((ckey[mid] >> nsh) < prefix) lo = mid + 1; else hi = mid;
+    }
+    const uint32_t first = lo;
+    hi = nc;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if ((ckey[mid] >> nsh) <= prefix) lo = mid + 1; else hi = mid;
+    }
+    r = (uint64_t)(lo - first) > max_points ? 1 : 0;
+  }
+  indep[j] = r;
+}
+__device__ __forceinline__ bool sbi_sampled(const SbiArgs& a, uint32_t i, uint32_t* node) {
+  *node = a.nid[i];
+  return a.all_sampled || a.nmode[*node] == MODE_SAMPLE;
+}
+__device__ __forceinline__ bool sbi_is_old(const SbiArgs& a, uint32_t i, uint32_t node) {
+  return a.aidx[i] - a.old_lo < a.old_n && a.indep[node];
+}
+__device__ __forceinline__ uint64_t sbi_cell_base(const SbiArgs& a, uint32_t node) {
+  return (uint64_t)(a.all_sampled ? node : a.snode_of[node]) << (3u * a.cl);
+}
+__global__ __launch_bounds__(256) void sbi_mark_kernel(SbiArgs a) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.m) return;
+  uint32_t node;
+  if (!sbi_sampled(a, i, &node) || sbi_is_old(a, i, node)) return;
+  const uint64_t base = sbi_cell_base(a, node);
+  const uint32_t code = (uint32_t)(a.akey[i] >> a.cell_shift) & a.cell_mask;
+  // the cell's three coordinates stay interleaved: +-1 on one axis is an add / subtract on that axis' bits alone
+  const uint32_t M[3] = {0x09249249u & a.cell_mask, 0x12492492u & a.cell_mask, 0x24924924u & a.cell_mask};
+  uint32_t v[3][3];
+  int n[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const uint32_t x = code & M[d];
+    n[d] = 0;
+    v[d][n[d]++] = x;
+    if (x) v[d][n[d]++] = (x - 1u) & M[d];
+    if (x != M[d]) v[d][n[d]++] = ((x | ~M[d]) + 1u) & M[d];
+  }
+  for (int iz = 0; iz < n[2]; ++iz)
+    for (int iy = 0; iy < n[1]; ++iy)
+      for (int ix = 0; ix < n[0]; ++ix) {
+        const uint64_t bit = base + (v[0][ix] | v[1][iy] | v[2][iz]);
+        const uint32_t b = 1u << (uint32_t)(bit & 31ull);
+        uint32_t* w = a.bits + (bit >> 5);
+        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(w, b);
+      }
+}
+__global__ __launch_bounds__(256) void sbi_select_kernel(SbiArgs a) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.m) return;
+  uint32_t node;
+  uint8_t s = 0;
+  if (sbi_sampled(a, i, &node)) {
+    s = 1;
+    if (sbi_is_old(a, i, node)) {
+      const uint64_t bit = sbi_cell_base(a, node) + ((uint32_t)(a.akey[i] >> a.cell_shift) & a.cell_mask);
+      s = (a.bits[bit >> 5] >> (uint32_t)(bit & 31ull)) & 1u;
+      if (!s) a.taken[i] = 1;  // no new point within a spacing: nothing can reject it
+    }
+  }
+  a.sel[i] = s;
+}
+struct SbiSelF {
+  const uint8_t* sel;
+  __device__ uint32_t operator()(uint32_t i) const { return sel[i]; }
+};
+struct SbiPackG {
+  const uint64_t* akey;
+  const uint32_t* aidx;
+  const uint32_t* nid;
+  const uint32_t* snode_of;
+  uint32_t all_sampled;
+  uint64_t* skey;
+  uint32_t* saidx;
+  uint32_t* ssn;
+  uint32_t* sidx;
+  __device__ void operator()(uint32_t i, uint32_t excl, uint32_t v) const {
+    if (!v) return;
+    skey[excl] = akey[i];
+    saidx[excl] = aidx[i];
+    const uint32_t node = nid[i];
+    ssn[excl] = all_sampled ? node : snode_of[node];
+    sidx[excl] = i;
+  }
+};
+// occupied cells of the subset per cell level (as md_cell_hist_kernel counts them for the whole level): hist[0] counts the
+// firsts of the nodes, hist[b] the points whose first digit below the node prefix that differs from their predecessor's is b
+__global__ __launch_bounds__(256) void sbi_hist_kernel(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ ssn, uint32_t n,
+                                                       uint32_t node_shift, uint32_t cl_geo, uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[12];
+  if (threadIdx.x < 12) h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n) {
+    uint32_t bin = 0xFFu;
+    if (j == 0 || ssn[j - 1] != ssn[j]) {
+      bin = 0;
+    } else if (cl_geo) {
+      const uint64_t diff = ((skey[j] ^ skey[j - 1]) >> (node_shift - 3u * cl_geo)) & ((1ull << (3u * cl_geo)) - 1ull);
+      if (diff) bin = cl_geo - (uint32_t)(63 - __clzll((unsigned long long)diff)) / 3u;  // 1 .. cl_geo
+    }
+    if (bin < 12u) atomicAdd(&h[bin], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 12 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void sbi_scatter_kernel(const uint8_t* __restrict__ staken, const uint32_t* __restrict__ sidx, uint32_t n,
+                                                          uint8_t* __restrict__ taken) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  if (j < n && staken[j]) taken[sidx[j]] = 1;
+}
+
+// *done = false: not worth it (or a block of the subset did not fit): the whole level is sampled as usual.  Old points that
+// no new point can reach are marked taken either way -- they are in the exact result.
+static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+                          const uint32_t* snode_of, bool all_sampled, uint32_t num_nodes, uint32_t sample_nodes, uint32_t sample_points,
+                          const KeyMetric& km, bool* done) {
+  *done = false;
+  const bool dbg = c->opt("SWZ_DEBUG") != nullptr;
+  int cl = std::min(plan.cell_levels_geo, 10);
+  while (cl > 0 && ((uint64_t)sample_nodes << (3 * cl)) > (1ull << 34)) --cl;  // 2 GB of marks at most; coarser cells mark more
+  if (cl < 1) return SWZ_OK;
+  const uint64_t nbits = (uint64_t)sample_nodes << (3 * cl);
+  const size_t words = (size_t)((nbits + 31ull) / 32ull);
+  const uint32_t node_shift = plan.node_shift == 63u ? 63u : plan.node_shift;
+  SbiArgs a{};
+  a.akey = as.akey;
+  a.aidx = as.aidx;
+  a.nid = lb.nid;
+  a.nmode = lb.nmode;
+  a.snode_of = snode_of;
+  a.all_sampled = all_sampled ? 1u : 0u;
+  a.m = as.m;
+  a.old_lo = as.old_lo;
+  a.old_n = as.old_hi - as.old_lo;
+  a.cell_shift = node_shift - 3u * (uint32_t)cl;
+  a.cell_mask = (uint32_t)((1ull << (3 * cl)) - 1ull);
+  a.cl = (uint32_t)cl;
+  a.taken = lb.taken;
+  uint8_t* indep = nullptr;
+  SWZ_TRY(c->get("sbi_indep", (size_t)num_nodes, &indep));
+  SWZ_TRY(c->get("sbi_bits", words, &a.bits));
+  SWZ_TRY(c->get("sbi_sel", (size_t)as.m, &a.sel));
+  a.indep = indep;
+  uint32_t* d_cnt = nullptr;  // [0]: |S|, [1..12]: the subset's cell histogram
+  SWZ_TRY(c->get("sbi_counts", (size_t)16, &d_cnt));
+  uint32_t total = 0;
+  uint32_t* d_partial = nullptr;
+  {
+    ProfScope ps(c, "sample_min_distance", (uint64_t)as.m * 30ull, 1);
+    hipLaunchKernelGGL(sbi_indep_kernel, dim3(div_up(num_nodes, 256)), dim3(256), 0, c->stream, lb.nstart, lb.nmode, num_nodes, as.akey,
+                       node_shift, as.ckey, as.nc, plan.max_points, indep);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_HIP(c, memset_large(a.bits, 0, words * sizeof(uint32_t), c->stream));
+    SWZ_HIP(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(sbi_mark_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, a);
+    SWZ_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(sbi_select_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, a);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(fused_scan_sums(c, SbiSelF{a.sel}, as.m, d_cnt, "sbi", &d_partial));
+    SWZ_HIP(c, hipMemcpyAsync(&total, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  double worth = 0.6;  // of the level's points: above it the subset's own passes cost more than they save
+  if (const char* e = c->opt("SWZ_SP_INCREMENTAL_MAX")) worth = atof(e);
+  if (dbg)
+    fprintf(stderr, "[swz] MIN_DISTANCE level %d: %u of %u points are files of earlier batches, %u of %u can change (marks at cell level %d)\n",
+            plan.level, as.nc, as.m, total, sample_points, cl);
+  if (total == 0) {
+    *done = true;
+    return SWZ_OK;
+  }
+  if ((double)total > worth * (double)sample_points) return SWZ_OK;
+  uint64_t* skey = nullptr;
+  uint32_t *saidx = nullptr, *ssn = nullptr, *sidx = nullptr;
+  uint8_t* staken = nullptr;
+  SWZ_TRY(c->get("sbi_key", (size_t)total, &skey));
+  SWZ_TRY(c->get("sbi_aidx", (size_t)total, &saidx));
+  SWZ_TRY(c->get("sbi_sn", (size_t)total, &ssn));
+  SWZ_TRY(c->get("sbi_idx", (size_t)total, &sidx));
+  SWZ_TRY(c->get("sbi_taken", (size_t)total, &staken));
+  uint32_t hist[12] = {0};
+  {
+    ProfScope ps(c, "sample_min_distance", (uint64_t)as.m * 17ull + (uint64_t)total * 33ull, 1);
+    SWZ_TRY(fused_scan_apply(c, SbiSelF{a.sel}, SbiPackG{as.akey, as.aidx, lb.nid, snode_of, a.all_sampled, skey, saidx, ssn, sidx}, as.m,
+                             d_partial));
+    SWZ_HIP(c, hipMemsetAsync(staken, 0, (size_t)total, c->stream));
+    hipLaunchKernelGGL(sbi_hist_kernel, dim3(div_up(total, 256)), dim3(256), 0, c->stream, skey, ssn, total, node_shift,
+                       (uint32_t)std::min(plan.cell_levels_geo, 11), d_cnt + 1);
+    SWZ_LAUNCH_CHECK(c);
+    SWZ_HIP(c, hipMemcpyAsync(hist, d_cnt + 1, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+  }
+  uint32_t occ[12];
+  for (int l = 0, s = 0; l < 12; ++l) occ[l] = (uint32_t)(s += (int)hist[l]);
+  SbInput in;
+  in.akey = skey;
+  in.m = total;
+  in.aidx = saidx;
+  in.sn_direct = ssn;
+  in.taken = staken;
+  in.points = total;
+  in.occupied = occ;
+  // (what a new point brings into a block it brings at once: itself and the old points of 27 cells)
+  in.spread = 12.0;
+  if (const char* e = c->opt("SWZ_SP_INCREMENTAL_SPREAD")) in.spread = std::max(1.0, atof(e));
+  in.what = " (what the new points can change)";
+  bool ok = false;
+  SWZ_TRY(sb_run(c, plan, sp, lb, snode_of, all_sampled, sample_nodes, km, in, &ok));
+  if (!ok) return SWZ_OK;
+  hipLaunchKernelGGL(sbi_scatter_kernel, dim3(div_up(total, 256)), dim3(256), 0, c->stream, staken, sidx, total, lb.taken);
+  SWZ_LAUNCH_CHECK(c);
+  *done = true;
+  return SWZ_OK;
+}
+
+// *done = false: the level does not qualify or a block did not fit -- the caller goes on with the thread-per-point path.
+int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp, const LevelBuffers& lb,
+                             const uint32_t* snode_of, bool all_sampled, uint32_t num_nodes, uint32_t sample_nodes,
+                             uint32_t sample_points, const uint32_t occupied[12], const KeyMetric& km, bool* done) {
+  *done = false;
+  if (const char* e = c->opt("SWZ_SP_BLOCK"))
+    if (atoi(e) == 0) return SWZ_OK;
+  if (!km.ok || !sp.xyz || !sp.perm || sp.ghosts) return SWZ_OK;
+  if (plan.cell_levels_geo < 3) return SWZ_OK;
+  // a batch on top of the files of earlier ones: when those are most of the level, only what the batch can change
+  bool inc = as.ckey && as.aidx && as.old_hi > as.old_lo;
+  double old_share = 0.5;
+  if (const char* e = c->opt("SWZ_SP_INCREMENTAL")) {
+    if (atof(e) <= 0.0) inc = false;
+    else old_share = std::min(1.0, atof(e));
+  }
+  if (inc && (double)(as.old_hi - as.old_lo) >= old_share * (double)as.m) {
+    SWZ_TRY(sb_incremental(c, plan, as, sp, lb, snode_of, all_sampled, num_nodes, sample_nodes, sample_points, km, done));
+    if (*done) return SWZ_OK;
+  }
+  SbInput in;
+  in.akey = as.akey;
+  in.m = as.m;
+  in.aidx = as.aidx;
+  in.taken = lb.taken;
+  in.points = sample_points;
+  in.occupied = occupied;
+  return sb_run(c, plan, sp, lb, snode_of, all_sampled, sample_nodes, km, in, done);
 }
 
 }  // namespace swz

@@ -572,7 +572,7 @@ int min_distance_property_level(swz_ctx* c, const LevelPlan& plan, const ActiveS
     // dependent rounds there and one thread per point beats one wavefront per (nearly empty) cell -- the exact set
     // has the property a fortiori (swz_mdsparse.hip).
     bool used = false;
-    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, sample_nodes, sample_points, occupied, phases_out, &used));
+    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, nnodes, sample_nodes, sample_points, occupied, phases_out, &used));
     if (used) return SWZ_OK;
     // it may have given up half way (locally dense data): its decisions are those of ANOTHER priority order.  (A level it
     // declined at the door -- two or more points per occupied cell, the same test as in swz_mdsparse.hip -- is untouched.)

@@ -517,8 +517,9 @@ __global__ void sp_zero_kernel(uint32_t* p) { *p = 0; }
 // positions already in active order (X/Y/Z); snode_of already scanned.  Returns SWZ_OK and sets *used
 // to false when the level does not qualify (the caller then runs the frontier sweep).
 int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, const SortedPoints& sp,
-                              const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t sample_nodes,
-                              uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out, bool* used) {
+                              const LevelBuffers& lb, const uint32_t* snode_of, bool all_sampled, uint32_t num_nodes,
+                              uint32_t sample_nodes, uint32_t sample_points, const uint32_t occupied[12], uint32_t* rounds_out,
+                              bool* used) {
   *used = false;
   int cl = plan.cell_levels_geo;
   // the table must stay addressable and affordable: at most 2^31 entries
@@ -536,7 +537,8 @@ int min_distance_sparse_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     // round 6: blocks of cells out of LDS, decisions in the same launch (swz_mdblock.hip); levels it cannot take --
     // no key metric, a block that does not fit its LDS capacity -- go on below as before
     bool done = false;
-    SWZ_TRY(min_distance_block_level(c, plan, as, sp, lb, snode_of, all_sampled, sample_nodes, sample_points, occupied, km, &done));
+    SWZ_TRY(min_distance_block_level(c, plan, as, sp, lb, snode_of, all_sampled, num_nodes, sample_nodes, sample_points, occupied, km,
+                                     &done));
     if (done) {
       if (rounds_out) *rounds_out += 1;
       *used = true;

@@ -1078,7 +1078,7 @@ int min_distance_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as, c
   {
     // sparse levels (about one point per spacing-sized cell or fewer): one thread per point
     bool used = false;
-    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, sample_nodes, sample_points, occupied, rounds_out, &used));
+    SWZ_TRY(min_distance_sparse_level(c, plan, as, sp, lb, snode, sample_nodes == nnodes, nnodes, sample_nodes, sample_points, occupied, rounds_out, &used));
     if (used) return SWZ_OK;
   }
   {

@@ -1013,6 +1013,10 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     ms.m = as.m + nc + ng;
     ms.ckey = sr ? nullptr : ckey;  // a sharded root decides from the global counts
     ms.nc = sr ? 0u : nc;
+    if (!sr && !ng && nc) {
+      ms.old_lo = pull_lo;
+      ms.old_hi = pull_lo + nc;
+    }
   }
   if (ms.m == 0) {  // a shard without new points and without a root file
     res->remaining = 0;

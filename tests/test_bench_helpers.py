@@ -69,3 +69,11 @@ def test_shard_stamps_that_do_not_fit_a_step_are_refused():
     assert bench.check_shard_stamps([{"shard": 0, "exchange_ms": float("nan")}], 10.0) is not None
     assert bench.shard_stamp_error([{"rank": 0, "exchange_ms": 2.0, "levels_ms": 5.0, "root_mode": "joint", "points": 7}], 9.0) is None
     assert bench.shard_stamp_error([{"rank": 0, "exchange_ms": 2.0e9, "root_mode": "joint"}], 9.0) is not None
+
+
+def test_bench_looks_for_the_newest_committed_profile_first():
+    import bench
+    rounds = bench.profile_rounds()
+    assert rounds == sorted(rounds, reverse=True) and all(r[0] == "r" and r[1:].isdigit() for r in rounds)
+    newest = sorted(d for d in os.listdir(os.path.join(bench.ROOT, "profiles")) if d[:1] == "r" and d[1:].isdigit())[-1]
+    assert rounds[0] == newest

@@ -232,6 +232,80 @@ def test_gpu_multibatch_spatially_coherent_batches(ctx, sampler, strategy):
     ctx2.close()
 
 
+INCREMENTAL = {
+    # every level the keys can decide goes to the block path; a batch on top of files samples only what it can change
+    "always": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_INCREMENTAL": "0.001", "SWZ_SP_INCREMENTAL_MAX": "1.0"},
+    "always, subset blocks that do not fit": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_INCREMENTAL": "0.001", "SWZ_SP_INCREMENTAL_MAX": "1.0",
+                                              "SWZ_SP_BLOCK_OWN": "64", "SWZ_SP_BLOCK_HALO": "64"},
+    "default thresholds": {},
+    "never": {"SWZ_SP_INCREMENTAL": "0"},
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(INCREMENTAL))
+@pytest.mark.parametrize("strategy", [O.ACCURATE, O.FAST])
+@pytest.mark.parametrize("clustered", [False, True])
+def test_gpu_multibatch_min_distance_samples_only_what_a_batch_can_change(ctx, name, strategy, clustered):
+    """MIN_DISTANCE on a batch merged with the files of earlier batches (swz_mdblock.hip, sb_incremental): the entries of a
+    file with more than max_points points never reject one another, so only the new points and the old points within a
+    spacing of one are sampled again -- the files must be the oracle's, which samples the whole union (tile_node,
+    TilingAlgorithms.cpp:421-442; the behaviour switch on the cached count :272-275)."""
+    rng = np.random.default_rng(900 + 2 * strategy + clustered)
+    n, k = 400000, 8
+    xyz = _points(rng, n, UNIT, clustered=clustered)
+    if not clustered:
+        # later batches thin out: new points few and far between on top of full files
+        xyz = np.vstack([xyz[:300000], xyz[300000:][np.argsort(rng.random(100000))]])
+    sp = O.spacing_from_diagonal(*UNIT, 128)
+    ex, c = _oracle_files(UNIT, xyz, k, O.MIN_DISTANCE, 1000, sp, strategy, 2)
+    try:
+        for key, v in INCREMENTAL[name].items():
+            ctx.set_option(key, v)
+        g = _gpu_files(ctx, UNIT, xyz, k, O.MIN_DISTANCE, 1000, sp, strategy, 2, staged=False)
+    finally:
+        for key in INCREMENTAL[name]:
+            ctx.set_option(key, None)
+    _compare(g, ex, c)
+
+
+@pytest.mark.gpu
+def test_gpu_multibatch_uneven_batches_on_full_files(ctx):
+    """One big batch fills the files, then many small ones arrive: almost every point of a level is an old one and only the
+    neighbourhoods of the few new points are looked at (the case the subset is for)."""
+    rng = np.random.default_rng(77)
+    n = 600000
+    xyz = _points(rng, n, ODD, clustered=False)
+    sizes = [500000] + [10000] * 10
+    sp = O.spacing_from_diagonal(*ODD, 160)
+    t = O.Tiler(ODD[0], ODD[1], O.MIN_DISTANCE, 2000, sp, max_depth=100, strategy=O.ACCURATE, fast_concurrency=2)
+    off = 0
+    for sz in sizes:
+        assert t.add_batch(xyz[off:off + sz]) == 0
+        off += sz
+    assert t.finalize() == 0
+    ex, c = t.export(), t.counts()
+    t.close()
+    import schwarzwald_amd as swz
+    import torch
+    params = swz.TileParams(sampler=O.MIN_DISTANCE, max_points_per_node=2000, spacing_at_root=sp, max_depth=100, strategy=O.ACCURATE,
+                            fast_concurrency=2)
+    with swz.Tiler(ctx, ODD[0], ODD[1], params) as tl:
+        off = 0
+        for sz in sizes:
+            d = torch.from_numpy(np.ascontiguousarray(xyz[off:off + sz])).cuda()
+            torch.cuda.synchronize()
+            tl.add_batch_device(d.data_ptr(), sz)
+            off += sz
+        tl.finalize()
+        tb = tl.node_table()
+        ns = int(tl.info()["num_stored"])
+        d_ids = torch.empty(ns, dtype=torch.int32, device="cuda")
+        tl.export_device(None, d_ids.data_ptr(), None)
+        assert np.array_equal(tb["count"], ex["count"]) and np.array_equal(tb["key"], ex["key"])
+        assert np.array_equal(d_ids.cpu().numpy().view(np.uint32), ex["ids"])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, 1])
 def test_gpu_fast_finalize_survives_out_of_memory_inside_its_levels(flags):
