@@ -41,6 +41,8 @@ struct ActiveSet {
   // file that holds more than max_points were the OUTPUT of this sampler at this spacing, so they are pairwise at least
   // one spacing apart, and MIN_DISTANCE only has to look at what the new points can change (swz_mdblock.hip).
   uint32_t old_lo = 0, old_hi = 0;
+  const uint64_t* new_key = nullptr;  // the batch's own points before the merge, ascending
+  uint32_t new_m = 0;
   // the nodes of the level above (LevelResult::node_prefix of the step whose survivors these are), when the caller has
   // them: every node of this level is a child of one of them, so its first point is found by searching the sorted keys
   // instead of by a scan over all points (level_step; null: scan)

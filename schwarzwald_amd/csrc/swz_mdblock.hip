@@ -45,7 +45,7 @@ namespace swz {
 constexpr int SB_THREADS = 256;
 constexpr int SB_K = 4;               // undecided earlier neighbours recorded per point (0.73 expected at level 2 of the 1 B run); more: the point searches again
 constexpr int SB_PEND = 63;            // in-band pairs a wavefront puts aside per block (more: compared on the spot)
-constexpr int SB_PMAX = 6;            // staged points per thread: a block and its halo hold at most SB_THREADS * SB_PMAX points
+constexpr int SB_PMAX = 12;           // staged points per thread: a block and its halo hold at most SB_THREADS * SB_PMAX points
 constexpr uint32_t SB_NC = 64;        // ticket counters (one per 128-byte line): nodes sn with sn % SB_NC == k draw from counter k
 constexpr uint32_t SB_CTR_STRIDE = 32;
 constexpr uint32_t SB_NONE = 0xFFFFFFFFu;
@@ -866,27 +866,36 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
   if (const char* e = c->opt("SWZ_SP_BLOCK_MIN")) min_block = atof(e);
   auto per_block = [&](int l) { return (double)in.points / (double)std::max(1u, in.occupied[std::max(0, l - 3)]); };
   while (cl > 3 && per_block(cl) < min_block) --cl;
-  if (const char* e = c->opt("SWZ_SP_BLOCK_CL")) cl = std::min(plan.cell_levels_geo, atoi(e));
-  if (cl < 3 || cl > 10) return SWZ_OK;
-  const uint64_t gran_per_node = 1ull << (3 * (cl - 1));
-  const uint64_t entries = (uint64_t)sample_nodes * gran_per_node;
-  if (entries > (1ull << 30)) return SWZ_OK;  // 8 GB of table
-  // LDS capacity from the expected population (an estimate: blocks that do not fit make the level fall back)
-  const double expect = per_block(cl);
-  // (uniform data: a block's population is Poisson -- 416 +- 20 at level 2 of the 1 B run --, its halo's, counted in whole
-  // granules, about 1.2 times that)
-  const double dev = std::sqrt(expect * in.spread);
-  uint32_t own_cap = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + 8.0 * dev + 32.0) / 32.0));
-  uint32_t halo_cap = (uint32_t)(32.0 * std::ceil((1.25 * expect + 10.0 * std::sqrt(1.25) * dev + 64.0) / 32.0));
-  if (const char* e = c->opt("SWZ_SP_BLOCK_OWN")) own_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
-  if (const char* e = c->opt("SWZ_SP_BLOCK_HALO")) halo_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
-  if (own_cap + halo_cap > (uint32_t)(SB_THREADS * SB_PMAX)) {  // what a workgroup stages at once
-    if (own_cap >= (uint32_t)(SB_THREADS * SB_PMAX) / 2u) return SWZ_OK;
-    halo_cap = (uint32_t)(SB_THREADS * SB_PMAX) - own_cap;
+  bool cl_forced = false, caps_forced = false;
+  if (const char* e = c->opt("SWZ_SP_BLOCK_CL")) {
+    cl = std::min(plan.cell_levels_geo, atoi(e));
+    cl_forced = true;
   }
-  const size_t lds = sb_lds_bytes(own_cap, halo_cap);
-  if (lds > 160u * 1024u) return SWZ_OK;
-
+  if (cl < 3 || cl > 10) return SWZ_OK;
+  const uint32_t limit = (uint32_t)(SB_THREADS * SB_PMAX);  // what a workgroup stages at once
+  // LDS capacity from the expected population (an estimate: a block that does not fit stops the launch, see below).
+  // Uniform data: a block's population is Poisson -- 416 +- 20 at level 2 of the 1 B run --, its halo's, counted in whole
+  // granules, about 1.2 times that.
+  auto estimate = [&](int l, uint32_t* own, uint32_t* halo) {
+    const double expect = per_block(l), dev = std::sqrt(expect * in.spread);
+    *own = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + (in.spread > 1.0 ? 6.0 : 8.0) * dev + 32.0) / 32.0));
+    *halo = (uint32_t)(32.0 * std::ceil((1.25 * expect + (in.spread > 1.0 ? 7.0 : 10.0) * std::sqrt(1.25) * dev + 64.0) / 32.0));
+  };
+  uint32_t own_cap = 0, halo_cap = 0;
+  estimate(cl, &own_cap, &halo_cap);
+  if (const char* e = c->opt("SWZ_SP_BLOCK_CAP_SCALE")) {  // tests: an estimate that is too small, so that launches are repeated
+    own_cap = std::max(32u, (uint32_t)(own_cap * atof(e)) / 32u * 32u);
+    halo_cap = std::max(32u, (uint32_t)(halo_cap * atof(e)) / 32u * 32u);
+  }
+  if (const char* e = c->opt("SWZ_SP_BLOCK_OWN")) {
+    own_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
+    caps_forced = true;
+  }
+  if (const char* e = c->opt("SWZ_SP_BLOCK_HALO")) {
+    halo_cap = (uint32_t)std::max(64, atoi(e)) / 16u * 16u;
+    caps_forced = true;
+  }
+  const uint32_t node_shift = plan.node_shift == 63u ? 63u : plan.node_shift;
   SbTabArgs t{};
   t.akey = in.akey;
   t.nid = lb.nid;
@@ -895,14 +904,9 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
   t.sn_direct = in.sn_direct;
   t.all_sampled = all_sampled ? 1u : 0u;
   t.m = in.m;
-  const uint32_t node_shift = plan.node_shift == 63u ? 63u : plan.node_shift;
-  t.gran_shift = node_shift - 3u * (uint32_t)(cl - 1);
-  t.gran_per_node = gran_per_node;
-  SWZ_TRY(c->get("sb_gtab", (size_t)entries, &t.gtab));
   SbArgs a{};
   a.akey = in.akey;
   a.m = in.m;
-  a.gtab = t.gtab;
   SWZ_TRY(c->get("sb_state", (size_t)in.m / 16 + 2, &a.st2));
   a.taken = in.taken;
   a.aidx = in.aidx;
@@ -918,70 +922,106 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
   a.i_lo = a.f_lo >= 4294967040.f ? 0xFFFFFFFFu : (uint32_t)std::floor(a.f_lo);
   a.i_hi = a.f_hi >= 4294967040.f ? 0xFFFFFFFFu : (uint32_t)std::ceil(a.f_hi);
   a.sq_spacing = plan.sq_spacing;
-  a.cell_bits = (node_shift - 3u * (uint32_t)cl) / 3u;
-  a.cl = (uint32_t)cl;
   a.ns = sample_nodes;
   SWZ_TRY(c->get("sb_counters", (size_t)(SB_NC * SB_CTR_STRIDE + SBW_COUNT), &a.ctr));
-  a.own_cap = own_cap;
-  a.halo_cap = halo_cap;
   double timeout_s = 10.0;
   if (const char* e = c->opt("SWZ_SP_BLOCK_TIMEOUT_MS")) timeout_s = atof(e) * 1e-3;
   a.timeout_ticks = (uint64_t)(timeout_s * 1e8);
   if (const char* e = c->opt("SWZ_SP_BLOCK_DBG")) a.dbg = (uint32_t)atoi(e);
-
-  ProfScope ps(c, "sample_min_distance", (uint64_t)in.points * 33ull, 1);
-  SWZ_HIP(c, memset_large(t.gtab, 0, (size_t)entries * sizeof(uint2), c->stream));
-  SWZ_HIP(c, hipMemsetAsync(a.st2, 0, ((size_t)in.m / 16 + 2) * sizeof(uint32_t), c->stream));
-  SWZ_HIP(c, hipMemsetAsync(a.ctr, 0, (size_t)(SB_NC * SB_CTR_STRIDE + SBW_COUNT) * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(sb_table_kernel, dim3(div_up(in.m, 256)), dim3(256), 0, c->stream, t);
-  SWZ_LAUNCH_CHECK(c);
-  // (every time: the attribute belongs to the function on the CURRENT device, and a process may drive several)
-  bool wide = a.cell_bits > 12u;  // a region of ten cells must fit sixteen bits
-  if (const char* e = c->opt("SWZ_SP_BLOCK_WIDE")) wide = wide || atoi(e) != 0;
-  SWZ_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(wide ? sb_block_kernel<true> : sb_block_kernel<false>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device);
-  uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / lds));
-  if (const char* e = c->opt("SWZ_SP_BLOCK_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
-  const uint64_t blocks_total = (uint64_t)sample_nodes << (3 * (cl - 3));
-  const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)cus * per_cu, std::max<uint64_t>(1, blocks_total));
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  if (dbg) {
-    ev0 = c->take_event();
-    ev1 = c->take_event();
-    (void)hipEventRecord(ev0, c->stream);
-  }
-  if (wide)
-    hipLaunchKernelGGL(sb_block_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, c->stream, a);
-  else
-    hipLaunchKernelGGL(sb_block_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, c->stream, a);
-  SWZ_LAUNCH_CHECK(c);
-  if (dbg) (void)hipEventRecord(ev1, c->stream);
-  uint32_t h[SBW_COUNT] = {0};
-  SWZ_HIP(c, hipMemcpyAsync(h, a.ctr + SB_NC * SB_CTR_STRIDE, sizeof(h), hipMemcpyDeviceToHost, c->stream));
-  SWZ_HIP(c, hipStreamSynchronize(c->stream));
-  if (dbg) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ev0, ev1);
-    c->event_pool.insert(c->event_pool.end(), {ev0, ev1});
-    fprintf(stderr,
-            "[swz] MIN_DISTANCE level %d block path%s: %u pts in %u nodes, cell_levels %d (geo %d), %.0f pts/block, caps %u / %u, LDS %zu B, "
-            "grid %u, %u blocks, %u search steps, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
-            plan.level, in.what, in.points, sample_nodes, cl, plan.cell_levels_geo, expect, own_cap, halo_cap, lds, grid, h[SBW_BLOCKS],
-            h[SBW_STEPS], h[SBW_ITER], h[SBW_WAITS], h[SBW_RESEARCH], h[SBW_ABORT], h[SBW_MAX_OWN], h[SBW_MAX_HALO], ms);
-  }
+
+  // A block or a halo beyond the capacity stops the launch (every decision taken so far is exact and simply taken again).
+  // The launch is then repeated with what the stopped blocks needed plus a quarter or, when that is more than a workgroup
+  // stages, with cells half the size; after four launches the level goes to the caller's other paths.
+  for (int attempt = 0; attempt < 4; ++attempt) {
+    if (own_cap + halo_cap > limit) {
+      if (own_cap >= limit / 2u) return SWZ_OK;
+      halo_cap = limit - own_cap;
+    }
+    const size_t lds = sb_lds_bytes(own_cap, halo_cap);
+    if (lds > 160u * 1024u) return SWZ_OK;
+    const uint64_t gran_per_node = 1ull << (3 * (cl - 1));
+    const uint64_t entries = (uint64_t)sample_nodes * gran_per_node;
+    if (entries > (1ull << 30)) return SWZ_OK;  // 8 GB of table
+    t.gran_shift = node_shift - 3u * (uint32_t)(cl - 1);
+    t.gran_per_node = gran_per_node;
+    SWZ_TRY(c->get("sb_gtab", (size_t)entries, &t.gtab));
+    a.gtab = t.gtab;
+    a.cell_bits = (node_shift - 3u * (uint32_t)cl) / 3u;
+    a.cl = (uint32_t)cl;
+    a.own_cap = own_cap;
+    a.halo_cap = halo_cap;
+
+    ProfScope ps(c, "sample_min_distance", (uint64_t)in.points * 33ull, 1);
+    SWZ_HIP(c, memset_large(t.gtab, 0, (size_t)entries * sizeof(uint2), c->stream));
+    SWZ_HIP(c, hipMemsetAsync(a.st2, 0, ((size_t)in.m / 16 + 2) * sizeof(uint32_t), c->stream));
+    SWZ_HIP(c, hipMemsetAsync(a.ctr, 0, (size_t)(SB_NC * SB_CTR_STRIDE + SBW_COUNT) * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(sb_table_kernel, dim3(div_up(in.m, 256)), dim3(256), 0, c->stream, t);
+    SWZ_LAUNCH_CHECK(c);
+    // (every time: the attribute belongs to the function on the CURRENT device, and a process may drive several)
+    bool wide = a.cell_bits > 12u;  // a region of ten cells must fit sixteen bits
+    if (const char* e = c->opt("SWZ_SP_BLOCK_WIDE")) wide = wide || atoi(e) != 0;
+    SWZ_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void*>(wide ? sb_block_kernel<true> : sb_block_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(8, (160u * 1024u) / lds));
+    if (const char* e = c->opt("SWZ_SP_BLOCK_PER_CU")) per_cu = (uint32_t)std::max(1, atoi(e));
+    const uint64_t blocks_total = (uint64_t)sample_nodes << (3 * (cl - 3));
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((uint64_t)cus * per_cu, std::max<uint64_t>(1, blocks_total));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (dbg) {
+      ev0 = c->take_event();
+      ev1 = c->take_event();
+      (void)hipEventRecord(ev0, c->stream);
+    }
+    if (wide)
+      hipLaunchKernelGGL(sb_block_kernel<true>, dim3(grid), dim3(SB_THREADS), lds, c->stream, a);
+    else
+      hipLaunchKernelGGL(sb_block_kernel<false>, dim3(grid), dim3(SB_THREADS), lds, c->stream, a);
+    SWZ_LAUNCH_CHECK(c);
+    if (dbg) (void)hipEventRecord(ev1, c->stream);
+    uint32_t h[SBW_COUNT] = {0};
+    SWZ_HIP(c, hipMemcpyAsync(h, a.ctr + SB_NC * SB_CTR_STRIDE, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    SWZ_HIP(c, hipStreamSynchronize(c->stream));
+    if (dbg) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, ev0, ev1);
+      c->event_pool.insert(c->event_pool.end(), {ev0, ev1});
+      fprintf(stderr,
+              "[swz] MIN_DISTANCE level %d block path%s: %u pts in %u nodes, cell_levels %d (geo %d), %.0f pts/block, caps %u / %u, LDS %zu B, "
+              "grid %u, %u blocks, %u search steps, %u passes, %u idle passes, %u searched again, abort %u (max %u / %u), %.2f ms\n",
+              plan.level, in.what, in.points, sample_nodes, cl, plan.cell_levels_geo, per_block(cl), own_cap, halo_cap, lds, grid, h[SBW_BLOCKS],
+              h[SBW_STEPS], h[SBW_ITER], h[SBW_WAITS], h[SBW_RESEARCH], h[SBW_ABORT], h[SBW_MAX_OWN], h[SBW_MAX_HALO], ms);
+    }
 #ifdef SWZ_SB_STATS
-  if (dbg && h[SBW_BLOCKS])
-    fprintf(stderr, "[swz]   thread 0, us per block: ticket %.2f, granules %.2f, stage %.2f, index %.2f, search %.2f, decide %.2f, tail %.2f\n",
-            h[SBW_T0] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 1] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 2] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 3] * 0.16 / h[SBW_BLOCKS],
-            h[SBW_T0 + 4] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 5] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 6] * 0.16 / h[SBW_BLOCKS]);
+    if (dbg && h[SBW_BLOCKS])
+      fprintf(stderr, "[swz]   thread 0, us per block: ticket %.2f, granules %.2f, stage %.2f, index %.2f, search %.2f, decide %.2f, tail %.2f\n",
+              h[SBW_T0] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 1] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 2] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 3] * 0.16 / h[SBW_BLOCKS],
+              h[SBW_T0 + 4] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 5] * 0.16 / h[SBW_BLOCKS], h[SBW_T0 + 6] * 0.16 / h[SBW_BLOCKS]);
 #endif
-  if (h[SBW_ABORT] == SB_ABORT_TIMEOUT)
-    return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE block path: a workgroup waited longer than the time-out for an earlier block");
-  if (h[SBW_ABORT] != SB_ABORT_NONE) return SWZ_OK;  // a block did not fit: the caller's other paths take the level
-  *done = true;
-  return SWZ_OK;
+    if (h[SBW_ABORT] == SB_ABORT_TIMEOUT)
+      return c->fail(SWZ_ERR_INTERNAL, "MIN_DISTANCE block path: a workgroup waited longer than the time-out for an earlier block");
+    if (h[SBW_ABORT] == SB_ABORT_NONE) {
+      *done = true;
+      return SWZ_OK;
+    }
+    if (caps_forced) return SWZ_OK;  // (tests)
+    const uint32_t need_own = std::max(own_cap, (h[SBW_MAX_OWN] + h[SBW_MAX_OWN] / 4u + 63u) / 32u * 32u);
+    const uint32_t need_halo = std::max(halo_cap, (h[SBW_MAX_HALO] + h[SBW_MAX_HALO] / 4u + 95u) / 32u * 32u);
+    if (need_own < limit / 2u && need_own + need_halo <= limit) {
+      own_cap = need_own;
+      halo_cap = need_halo;
+    } else if (cl < plan.cell_levels_geo && !cl_forced) {
+      ++cl;  // an eighth of the volume: what was seen says nothing exact about it, so from the estimate, and never below a quarter
+      uint32_t eo = 0, eh = 0;
+      estimate(cl, &eo, &eh);
+      own_cap = std::max(eo, (need_own / 4u + 31u) / 32u * 32u);
+      halo_cap = std::max(eh, (need_halo / 4u + 31u) / 32u * 32u);
+    } else {
+      return SWZ_OK;
+    }
+  }
+  return SWZ_OK;  // the caller's other paths take the level
 }
 
 // ----------------------------------------------------------------------------- multi-batch tiling: only what new points can change
@@ -992,8 +1032,8 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
 // of them are at least one spacing apart: they never reject one another.  The Morton-order greedy over the union therefore
 // decides an old point o exactly as the greedy over  S = {new points} + {old points within one spacing of a new point}
 // does (o's only possible rejectors are new points; a new point's are new points and old points of S), and old points
-// outside S are accepted.  S is found on the level's finest cells (one spacing wide or more): a new point marks the 27
-// cells around it, an old point belongs to S when its cell is marked.  With 10 M new points per batch on 390 M points of
+// outside S are accepted.  S is found on the level's finest cells (one spacing wide or more): a new point marks its cell,
+// an old point belongs to S when one of the 27 cells around it is marked.  With 10 M new points per batch on 390 M points of
 // files (level 2 of the 1 B run in 100 batches) S is a quarter of the level, on level 3 a thirtieth.
 // "New" also covers the entries of files with at most max_points points (they may come from a take-all).
 struct SbiArgs {
@@ -1047,33 +1087,52 @@ __device__ __forceinline__ bool sbi_is_old(const SbiArgs& a, uint32_t i, uint32_
 __device__ __forceinline__ uint64_t sbi_cell_base(const SbiArgs& a, uint32_t node) {
   return (uint64_t)(a.all_sampled ? node : a.snode_of[node]) << (3u * a.cl);
 }
-__global__ __launch_bounds__(256) void sbi_mark_kernel(SbiArgs a) {
+// One bit per cell that holds a new point, set by the batch's own points (their keys as they were before the merge with the
+// files: a hundredth of the level).  The node of a key: the last one whose first point's prefix is not above it.
+// (Marking the 27 cells around every new point instead and testing one bit per old point was the first version: 270 M
+// scattered device-scope atomics per level took 30-54 ms.)
+__global__ __launch_bounds__(256) void sbi_mark_kernel(SbiArgs a, const uint64_t* __restrict__ new_key, uint32_t new_m,
+                                                       const uint32_t* __restrict__ nstart, uint32_t nnodes, uint32_t nsh) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= a.m) return;
-  uint32_t node;
-  if (!sbi_sampled(a, i, &node) || sbi_is_old(a, i, node)) return;
-  const uint64_t base = sbi_cell_base(a, node);
-  const uint32_t code = (uint32_t)(a.akey[i] >> a.cell_shift) & a.cell_mask;
-  // the cell's three coordinates stay interleaved: +-1 on one axis is an add / subtract on that axis' bits alone
-  const uint32_t M[3] = {0x09249249u & a.cell_mask, 0x12492492u & a.cell_mask, 0x24924924u & a.cell_mask};
-  uint32_t v[3][3];
-  int n[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    const uint32_t x = code & M[d];
-    n[d] = 0;
-    v[d][n[d]++] = x;
-    if (x) v[d][n[d]++] = (x - 1u) & M[d];
-    if (x != M[d]) v[d][n[d]++] = ((x | ~M[d]) + 1u) & M[d];
+  if (i >= new_m) return;
+  const uint64_t key = new_key[i], prefix = key >> nsh;
+  uint32_t lo = 0, hi = nnodes;  // first node with a prefix above this one
+  while (lo < hi) {
+    const uint32_t mid = lo + (hi - lo) / 2u;
+    if ((a.akey[nstart[mid]] >> nsh) <= prefix) lo = mid + 1u; else hi = mid;
   }
-  for (int iz = 0; iz < n[2]; ++iz)
-    for (int iy = 0; iy < n[1]; ++iy)
-      for (int ix = 0; ix < n[0]; ++ix) {
-        const uint64_t bit = base + (v[0][ix] | v[1][iy] | v[2][iz]);
-        const uint32_t b = 1u << (uint32_t)(bit & 31ull);
-        uint32_t* w = a.bits + (bit >> 5);
-        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(w, b);
-      }
+  if (lo == 0) return;
+  const uint32_t node = lo - 1u;
+  // (a node whose file may hold close pairs is sampled as a whole: nobody looks at its marks)
+  if ((a.akey[nstart[node]] >> nsh) != prefix || !(a.all_sampled || a.nmode[node] == MODE_SAMPLE) || !a.indep[node]) return;
+  const uint64_t bit = sbi_cell_base(a, node) + ((uint32_t)(key >> a.cell_shift) & a.cell_mask);
+  const uint32_t b = 1u << (uint32_t)(bit & 31ull);
+  uint32_t* w = a.bits + (bit >> 5);
+  if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(w, b);
+}
+// Is there a new point in the 27 cells around this one?  The marks of an aligned group of 2 x 2 x 2 cells are one byte (the
+// cell code is a Morton code: bit 0 x, bit 1 y, bit 2 z), the 27 cells lie in two groups per axis -- the cell's own, whole,
+// and the one before it (its upper half) or behind it (its lower half): eight byte loads instead of 27 bit tests.  The
+// groups' coordinates stay interleaved: +-1 on one axis is an add / subtract on that axis' bits alone.
+__device__ __forceinline__ bool sbi_near_new(const SbiArgs& a, uint64_t base, uint32_t code) {
+  const uint32_t gmask = a.cell_mask >> 3;
+  const uint32_t MX = 0x09249249u & gmask, MY = 0x12492492u & gmask, MZ = 0x24924924u & gmask;
+  const uint32_t g = code >> 3, x = g & MX, y = g & MY, z = g & MZ;
+  const uint8_t* marks = reinterpret_cast<const uint8_t*>(a.bits) + (base >> 3);
+  // per axis: the own group with every cell, the other one with the half that touches (nothing beyond the node's faces)
+  uint32_t gx[2] = {x, x}, gy[2] = {y, y}, gz[2] = {z, z};
+  uint32_t mx[2] = {0xFFu, 0u}, my[2] = {0xFFu, 0u}, mz[2] = {0xFFu, 0u};
+  if (code & 1u) { if (x != MX) gx[1] = ((x | ~MX) + 1u) & MX, mx[1] = 0x55u; } else { if (x) gx[1] = (x - 1u) & MX, mx[1] = 0xAAu; }
+  if (code & 2u) { if (y != MY) gy[1] = ((y | ~MY) + 1u) & MY, my[1] = 0x33u; } else { if (y) gy[1] = (y - 1u) & MY, my[1] = 0xCCu; }
+  if (code & 4u) { if (z != MZ) gz[1] = ((z | ~MZ) + 1u) & MZ, mz[1] = 0x0Fu; } else { if (z) gz[1] = (z - 1u) & MZ, mz[1] = 0xF0u; }
+  uint32_t any = 0;
+#pragma unroll
+  for (int iz = 0; iz < 2; ++iz)
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy)
+#pragma unroll
+      for (int ix = 0; ix < 2; ++ix) any |= (uint32_t)marks[gx[ix] | gy[iy] | gz[iz]] & mx[ix] & my[iy] & mz[iz];
+  return any != 0;
 }
 __global__ __launch_bounds__(256) void sbi_select_kernel(SbiArgs a) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1083,8 +1142,7 @@ __global__ __launch_bounds__(256) void sbi_select_kernel(SbiArgs a) {
   if (sbi_sampled(a, i, &node)) {
     s = 1;
     if (sbi_is_old(a, i, node)) {
-      const uint64_t bit = sbi_cell_base(a, node) + ((uint32_t)(a.akey[i] >> a.cell_shift) & a.cell_mask);
-      s = (a.bits[bit >> 5] >> (uint32_t)(bit & 31ull)) & 1u;
+      s = sbi_near_new(a, sbi_cell_base(a, node), (uint32_t)(a.akey[i] >> a.cell_shift) & a.cell_mask) ? 1 : 0;
       if (!s) a.taken[i] = 1;  // no new point within a spacing: nothing can reject it
     }
   }
@@ -1117,20 +1175,27 @@ struct SbiPackG {
 // firsts of the nodes, hist[b] the points whose first digit below the node prefix that differs from their predecessor's is b
 __global__ __launch_bounds__(256) void sbi_hist_kernel(const uint64_t* __restrict__ skey, const uint32_t* __restrict__ ssn, uint32_t n,
                                                        uint32_t node_shift, uint32_t cl_geo, uint32_t* __restrict__ hist) {
-  __shared__ uint32_t h[12];
-  if (threadIdx.x < 12) h[threadIdx.x] = 0;
+  __shared__ uint32_t h[16];
+  if (threadIdx.x < 16) h[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
-  if (j < n) {
+  uint32_t mine = 0;  // lane b accumulates the wavefront's count of bin b
+  for (uint64_t j0 = (uint64_t)blockIdx.x * 256u; j0 < n; j0 += (uint64_t)gridDim.x * 256u) {
+    const uint32_t j = (uint32_t)j0 + threadIdx.x;
     uint32_t bin = 0xFFu;
-    if (j == 0 || ssn[j - 1] != ssn[j]) {
-      bin = 0;
-    } else if (cl_geo) {
-      const uint64_t diff = ((skey[j] ^ skey[j - 1]) >> (node_shift - 3u * cl_geo)) & ((1ull << (3u * cl_geo)) - 1ull);
-      if (diff) bin = cl_geo - (uint32_t)(63 - __clzll((unsigned long long)diff)) / 3u;  // 1 .. cl_geo
+    if (j < n) {
+      if (j == 0 || ssn[j - 1] != ssn[j]) {
+        bin = 0;
+      } else if (cl_geo) {
+        const uint64_t diff = ((skey[j] ^ skey[j - 1]) >> (node_shift - 3u * cl_geo)) & ((1ull << (3u * cl_geo)) - 1ull);
+        if (diff) bin = cl_geo - (uint32_t)(63 - __clzll((unsigned long long)diff)) / 3u;  // 1 .. cl_geo
+      }
     }
-    if (bin < 12u) atomicAdd(&h[bin], 1u);
+    for (uint32_t b = 0; b <= cl_geo; ++b) {
+      const uint32_t cnt = (uint32_t)__popcll(__ballot(bin == b));
+      if ((threadIdx.x & 63u) == b) mine += cnt;
+    }
   }
+  if ((threadIdx.x & 63u) <= cl_geo && mine) atomicAdd(&h[threadIdx.x & 63u], mine);
   __syncthreads();
   if (threadIdx.x < 12 && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
@@ -1183,7 +1248,8 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
     SWZ_LAUNCH_CHECK(c);
     SWZ_HIP(c, memset_large(a.bits, 0, words * sizeof(uint32_t), c->stream));
     SWZ_HIP(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(sbi_mark_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(sbi_mark_kernel, dim3(div_up(as.new_m, 256)), dim3(256), 0, c->stream, a, as.new_key, as.new_m, lb.nstart, num_nodes,
+                       node_shift);
     SWZ_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(sbi_select_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, a);
     SWZ_LAUNCH_CHECK(c);
@@ -1215,7 +1281,7 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
     SWZ_TRY(fused_scan_apply(c, SbiSelF{a.sel}, SbiPackG{as.akey, as.aidx, lb.nid, snode_of, a.all_sampled, skey, saidx, ssn, sidx}, as.m,
                              d_partial));
     SWZ_HIP(c, hipMemsetAsync(staken, 0, (size_t)total, c->stream));
-    hipLaunchKernelGGL(sbi_hist_kernel, dim3(div_up(total, 256)), dim3(256), 0, c->stream, skey, ssn, total, node_shift,
+    hipLaunchKernelGGL(sbi_hist_kernel, dim3(std::min<uint32_t>(div_up(total, 256), 2048u)), dim3(256), 0, c->stream, skey, ssn, total, node_shift,
                        (uint32_t)std::min(plan.cell_levels_geo, 11), d_cnt + 1);
     SWZ_LAUNCH_CHECK(c);
     SWZ_HIP(c, hipMemcpyAsync(hist, d_cnt + 1, sizeof(hist), hipMemcpyDeviceToHost, c->stream));
@@ -1232,7 +1298,7 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
   in.points = total;
   in.occupied = occ;
   // (what a new point brings into a block it brings at once: itself and the old points of 27 cells)
-  in.spread = 12.0;
+  in.spread = 10.0;
   if (const char* e = c->opt("SWZ_SP_INCREMENTAL_SPREAD")) in.spread = std::max(1.0, atof(e));
   in.what = " (what the new points can change)";
   bool ok = false;
@@ -1254,13 +1320,15 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
   if (!km.ok || !sp.xyz || !sp.perm || sp.ghosts) return SWZ_OK;
   if (plan.cell_levels_geo < 3) return SWZ_OK;
   // a batch on top of the files of earlier ones: when those are most of the level, only what the batch can change
-  bool inc = as.ckey && as.aidx && as.old_hi > as.old_lo;
-  double old_share = 0.5;
-  if (const char* e = c->opt("SWZ_SP_INCREMENTAL")) {
+  bool inc = as.ckey && as.aidx && as.old_hi > as.old_lo && as.new_key;
+  double old_share = 0.5, file_share = 0.5;
+  if (const char* e = c->opt("SWZ_SP_INCREMENTAL")) {  // 0: never; a share: whenever the files are that much of the level
     if (atof(e) <= 0.0) inc = false;
-    else old_share = std::min(1.0, atof(e));
+    else old_share = std::min(1.0, atof(e)), file_share = 0.0;
   }
-  if (inc && (double)(as.old_hi - as.old_lo) >= old_share * (double)as.m) {
+  // (... and when the files are big enough for that: one of at most max_points points may come from a node that took everything)
+  if (inc && (double)(as.old_hi - as.old_lo) >= old_share * (double)as.m &&
+      (double)(as.old_hi - as.old_lo) >= file_share * (double)plan.max_points * (double)num_nodes) {
     SWZ_TRY(sb_incremental(c, plan, as, sp, lb, snode_of, all_sampled, num_nodes, sample_nodes, sample_points, km, done));
     if (*done) return SWZ_OK;
   }

@@ -1016,6 +1016,8 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
     if (!sr && !ng && nc) {
       ms.old_lo = pull_lo;
       ms.old_hi = pull_lo + nc;
+      ms.new_key = as.akey;
+      ms.new_m = as.m;
     }
   }
   if (ms.m == 0) {  // a shard without new points and without a root file

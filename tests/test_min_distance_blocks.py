@@ -51,6 +51,8 @@ VARIANTS = {
     "every level, wide": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_WIDE": "1"},
     "coarse cells": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_CL": "4"},
     "blocks that do not fit": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_OWN": "64", "SWZ_SP_BLOCK_HALO": "64"},
+    "capacities estimated too small (launches repeated)": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_CAP_SCALE": "0.3"},
+    "... and coarse cells on top (finer cells in the end)": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_CAP_SCALE": "0.1", "SWZ_SP_BLOCK_MIN": "1500"},
     "one workgroup per CU": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_BLOCK_PER_CU": "1"},
     "every pair on the original positions": {"SWZ_MD_SPARSE_LIMIT": "1000", "SWZ_SP_FILTER_EPS": "1e30"},
 }

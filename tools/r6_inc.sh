@@ -2,8 +2,8 @@
 # same box: tests first, then 1 B points in 100 uniform / tile batches with and without, then a debug log of a short run
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r6
-timeout 1500 python -m pytest tests/test_multibatch.py tests/test_min_distance_blocks.py -x -q -m gpu 2>&1 | tail -5
-for order in uniform tiles; do
+timeout 1500 python -m pytest tests/test_multibatch.py tests/test_min_distance_blocks.py -x -q -m gpu --durations=8 2>&1 | tail -16
+for order in ${INC_ORDERS:-uniform tiles}; do
   for inc in ${INC_VARIANTS:-default 0}; do
     f=gpurun_out/r6/inc_${order}_${inc}.json
     if [ "$inc" = default ]; then unset SWZ_SP_INCREMENTAL; else export SWZ_SP_INCREMENTAL=$inc; fi
