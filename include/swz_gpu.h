@@ -82,7 +82,7 @@ int swz_set_stream(swz_ctx* ctx, void* hip_stream);
  * sampled as a subset, SWZ_SP_INCREMENTAL_SPREAD: how far from Poisson the subset's blocks are assumed to be -- results
  * unchanged; SWZ_SP_BLOCK_TIMEOUT_MS (default 10 000) bounds how long a wavefront waits for an earlier
  * block: when it expires the call returns SWZ_ERR_INTERNAL, nothing is restarted; SWZ_SP_BLOCK_DBG switches parts of the
- * search off for timing experiments and DOES change the result -- never set it outside tools/r6_dbg.sh. */
+ * search off for timing experiments and DOES change the result -- never set it outside a timing experiment (tools/probe.sh variants). */
 int swz_set_option(swz_ctx* ctx, const char* name, const char* value);
 /* Frees all device workspace held by the context (it regrows on demand). */
 int swz_release_workspace(swz_ctx* ctx);

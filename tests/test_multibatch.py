@@ -270,7 +270,7 @@ def test_gpu_multibatch_min_distance_samples_only_what_a_batch_can_change(ctx, n
 
 
 @pytest.mark.gpu
-def test_gpu_multibatch_uneven_batches_on_full_files(ctx):
+def test_gpu_multibatch_uneven_batches_on_full_files(ctx, capfd):
     """One big batch fills the files, then many small ones arrive: almost every point of a level is an old one and only the
     neighbourhoods of the few new points are looked at (the case the subset is for)."""
     rng = np.random.default_rng(77)
@@ -295,8 +295,15 @@ def test_gpu_multibatch_uneven_batches_on_full_files(ctx):
         for sz in sizes:
             d = torch.from_numpy(np.ascontiguousarray(xyz[off:off + sz])).cuda()
             torch.cuda.synchronize()
-            tl.add_batch_device(d.data_ptr(), sz)
+            ctx.set_option("SWZ_DEBUG", "1")  # (the library then says which path a level took)
+            try:
+                tl.add_batch_device(d.data_ptr(), sz)
+            finally:
+                ctx.set_option("SWZ_DEBUG", None)
             off += sz
+        said = capfd.readouterr().err
+        # with the default thresholds: some level of some small batch was sampled as the subset the batch can change
+        assert "(what the new points can change)" in said, said[-2000:]
         tl.finalize()
         tb = tl.node_table()
         ns = int(tl.info()["num_stored"])

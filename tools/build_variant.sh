@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds schwarzwald_amd/lib/libswz_v<name>.so: the library with ONE translation unit recompiled with extra flags
-# (experiments; tools/variants.sh times them through SWZ_GPU_LIBRARY).  usage: build_variant.sh <name> <file.hip> <flags...>
+# (experiments; tools/probe.sh variants times them through SWZ_GPU_LIBRARY).  usage: build_variant.sh <name> <file.hip> <flags...>
 set -euo pipefail
 cd "$(dirname "$0")/../schwarzwald_amd/csrc"
 name=$1; src=$2; shift 2
