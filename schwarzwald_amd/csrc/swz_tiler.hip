@@ -947,7 +947,6 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
   ActiveSet ms = as;
   if (ng) SWZ_TRY(work_need_positions(t, w));  // (the ghosts bring their positions: the working pool holds them from here on)
   if (nc || ng) {
-    const bool stored_keys = st.rekeyed;  // the files carry the keys they were sorted by: what is pulled is ascending as it comes
     if (nc && !st.rekeyed) {
       // ("tiler_rekey": the pulled points' keys against their NODE's bounds -- a random 24-byte read per point from the
       // pool; only for files the level loop did not write itself, see TakeStoreG)
@@ -956,7 +955,9 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
                          root_box(t), plan.level);
       SWZ_LAUNCH_CHECK(c);
     }
-    if (nc && !plan.terminal && (!stored_keys || c->opt("SWZ_DEBUG"))) {
+    // (needed for files the level loop wrote as well: TakeStoreG stores the key against the NODE's bounds, which may order two
+    // points the other way round than the key they were sorted by -- tests/test_multibatch.py constructs such a pair)
+    if (nc && !plan.terminal) {
       SWZ_HIP(c, hipMemsetAsync(counters + 1, 0, 4, c->stream));
       hipLaunchKernelGGL(tl_inversion_kernel, dim3(div_up(nc, 256)), dim3(256), 0, c->stream, ckey, nc, nsh, counters + 1);
       SWZ_LAUNCH_CHECK(c);
