@@ -314,6 +314,47 @@ def test_gpu_multibatch_uneven_batches_on_full_files(ctx, capfd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["uniform", "clustered"])
+def test_gpu_multibatch_subset_sampling_changes_nothing_at_scale(kind):
+    """40 M points in 20 batches cut out of the whole cloud, BASELINE's spacing and node size, FAST: the files with the subset
+    path (levels of hundreds of nodes, subset blocks that are clumps, launches repeated when a clump does not fit) are the
+    files without it, entry for entry -- the oracle would take minutes at this size, the small cases above are against it."""
+    import torch
+    import schwarzwald_amd as swz
+    from test_gpu_fullsize import make_cloud
+    dev = torch.device("cuda:0")
+    torch.cuda.empty_cache()
+    n, k = 40_000_000, 20
+    ctx = swz.Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    xyz = make_cloud(torch, ctx, dev, n, kind)
+    xyz = xyz[torch.randperm(n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))].contiguous()
+    torch.cuda.synchronize()
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=20000, spacing_at_root=swz.spacing_from_diagonal(*UNIT, 250),
+                            strategy=swz.FAST, fast_concurrency=8)
+    out = {}
+    for inc in ("0.3", "0"):
+        ctx.set_option("SWZ_SP_INCREMENTAL", inc)
+        with swz.Tiler(ctx, UNIT[0], UNIT[1], params, capacity_hint=n) as t:
+            for i in range(k):
+                lo, hi = (i * n) // k, ((i + 1) * n) // k
+                t.add_batch_device(xyz[lo:hi].data_ptr(), hi - lo)
+            t.finalize()
+            tb = t.node_table()
+            ns = int(t.info()["num_stored"])
+            d_ids = torch.empty(ns, dtype=torch.int32, device=dev)
+            t.export_device(None, d_ids.data_ptr(), None)
+            out[inc] = (tb, d_ids.cpu().numpy().view(np.uint32))
+    ctx.set_option("SWZ_SP_INCREMENTAL", None)
+    ctx.close()
+    a, b = out["0.3"], out["0"]
+    assert len(a[1]) >= n  # (FAST: the levels above the start level are rebuilt from copies of their children's points)
+    for col in ("level", "key", "offset", "count"):
+        assert np.array_equal(a[0][col], b[0][col]), col
+    assert np.array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [0, 1])
 def test_gpu_fast_finalize_survives_out_of_memory_inside_its_levels(flags):
     """FAST + MIN_DISTANCE: finalize rebuilds the skipped levels from ALL stored points, so its levels are larger than any
