@@ -78,7 +78,7 @@ int swz_set_stream(swz_ctx* ctx, void* hip_stream);
  * SWZ_SP_BLOCK_CAP_SCALE scales the estimated capacities so that a test can make that happen);
  * SWZ_SP_INCREMENTAL (multi-batch tilers: a batch merged with node files samples only what its points can change) = 0
  * never, = a share in (0, 1]: whenever the files are that much of a level (default: half of it, and files of
- * max_points/2 per node on average), SWZ_SP_INCREMENTAL_MAX (0.6): the largest share of a level that is still
+ * max_points/2 per node on average), SWZ_SP_INCREMENTAL_MAX (0.35): the largest share of a level that is still
  * sampled as a subset, SWZ_SP_INCREMENTAL_SPREAD: how far from Poisson the subset's blocks are assumed to be -- results
  * unchanged; SWZ_SP_BLOCK_TIMEOUT_MS (default 10 000) bounds how long a wavefront waits for an earlier
  * block: when it expires the call returns SWZ_ERR_INTERNAL, nothing is restarted; SWZ_SP_BLOCK_DBG switches parts of the

@@ -878,11 +878,25 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
   // granules, about 1.2 times that.
   auto estimate = [&](int l, uint32_t* own, uint32_t* halo) {
     const double expect = per_block(l), dev = std::sqrt(expect * in.spread);
-    *own = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + (in.spread > 1.0 ? 6.0 : 8.0) * dev + 32.0) / 32.0));
-    *halo = (uint32_t)(32.0 * std::ceil((1.25 * expect + (in.spread > 1.0 ? 7.0 : 10.0) * std::sqrt(1.25) * dev + 64.0) / 32.0));
+    *own = (uint32_t)std::max(128.0, 32.0 * std::ceil((expect + (in.spread > 2.0 ? 6.0 : 8.0) * dev + 32.0) / 32.0));
+    *halo = (uint32_t)(32.0 * std::ceil((1.25 * expect + (in.spread > 2.0 ? 7.0 : 10.0) * std::sqrt(1.25) * dev + 64.0) / 32.0));
+  };
+  // ... and what the estimate leaves of the LDS a workgroup gets anyway (six per CU by registers) is handed out too: the
+  // batches of a tiler that arrive as tiles have blocks half inside their tile, which pull the mean below what a full
+  // block holds (a level of 14.5 M points with 336 per block: capacities 544 / 704 for blocks of up to 550 / 746)
+  auto fill_free_lds = [&](uint32_t* own, uint32_t* halo) {
+    const size_t free_lds = 26u * 1024u;  // (six of them, each rounded up to the allocation granule, fit the CU's 160 KB)
+    const uint32_t own_max = *own + *own / 2u, halo_max = *halo + *halo / 2u;
+    for (bool grew = true; grew;) {
+      grew = false;
+      if (*halo + 32u <= halo_max && *own + *halo + 32u <= limit && sb_lds_bytes(*own, *halo + 32u) <= free_lds) *halo += 32u, grew = true;
+      if (*own + 32u <= own_max && *own + 32u < limit / 2u && *own + *halo + 32u <= limit && sb_lds_bytes(*own + 32u, *halo) <= free_lds)
+        *own += 32u, grew = true;
+    }
   };
   uint32_t own_cap = 0, halo_cap = 0;
   estimate(cl, &own_cap, &halo_cap);
+  fill_free_lds(&own_cap, &halo_cap);
   if (const char* e = c->opt("SWZ_SP_BLOCK_CAP_SCALE")) {  // tests: an estimate that is too small, so that launches are repeated
     own_cap = std::max(32u, (uint32_t)(own_cap * atof(e)) / 32u * 32u);
     halo_cap = std::max(32u, (uint32_t)(halo_cap * atof(e)) / 32u * 32u);
@@ -1017,6 +1031,7 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
       estimate(cl, &eo, &eh);
       own_cap = std::max(eo, (need_own / 4u + 31u) / 32u * 32u);
       halo_cap = std::max(eh, (need_halo / 4u + 31u) / 32u * 32u);
+      fill_free_lds(&own_cap, &halo_cap);
     } else {
       return SWZ_OK;
     }
@@ -1232,6 +1247,9 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
   a.cell_mask = (uint32_t)((1ull << (3 * cl)) - 1ull);
   a.cl = (uint32_t)cl;
   a.taken = lb.taken;
+  double worth = 0.35;  // of the level's points: above it the subset's own passes and its clumpier blocks cost what they save
+  if (const char* e = c->opt("SWZ_SP_INCREMENTAL_MAX")) worth = atof(e);
+  if ((double)as.new_m > worth * (double)sample_points) return SWZ_OK;  // (the new points alone are more than that)
   uint8_t* indep = nullptr;
   SWZ_TRY(c->get("sbi_indep", (size_t)num_nodes, &indep));
   SWZ_TRY(c->get("sbi_bits", words, &a.bits));
@@ -1257,8 +1275,6 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
     SWZ_HIP(c, hipMemcpyAsync(&total, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
   }
-  double worth = 0.6;  // of the level's points: above it the subset's own passes cost more than they save
-  if (const char* e = c->opt("SWZ_SP_INCREMENTAL_MAX")) worth = atof(e);
   if (dbg)
     fprintf(stderr, "[swz] MIN_DISTANCE level %d: %u of %u points are files of earlier batches, %u of %u can change (marks at cell level %d)\n",
             plan.level, as.nc, as.m, total, sample_points, cl);
@@ -1297,8 +1313,9 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
   in.taken = staken;
   in.points = total;
   in.occupied = occ;
-  // (what a new point brings into a block it brings at once: itself and the old points of 27 cells)
-  in.spread = 10.0;
+  // (what a new point brings into a block it brings at once: itself and the old points around it -- ten of them when the batch
+  // is thin on top of full files, none when it is a tile of its own beside the files of its neighbours)
+  in.spread = 1.0 + 9.0 * std::min(1.0, std::max(0.0, ((double)total - (double)as.new_m) / (double)total));
   if (const char* e = c->opt("SWZ_SP_INCREMENTAL_SPREAD")) in.spread = std::max(1.0, atof(e));
   in.what = " (what the new points can change)";
   bool ok = false;
