@@ -1025,12 +1025,14 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
     if (need_own < limit / 2u && need_own + need_halo <= limit) {
       own_cap = need_own;
       halo_cap = need_halo;
-    } else if (cl < plan.cell_levels_geo && !cl_forced) {
-      ++cl;  // an eighth of the volume: what was seen says nothing exact about it, so from the estimate, and never below a quarter
-      uint32_t eo = 0, eh = 0;
-      estimate(cl, &eo, &eh);
-      own_cap = std::max(eo, (need_own / 4u + 31u) / 32u * 32u);
-      halo_cap = std::max(eh, (need_halo / 4u + 31u) / 32u * 32u);
+    } else if (cl < plan.cell_levels_geo && !cl_forced && per_block(cl + 1) >= 0.5 * min_block) {
+      // cells half the size, capacities from the estimate again (what was seen says nothing about an eighth of the volume).
+      // Only while a block still holds half a workgroup's worth of points: a level that is dense in a few places and thin
+      // everywhere else (the blob of the surface-like test cloud: 323 points per block on average, 4 238 in the largest)
+      // would end up with blocks of 57 points and capacities for 500 -- 21 ms for a level the thread-per-point path takes
+      // in 5.
+      ++cl;
+      estimate(cl, &own_cap, &halo_cap);
       fill_free_lds(&own_cap, &halo_cap);
     } else {
       return SWZ_OK;
