@@ -3,6 +3,7 @@
 #
 #   tests [pytest args]      GPU tests, default the whole -m gpu suite
 #   list < file              lines "tag|ENV=.. ENV=..|bench.py args": one bench.py run each -> <tag>.json (+ .err), ms_per_step printed
+#                            (a tag that starts with sleep<seconds>_ waits first: the driver wipes the memory a process frees)
 #   levels [bench args]      bench.py with SWZ_DEBUG=1: the library's per-level lines (block path, sweeps, rounds, the incremental subset)
 #   variants [bench args]    the same with the default library and every schwarzwald_amd/lib/libswz_v*.so (tools/build_variant.sh;
 #                            -DSWZ_SB_STATS builds print the block kernel's phase times); VAR_ENV="SWZ_SP_BLOCK_DBG=8" passes switches on
@@ -38,6 +39,7 @@ tests)
 list)
   while IFS='|' read -r tag envs args; do
     [ -z "$tag" ] && continue
+    case $tag in sleep*) t=${tag#sleep}; sleep ${t%%_*} ;; esac   # (a tag "sleep20_..." waits that long first)
     env $envs timeout 900 python bench.py $args > $O/$tag.json 2> $O/$tag.err
     line $O/$tag.json
   done ;;
