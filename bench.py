@@ -642,7 +642,9 @@ def main():
     warm_left = args.warmup
     if mb is not None:
         # what a one-shot user pays: the FIRST data set of this context, workspace allocation and all (a real `Schwarzwald
-        # --tiler` run is one data set, executable/main.cpp:233-301); it doubles as the first warm-up step
+        # --tiler` run is one data set, executable/main.cpp:233-301); it doubles as the first warm-up step.  (The driver
+        # wipes the memory of a process that has exited, and the allocations of the next one wait for it: 0.95 s on an
+        # idle device, 4.2 s when this process starts right after one that held 100 GB -- tools/lists/first_data_set.txt.)
         torch.cuda.synchronize(dev)
         tf = time.perf_counter()
         step()

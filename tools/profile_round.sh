@@ -22,13 +22,17 @@ if [[ $PARTS == *lines* ]]; then
   # 10 M points -- 1 B points in 100 batches, cut out of the whole cloud and as x-y tiles, exact and property mode
   # (bench.py keeps warming up until a data set leaves the workspace as it found it: a multi-GB hipMalloc in the middle of
   # a data set stalls it for 0.25-2 s, tools/default_op_probe.py)
+  # Every multi-batch line reports `first_data_set_ms`, and the driver wipes the memory a process frees when it exits: a process
+  # that starts right after one that held 100 GB waits for that inside its first allocations (tools/lists/first_data_set.txt: first
+  # data set 0.95 s on a fresh device, 4.2 s right after the headline bench, 0.95 s half a minute later) -- hence the pauses.
+  MB() { sleep 30; B "$@"; }
   for o in uniform tiles; do
-    B 1B_100batches_MIN_DISTANCE_FAST_$o --points 1000000000 --batches 100 --batch-order $o --strategy FAST --steps 2 --warmup 1 --cpu-sample 0 --md-mode exact
-    B 1B_100batches_MIN_DISTANCE_FAST_${o}_property --points 1000000000 --batches 100 --batch-order $o --strategy FAST --steps 2 --warmup 1 --cpu-sample 0 --md-mode property
-    B 1B_100batches_MIN_DISTANCE_$o --points 1000000000 --batches 100 --batch-order $o --steps 1 --warmup 1 --cpu-sample 0 --md-mode exact
-    B 1B_100batches_RANDOM_GRID_$o --points 1000000000 --batches 100 --batch-order $o --sampler RANDOM_GRID --steps 2 --warmup 1 --cpu-sample 0
+    MB 1B_100batches_MIN_DISTANCE_FAST_$o --points 1000000000 --batches 100 --batch-order $o --strategy FAST --steps 2 --warmup 1 --cpu-sample 0 --md-mode exact
+    MB 1B_100batches_MIN_DISTANCE_FAST_${o}_property --points 1000000000 --batches 100 --batch-order $o --strategy FAST --steps 2 --warmup 1 --cpu-sample 0 --md-mode property
+    MB 1B_100batches_MIN_DISTANCE_$o --points 1000000000 --batches 100 --batch-order $o --steps 1 --warmup 1 --cpu-sample 0 --md-mode exact
+    MB 1B_100batches_RANDOM_GRID_$o --points 1000000000 --batches 100 --batch-order $o --sampler RANDOM_GRID --steps 2 --warmup 1 --cpu-sample 0
   done
-  B 500M_5batches_staged --points 500000000 --batches 5 --staged --payload rgb,intensity --steps 2 --warmup 1 --cpu-sample 0
+  MB 500M_5batches_staged --points 500000000 --batches 5 --staged --payload rgb,intensity --steps 2 --warmup 1 --cpu-sample 0
   timeout 600 python tools/clustered_probe.py 100000000 MIN_DISTANCE > $OUT/clustered_100M.txt 2>> $OUT/bench.err
   timeout 600 python tools/clustered_probe.py 100000000 MIN_DISTANCE property >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
   timeout 600 python tools/clustered_probe.py 100000000 GRID_CENTER >> $OUT/clustered_100M.txt 2>> $OUT/bench.err
