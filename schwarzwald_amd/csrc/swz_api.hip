@@ -101,6 +101,7 @@ void swz_ctx::release_all() {
 }
 
 void swz_ctx::free_buf(swz::DevBuf& b) {
+  if (b.ptr && b.ptr == sbi_clean_ptr) sbi_clean_ptr = nullptr;  // (what comes back at this address later is not known to be zero)
   if (b.ptr) (void)(b.host ? hipHostFree(b.ptr) : hipFree(b.ptr));
   b.ptr = nullptr;
   b.cap = 0;

@@ -86,6 +86,9 @@ struct swz_ctx {
   void* shard = nullptr;  // swz::ShardState of an open sharded batch (swz_level.hip)
   const void* md_shard_root = nullptr;  // swz::MdShardRoot while swz_group runs the MIN_DISTANCE root of a sharded batch on all shards at once
   bool md_shard_root_published = false;  // the "md_*_sr" arrays of this context are mapped by other shards: they stay (see get())
+  // swz_mdblock.hip, sb_incremental: [sbi_clean_ptr, + sbi_clean_bytes) of the "sbi_bits" buffer is known to be zero
+  const void* sbi_clean_ptr = nullptr;
+  size_t sbi_clean_bytes = 0;
   bool tiler_active = false;  // a swz_tiler lives on this context: its node store is part of the workspace
   swz_tiler* nodes_tiler = nullptr;  // the tiler of an open swz_tile_nodes_begin_device / _end_device pair
   // no batch of the tiler is open: its per-batch scratch ("tl_*") holds nothing anybody will read again, and get() may free

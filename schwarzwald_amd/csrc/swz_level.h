@@ -43,6 +43,11 @@ struct ActiveSet {
   uint32_t old_lo = 0, old_hi = 0;
   const uint64_t* new_key = nullptr;  // the batch's own points before the merge, ascending
   uint32_t new_m = 0;
+  // the nodes that hold files one level further down (their keys with the bits below the node cleared, ascending): a node with a
+  // child there has handed points down, i.e. it has been sampled, and its file -- rewritten by every visit since -- is a sampler's
+  // output whatever its size
+  const uint64_t* child_nkey = nullptr;
+  uint32_t child_nn = 0;
   // the nodes of the level above (LevelResult::node_prefix of the step whose survivors these are), when the caller has
   // them: every node of this level is a child of one of them, so its first point is found by searching the sorted keys
   // instead of by a scan over all points (level_step; null: scan)

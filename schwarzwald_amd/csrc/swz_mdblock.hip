@@ -1052,7 +1052,9 @@ static int sb_run(swz_ctx* c, const LevelPlan& plan, const SortedPoints& sp, con
 // outside S are accepted.  S is found on the level's finest cells (one spacing wide or more): a new point marks its cell,
 // an old point belongs to S when one of the 27 cells around it is marked.  With 10 M new points per batch on 390 M points of
 // files (level 2 of the 1 B run in 100 batches) S is a quarter of the level, on level 3 a thirtieth.
-// "New" also covers the entries of files with at most max_points points (they may come from a take-all).
+// "New" also covers the entries of files with at most max_points points of nodes without a child one level down: such a file
+// may be everything the node has ever seen (a take-all).  A node that has a child has handed points down, so it has been sampled,
+// and every visit since has sampled it again: its file is an output of the sampler whatever its size.
 struct SbiArgs {
   const uint64_t* akey;
   const uint32_t* aidx;
@@ -1073,6 +1075,7 @@ struct SbiArgs {
 __global__ __launch_bounds__(256) void sbi_indep_kernel(const uint32_t* __restrict__ nstart, const uint8_t* __restrict__ nmode,
                                                         uint32_t nnodes, const uint64_t* __restrict__ akey, uint32_t nsh,
                                                         const uint64_t* __restrict__ ckey, uint32_t nc, uint64_t max_points,
+                                                        const uint64_t* __restrict__ child_nkey, uint32_t child_nn,
                                                         uint8_t* __restrict__ indep) {
   const uint32_t j = blockIdx.x * 256 + threadIdx.x;
   if (j >= nnodes) return;
@@ -1090,7 +1093,19 @@ __global__ __launch_bounds__(256) void sbi_indep_kernel(const uint32_t* __restri
       const uint32_t mid = lo + (hi - lo) / 2;
       if ((ckey[mid] >> nsh) <= prefix) lo = mid + 1; else hi = mid;
     }
-    r = (uint64_t)(lo - first) > max_points ? 1 : 0;
+    const uint32_t cached = lo - first;
+    r = (uint64_t)cached > max_points ? 1 : 0;
+    if (!r && cached && child_nn) {
+      // a smaller file: the node's own output all the same once it has handed points down (a take-all keeps everything)
+      const uint64_t from = prefix << nsh;
+      lo = 0;
+      hi = child_nn;
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (child_nkey[mid] < from) lo = mid + 1; else hi = mid;
+      }
+      r = lo < child_nn && (child_nkey[lo] >> nsh) == prefix ? 1 : 0;
+    }
   }
   indep[j] = r;
 }
@@ -1108,6 +1123,7 @@ __device__ __forceinline__ uint64_t sbi_cell_base(const SbiArgs& a, uint32_t nod
 // files: a hundredth of the level).  The node of a key: the last one whose first point's prefix is not above it.
 // (Marking the 27 cells around every new point instead and testing one bit per old point was the first version: 270 M
 // scattered device-scope atomics per level took 30-54 ms.)
+template <bool CLEAR>  // (true: the words that were marked go back to zero, so that the array is never cleared as a whole)
 __global__ __launch_bounds__(256) void sbi_mark_kernel(SbiArgs a, const uint64_t* __restrict__ new_key, uint32_t new_m,
                                                        const uint32_t* __restrict__ nstart, uint32_t nnodes, uint32_t nsh) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -1125,7 +1141,11 @@ __global__ __launch_bounds__(256) void sbi_mark_kernel(SbiArgs a, const uint64_t
   const uint64_t bit = sbi_cell_base(a, node) + ((uint32_t)(key >> a.cell_shift) & a.cell_mask);
   const uint32_t b = 1u << (uint32_t)(bit & 31ull);
   uint32_t* w = a.bits + (bit >> 5);
-  if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) atomicOr(w, b);
+  if (CLEAR) {
+    *w = 0u;
+  } else if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & b)) {
+    atomicOr(w, b);
+  }
 }
 // Is there a new point in the 27 cells around this one?  The marks of an aligned group of 2 x 2 x 2 cells are one byte (the
 // cell code is a Morton code: bit 0 x, bit 1 y, bit 2 z), the 27 cells lie in two groups per axis -- the cell's own, whole,
@@ -1264,15 +1284,25 @@ static int sb_incremental(swz_ctx* c, const LevelPlan& plan, const ActiveSet& as
   {
     ProfScope ps(c, "sample_min_distance", (uint64_t)as.m * 30ull, 1);
     hipLaunchKernelGGL(sbi_indep_kernel, dim3(div_up(num_nodes, 256)), dim3(256), 0, c->stream, lb.nstart, lb.nmode, num_nodes, as.akey,
-                       node_shift, as.ckey, as.nc, plan.max_points, indep);
+                       node_shift, as.ckey, as.nc, plan.max_points, as.child_nkey, as.child_nn, indep);
     SWZ_LAUNCH_CHECK(c);
-    SWZ_HIP(c, memset_large(a.bits, 0, words * sizeof(uint32_t), c->stream));
+    // The marks (up to 2 GB) are cleared as a whole only when the array is new or a call before this one did not get to take
+    // its marks back: afterwards the batch's points clear the words they set (a memset of 1 GB per level and batch is 0.35 ms).
+    if (c->sbi_clean_ptr != a.bits || c->sbi_clean_bytes < words * sizeof(uint32_t)) {
+      SWZ_HIP(c, memset_large(a.bits, 0, words * sizeof(uint32_t), c->stream));
+      c->sbi_clean_bytes = words * sizeof(uint32_t);
+    }
+    c->sbi_clean_ptr = nullptr;  // (until the marks have been taken back)
     SWZ_HIP(c, hipMemsetAsync(d_cnt, 0, 16 * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(sbi_mark_kernel, dim3(div_up(as.new_m, 256)), dim3(256), 0, c->stream, a, as.new_key, as.new_m, lb.nstart, num_nodes,
-                       node_shift);
+    hipLaunchKernelGGL(sbi_mark_kernel<false>, dim3(div_up(as.new_m, 256)), dim3(256), 0, c->stream, a, as.new_key, as.new_m, lb.nstart,
+                       num_nodes, node_shift);
     SWZ_LAUNCH_CHECK(c);
     hipLaunchKernelGGL(sbi_select_kernel, dim3(div_up(as.m, 256)), dim3(256), 0, c->stream, a);
     SWZ_LAUNCH_CHECK(c);
+    hipLaunchKernelGGL(sbi_mark_kernel<true>, dim3(div_up(as.new_m, 256)), dim3(256), 0, c->stream, a, as.new_key, as.new_m, lb.nstart,
+                       num_nodes, node_shift);
+    SWZ_LAUNCH_CHECK(c);
+    c->sbi_clean_ptr = a.bits;
     SWZ_TRY(fused_scan_sums(c, SbiSelF{a.sel}, as.m, d_cnt, "sbi", &d_partial));
     SWZ_HIP(c, hipMemcpyAsync(&total, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     SWZ_HIP(c, hipStreamSynchronize(c->stream));
@@ -1346,8 +1376,9 @@ int min_distance_block_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet&
     else old_share = std::min(1.0, atof(e)), file_share = 0.0;
   }
   // (... and when the files are big enough for that: one of at most max_points points may come from a node that took everything)
+  // (with the node table of the level below a small file can be told from a take-all: then any level of files qualifies)
   if (inc && (double)(as.old_hi - as.old_lo) >= old_share * (double)as.m &&
-      (double)(as.old_hi - as.old_lo) >= file_share * (double)plan.max_points * (double)num_nodes) {
+      (as.child_nn || (double)(as.old_hi - as.old_lo) >= file_share * (double)plan.max_points * (double)num_nodes)) {
     SWZ_TRY(sb_incremental(c, plan, as, sp, lb, snode_of, all_sampled, num_nodes, sample_nodes, sample_points, km, done));
     if (*done) return SWZ_OK;
   }

@@ -1020,6 +1020,14 @@ static int tiler_level(swz_tiler* t, BatchWork& w, const LevelPlan& plan_in, Act
       ms.old_hi = pull_lo + nc;
       ms.new_key = as.akey;
       ms.new_m = as.m;
+      if (plan.sampler == SWZ_MIN_DISTANCE && !plan.terminal && plan.level + 2 < 22) {
+        StoreLevel& below = t->lv[plan.level + 2];
+        if (below.cnt) {  // (the table this batch's next level asks for anyway)
+          SWZ_TRY(store_table(c, below, plan.level + 2));
+          ms.child_nkey = below.nkey[below.ncur];
+          ms.child_nn = below.nn;
+        }
+      }
     }
   }
   if (ms.m == 0) {  // a shard without new points and without a root file
