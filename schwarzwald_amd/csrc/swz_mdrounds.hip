@@ -314,6 +314,189 @@ __global__ __launch_bounds__(256) void pr_kill_wlist_kernel(PrArgs a, uint32_t c
   }
 }
 
+// (3''): the kill pass of the rounds that still look at every point, by BLOCKS of cells (round 6).  Both passes above spend their
+// instructions on finding the cells around a point's cell in a Morton-coded table (160 of ~830 per wavefront) and on fetching and
+// unpacking one winner at a time from memory (~60 each), or need 448 bytes of records per cell.  Here a workgroup takes a block
+// of B x B x B cells (B = 8, 4 or 2: at least some thousand blocks per level) -- one run of the sorted keys --, stages the winners of the
+// (B + 2)^3 cells of and around it in LDS as ready-made {x, y, z, index} entries (a cell without a winner: coordinates that are far
+// from everything), and a point finds the 27 entries around its cell by adding constants to one LDS index: a dozen instructions
+// per winner, no table of masks, no records.  Same winners, same kills: the result is the one of the passes above.
+struct PrBlockArgs {
+  const uint32_t* bstart;  // [blocks + 1] first active point of every block (PR_NONE: none), [blocks] = m
+  uint32_t blocks;
+  uint32_t bl;             // log2 of B
+  uint32_t cl;             // cell levels of the grid
+};
+__device__ __forceinline__ uint32_t pr_dilate3(uint32_t v) {  // bit j -> bit 3j (v < 1024)
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+// first point of every block: the head of its first occupied cell (cand[0] holds the heads before the first round)
+__global__ __launch_bounds__(256) void pr_block_start_kernel(PrArgs a, PrBlockArgs g, uint32_t* __restrict__ bstart) {
+  const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b > g.blocks) return;
+  uint32_t first = PR_NONE;
+  if (b == g.blocks) {
+    first = a.m;
+  } else {
+    const uint64_t c0 = (uint64_t)b << (3u * g.bl);
+    const uint32_t n = 1u << (3u * g.bl);
+    for (uint32_t k = 0; k < n && first == PR_NONE; ++k) first = a.cand[0][c0 + k];
+  }
+  bstart[b] = first;
+}
+// Two phases per point: the winners of its own cell and of the six cells across a face first -- most points of a dense level die
+// there --, and only the survivors, collected in a queue in LDS until they fill the workgroup, go on to the other twenty (a
+// wavefront executes every test one of its lanes still needs: with 64 consecutive points that meant all 27 for nearly every
+// wavefront).
+constexpr uint32_t PR_BQ = 512;       // queue entries (a workgroup appends at most 256 between two drains of 256)
+#ifndef SWZ_PR_NEAR
+#define SWZ_PR_NEAR 7
+#endif
+constexpr int PR_NEAR = SWZ_PR_NEAR;  // tests of the first phase
+__global__ __launch_bounds__(256) void pr_kill_block_kernel(PrArgs a, PrBlockArgs g, uint32_t cur) {
+  extern __shared__ float4 pr_lw[];  // (B + 2)^3 winners
+  __shared__ uint32_t range[2];
+  __shared__ uint32_t qn[1];          // entries appended so far (the queue is a ring; every thread counts the drained ones)
+  __shared__ uint32_t qi[PR_BQ], qc[PR_BQ];
+  __shared__ int qr[PR_BQ];
+  __shared__ float qx[PR_BQ], qy[PR_BQ], qz[PR_BQ];
+  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t B = 1u << g.bl, R = B + 2u, R2 = R * R, R3 = R2 * R;
+  if (tid == 0) {
+    const uint32_t lo = g.bstart[b];
+    uint32_t hi = lo;
+    if (lo != PR_NONE) {
+      // the block's points end where the next occupied block begins (what lies in between belongs to nodes that are not sampled:
+      // dead from the start); [blocks] holds m
+      uint32_t nb = b + 1u;
+      while ((hi = g.bstart[nb]) == PR_NONE) ++nb;
+    }
+    range[0] = lo;
+    range[1] = hi;
+    qn[0] = 0u;
+  }
+  // the block inside its node: cell coordinates of its origin (key bit 3j + 2 is bit j of x, 3j + 1 of y, 3j of z)
+  const uint32_t per_node_bits = 3u * (g.cl - g.bl);
+  const uint32_t bcode = b & ((1u << per_node_bits) - 1u);
+  const uint64_t base = ((uint64_t)(b >> per_node_bits)) << (3u * g.cl);  // first cell of the node
+  const uint32_t ox = contract_bits_by_3_u32(bcode >> 2) << g.bl, oy = contract_bits_by_3_u32(bcode >> 1) << g.bl, oz = contract_bits_by_3_u32(bcode) << g.bl;
+  const uint32_t cmask = (1u << g.cl) - 1u;
+  for (uint32_t r = tid; r < R3; r += 256u) {
+    const uint32_t ix = r % R, iy = (r / R) % R, iz = r / R2;
+    const uint32_t cx = ox + ix - 1u, cy = oy + iy - 1u, cz = oz + iz - 1u;  // (wraps below zero: > cmask)
+    float4 e = make_float4(1e30f, 1e30f, 1e30f, __uint_as_float(PR_NONE));
+    if (cx <= cmask && cy <= cmask && cz <= cmask) {
+      const uint64_t c = base + ((pr_dilate3(cx) << 2) | (pr_dilate3(cy) << 1) | pr_dilate3(cz));
+      const uint64_t q = a.wonq[c];
+      if (q) {
+        float qx_, qy_, qz_;
+        pr_unpack(q, qx_, qy_, qz_);
+        e = make_float4(qx_, qy_, qz_, __uint_as_float(a.woni[c]));
+      }
+    }
+    pr_lw[r] = e;
+  }
+  __syncthreads();
+  const uint32_t lo = range[0], hi = range[1];
+  if (lo == PR_NONE) return;
+  const uint32_t cb = a.cell_shift / 3u;
+  const int iR = (int)R, iR2 = (int)R2;
+  // the cell itself first, then the cells across a face, an edge, a corner: the closer winners kill most of the points
+  constexpr int ORDER[27] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25, 0, 2, 6, 8, 18, 20, 24, 26};
+  uint32_t nband = 0;
+  // second phase for the queue's entries [from, from + 256) (fewer at the very end)
+  auto drain = [&](uint32_t from, uint32_t count) {
+    if (tid < count) {
+      const uint32_t s = (from + tid) % PR_BQ;
+      const uint32_t i = qi[s];
+      const int r0 = qr[s];
+      const float x = qx[s], y = qy[s], z = qz[s];
+      bool dead = false;
+#pragma unroll
+      for (int kk = PR_NEAR; kk < 27; ++kk) {
+        const int k = ORDER[kk];
+        if (!dead) {
+          const float4 e = pr_lw[r0 + (k % 3 - 1) + iR * ((k / 3) % 3 - 1) + iR2 * (k / 9 - 1)];
+          const float d2 = pr_d2(x, y, z, e.x, e.y, e.z);
+          if (d2 < a.f_lo) dead = true;
+          else if (d2 < a.f_hi) {
+            ++nband;
+            dead = pr_exact_near(a, i, __float_as_uint(e.w));
+          }
+        }
+      }
+      if (dead) a.state[i] = PR_DEAD;
+      else atomicMin(&a.cand[cur ^ 1u][base + qc[s]], i);  // a survivor: the smallest index of its cell is the next round's candidate
+    }
+  };
+  uint32_t drained = 0;  // (every thread keeps the same count)
+  for (uint32_t i0 = lo; i0 < hi; i0 += 256u) {
+    const uint32_t i = i0 + tid;
+    bool alive = i < hi && a.state[i] == PR_ALIVE;
+    uint32_t code = 0;
+    int r0 = 0;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (alive) {
+      const uint64_t key = a.akey[i];
+      uint32_t ux, uy, uz;
+      pr_coords_u(key, ux, uy, uz);
+      x = (float)ux;
+      y = (float)uy;
+      z = (float)uz;
+      code = (uint32_t)((key >> a.cell_shift) & (a.cells_per_node - 1ull));
+      r0 = (int)((((ux >> cb) & cmask) - ox + 1u) + R * (((uy >> cb) & cmask) - oy + 1u) + R2 * (((uz >> cb) & cmask) - oz + 1u));
+      bool dead = false;
+#pragma unroll
+      for (int kk = 0; kk < PR_NEAR; ++kk) {
+        const int k = ORDER[kk];
+        if (!dead) {
+          const float4 e = pr_lw[r0 + (k % 3 - 1) + iR * ((k / 3) % 3 - 1) + iR2 * (k / 9 - 1)];
+          const float d2 = pr_d2(x, y, z, e.x, e.y, e.z);
+          if (d2 < a.f_lo) dead = true;
+          else if (d2 < a.f_hi) {
+            ++nband;
+            dead = pr_exact_near(a, i, __float_as_uint(e.w));
+          }
+        }
+      }
+      if (dead) {
+        a.state[i] = PR_DEAD;
+        alive = false;
+      }
+    }
+    // the survivors of the first phase queue up (one LDS atomic per wavefront)
+    const uint64_t am = __ballot(alive);
+    if (am) {
+      uint32_t at = 0;
+      const int leader = __ffsll((unsigned long long)am) - 1;
+      if ((int)(tid & 63u) == leader) at = atomicAdd(&qn[0], (uint32_t)__popcll(am));
+      at = (uint32_t)__shfl((int)at, leader, WAVE);
+      if (alive) {
+        const uint32_t s = (at + (uint32_t)__popcll(am & lanemask_lt())) % PR_BQ;
+        qi[s] = i;
+        qc[s] = code;
+        qr[s] = r0;
+        qx[s] = x;
+        qy[s] = y;
+        qz[s] = z;
+      }
+    }
+    __syncthreads();
+    if (qn[0] - drained >= 256u) {  // (uniform: everybody reads the same counter between two barriers)
+      drain(drained, 256u);
+      drained += 256u;
+    }
+    __syncthreads();
+  }
+  const uint32_t rest = qn[0] - drained;  // < 256
+  if (rest) drain(drained, rest);
+  if (nband) atomicAdd(&a.counters[PRC_BAND], nband);
+}
+
 // ---- the per-cell steps over a LIST of alive points.  Once the alive points are listed (in order: a cell's points are
 // consecutive in the list) the cells that still matter are the cells of the list's entries -- a tenth of the grid after one
 // round, a hundredth after two -- and the first entry of every cell (its head in the list) does the cell's work; the
@@ -498,6 +681,18 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   double wl_min_pop = 24.0;
   if (const char* e = c->opt("SWZ_MD_ROUNDS_WLIST_MIN_POP")) wl_min_pop = atof(e);
   bool wl = (double)sample_points / (double)a.ncells >= wl_min_pop;
+  // ... or, round 6, by blocks of cells with the winners around them in LDS (pr_kill_block_kernel): no records, no masks
+  PrBlockArgs g{};
+  bool blk = cl >= 1 && !(c->opt("SWZ_MD_ROUNDS_BLOCK") && atoi(c->opt("SWZ_MD_ROUNDS_BLOCK")) == 0);
+  if (blk) {
+    g.cl = (uint32_t)cl;
+    g.bl = (uint32_t)std::min(cl, 3);
+    while (g.bl > 1u && ((uint64_t)sample_nodes << (3u * (g.cl - g.bl))) < 8192ull) --g.bl;  // (the root: 32 768 blocks of 2^3 cells)
+    const uint64_t nblocks = (uint64_t)sample_nodes << (3u * (g.cl - g.bl));
+    if (nblocks >= (1ull << 31)) blk = false;
+    g.blocks = (uint32_t)nblocks;
+  }
+  if (blk) wl = false;
   float4* wlist = nullptr;
   uint8_t* wcount = nullptr;
   if (wl) {
@@ -508,6 +703,14 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
       wlist = nullptr;
       wcount = nullptr;
     }
+  }
+  if (blk) {
+    uint32_t* bstart = nullptr;
+    SWZ_TRY(c->get("md_pr_bstart", (size_t)g.blocks + 1, &bstart));
+    g.bstart = bstart;
+    // (cand[0] holds the cells' heads until the first round's kill pass hands the survivors to cand[1]: taken now)
+    hipLaunchKernelGGL(pr_block_start_kernel, dim3(div_up(g.blocks + 1u, 256)), dim3(256), 0, c->stream, a, g, bstart);
+    SWZ_LAUNCH_CHECK(c);
   }
   const bool cell_lists = !(c->opt("SWZ_MD_ROUNDS_CELL_LISTS") && atoi(c->opt("SWZ_MD_ROUNDS_CELL_LISTS")) == 0);
   bool prev_list = false;   // the round before ran over a list (list[cur ^ 1], nprev entries: still intact)
@@ -534,12 +737,20 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     } else {
       hipLaunchKernelGGL(pr_candidates_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
       hipLaunchKernelGGL(pr_winners_kernel, dim3(cblocks), dim3(256), 0, c->stream, a, cur);
-      if (wl && !use_list) hipLaunchKernelGGL(pr_mask_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, a, wlist, wcount);
-      else hipLaunchKernelGGL(pr_mask_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, a, (float4*)nullptr, (uint8_t*)nullptr);
+      if (blk && !use_list) {
+        // (the kill pass below reads the winners themselves)
+      } else if (wl && !use_list) {
+        hipLaunchKernelGGL(pr_mask_kernel<true>, dim3(cblocks), dim3(256), 0, c->stream, a, wlist, wcount);
+      } else {
+        hipLaunchKernelGGL(pr_mask_kernel<false>, dim3(cblocks), dim3(256), 0, c->stream, a, (float4*)nullptr, (uint8_t*)nullptr);
+      }
     }
     const uint32_t threads = use_list ? nlist : m;
     if (threads) {
-      if (!use_list && wl)
+      if (!use_list && blk) {
+        const uint32_t R = (1u << g.bl) + 2u;
+        hipLaunchKernelGGL(pr_kill_block_kernel, dim3(g.blocks), dim3(256), (size_t)R * R * R * sizeof(float4), c->stream, a, g, cur);
+      } else if (!use_list && wl)
         hipLaunchKernelGGL(pr_kill_wlist_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, wlist, wcount);
       else
         hipLaunchKernelGGL(pr_kill_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, use_list ? 1u : 0u, nlist);

@@ -130,15 +130,50 @@ def test_property_mode_kill_paths_agree(ctx):
     sp = O.spacing_from_diagonal(*UNIT, 40)  # root cells of ~700 points, level 0 ~90: records; level 1 ~11: the mask loop
     params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=2000, spacing_at_root=sp, flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
     base = ctx.tile(xyz, *UNIT, params)
-    for opt, val in (("SWZ_MD_ROUNDS_WLIST_MIN_POP", "1e9"), ("SWZ_MD_ROUNDS_CELL_LISTS", "0"), ("SWZ_MD_ROUNDS_LIST", "0")):
-        ctx.set_option(opt, val)
+    # round 6: the kill pass of the rounds over all points runs by blocks of cells with the winners around them in LDS (default);
+    # without it the records / the mask loop of round 5 take over -- alone and combined with the older switches
+    variants = ({"SWZ_MD_ROUNDS_BLOCK": "0"}, {"SWZ_MD_ROUNDS_BLOCK": "0", "SWZ_MD_ROUNDS_WLIST_MIN_POP": "1e9"},
+                {"SWZ_MD_ROUNDS_CELL_LISTS": "0"}, {"SWZ_MD_ROUNDS_LIST": "0"}, {"SWZ_MD_ROUNDS_BLOCK": "0", "SWZ_MD_ROUNDS_LIST": "0"})
+    for opts in variants:
+        for opt, val in opts.items():
+            ctx.set_option(opt, val)
         try:
             other = ctx.tile(xyz, *UNIT, params)
         finally:
-            ctx.set_option(opt, None)
-        assert np.array_equal(other.level, base.level), opt
+            for opt in opts:
+                ctx.set_option(opt, None)
+        assert np.array_equal(other.level, base.level), opts
     a, b = _check_property(base.keys, base.level, base.xyz_clamped[base.perm], sp, 2000, base.stats["max_level"])
     assert a > 0 and b > 0
+
+
+@pytest.mark.parametrize("kind", ["uniform", "clustered", "odd bounds"])
+def test_property_mode_block_kill_pass_changes_nothing(ctx, kind):
+    """The same comparison on clouds whose levels differ in cell population (blocks of 8, 4 and 2 cells per edge), on bounds
+    that are not a power of two wide, and with nodes that take everything beside sampled ones."""
+    import schwarzwald_amd as swz
+    rng = np.random.default_rng(91)
+    n = 2500000
+    if kind == "clustered":
+        xyz, bounds, d, mppn = _clustered(rng, n), UNIT, 250, 1500
+    elif kind == "odd bounds":
+        lo, side = np.array([-512.25, 1000.5, -3.125]), 777.7
+        xyz, bounds, d, mppn = lo + rng.random((n, 3)) * side, (list(lo), list(lo + side)), 120, 5000
+        xyz[: n // 3] = lo + (0.2 + 0.1 * rng.random((n // 3, 3))) * side   # a dense corner: sampled nodes beside take-all ones
+    else:
+        xyz, bounds, d, mppn = rng.random((n, 3)), UNIT, 100, 3000
+    sp = O.spacing_from_diagonal(*bounds, d)
+    params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=mppn, spacing_at_root=sp, flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
+    base = ctx.tile(xyz, *bounds, params)
+    ctx.set_option("SWZ_MD_ROUNDS_BLOCK", "0")
+    try:
+        other = ctx.tile(xyz, *bounds, params)
+    finally:
+        ctx.set_option("SWZ_MD_ROUNDS_BLOCK", None)
+    assert np.array_equal(other.level, base.level)
+    if bounds is UNIT:
+        a, b = _check_property(base.keys, base.level, base.xyz_clamped[base.perm], sp, mppn, base.stats["max_level"])
+        assert a > 0 and b > 0
 
 
 def test_property_mode_fast_strategy_and_multibatch(ctx):

@@ -52,7 +52,7 @@ variants)
     [ -f "$lib" ] || continue
     echo "== $lib $VAR_ENV"
     env $VAR_ENV SWZ_GPU_LIBRARY=$PWD/$lib SWZ_DEBUG=1 timeout 600 python bench.py --steps 2 --warmup 1 --cpu-sample 0 --also "" "$@" 2>&1 >$O/variant.json \
-      | grep -E "block path|thread 0" | tail -4 | cut -c1-60,150-500
+      | grep -E "block path|thread 0|property level" | tail -${TAIL:-4} | cut -c1-60,150-500
     line $O/variant.json
   done ;;
 multibatch)
