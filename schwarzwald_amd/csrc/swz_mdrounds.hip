@@ -127,7 +127,8 @@ __global__ __launch_bounds__(256) void pr_init_kernel(PrArgs a) {
     return;
   }
   a.state[i] = PR_ALIVE;
-  const bool head = i == 0 || a.nid[i - 1] != a.nid[i] || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
+  // (the key above the cell's bits names the node as well: a point of another node differs there, no node ids needed)
+  const bool head = i == 0 || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
   if (head) a.cand[0][pr_cell_of(a, i)] = i;
 }
 
