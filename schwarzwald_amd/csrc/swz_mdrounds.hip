@@ -380,6 +380,8 @@ __global__ __launch_bounds__(256) void pr_kill_block_kernel(PrArgs a, PrBlockArg
     range[1] = hi;
     qn[0] = 0u;
   }
+  __syncthreads();
+  if (range[0] == PR_NONE) return;  // an empty block (most of them, on surface-like data) costs one load
   // the block inside its node: cell coordinates of its origin (key bit 3j + 2 is bit j of x, 3j + 1 of y, 3j of z)
   const uint32_t per_node_bits = 3u * (g.cl - g.bl);
   const uint32_t bcode = b & ((1u << per_node_bits) - 1u);
@@ -403,7 +405,6 @@ __global__ __launch_bounds__(256) void pr_kill_block_kernel(PrArgs a, PrBlockArg
   }
   __syncthreads();
   const uint32_t lo = range[0], hi = range[1];
-  if (lo == PR_NONE) return;
   const uint32_t cb = a.cell_shift / 3u;
   const int iR = (int)R, iR2 = (int)R2;
   // the cell itself first, then the cells across a face, an edge, a corner: the closer winners kill most of the points
