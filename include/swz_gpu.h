@@ -72,7 +72,7 @@ int swz_set_stream(swz_ctx* ctx, void* hip_stream);
  * MIN_DISTANCE repeats a compare on the exact positions below its proven width and exists so that a test can show that
  * the band is needed (tests/test_min_distance_keys.py).
  * SWZ_MD_ROUNDS_BLOCK=0: property mode's first kill pass by per-cell records / the mask loop of round 5 instead of by blocks
- * of cells (same set).
+ * of cells (same set); SWZ_MD_ROUNDS_BLOCK_MIN_POP (0): the points per cell of a level from which the blocks are used.
  * Round 6, the sparse MIN_DISTANCE levels by blocks of cells (swz_mdblock.hip): SWZ_SP_BLOCK=0 keeps them on the
  * thread-per-point path; SWZ_SP_BLOCK_WIDE=1, _CL, _OWN, _HALO, _PER_CU, _MIN force the point format, the cell level, the
  * LDS capacities, the workgroups per CU, the points a block should hold -- results unchanged (a block that does not fit

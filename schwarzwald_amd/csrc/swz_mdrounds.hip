@@ -57,6 +57,11 @@ struct PrArgs {
   uint32_t* woni;        // [cell] ... its active index
   uint32_t* wmask;       // [cell] bit k: the adjacent cell in direction k holds a winner of this round
   uint32_t* list[2];     // alive points (compacted once few are left)
+  // blocks of cells for pr_kill_block_kernel (null: not used): first point of every block's run of the sorted keys and the index
+  // behind its last one, written by pr_init_kernel where the key above the block's bits changes
+  uint32_t* bstart;
+  uint32_t* bend;
+  uint32_t block_bits;   // 3 x log2 of the block's edge in cells
   uint64_t ncells;       // sampled nodes x cells per node
   uint32_t cell_shift;
   uint64_t cells_per_node;
@@ -129,7 +134,18 @@ __global__ __launch_bounds__(256) void pr_init_kernel(PrArgs a) {
   a.state[i] = PR_ALIVE;
   // (the key above the cell's bits names the node as well: a point of another node differs there, no node ids needed)
   const bool head = i == 0 || ((a.akey[i] >> a.cell_shift) != (a.akey[i - 1] >> a.cell_shift));
-  if (head) a.cand[0][pr_cell_of(a, i)] = i;
+  uint64_t cell = 0;
+  if (head) {
+    cell = pr_cell_of(a, i);
+    a.cand[0][cell] = i;
+  }
+  if (a.bstart) {
+    const uint32_t bsh = a.cell_shift + a.block_bits;
+    if (head && (i == 0 || (a.akey[i] >> bsh) != (a.akey[i - 1] >> bsh))) a.bstart[cell >> a.block_bits] = i;
+    // the block's run ends where the key above the block's bits changes next (whoever follows: a point of a node that is not
+    // sampled is dead from the start and only skipped)
+    if (i + 1u == a.m || (a.akey[i + 1u] >> bsh) != (a.akey[i] >> bsh)) a.bend[pr_cell_of(a, i) >> a.block_bits] = i + 1u;
+  }
 }
 
 // (1) the candidates' coordinates beside their index; the next round's candidate slots emptied
@@ -323,7 +339,7 @@ __global__ __launch_bounds__(256) void pr_kill_wlist_kernel(PrArgs a, uint32_t c
 // from everything), and a point finds the 27 entries around its cell by adding constants to one LDS index: a dozen instructions
 // per winner, no table of masks, no records.  Same winners, same kills: the result is the one of the passes above.
 struct PrBlockArgs {
-  const uint32_t* bstart;  // [blocks + 1] first active point of every block (PR_NONE: none), [blocks] = m
+  const uint32_t* eoff;    // [blocks + 1] chunks beyond the first of the blocks before this one ([blocks]: of all)
   uint32_t blocks;
   uint32_t bl;             // log2 of B
   uint32_t cl;             // cell levels of the grid
@@ -335,19 +351,14 @@ __device__ __forceinline__ uint32_t pr_dilate3(uint32_t v) {  // bit j -> bit 3j
   v = (v | (v << 2)) & 0x09249249u;
   return v;
 }
-// first point of every block: the head of its first occupied cell (cand[0] holds the heads before the first round)
-__global__ __launch_bounds__(256) void pr_block_start_kernel(PrArgs a, PrBlockArgs g, uint32_t* __restrict__ bstart) {
+// A block of more than PR_CHUNK points is shared: its first PR_CHUNK points go to the workgroup of the block, every further
+// chunk to a workgroup of its own behind them (surface-like data: a blob of 30 M points sits in a handful of blocks).
+constexpr uint32_t PR_CHUNK = 32768;
+__global__ __launch_bounds__(256) void pr_block_extra_kernel(const uint32_t* __restrict__ bstart, const uint32_t* __restrict__ bend, uint32_t blocks,
+                                                             uint32_t* __restrict__ extra) {
   const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-  if (b > g.blocks) return;
-  uint32_t first = PR_NONE;
-  if (b == g.blocks) {
-    first = a.m;
-  } else {
-    const uint64_t c0 = (uint64_t)b << (3u * g.bl);
-    const uint32_t n = 1u << (3u * g.bl);
-    for (uint32_t k = 0; k < n && first == PR_NONE; ++k) first = a.cand[0][c0 + k];
-  }
-  bstart[b] = first;
+  if (b > blocks) return;
+  extra[b] = (b < blocks && bstart[b] != PR_NONE) ? (bend[b] - bstart[b] - 1u) / PR_CHUNK : 0u;
 }
 // Two phases per point: the winners of its own cell and of the six cells across a face first -- most points of a dense level die
 // there --, and only the survivors, collected in a queue in LDS until they fill the workgroup, go on to the other twenty (a
@@ -360,28 +371,42 @@ constexpr uint32_t PR_BQ = 512;       // queue entries (a workgroup appends at m
 constexpr int PR_NEAR = SWZ_PR_NEAR;  // tests of the first phase
 __global__ __launch_bounds__(256) void pr_kill_block_kernel(PrArgs a, PrBlockArgs g, uint32_t cur) {
   extern __shared__ float4 pr_lw[];  // (B + 2)^3 winners
-  __shared__ uint32_t range[2];
+  __shared__ uint32_t range[3];
   __shared__ uint32_t qn[1];          // entries appended so far (the queue is a ring; every thread counts the drained ones)
   __shared__ uint32_t qi[PR_BQ], qc[PR_BQ];
   __shared__ int qr[PR_BQ];
   __shared__ float qx[PR_BQ], qy[PR_BQ], qz[PR_BQ];
-  const uint32_t b = blockIdx.x, tid = threadIdx.x;
+  const uint32_t tid = threadIdx.x;
   const uint32_t B = 1u << g.bl, R = B + 2u, R2 = R * R, R3 = R2 * R;
   if (tid == 0) {
-    const uint32_t lo = g.bstart[b];
-    uint32_t hi = lo;
-    if (lo != PR_NONE) {
-      // the block's points end where the next occupied block begins (what lies in between belongs to nodes that are not sampled:
-      // dead from the start); [blocks] holds m
-      uint32_t nb = b + 1u;
-      while ((hi = g.bstart[nb]) == PR_NONE) ++nb;
+    // workgroups [0, blocks): the first chunk of their block; behind them one per further chunk, found by search
+    uint32_t b = blockIdx.x, k = 0;
+    if (b >= g.blocks) {
+      const uint32_t e = b - g.blocks;
+      b = PR_NONE;
+      if (e < g.eoff[g.blocks]) {
+        uint32_t lo = 0, hi = g.blocks;  // the last block with eoff <= e (its own extra chunks follow it)
+        while (hi - lo > 1u) {
+          const uint32_t mid = lo + (hi - lo) / 2u;
+          if (g.eoff[mid] <= e) lo = mid; else hi = mid;
+        }
+        b = lo;
+        k = e - g.eoff[lo] + 1u;
+      }
+    }
+    uint32_t lo = PR_NONE, hi = 0;
+    if (b != PR_NONE && a.bstart[b] != PR_NONE) {
+      lo = a.bstart[b] + k * PR_CHUNK;
+      hi = min(a.bend[b], lo + PR_CHUNK);
     }
     range[0] = lo;
     range[1] = hi;
+    range[2] = b;
     qn[0] = 0u;
   }
   __syncthreads();
-  if (range[0] == PR_NONE) return;  // an empty block (most of them, on surface-like data) costs one load
+  if (range[0] == PR_NONE) return;  // an empty block (most of them, on surface-like data) costs two loads
+  const uint32_t b = range[2];
   // the block inside its node: cell coordinates of its origin (key bit 3j + 2 is bit j of x, 3j + 1 of y, 3j of z)
   const uint32_t per_node_bits = 3u * (g.cl - g.bl);
   const uint32_t bcode = b & ((1u << per_node_bits) - 1u);
@@ -669,8 +694,6 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   SWZ_TRY(c->get("md_pr_wmask", (size_t)a.ncells, &a.wmask));
   SWZ_HIP(c, memset_large(a.cand[0], 0xFF, (size_t)a.ncells * 4, c->stream));
   SWZ_HIP(c, hipMemsetAsync(lb.counters + CTR_DBG_HIST, 0, 8 * sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(pr_init_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, a);
-  SWZ_LAUNCH_CHECK(c);
   const uint32_t cblocks = div_up(a.ncells, 256);
   uint32_t cur = 0, rounds = 0, alive = sample_points, nlist = 0;
   bool use_list = false;
@@ -685,7 +708,13 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
   bool wl = (double)sample_points / (double)a.ncells >= wl_min_pop;
   // ... or, round 6, by blocks of cells with the winners around them in LDS (pr_kill_block_kernel): no records, no masks
   PrBlockArgs g{};
-  bool blk = cl >= 1 && !(c->opt("SWZ_MD_ROUNDS_BLOCK") && atoi(c->opt("SWZ_MD_ROUNDS_BLOCK")) == 0);
+  // (on every level: also on grids that are mostly empty -- the thin levels of surface-like data, 0.1-0.7 points per cell -- once an
+  // empty block costs two loads and a block of millions of points, the blob of that cloud, is shared by many workgroups:
+  // 100 M clustered points 60.5 ms against 70.1 with the mask loop; the first version, whole blocks only, took 100-112)
+  double blk_min_pop = 0.0;
+  if (const char* e = c->opt("SWZ_MD_ROUNDS_BLOCK_MIN_POP")) blk_min_pop = atof(e);
+  bool blk = cl >= 1 && !(c->opt("SWZ_MD_ROUNDS_BLOCK") && atoi(c->opt("SWZ_MD_ROUNDS_BLOCK")) == 0) &&
+             (double)sample_points / (double)a.ncells >= blk_min_pop;
   if (blk) {
     g.cl = (uint32_t)cl;
     g.bl = (uint32_t)std::min(cl, 3);
@@ -707,12 +736,23 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     }
   }
   if (blk) {
-    uint32_t* bstart = nullptr;
-    SWZ_TRY(c->get("md_pr_bstart", (size_t)g.blocks + 1, &bstart));
-    g.bstart = bstart;
-    // (cand[0] holds the cells' heads until the first round's kill pass hands the survivors to cand[1]: taken now)
-    hipLaunchKernelGGL(pr_block_start_kernel, dim3(div_up(g.blocks + 1u, 256)), dim3(256), 0, c->stream, a, g, bstart);
+    SWZ_TRY(c->get("md_pr_bstart", (size_t)g.blocks, &a.bstart));
+    SWZ_TRY(c->get("md_pr_bend", (size_t)g.blocks, &a.bend));
+    a.block_bits = 3u * g.bl;
+    SWZ_HIP(c, memset_large(a.bstart, 0xFF, (size_t)g.blocks * 4, c->stream));
+    SWZ_HIP(c, memset_large(a.bend, 0, (size_t)g.blocks * 4, c->stream));
+  }
+  hipLaunchKernelGGL(pr_init_kernel, dim3(div_up(m, 256)), dim3(256), 0, c->stream, a);
+  SWZ_LAUNCH_CHECK(c);
+  uint32_t kill_grid = 0;
+  if (blk) {
+    uint32_t* eoff = nullptr;
+    SWZ_TRY(c->get("md_pr_eoff", (size_t)g.blocks + 1, &eoff));
+    hipLaunchKernelGGL(pr_block_extra_kernel, dim3(div_up(g.blocks + 1u, 256)), dim3(256), 0, c->stream, a.bstart, a.bend, g.blocks, eoff);
     SWZ_LAUNCH_CHECK(c);
+    SWZ_TRY(scan_exclusive_u32(c, eoff, eoff, g.blocks + 1u, nullptr, "mdpe"));
+    g.eoff = eoff;
+    kill_grid = g.blocks + m / PR_CHUNK + 1u;  // (as many further chunks as there can be: who finds none leaves at once)
   }
   const bool cell_lists = !(c->opt("SWZ_MD_ROUNDS_CELL_LISTS") && atoi(c->opt("SWZ_MD_ROUNDS_CELL_LISTS")) == 0);
   bool prev_list = false;   // the round before ran over a list (list[cur ^ 1], nprev entries: still intact)
@@ -751,7 +791,7 @@ int min_distance_rounds_level(swz_ctx* c, const LevelPlan& plan, const ActiveSet
     if (threads) {
       if (!use_list && blk) {
         const uint32_t R = (1u << g.bl) + 2u;
-        hipLaunchKernelGGL(pr_kill_block_kernel, dim3(g.blocks), dim3(256), (size_t)R * R * R * sizeof(float4), c->stream, a, g, cur);
+        hipLaunchKernelGGL(pr_kill_block_kernel, dim3(kill_grid), dim3(256), (size_t)R * R * R * sizeof(float4), c->stream, a, g, cur);
       } else if (!use_list && wl)
         hipLaunchKernelGGL(pr_kill_wlist_kernel, dim3(div_up(threads, 256)), dim3(256), 0, c->stream, a, cur, wlist, wcount);
       else

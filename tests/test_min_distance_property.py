@@ -164,13 +164,18 @@ def test_property_mode_block_kill_pass_changes_nothing(ctx, kind):
         xyz, bounds, d, mppn = rng.random((n, 3)), UNIT, 100, 3000
     sp = O.spacing_from_diagonal(*bounds, d)
     params = swz.TileParams(sampler=swz.MIN_DISTANCE, max_points_per_node=mppn, spacing_at_root=sp, flags=swz.FLAG_MIN_DISTANCE_PROPERTY)
-    base = ctx.tile(xyz, *bounds, params)
+    ctx.set_option("SWZ_MD_ROUNDS_BLOCK_MIN_POP", "3")   # blocks only on levels of three points per cell or more (default: all)
+    try:
+        base = ctx.tile(xyz, *bounds, params)
+    finally:
+        ctx.set_option("SWZ_MD_ROUNDS_BLOCK_MIN_POP", None)
     ctx.set_option("SWZ_MD_ROUNDS_BLOCK", "0")
     try:
         other = ctx.tile(xyz, *bounds, params)
     finally:
         ctx.set_option("SWZ_MD_ROUNDS_BLOCK", None)
     assert np.array_equal(other.level, base.level)
+    assert np.array_equal(ctx.tile(xyz, *bounds, params).level, base.level)   # ... and with the default choice per level
     if bounds is UNIT:
         a, b = _check_property(base.keys, base.level, base.xyz_clamped[base.perm], sp, mppn, base.stats["max_level"])
         assert a > 0 and b > 0
